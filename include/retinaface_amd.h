@@ -1,0 +1,162 @@
+/*
+ * retinaface_amd.h -- C ABI of the MI355X-native RetinaFace detect() engine.
+ *
+ * The reference (clancylian/retinaface) has no C ABI and no plugin registry: its only public
+ * surface for this path is the C++ class in retinaface/RetinaFace.h:63-78.  This header is the
+ * boundary a binding for that class (or any FFI: ctypes / cgo / JNI) would sit on; every entry
+ * point cites the reference interface it replaces.  include/RetinaFace.h re-creates the C++
+ * class verbatim on top of it.  No torch / OpenCV / HIP types appear in any signature.
+ *
+ * Threading: one handle = one caller thread at a time (the reference is single-threaded and
+ * not re-entrant either: shared staging buffers, RetinaFace.cpp:323-336).
+ * Errors: every call returns RF_OK (0) or a negative rf_status; rf_last_error() gives text.
+ * (The reference abort()s / exit(0)s / bare-throws instead: trtutility.h:9-16,
+ * trtnetbase.cpp:201-204, RetinaFace.cpp:327-335.)
+ */
+#ifndef RETINAFACE_AMD_H
+#define RETINAFACE_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RF_ABI_VERSION 1
+
+typedef enum rf_status {
+    RF_OK = 0,
+    RF_ERR_INVALID_ARG = -1,
+    RF_ERR_IO = -2,             /* model file missing / unreadable */
+    RF_ERR_MODEL = -3,          /* graph is not the mnet0.25 + FPN + SSH topology this engine implements */
+    RF_ERR_HIP = -4,            /* a HIP runtime call failed (no GPU, OOM, launch failure) */
+    RF_ERR_UNSUPPORTED = -5,    /* e.g. int8 requested without a calibration table */
+    RF_ERR_TRUNCATED = -6       /* more candidates / detections than the configured caps; counts[] hold the true numbers */
+} rf_status;
+
+typedef enum rf_precision {
+    RF_PRECISION_FP32 = 0,      /* fp32 storage, exact-f32 MFMA (parity reference path)            */
+    RF_PRECISION_FP16 = 1,      /* fp16 storage, fp32 accumulate (reference: kHALF, trtnetbase.cpp:268-274) */
+    RF_PRECISION_INT8 = 2       /* reserved: int8 via the TensorRT calibration table (trtnetbase.cpp:295-311) */
+} rf_precision;
+
+/* Result record: byte-identical to the reference's FaceDetectInfo (RetinaFace.h:15-42):
+ * score, rect{x1,y1,x2,y2}, pts{x[5], y[5]} = 15 floats, coordinates in network-input pixels. */
+typedef struct rf_face {
+    float score;
+    float x1, y1, x2, y2;
+    float px[5];
+    float py[5];
+} rf_face;
+
+/* Replaces the compile-time / hard-coded configuration of the reference:
+ * precision (trtnetbase.cpp:268-274,295), net H x W (prototxt line 7 via trtnetbase.cpp:149-197),
+ * maxBatchSize = 8 (trtretinafacenet.cpp:21), model stem (RetinaFace.cpp:276).
+ * Zero-initialise, set struct_size = sizeof(rf_options), fill what you need; 0 = default. */
+typedef struct rf_options {
+    uint32_t struct_size;
+    int32_t precision;          /* rf_precision; default RF_PRECISION_FP16 */
+    int32_t net_h, net_w;       /* 0 = the prototxt / .rfw input dims; must be multiples of 32 */
+    int32_t max_batch;          /* images per launch (default 8); larger batches are chunked */
+    int32_t device;             /* HIP device ordinal + 1; 0 = the calling thread's current HIP device */
+    int32_t max_candidates;     /* pre-NMS candidates kept per image (default 4096, power of two) */
+    int32_t max_detections;     /* post-NMS faces returned per image (default 256) */
+    int32_t use_graph;          /* 1 (default) = replay a captured hipGraph per batch size; 2 = off */
+    int32_t keep_outputs;       /* 1 = also materialise the 9 NCHW fp32 head blobs for rf_get_output() */
+    const char *model_stem;     /* default "mnet-deconv-0517" (RetinaFace.cpp:276) */
+} rf_options;
+
+typedef struct rf_engine *rf_handle;
+
+/* RetinaFace::RetinaFace(string &model, string network = "net3", float nms = 0.4)
+ * (RetinaFace.h:66, RetinaFace.cpp:205-337).  model_dir holds either <stem>.rfw (this repo's packed
+ * model, the analogue of the reference's serialized-engine cache, trtnetbase.cpp:205-243) or
+ * <stem>.prototxt + <stem>.caffemodel (+ <stem>.table.int8).  Only network == "net3" has an anchor
+ * configuration in the reference (RetinaFace.cpp:245-271); others return RF_ERR_UNSUPPORTED. */
+int rf_create(const char *model_dir, const char *network, float nms_threshold,
+              const rf_options *options, rf_handle *out_handle);
+
+/* RetinaFace::~RetinaFace() (RetinaFace.cpp:339-345) -- unlike the reference this frees everything. */
+void rf_destroy(rf_handle h);
+
+/* Text of the last failure on this handle (h == NULL: last rf_create failure on this thread). */
+const char *rf_last_error(rf_handle h);
+
+/* TrtNetBase::getNetHeight/getNetWidth/getMaxBatchSize (trtnetbase.h) */
+int rf_get_net_size(rf_handle h, int *net_h, int *net_w, int *max_batch);
+
+/* void RetinaFace::detectBatchImages(vector<cv::Mat> imgs, float threshold = 0.5)
+ * (RetinaFace.h:69, RetinaFace.cpp:749-940) and, with n == 1, RetinaFace::detect (RetinaFace.h:70,
+ * RetinaFace.cpp:576-747).  Frames are HOST pointers to CV_8UC3 BGR pixels: bgr[i] + y*steps[i] is row y
+ * (cv::Mat data/step).  Frames no larger than the net are placed top-left on a zero canvas
+ * (resizeconvertion.cu:298-303 with the scale factor clamped to 1); larger frames are area-averaged
+ * down first.  Unlike the reference (which returns void and drops faceInfo, RetinaFace.cpp:726-747)
+ * results are returned: out[i*cap_per_image + k], k < min(counts[i], cap_per_image), score-descending,
+ * coordinates in network-input pixels (as in the reference).  A NULL/0x0 frame yields count 0
+ * (img.empty() early return, RetinaFace.cpp:578-580). */
+int rf_detect_batch(rf_handle h, const uint8_t *const *bgr, const int *rows, const int *cols,
+                    const int *steps, int n, float threshold,
+                    rf_face *out, int cap_per_image, int *counts);
+
+/* Same, frames already resident in device memory (HBM) on the engine's device. */
+int rf_detect_batch_device(rf_handle h, const void *const *d_bgr, const int *rows, const int *cols,
+                           const int *steps, int n, float threshold,
+                           rf_face *out, int cap_per_image, int *counts);
+
+/* Asynchronous form of rf_detect_batch_device for serving loops: enqueue returns as soon as the
+ * batch is queued on the engine's stream (n <= max_batch); `ticket` identifies one of
+ * rf_num_slots() result slots.  rf_wait blocks until that batch has finished and copies its results.
+ * Enqueueing into a slot that has not been waited for waits for it first. */
+int rf_num_slots(rf_handle h);
+int rf_enqueue_batch_device(rf_handle h, const void *const *d_bgr, const int *rows, const int *cols,
+                            const int *steps, int n, float threshold, int *ticket);
+int rf_wait(rf_handle h, int ticket, rf_face *out, int cap_per_image, int *counts);
+
+/* Global anchor index (offset(stride) + a*h*w + iy*w + ix, strides 32,16,8) of each
+ * detection of image `image` of the most recent completed batch, in the same order as out[]. */
+int rf_last_anchor_indices(rf_handle h, int image, int32_t *out, int cap);
+/* Number of above-threshold anchors (pre-NMS) per image of the most recent completed batch. */
+int rf_last_candidate_counts(rf_handle h, int *counts, int n);
+
+/* The reference's three timers (RetinaFace.cpp:757,836,840-842,846,920; README columns pre/infer/post),
+ * measured with HIP events on the engine's stream for the most recent *synchronous* detect call.
+ * Only filled when the call ran un-graphed (options.use_graph == 2); otherwise returns total only. */
+int rf_last_timings(rf_handle h, float *pre_ms, float *infer_ms, float *post_ms, float *total_ms);
+
+/* TrtRetinaFaceNet::blob_by_name(name)->result[image] (trtretinafacenet.cpp:104-114): one of the 9
+ * output blobs ("face_rpn_cls_prob_reshape_stride32", "face_rpn_bbox_pred_stride16", ...) as NCHW fp32.
+ * Requires options.keep_outputs = 1.  Returns the number of floats written (or needed if dst == NULL). */
+long rf_get_output(rf_handle h, const char *blob_name, int image, float *dst, size_t cap_floats);
+
+/* Test / profiling hooks (no reference equivalent).
+ * rf_debug_activation: copy an internal NHWC activation of the last batch, converted to fp32, by the
+ *   name of the reference blob it corresponds to (e.g. "mobilenet0_relu10_fwd", "rf_c2_aggr_relu").
+ *   dims = {H, W, C}.  Returns floats written (or needed if dst == NULL), negative on error.
+ * rf_profile: run the per-kernel launch sequence for a batch of n net-sized device frames `iters`
+ *   times with a HIP event pair around every launch; returns the number of kernels, fills
+ *   names (up to cap entries, pointers owned by the engine), avg_ms, and the algorithmic bytes /
+ *   MACs each launch covers (layer-wise input+output elements x element size). */
+long rf_debug_activation(rf_handle h, const char *blob_name, int image, float *dst, size_t cap_floats,
+                         int dims[3]);
+int rf_profile(rf_handle h, const void *const *d_bgr, int n, int iters, int cap,
+               const char **names, float *avg_ms, double *alg_bytes, double *macs);
+
+/* Offline: pack <prototxt, caffemodel[, int8 table]> into a .rfw file (the analogue of the reference's
+ * first-run engine serialisation, trtnetbase.cpp:231-243).  int8_table may be NULL. */
+int rf_convert_model(const char *prototxt, const char *caffemodel, const char *int8_table,
+                     const char *out_rfw);
+
+/* Host-only test hook (runs without a GPU): BN-folded weights of one fused op of the plan compiled from
+ * <model_dir>/<stem>.  op = "conv0", "dw<i>" / "pw<i>" (i = 0..12), "lateral<i>" (0..2), "aggr<i>" (0..1),
+ * "ssh<i>.a" / ".b" / ".c" / ".head" (i = 0..2 for strides 32, 16, 8).  dims = {cout, k, k, cin/group};
+ * w is [cout][k][k][cin/group], b is [cout].  Returns RF_OK or an error; pass NULL buffers to query dims. */
+int rf_plan_folded(const char *model_dir, const char *stem, const char *op, float *w, size_t cap_w,
+                   float *b, size_t cap_b, int dims[4]);
+
+int rf_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RETINAFACE_AMD_H */

@@ -1,0 +1,197 @@
+// capi.cpp -- extern "C" boundary (include/retinaface_amd.h) over rf::Engine.  Exceptions never cross it.
+#include <cstdlib>
+#include <cstring>
+#include <string>
+
+#include "engine.h"
+
+namespace {
+thread_local std::string g_create_error;
+}
+
+struct rf_engine {
+    std::unique_ptr<rf::Engine> eng;
+    std::string error;
+};
+
+namespace {
+
+template <typename F> int guarded(rf_engine *h, F &&f) {
+    std::string &err = h ? h->error : g_create_error;
+    try {
+        return f();
+    } catch (const rf::ArgError &e) { err = e.what(); return RF_ERR_INVALID_ARG;
+    } catch (const rf::IoError &e) { err = e.what(); return RF_ERR_IO;
+    } catch (const rf::ModelError &e) { err = e.what(); return RF_ERR_MODEL;
+    } catch (const rf::HipError &e) { err = e.what(); return RF_ERR_HIP;
+    } catch (const rf::Unsupported &e) { err = e.what(); return RF_ERR_UNSUPPORTED;
+    } catch (const std::exception &e) { err = e.what(); return RF_ERR_INVALID_ARG; }
+}
+
+}  // namespace
+
+extern "C" {
+
+int rf_abi_version(void) { return RF_ABI_VERSION; }
+
+int rf_create(const char *model_dir, const char *network, float nms_threshold, const rf_options *o, rf_handle *out) {
+    return guarded(nullptr, [&]() -> int {
+        if (!model_dir || !out) throw rf::ArgError("model_dir / out_handle is null");
+        *out = nullptr;
+        rf::EngineOptions eo;
+        if (o) {
+            if (o->struct_size != sizeof(rf_options)) throw rf::ArgError("rf_options.struct_size mismatch");
+            if (o->precision == RF_PRECISION_FP32 || o->precision == RF_PRECISION_FP16 || o->precision == RF_PRECISION_INT8)
+                eo.precision = o->precision;
+            else throw rf::ArgError("unknown precision");
+            eo.net_h = o->net_h; eo.net_w = o->net_w;
+            if (o->max_batch) eo.max_batch = o->max_batch;
+            eo.device = o->device > 0 ? o->device - 1 : -1;
+            if (o->max_candidates) eo.max_candidates = o->max_candidates;
+            if (o->max_detections) eo.max_detections = o->max_detections;
+            eo.use_graph = o->use_graph != 2;
+            eo.keep_outputs = o->keep_outputs == 1;
+            if (o->model_stem && *o->model_stem) eo.model_stem = o->model_stem;
+        }
+        auto eng = rf::Engine::create(model_dir, network ? network : "net3", nms_threshold, eo);
+        rf_engine *h = new rf_engine;
+        h->eng = std::move(eng);
+        *out = h;
+        return RF_OK;
+    });
+}
+
+void rf_destroy(rf_handle h) { delete h; }
+
+const char *rf_last_error(rf_handle h) { return h ? h->error.c_str() : g_create_error.c_str(); }
+
+int rf_get_net_size(rf_handle h, int *net_h, int *net_w, int *max_batch) {
+    if (!h) return RF_ERR_INVALID_ARG;
+    if (net_h) *net_h = h->eng->net_h();
+    if (net_w) *net_w = h->eng->net_w();
+    if (max_batch) *max_batch = h->eng->max_batch();
+    return RF_OK;
+}
+
+static int detect_common(rf_handle h, const uint8_t *const *frames, const int *rows, const int *cols, const int *steps,
+                         int n, bool on_device, float thr, rf_face *out, int cap, int *counts) {
+    if (!h) return RF_ERR_INVALID_ARG;
+    return guarded(h, [&]() -> int {
+        bool tr = false;
+        h->eng->detect(frames, rows, cols, steps, n, on_device, thr, out, cap, counts, &tr);
+        if (tr) { h->error = "more candidates / detections than the configured caps"; return RF_ERR_TRUNCATED; }
+        return RF_OK;
+    });
+}
+
+int rf_detect_batch(rf_handle h, const uint8_t *const *bgr, const int *rows, const int *cols, const int *steps, int n,
+                    float threshold, rf_face *out, int cap_per_image, int *counts) {
+    return detect_common(h, bgr, rows, cols, steps, n, false, threshold, out, cap_per_image, counts);
+}
+
+int rf_detect_batch_device(rf_handle h, const void *const *d_bgr, const int *rows, const int *cols, const int *steps,
+                           int n, float threshold, rf_face *out, int cap_per_image, int *counts) {
+    return detect_common(h, (const uint8_t *const *)d_bgr, rows, cols, steps, n, true, threshold, out, cap_per_image, counts);
+}
+
+int rf_num_slots(rf_handle h) { return h ? h->eng->num_slots() : RF_ERR_INVALID_ARG; }
+
+int rf_enqueue_batch_device(rf_handle h, const void *const *d_bgr, const int *rows, const int *cols, const int *steps,
+                            int n, float threshold, int *ticket) {
+    if (!h || !ticket) return RF_ERR_INVALID_ARG;
+    return guarded(h, [&]() -> int { *ticket = h->eng->enqueue(d_bgr, rows, cols, steps, n, threshold); return RF_OK; });
+}
+
+int rf_wait(rf_handle h, int ticket, rf_face *out, int cap_per_image, int *counts) {
+    if (!h) return RF_ERR_INVALID_ARG;
+    return guarded(h, [&]() -> int {
+        bool tr = false;
+        h->eng->wait(ticket, out, cap_per_image, counts, &tr);
+        if (tr) { h->error = "more candidates / detections than the configured caps"; return RF_ERR_TRUNCATED; }
+        return RF_OK;
+    });
+}
+
+int rf_last_anchor_indices(rf_handle h, int image, int32_t *out, int cap) {
+    if (!h || (cap > 0 && !out)) return RF_ERR_INVALID_ARG;
+    return guarded(h, [&]() -> int { return h->eng->last_anchor_indices(image, out, cap); });
+}
+
+int rf_last_candidate_counts(rf_handle h, int *counts, int n) {
+    if (!h || !counts) return RF_ERR_INVALID_ARG;
+    return guarded(h, [&]() -> int { return h->eng->last_candidate_counts(counts, n); });
+}
+
+int rf_last_timings(rf_handle h, float *pre_ms, float *infer_ms, float *post_ms, float *total_ms) {
+    if (!h) return RF_ERR_INVALID_ARG;
+    h->eng->last_timings(pre_ms, infer_ms, post_ms, total_ms);
+    return RF_OK;
+}
+
+long rf_get_output(rf_handle h, const char *blob_name, int image, float *dst, size_t cap_floats) {
+    if (!h || !blob_name) return RF_ERR_INVALID_ARG;
+    long r = 0;
+    int st = guarded(h, [&]() -> int { r = h->eng->get_output(blob_name, image, dst, cap_floats); return RF_OK; });
+    return st == RF_OK ? r : st;
+}
+
+long rf_debug_activation(rf_handle h, const char *blob_name, int image, float *dst, size_t cap_floats, int dims[3]) {
+    if (!h || !blob_name) return RF_ERR_INVALID_ARG;
+    long r = 0;
+    int st = guarded(h, [&]() -> int { r = h->eng->debug_activation(blob_name, image, dst, cap_floats, dims); return RF_OK; });
+    return st == RF_OK ? r : st;
+}
+
+int rf_profile(rf_handle h, const void *const *d_bgr, int n, int iters, int cap, const char **names, float *avg_ms,
+               double *alg_bytes, double *macs) {
+    if (!h || !d_bgr) return RF_ERR_INVALID_ARG;
+    return guarded(h, [&]() -> int { return h->eng->profile(d_bgr, n, iters, cap, names, avg_ms, alg_bytes, macs); });
+}
+
+int rf_convert_model(const char *prototxt, const char *caffemodel, const char *int8_table, const char *out_rfw) {
+    return guarded(nullptr, [&]() -> int {
+        if (!prototxt || !caffemodel || !out_rfw) throw rf::ArgError("null path");
+        rf::Model m = rf::load_prototxt(prototxt);
+        rf::attach_caffemodel(m, caffemodel);
+        if (int8_table && *int8_table) rf::attach_int8_table(m, int8_table);
+        (void)rf::compile_plan(m);      // refuse to pack a graph the engine cannot run
+        rf::save_rfw(m, out_rfw);
+        return RF_OK;
+    });
+}
+
+int rf_plan_folded(const char *model_dir, const char *stem, const char *op, float *w, size_t cap_w, float *b,
+                   size_t cap_b, int dims[4]) {
+    return guarded(nullptr, [&]() -> int {
+        if (!model_dir || !op) throw rf::ArgError("null argument");
+        rf::Model m = rf::load_model_dir(model_dir, stem && *stem ? stem : "mnet-deconv-0517");
+        rf::Plan p = rf::compile_plan(m);
+        std::string name = op;
+        const rf::FoldedConv *f = nullptr;
+        auto idx = [&](const std::string &prefix, int limit) -> int {
+            if (name.compare(0, prefix.size(), prefix) != 0) return -1;
+            int i = std::atoi(name.c_str() + prefix.size());
+            return i >= 0 && i < limit ? i : -1;
+        };
+        int i;
+        if (name == "conv0") f = &p.conv0;
+        else if ((i = idx("dw", 13)) >= 0 && name.find('.') == std::string::npos) f = &p.blocks[i].dw;
+        else if ((i = idx("pw", 13)) >= 0) f = &p.blocks[i].pw;
+        else if ((i = idx("lateral", 3)) >= 0) f = &p.lateral[i];
+        else if ((i = idx("aggr", 2)) >= 0) f = &p.aggr[i];
+        else if ((i = idx("ssh", 3)) >= 0) {
+            std::string tail = name.substr(name.find('.') == std::string::npos ? name.size() : name.find('.'));
+            if (tail == ".a") f = &p.ssh[i].conv_a;
+            else if (tail == ".b") f = &p.ssh[i].conv_b;
+            else if (tail == ".c") f = &p.ssh[i].conv_c;
+            else if (tail == ".head") f = &p.ssh[i].head;
+        }
+        if (!f) throw rf::ArgError("unknown plan op '" + name + "'");
+        if (dims) { dims[0] = f->cout; dims[1] = f->k; dims[2] = f->k; dims[3] = f->cin / f->group; }
+        if (w) { if (cap_w < f->w.size()) throw rf::ArgError("w too small"); memcpy(w, f->w.data(), f->w.size() * 4); }
+        if (b) { if (cap_b < f->b.size()) throw rf::ArgError("b too small"); memcpy(b, f->b.data(), f->b.size() * 4); }
+        return RF_OK;
+    });
+}
+
+}  // extern "C"

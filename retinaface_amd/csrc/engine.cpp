@@ -1,0 +1,658 @@
+// engine.cpp -- see engine.h.
+#include "engine.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <set>
+
+#include "pack.h"
+
+namespace rf {
+
+#define RF_HIP(expr)                                                                                   \
+    do {                                                                                               \
+        hipError_t e_ = (expr);                                                                        \
+        if (e_ != hipSuccess)                                                                          \
+            throw HipError(std::string(#expr) + " failed: " + hipGetErrorString(e_));                  \
+    } while (0)
+
+namespace {
+
+template <typename T> struct Cast;
+template <> struct Cast<float> { static float from(float v) { return v; } static float to(float v) { return v; } };
+template <> struct Cast<half_t> {
+    static half_t from(float v) { return (half_t)v; }
+    static float to(half_t v) { return (float)v; }
+};
+
+// Device memory arena for the read-only weights: one allocation, 256-byte aligned sub-buffers.
+class Arena {
+public:
+    size_t reserve(size_t bytes) {
+        size_t off = host_.size();
+        host_.resize(off + ((bytes + 255) / 256) * 256, 0);
+        return off;
+    }
+    template <typename U> size_t put(const std::vector<U> &v) {
+        size_t off = reserve(v.size() * sizeof(U));
+        memcpy(host_.data() + off, v.data(), v.size() * sizeof(U));
+        return off;
+    }
+    void upload() {
+        RF_HIP(hipMalloc(&dev_, host_.size() ? host_.size() : 256));
+        RF_HIP(hipMemcpy(dev_, host_.data(), host_.size(), hipMemcpyHostToDevice));
+    }
+    template <typename U> const U *ptr(size_t off) const { return (const U *)((const char *)dev_ + off); }
+    void release() { if (dev_) (void)hipFree(dev_); dev_ = nullptr; }
+    size_t bytes() const { return host_.size(); }
+private:
+    std::vector<unsigned char> host_;
+    void *dev_ = nullptr;
+};
+
+// GEMM-shaped weights [cout][k_total] -> MFMA A-fragment order (pack.h), zero padded to whole K chunks
+template <typename T> std::vector<T> pack_gemm(const std::vector<float> &w, int cout, int k_total, int K, int KPL) {
+    int kch = k_chunks_for(k_total, K);
+    std::vector<T> out((size_t)(cout / 16) * kch * 64 * KPL, Cast<T>::from(0.f));
+    for (int o = 0; o < cout; o++)
+        for (int k = 0; k < k_total; k++)
+            out[packed_weight_index(o, k, kch, K, KPL)] = Cast<T>::from(w[(size_t)o * k_total + k]);
+    return out;
+}
+
+template <typename T> constexpr int mma_k() { return sizeof(T) == 2 ? 32 : 4; }
+template <typename T> constexpr int mma_kpl() { return sizeof(T) == 2 ? 8 : 1; }
+
+// base anchor of generate_anchors(base_size 16, ratios {1.0}, scales {scale}) -- RetinaFace.cpp:34-103
+void base_anchor(int scale, float out[4]) {
+    float w = 15.f - 0.f + 1, h = 15.f - 0.f + 1;
+    float xc = 0.f + 0.5 * (w - 1), yc = 0.f + 0.5 * (h - 1);
+    float size = w * h, sc = size / 1.0f;
+    float w2 = std::round(std::sqrt(sc)), h2 = std::round(w2 * 1.0f);
+    float rx1 = xc - 0.5 * (w2 - 1), ry1 = yc - 0.5 * (h2 - 1), rx2 = xc + 0.5 * (w2 - 1), ry2 = yc + 0.5 * (h2 - 1);
+    w = rx2 - rx1 + 1; h = ry2 - ry1 + 1;
+    xc = rx1 + 0.5 * (w - 1); yc = ry1 + 0.5 * (h - 1);
+    w = w * scale; h = h * scale;
+    out[0] = xc - 0.5 * (w - 1); out[1] = yc - 0.5 * (h - 1);
+    out[2] = xc + 0.5 * (w - 1); out[3] = yc + 0.5 * (h - 1);
+}
+
+constexpr int kSlots = 4;
+
+template <typename T>
+class EngineImpl final : public Engine {
+public:
+    EngineImpl(const Plan &plan, float nms, const EngineOptions &opt) {
+        opt_ = opt;
+        nms_threshold_ = nms;
+        net_h_ = opt.net_h > 0 ? opt.net_h : plan.net_h;
+        net_w_ = opt.net_w > 0 ? opt.net_w : plan.net_w;
+        if (net_h_ <= 0 || net_w_ <= 0 || net_h_ % 32 || net_w_ % 32)
+            throw ArgError("network input size must be a positive multiple of 32 (got " + std::to_string(net_h_) + "x" +
+                           std::to_string(net_w_) + ")");
+        if (opt_.max_batch < 1) throw ArgError("max_batch must be >= 1");
+        int mc = opt_.max_candidates;
+        if (mc < 64 || mc > 4096 || (mc & (mc - 1))) throw ArgError("max_candidates must be a power of two in [64, 4096]");
+        if (opt_.max_detections < 1 || opt_.max_detections > 4096) throw ArgError("max_detections must be in [1, 4096]");
+        if (opt_.device >= 0) RF_HIP(hipSetDevice(opt_.device));
+        RF_HIP(hipGetDevice(&device_));
+        RF_HIP(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+        for (auto &e : ev_) RF_HIP(hipEventCreate(&e));
+        build(plan);
+    }
+
+    ~EngineImpl() override {
+        (void)hipStreamSynchronize(stream_);
+        for (auto &kv : graphs_) (void)hipGraphExecDestroy(kv.second);
+        for (void *p : dev_allocs_) (void)hipFree(p);
+        for (void *p : host_allocs_) (void)hipHostFree(p);
+        if (d_raw_) (void)hipFree(d_raw_);
+        arena_.release();
+        for (auto &s : slots_) (void)hipEventDestroy(s.done);
+        for (auto &e : ev_) (void)hipEventDestroy(e);
+        for (auto &e : prof_ev_) (void)hipEventDestroy(e);
+        (void)hipStreamDestroy(stream_);
+    }
+
+    // ------------------------------------------------------------------------------------------ API
+    void detect(const uint8_t *const *frames, const int *rows, const int *cols, const int *steps, int n, bool on_device,
+                float threshold, rf_face *out, int cap_per_image, int *counts, bool *truncated) override {
+        if (n < 0 || (n > 0 && (!frames || !rows || !cols || !counts))) throw ArgError("null argument");
+        if (cap_per_image < 0 || (cap_per_image > 0 && !out)) throw ArgError("out is null");
+        *truncated = false;
+        for (int base = 0; base < n; base += opt_.max_batch) {
+            int m = std::min(opt_.max_batch, n - base);
+            std::vector<int> st(m);
+            for (int i = 0; i < m; i++) st[i] = steps ? steps[base + i] : cols[base + i] * 3;
+            int ticket = submit(frames + base, rows + base, cols + base, st.data(), m, on_device, threshold, true);
+            bool tr = false;
+            wait(ticket, out ? out + (size_t)base * cap_per_image : nullptr, cap_per_image, counts + base, &tr);
+            *truncated = *truncated || tr;
+        }
+    }
+
+    int enqueue(const void *const *d_frames, const int *rows, const int *cols, const int *steps, int n,
+                float threshold) override {
+        if (n < 1 || n > opt_.max_batch) throw ArgError("enqueue: n must be in [1, max_batch]");
+        if (!d_frames || !rows || !cols) throw ArgError("null argument");
+        std::vector<int> st(n);
+        for (int i = 0; i < n; i++) st[i] = steps ? steps[i] : cols[i] * 3;
+        return submit((const uint8_t *const *)d_frames, rows, cols, st.data(), n, true, threshold, false);
+    }
+
+    void wait(int ticket, rf_face *out, int cap_per_image, int *counts, bool *truncated) override {
+        if (ticket < 0 || ticket >= kSlots || !slots_[ticket].busy) throw ArgError("wait: invalid ticket");
+        Slot &s = slots_[ticket];
+        RF_HIP(hipEventSynchronize(s.done));
+        s.busy = false;
+        bool tr = false;
+        last_n_ = s.n;
+        last_cand_counts_.assign(s.n, 0);
+        last_anchor_.assign(s.n, std::vector<int32_t>());
+        for (int i = 0; i < s.n; i++) {
+            int kept = s.empty[i] ? 0 : s.h_counts[i];
+            int ncand = s.empty[i] ? 0 : s.h_counts[opt_.max_batch + i];
+            last_cand_counts_[i] = ncand;
+            if (ncand > opt_.max_candidates) tr = true;
+            int avail = std::min(kept, opt_.max_detections);
+            if (kept > opt_.max_detections) tr = true;
+            if (counts) counts[i] = kept;
+            int ncopy = std::min(avail, cap_per_image);
+            if (avail > cap_per_image) tr = true;
+            const Candidate *src = s.h_out + (size_t)i * opt_.max_detections;
+            last_anchor_[i].resize(avail);
+            for (int k = 0; k < avail; k++) last_anchor_[i][k] = src[k].anchor;
+            for (int k = 0; k < ncopy; k++) memcpy(&out[(size_t)i * cap_per_image + k], &src[k], sizeof(rf_face));
+        }
+        if (s.timed) {
+            float a = 0, b = 0, c = 0;
+            (void)hipEventElapsedTime(&a, ev_[0], ev_[1]);
+            (void)hipEventElapsedTime(&b, ev_[1], ev_[2]);
+            (void)hipEventElapsedTime(&c, ev_[2], ev_[3]);
+            t_pre_ = a; t_infer_ = b; t_post_ = c; t_total_ = a + b + c;
+            have_split_ = true;
+        }
+        if (truncated) *truncated = tr;
+    }
+
+    int num_slots() const override { return kSlots; }
+
+    int last_anchor_indices(int image, int32_t *out, int cap) const override {
+        if (image < 0 || image >= last_n_) throw ArgError("image index out of range");
+        int n = (int)last_anchor_[image].size();
+        for (int i = 0; i < std::min(n, cap); i++) out[i] = last_anchor_[image][i];
+        return n;
+    }
+    int last_candidate_counts(int *counts, int n) const override {
+        for (int i = 0; i < std::min(n, last_n_); i++) counts[i] = last_cand_counts_[i];
+        return last_n_;
+    }
+    void last_timings(float *pre, float *infer, float *post, float *total) const override {
+        if (pre) *pre = have_split_ ? t_pre_ : -1.f;
+        if (infer) *infer = have_split_ ? t_infer_ : -1.f;
+        if (post) *post = have_split_ ? t_post_ : -1.f;
+        if (total) *total = have_split_ ? t_total_ : -1.f;
+    }
+
+    long get_output(const std::string &blob, int image, float *dst, size_t cap) override {
+        if (!opt_.keep_outputs) throw ArgError("rf_get_output needs options.keep_outputs = 1");
+        static const char *kinds[3] = {"face_rpn_cls_prob_reshape_stride", "face_rpn_bbox_pred_stride",
+                                       "face_rpn_landmark_pred_stride"};
+        static const int chans[3] = {4, 8, 20};
+        for (int si = 0; si < 3; si++)
+            for (int k = 0; k < 3; k++) {
+                if (blob != std::string(kinds[k]) + std::to_string(strides_[si])) continue;
+                if (image < 0 || image >= opt_.max_batch) throw ArgError("image index out of range");
+                size_t hw = (size_t)(net_h_ / strides_[si]) * (net_w_ / strides_[si]);
+                size_t cnt = hw * chans[k];
+                if (!dst) return (long)cnt;
+                if (cap < cnt) throw ArgError("destination too small");
+                RF_HIP(hipStreamSynchronize(stream_));
+                RF_HIP(hipMemcpy(dst, d_dump_[si][k] + (size_t)image * cnt, cnt * sizeof(float), hipMemcpyDeviceToHost));
+                return (long)cnt;
+            }
+        throw ArgError("unknown output blob '" + blob + "'");
+    }
+
+    long debug_activation(const std::string &blob, int image, float *dst, size_t cap, int dims[3]) override {
+        auto it = acts_.find(blob);
+        if (it == acts_.end()) throw ArgError("unknown activation '" + blob + "'");
+        const ActInfo &ai = it->second;
+        if (image < 0 || image >= opt_.max_batch) throw ArgError("image index out of range");
+        size_t cnt = (size_t)ai.h * ai.w * ai.c;
+        if (dims) { dims[0] = ai.h; dims[1] = ai.w; dims[2] = ai.c; }
+        if (!dst) return (long)cnt;
+        if (cap < cnt) throw ArgError("destination too small");
+        RF_HIP(hipStreamSynchronize(stream_));
+        std::vector<T> tmp(cnt);
+        RF_HIP(hipMemcpy(tmp.data(), (const T *)ai.ptr + (size_t)image * cnt, cnt * sizeof(T), hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < cnt; i++) dst[i] = Cast<T>::to(tmp[i]);
+        return (long)cnt;
+    }
+
+    int profile(const void *const *d_frames, int n, int iters, int cap, const char **names, float *avg_ms,
+                double *alg_bytes, double *macs) override {
+        if (n < 1 || n > opt_.max_batch || iters < 1) throw ArgError("profile: bad n / iters");
+        RF_HIP(hipStreamSynchronize(stream_));
+        std::vector<FrameDesc> fd(2 * opt_.max_batch);
+        for (int i = 0; i < n; i++) fd[opt_.max_batch + i] = FrameDesc{(const uint8_t *)d_frames[i], net_h_, net_w_, net_w_ * 3, 0};
+        RunParams rp{0.5f, nms_threshold_, n, 0};
+        RF_HIP(hipMemcpy(d_frames_, fd.data(), fd.size() * sizeof(FrameDesc), hipMemcpyHostToDevice));
+        RF_HIP(hipMemcpy(d_params_, &rp, sizeof(rp), hipMemcpyHostToDevice));
+        size_t nops = ops_.size();
+        while (prof_ev_.size() < 2 * nops) { hipEvent_t e; RF_HIP(hipEventCreate(&e)); prof_ev_.push_back(e); }
+        std::vector<double> sum(nops, 0.0);
+        for (int it = -2; it < iters; it++) {      // two untimed warm-up passes
+            RF_HIP(hipMemsetAsync(d_counts_, 0, 2 * opt_.max_batch * sizeof(int), stream_));
+            for (size_t k = 0; k < nops; k++) {
+                RF_HIP(hipEventRecord(prof_ev_[2 * k], stream_));
+                ops_[k].launch(stream_, n);
+                RF_HIP(hipEventRecord(prof_ev_[2 * k + 1], stream_));
+            }
+            RF_HIP(hipStreamSynchronize(stream_));
+            RF_HIP(hipGetLastError());
+            if (it < 0) continue;
+            for (size_t k = 0; k < nops; k++) {
+                float ms = 0;
+                RF_HIP(hipEventElapsedTime(&ms, prof_ev_[2 * k], prof_ev_[2 * k + 1]));
+                sum[k] += ms;
+            }
+        }
+        for (size_t k = 0; k < nops && (int)k < cap; k++) {
+            if (names) names[k] = ops_[k].name.c_str();
+            if (avg_ms) avg_ms[k] = (float)(sum[k] / iters);
+            if (alg_bytes) alg_bytes[k] = n * (ops_[k].alg_u8_in + sizeof(T) * (ops_[k].alg_elems_in + ops_[k].alg_elems_out));
+            if (macs) macs[k] = n * ops_[k].macs;
+        }
+        return (int)nops;
+    }
+
+private:
+    struct Slot {
+        FrameDesc *h_frames = nullptr;   // [2*max_batch]: [0,mb) source frames, [mb,2mb) what conv0 reads
+        RunParams *h_params = nullptr;
+        int *h_counts = nullptr;         // [2*max_batch]: kept counts, candidate counts
+        Candidate *h_out = nullptr;      // [max_batch*max_det]
+        hipEvent_t done;
+        bool busy = false, timed = false;
+        int n = 0;
+        std::vector<char> empty;
+    };
+
+    // ------------------------------------------------------------------------------------------ build
+    template <typename U> U *dalloc(size_t count) {
+        void *p = nullptr;
+        RF_HIP(hipMalloc(&p, std::max<size_t>(count * sizeof(U), 256)));
+        dev_allocs_.push_back(p);
+        return (U *)p;
+    }
+    template <typename U> U *halloc(size_t count) {
+        void *p = nullptr;
+        RF_HIP(hipHostMalloc(&p, std::max<size_t>(count * sizeof(U), 256), hipHostMallocDefault));
+        host_allocs_.push_back(p);
+        return (U *)p;
+    }
+    T *act(const std::string &name, int h, int w, int c) {
+        T *p = dalloc<T>((size_t)opt_.max_batch * h * w * c);
+        acts_[name] = ActInfo{p, h, w, c};
+        return p;
+    }
+
+    void build(const Plan &plan) {
+        const int mb = opt_.max_batch;
+        const int K = mma_k<T>(), KPL = mma_kpl<T>();
+        const int H = net_h_, W = net_w_;
+        const double P = (double)H * W;
+
+        // ---- run-time tables
+        d_frames_ = dalloc<FrameDesc>(2 * mb);
+        d_params_ = dalloc<RunParams>(1);
+        const size_t hdr = ((2 * mb * sizeof(int) + 255) / 256) * 256;
+        result_bytes_ = hdr + (size_t)mb * opt_.max_detections * sizeof(Candidate);
+        d_result_ = dalloc<unsigned char>(result_bytes_);
+        d_counts_ = (int *)d_result_;
+        d_out_ = (Candidate *)(d_result_ + hdr);
+        result_hdr_ = hdr;
+        d_cand_ = dalloc<Candidate>((size_t)mb * opt_.max_candidates);
+        d_canvas_ = dalloc<uint8_t>((size_t)mb * H * W * 3);
+        slots_.resize(kSlots);
+        for (auto &s : slots_) {
+            s.h_frames = halloc<FrameDesc>(2 * mb);
+            s.h_params = halloc<RunParams>(1);
+            unsigned char *res = halloc<unsigned char>(result_bytes_);
+            s.h_counts = (int *)res;
+            s.h_out = (Candidate *)(res + hdr);
+            RF_HIP(hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
+        }
+
+        // ---- weights -> arena (offsets first, pointers after upload)
+        struct GemmW { size_t w, b; };
+        auto put_gemm = [&](const FoldedConv &f) {
+            int ktot = f.k * f.k * (f.cin / f.group);
+            GemmW g;
+            g.w = arena_.put(pack_gemm<T>(f.w, f.cout, ktot, K, KPL));
+            g.b = arena_.put(f.b);
+            return g;
+        };
+        size_t c0_w = arena_.put(plan.conv0.w), c0_b = arena_.put(plan.conv0.b);
+        struct DwW { size_t w, b; };
+        std::vector<DwW> dw_w;
+        std::vector<GemmW> pw_w;
+        for (const auto &blk : plan.blocks) {
+            // depthwise weights [c][3][3][1] -> [tap][c]
+            int c = blk.dw.cout;
+            std::vector<T> w((size_t)9 * c);
+            for (int ch = 0; ch < c; ch++)
+                for (int t = 0; t < 9; t++) w[(size_t)t * c + ch] = Cast<T>::from(blk.dw.w[(size_t)ch * 9 + t]);
+            dw_w.push_back(DwW{arena_.put(w), arena_.put(blk.dw.b)});
+            pw_w.push_back(put_gemm(blk.pw));
+        }
+        GemmW lat_w[3] = {put_gemm(plan.lateral[0]), put_gemm(plan.lateral[1]), put_gemm(plan.lateral[2])};
+        GemmW aggr_w[2] = {put_gemm(plan.aggr[0]), put_gemm(plan.aggr[1])};
+        GemmW ssh_w[3][4];
+        for (int i = 0; i < 3; i++) {
+            ssh_w[i][0] = put_gemm(plan.ssh[i].conv_a);
+            ssh_w[i][1] = put_gemm(plan.ssh[i].conv_b);
+            ssh_w[i][2] = put_gemm(plan.ssh[i].conv_c);
+            ssh_w[i][3] = put_gemm(plan.ssh[i].head);
+        }
+        arena_.upload();
+
+        // ---- activations (one buffer per reference blob that survives fusion; 288 GB of HBM: nothing is recycled)
+        int h = H / 2, w = W / 2;
+        T *cur = act(plan.conv0.out_blob, h, w, 8);
+        T *conv0_out = cur;
+        {
+            OpInfo op;
+            op.name = "pre+" + plan.conv0.name;
+            op.alg_u8_in = 3.0 * P;
+            op.alg_elems_out = 8.0 * h * w;
+            op.macs = plan.conv0.macs_per_out_pixel() * h * w;
+            const float *wp = arena_.ptr<float>(c0_w), *bp = arena_.ptr<float>(c0_b);
+            const FrameDesc *fr = d_frames_ + mb;
+            op.launch = [fr, conv0_out, wp, bp, H, W](hipStream_t s, int n) { launch_conv0<T>(s, fr, conv0_out, wp, bp, n, H, W); };
+            ops_.push_back(op);
+        }
+        int c = 8;
+        T *taps[3] = {nullptr, nullptr, nullptr};   // c3 (stride 32), c2 (16), c1 (8)
+        for (size_t i = 0; i < plan.blocks.size(); i++) {
+            const auto &blk = plan.blocks[i];
+            int ho = h / blk.dw.stride, wo = w / blk.dw.stride;
+            T *out = act(blk.pw.out_blob, ho, wo, blk.pw.cout);
+            if (dwpw_tile_info<T>(c, blk.pw.cout, blk.dw.stride, true, ho, wo).th == 0)
+                throw ModelError("no kernel instance for depthwise/pointwise block " + blk.dw.name);
+            DwPwParams<T> p;
+            p.in = cur; p.out = out;
+            p.dw_w = arena_.ptr<T>(dw_w[i].w); p.dw_b = arena_.ptr<float>(dw_w[i].b);
+            p.pw_w = arena_.ptr<T>(pw_w[i].w); p.pw_b = arena_.ptr<float>(pw_w[i].b);
+            p.n = 0; p.hin = h; p.win = w; p.hout = ho; p.wout = wo;
+            p.cin = c; p.cout = blk.pw.cout; p.stride = blk.dw.stride; p.has_dw = true;
+            OpInfo op;
+            op.name = blk.dw.name + "+" + blk.pw.name;
+            op.alg_elems_in = (double)c * h * w + (double)c * ho * wo;
+            op.alg_elems_out = (double)c * ho * wo + (double)blk.pw.cout * ho * wo;
+            op.macs = (blk.dw.macs_per_out_pixel() + blk.pw.macs_per_out_pixel()) * ho * wo;
+            op.launch = [p](hipStream_t s, int n) { DwPwParams<T> q = p; q.n = n; launch_dwpw<T>(s, q); };
+            ops_.push_back(op);
+            cur = out; h = ho; w = wo; c = blk.pw.cout;
+            if (i == 4) taps[2] = out;
+            if (i == 10) taps[1] = out;
+            if (i == 12) taps[0] = out;
+        }
+        // FPN: laterals (1x1), then aggr convs with the upsample+add fused into their input staging
+        T *feat[3];
+        const int tap_c[3] = {256, 128, 64};
+        T *lat[3];
+        for (int i = 0; i < 3; i++) {
+            int fh = H / strides_[i], fw = W / strides_[i];
+            lat[i] = act(plan.lateral[i].out_blob, fh, fw, 64);
+            DwPwParams<T> p;
+            p.in = taps[i]; p.out = lat[i]; p.dw_w = nullptr; p.dw_b = nullptr;
+            p.pw_w = arena_.ptr<T>(lat_w[i].w); p.pw_b = arena_.ptr<float>(lat_w[i].b);
+            p.n = 0; p.hin = fh; p.win = fw; p.hout = fh; p.wout = fw;
+            p.cin = tap_c[i]; p.cout = 64; p.stride = 1; p.has_dw = false;
+            OpInfo op;
+            op.name = plan.lateral[i].name;
+            op.alg_elems_in = (double)tap_c[i] * fh * fw;
+            op.alg_elems_out = 64.0 * fh * fw;
+            op.macs = plan.lateral[i].macs_per_out_pixel() * fh * fw;
+            op.launch = [p](hipStream_t s, int n) { DwPwParams<T> q = p; q.n = n; launch_dwpw<T>(s, q); };
+            lat_ops_[i] = op;
+        }
+        feat[0] = lat[0];
+        // order: c3 lateral, c2 lateral, c2 aggr, c1 lateral, c1 aggr (dependencies of the prototxt order)
+        ops_.push_back(lat_ops_[0]);
+        for (int i = 0; i < 2; i++) {
+            ops_.push_back(lat_ops_[i + 1]);
+            int fh = H / strides_[i + 1], fw = W / strides_[i + 1];
+            feat[i + 1] = act(plan.aggr[i].out_blob, fh, fw, 64);
+            Conv3Params<T> p;
+            p.in = lat[i + 1]; p.in_ld = 64; p.in_off = 0; p.up = feat[i];
+            p.w = arena_.ptr<T>(aggr_w[i].w); p.b = arena_.ptr<float>(aggr_w[i].b);
+            p.out0 = feat[i + 1]; p.ld0 = 64; p.off0 = 0; p.n0 = 64; p.out1 = nullptr; p.ld1 = 0; p.off1 = 0;
+            p.n = 0; p.h = fh; p.w_ = fw; p.cin = 64; p.cout = 64;
+            OpInfo op;
+            op.name = std::string(i == 0 ? "rf_c3_upsampling" : "rf_c2_upsampling") + "+" + plan.aggr[i].name;
+            op.alg_elems_in = 64.0 * (fh / 2) * (fw / 2) + 64.0 * fh * fw;     // deconv input + conv input
+            op.alg_elems_out = 64.0 * fh * fw + 64.0 * fh * fw;               // deconv output + conv output
+            op.macs = plan.aggr[i].macs_per_out_pixel() * fh * fw + 16.0 * 64 * (fh / 2) * (fw / 2);
+            op.launch = [p](hipStream_t s, int n) { Conv3Params<T> q = p; q.n = n; launch_conv3x3<T>(s, q); };
+            ops_.push_back(op);
+        }
+        // SSH modules + heads
+        first_post_op_ = 0;
+        int anchor_off = 0;
+        std::vector<OpInfo> head_ops;
+        for (int i = 0; i < 3; i++) {
+            const SshModule &m = plan.ssh[i];
+            int fh = H / strides_[i], fw = W / strides_[i];
+            std::string pre = "rf_c" + std::to_string(3 - i) + "_det_";
+            T *cat = act(pre + "concat_relu", fh, fw, 64);
+            T *ctx1 = act(pre + "context_conv1_relu", fh, fw, 16);
+            T *ctx31 = act(pre + "context_conv3_1_relu", fh, fw, 16);
+            auto conv_op = [&](const FoldedConv &f, const GemmW &gw, const T *in, int cin, T *o0, int ld0, int off0, int n0,
+                               T *o1, int ld1, int off1, int nlayers) {
+                Conv3Params<T> p;
+                p.in = in; p.in_ld = cin; p.in_off = 0; p.up = nullptr;
+                p.w = arena_.ptr<T>(gw.w); p.b = arena_.ptr<float>(gw.b);
+                p.out0 = o0; p.ld0 = ld0; p.off0 = off0; p.n0 = n0; p.out1 = o1; p.ld1 = ld1; p.off1 = off1;
+                p.n = 0; p.h = fh; p.w_ = fw; p.cin = cin; p.cout = f.cout;
+                OpInfo op;
+                op.name = f.name;
+                op.alg_elems_in = (double)nlayers * cin * fh * fw;    // each merged sibling reads the input once, layer-wise
+                op.alg_elems_out = (double)f.cout * fh * fw;
+                op.macs = f.macs_per_out_pixel() * fh * fw;
+                op.launch = [p](hipStream_t s, int n) { Conv3Params<T> q = p; q.n = n; launch_conv3x3<T>(s, q); };
+                ops_.push_back(op);
+            };
+            conv_op(m.conv_a, ssh_w[i][0], feat[i], 64, cat, 64, 0, 32, ctx1, 16, 0, 2);
+            conv_op(m.conv_b, ssh_w[i][1], ctx1, 16, cat, 64, 32, 16, ctx31, 16, 0, 2);
+            conv_op(m.conv_c, ssh_w[i][2], ctx31, 16, cat, 64, 48, 16, nullptr, 0, 0, 1);
+            HeadParams<T> hp;
+            hp.in = cat; hp.w = arena_.ptr<T>(ssh_w[i][3].w); hp.b = arena_.ptr<float>(ssh_w[i][3].b);
+            hp.n = 0; hp.h = fh; hp.w_ = fw; hp.stride = strides_[i]; hp.anchor_offset = anchor_off;
+            static const int scales[3][2] = {{32, 16}, {8, 4}, {2, 1}};
+            base_anchor(scales[i][0], hp.base[0]);
+            base_anchor(scales[i][1], hp.base[1]);
+            hp.net_h = H; hp.net_w = W; hp.params = d_params_;
+            hp.cand = d_cand_; hp.cand_count = d_counts_ + mb; hp.cap = opt_.max_candidates;
+            hp.dump_prob = hp.dump_bbox = hp.dump_lmk = nullptr;
+            if (opt_.keep_outputs) {
+                static const int chans[3] = {4, 8, 20};
+                for (int k = 0; k < 3; k++) d_dump_[i][k] = dalloc<float>((size_t)mb * chans[k] * fh * fw);
+                hp.dump_prob = d_dump_[i][0]; hp.dump_bbox = d_dump_[i][1]; hp.dump_lmk = d_dump_[i][2];
+            }
+            OpInfo op;
+            op.name = m.head.name + "+softmax+decode";
+            op.alg_elems_in = 3.0 * 64 * fh * fw;
+            op.alg_elems_out = 32.0 * fh * fw;
+            op.macs = m.head.macs_per_out_pixel() * fh * fw;
+            op.launch = [hp](hipStream_t s, int n) { HeadParams<T> q = hp; q.n = n; launch_head<T>(s, q); };
+            head_ops.push_back(op);
+            anchor_off += 2 * fh * fw;
+        }
+        total_anchors_ = anchor_off;
+        first_post_op_ = ops_.size();
+        for (auto &op : head_ops) ops_.push_back(op);
+        {
+            NmsParams np;
+            np.cand = d_cand_; np.cand_count = d_counts_ + mb; np.cap = opt_.max_candidates; np.params = d_params_;
+            np.out = d_out_; np.out_count = d_counts_; np.max_det = opt_.max_detections; np.n = 0;
+            OpInfo op;
+            op.name = "sort+nms";
+            op.launch = [np](hipStream_t s, int n) { NmsParams q = np; q.n = n; launch_nms(s, q); };
+            ops_.push_back(op);
+        }
+    }
+
+    // ------------------------------------------------------------------------------------------ run
+    void ensure_raw(size_t per_image) {
+        if (per_image <= raw_stride_) return;
+        RF_HIP(hipStreamSynchronize(stream_));
+        if (d_raw_) RF_HIP(hipFree(d_raw_));
+        d_raw_ = nullptr;
+        raw_stride_ = ((per_image + 255) / 256) * 256;
+        RF_HIP(hipMalloc((void **)&d_raw_, raw_stride_ * opt_.max_batch));
+    }
+
+    int submit(const uint8_t *const *frames, const int *rows, const int *cols, const int *steps, int n, bool on_device,
+               float threshold, bool timed) {
+        const int mb = opt_.max_batch;
+        int ticket = next_slot_;
+        next_slot_ = (next_slot_ + 1) % kSlots;
+        Slot &s = slots_[ticket];
+        if (s.busy) { RF_HIP(hipEventSynchronize(s.done)); s.busy = false; }
+        s.n = n;
+        s.empty.assign(n, 0);
+        bool need_resize = false;
+        size_t max_raw = 0;
+        for (int i = 0; i < n; i++) {
+            bool empty = !frames[i] || rows[i] <= 0 || cols[i] <= 0;      // img.empty(), RetinaFace.cpp:578-580
+            s.empty[i] = empty;
+            if (empty) continue;
+            if (rows[i] > 4096 * 3072 / std::max(cols[i], 1)) throw ArgError("frame larger than 4096x3072 (RetinaFace.cpp:325)");
+            if (steps[i] < cols[i] * 3) throw ArgError("row step smaller than cols*3");
+            if (rows[i] > net_h_ || cols[i] > net_w_) need_resize = true;
+            max_raw = std::max(max_raw, (size_t)rows[i] * cols[i] * 3);
+        }
+        const bool eager = timed && !opt_.use_graph;
+        s.timed = eager;
+        if (eager) RF_HIP(hipEventRecord(ev_[0], stream_));
+        if (!on_device) ensure_raw(max_raw);
+        for (int i = 0; i < n; i++) {
+            FrameDesc src{nullptr, 0, 0, 0, 0};
+            if (!s.empty[i]) {
+                if (on_device) {
+                    src = FrameDesc{frames[i], rows[i], cols[i], steps[i], 0};
+                } else {
+                    uint8_t *dst = d_raw_ + (size_t)i * raw_stride_;
+                    RF_HIP(hipMemcpy2DAsync(dst, (size_t)cols[i] * 3, frames[i], (size_t)steps[i], (size_t)cols[i] * 3,
+                                            (size_t)rows[i], hipMemcpyHostToDevice, stream_));
+                    src = FrameDesc{dst, rows[i], cols[i], cols[i] * 3, 0};
+                }
+            }
+            s.h_frames[i] = src;
+            s.h_frames[mb + i] = need_resize
+                                     ? FrameDesc{d_canvas_ + (size_t)i * net_h_ * net_w_ * 3, net_h_, net_w_, net_w_ * 3, 0}
+                                     : src;
+        }
+        *s.h_params = RunParams{threshold, nms_threshold_, n, 0};
+        RF_HIP(hipMemcpyAsync(d_frames_, s.h_frames, 2 * mb * sizeof(FrameDesc), hipMemcpyHostToDevice, stream_));
+        RF_HIP(hipMemcpyAsync(d_params_, s.h_params, sizeof(RunParams), hipMemcpyHostToDevice, stream_));
+        if (need_resize) launch_resize_area(stream_, d_frames_, d_canvas_, n, net_h_, net_w_);
+        if (eager) RF_HIP(hipEventRecord(ev_[1], stream_));
+        if (opt_.use_graph && warmed_.count(n)) {
+            auto it = graphs_.find(n);
+            if (it == graphs_.end()) it = graphs_.emplace(n, capture(n)).first;
+            RF_HIP(hipGraphLaunch(it->second, stream_));
+        } else {
+            RF_HIP(hipMemsetAsync(d_counts_, 0, 2 * mb * sizeof(int), stream_));
+            for (size_t k = 0; k < ops_.size(); k++) {
+                if (eager && k == first_post_op_) RF_HIP(hipEventRecord(ev_[2], stream_));
+                ops_[k].launch(stream_, n);
+            }
+            warmed_.insert(n);     // first run of a batch size is always eager: function attributes get set outside capture
+        }
+        RF_HIP(hipGetLastError());
+        RF_HIP(hipMemcpyAsync(s.h_counts, d_result_, result_hdr_ + (size_t)n * opt_.max_detections * sizeof(Candidate),
+                              hipMemcpyDeviceToHost, stream_));
+        if (eager) RF_HIP(hipEventRecord(ev_[3], stream_));
+        RF_HIP(hipEventRecord(s.done, stream_));
+        s.busy = true;
+        return ticket;
+    }
+
+    hipGraphExec_t capture(int n) {
+        hipGraph_t g = nullptr;
+        hipGraphExec_t ge = nullptr;
+        RF_HIP(hipStreamBeginCapture(stream_, hipStreamCaptureModeThreadLocal));
+        hipError_t err = hipMemsetAsync(d_counts_, 0, 2 * opt_.max_batch * sizeof(int), stream_);
+        for (size_t k = 0; k < ops_.size() && err == hipSuccess; k++) ops_[k].launch(stream_, n);
+        hipError_t end = hipStreamEndCapture(stream_, &g);
+        if (err != hipSuccess || end != hipSuccess || !g)
+            throw HipError(std::string("hipGraph capture failed: ") + hipGetErrorString(err != hipSuccess ? err : end));
+        hipError_t inst = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(g);
+        if (inst != hipSuccess) throw HipError(std::string("hipGraphInstantiate failed: ") + hipGetErrorString(inst));
+        return ge;
+    }
+
+    // ------------------------------------------------------------------------------------------ state
+    int device_ = 0;
+    hipStream_t stream_ = nullptr;
+    hipEvent_t ev_[4];
+    std::vector<hipEvent_t> prof_ev_;
+    Arena arena_;
+    std::vector<void *> dev_allocs_, host_allocs_;
+    std::map<std::string, ActInfo> acts_;
+    std::vector<OpInfo> ops_;
+    OpInfo lat_ops_[3];
+    size_t first_post_op_ = 0;
+    const int strides_[3] = {32, 16, 8};
+    int total_anchors_ = 0;
+
+    FrameDesc *d_frames_ = nullptr;
+    RunParams *d_params_ = nullptr;
+    unsigned char *d_result_ = nullptr;
+    size_t result_bytes_ = 0, result_hdr_ = 0;
+    int *d_counts_ = nullptr;         // [0,mb) kept counts, [mb,2mb) candidate counts
+    Candidate *d_out_ = nullptr;
+    Candidate *d_cand_ = nullptr;
+    uint8_t *d_canvas_ = nullptr;
+    uint8_t *d_raw_ = nullptr;
+    size_t raw_stride_ = 0;
+    float *d_dump_[3][3] = {};
+
+    std::vector<Slot> slots_;
+    int next_slot_ = 0;
+    std::map<int, hipGraphExec_t> graphs_;
+    std::set<int> warmed_;
+
+    int last_n_ = 0;
+    std::vector<int> last_cand_counts_;
+    std::vector<std::vector<int32_t>> last_anchor_;
+    float t_pre_ = 0, t_infer_ = 0, t_post_ = 0, t_total_ = 0;
+    bool have_split_ = false;
+};
+
+}  // namespace
+
+std::unique_ptr<Engine> Engine::create(const std::string &model_dir, const std::string &network, float nms,
+                                       const EngineOptions &opt) {
+    // Only "net3" has an anchor configuration in the reference (RetinaFace.cpp:215-217, 245-271); the other
+    // presets print "please reconfig anchor_cfg" and leave cfg empty.
+    if (network != "net3") throw Unsupported("network preset '" + network + "' has no anchor configuration (only net3)");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) throw HipError("no HIP device available");
+    Model model = load_model_dir(model_dir, opt.model_stem);
+    Plan plan = compile_plan(model);
+    switch (opt.precision) {
+        case RF_PRECISION_FP16: return std::unique_ptr<Engine>(new EngineImpl<half_t>(plan, nms, opt));
+        case RF_PRECISION_FP32: return std::unique_ptr<Engine>(new EngineImpl<float>(plan, nms, opt));
+        case RF_PRECISION_INT8: throw Unsupported("int8 precision is not implemented yet");
+        default: throw ArgError("unknown precision");
+    }
+}
+
+}  // namespace rf

@@ -1,0 +1,81 @@
+// engine.h -- the device-side engine behind the C ABI: owns the stream, the packed weights, the NHWC
+// activation buffers and the per-batch-size hipGraphs.  Replaces TrtRetinaFaceNet (trtretinafacenet.cpp:
+// allocateMemory :146-210, doInference :48-102, blob_by_name :104-114) + the decode/NMS half of
+// RetinaFace::detect (RetinaFace.cpp:666-726).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <functional>
+#include <map>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/retinaface_amd.h"
+#include "kernels.h"
+#include "plan.h"
+
+namespace rf {
+
+struct HipError : std::runtime_error { using std::runtime_error::runtime_error; };
+struct ArgError : std::runtime_error { using std::runtime_error::runtime_error; };
+struct Unsupported : std::runtime_error { using std::runtime_error::runtime_error; };
+
+struct EngineOptions {
+    int precision = RF_PRECISION_FP16;
+    int net_h = 0, net_w = 0;
+    int max_batch = 8;
+    int device = -1;
+    int max_candidates = 4096;
+    int max_detections = 256;
+    bool use_graph = true;
+    bool keep_outputs = false;
+    std::string model_stem = "mnet-deconv-0517";
+};
+
+struct ActInfo { void *ptr; int h, w, c; };
+
+struct OpInfo {
+    std::string name;            // reference layer name(s) the launch covers
+    double alg_elems_in = 0;     // per image: layer-wise input elements (SURVEY.md 8d "E")
+    double alg_elems_out = 0;    // per image: layer-wise output elements
+    double alg_u8_in = 0;        // per image: bytes read as u8 (the frame), not scaled by the element size
+    double macs = 0;             // per image
+    std::function<void(hipStream_t, int)> launch;   // (stream, n_images)
+};
+
+class Engine {
+public:
+    static std::unique_ptr<Engine> create(const std::string &model_dir, const std::string &network, float nms,
+                                          const EngineOptions &opt);
+    virtual ~Engine() {}
+
+    // frames on host / device; synchronous
+    virtual void detect(const uint8_t *const *frames, const int *rows, const int *cols, const int *steps, int n,
+                        bool on_device, float threshold, rf_face *out, int cap_per_image, int *counts,
+                        bool *truncated) = 0;
+    virtual int enqueue(const void *const *d_frames, const int *rows, const int *cols, const int *steps, int n,
+                        float threshold) = 0;
+    virtual void wait(int ticket, rf_face *out, int cap_per_image, int *counts, bool *truncated) = 0;
+    virtual int num_slots() const = 0;
+
+    virtual int last_anchor_indices(int image, int32_t *out, int cap) const = 0;
+    virtual int last_candidate_counts(int *counts, int n) const = 0;
+    virtual void last_timings(float *pre, float *infer, float *post, float *total) const = 0;
+    virtual long get_output(const std::string &blob, int image, float *dst, size_t cap) = 0;
+    virtual long debug_activation(const std::string &blob, int image, float *dst, size_t cap, int dims[3]) = 0;
+    virtual int profile(const void *const *d_frames, int n, int iters, int cap, const char **names, float *avg_ms,
+                        double *alg_bytes, double *macs) = 0;
+
+    int net_h() const { return net_h_; }
+    int net_w() const { return net_w_; }
+    int max_batch() const { return opt_.max_batch; }
+
+protected:
+    EngineOptions opt_;
+    int net_h_ = 0, net_w_ = 0;
+    float nms_threshold_ = 0.4f;
+};
+
+}  // namespace rf

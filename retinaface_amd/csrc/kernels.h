@@ -1,0 +1,106 @@
+// kernels.h -- launch API of the hand-written gfx950 kernels (kernels.hip).  Everything NHWC.
+// T = rf::half_t (fp16 storage, fp32 accumulate, v_mfma_f32_16x16x32_f16) or float (fp32 storage,
+// exact-f32 v_mfma_f32_16x16x4_f32).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace rf {
+
+typedef _Float16 half_t;
+
+// One input frame: CV_8UC3 BGR, row y at ptr + y*step (cv::Mat data/step; RetinaFace.cpp:594).
+struct FrameDesc {
+    const uint8_t *ptr;
+    int rows, cols, step, pad_;
+};
+
+// Pre-NMS candidate written by the head kernel: the reference's FaceDetectInfo (RetinaFace.h:37-42) + the
+// global anchor index that defines the NMS tie order.  64 bytes.
+struct Candidate {
+    float score;
+    float x1, y1, x2, y2;
+    float px[5], py[5];
+    int32_t anchor;
+};
+
+// Per-call scalars that live in device memory so a captured hipGraph stays valid across calls.
+struct RunParams {
+    float threshold;       // keep iff conf > threshold   (RetinaFace.cpp:693)
+    float nms_threshold;   // suppress iff IoU > nms      (RetinaFace.cpp:486)
+    int32_t n_images;
+    int32_t pad_;
+};
+
+// ---- K_a: preprocess (BGR u8 HWC -> RGB, top-left placement on a zero canvas; resizeconvertion.cu:46-63,
+//      165-185, 279-316 with factor 1) fused with mobilenet0_conv0 (3x3 s2 p1 3->8) + BN + ReLU.
+template <typename T>
+void launch_conv0(hipStream_t s, const FrameDesc *frames, T *out, const float *w, const float *b,
+                  int n, int net_h, int net_w);
+
+// ---- K_b: depthwise 3x3 (+BN+ReLU) -> pointwise 1x1 (+BN+ReLU), the intermediate never leaves LDS.
+//      has_dw = false gives a plain 1x1 conv (+bias, +ReLU): the FPN laterals.
+template <typename T>
+struct DwPwParams {
+    const T *in; T *out;
+    const T *dw_w;        // [9][cin]
+    const float *dw_b;    // [cin]
+    const T *pw_w;        // MFMA-fragment packed (pack.h), k = cin
+    const float *pw_b;    // [cout]
+    int n, hin, win, hout, wout;
+    int cin, cout, stride;
+    bool has_dw;
+};
+template <typename T> void launch_dwpw(hipStream_t s, const DwPwParams<T> &p);
+
+// ---- K_c: dense 3x3 p1 s1 conv as an implicit GEMM on MFMA (+bias +ReLU).  Optional fused input
+//      "lateral + bilinear x2 upsample(coarser)" (Deconvolution k4 s2 p1 + Crop + Eltwise SUM,
+//      prototxt :1553-1592) and an output split into two NHWC destinations (merged sibling convs).
+template <typename T>
+struct Conv3Params {
+    const T *in; int in_ld, in_off;       // input pixel stride / channel offset (elements)
+    const T *up;                          // nullptr, or coarser level [n][h/2][w/2][64]
+    const T *w; const float *b;           // packed (k = 9*cin), bias[cout]
+    T *out0; int ld0, off0, n0;           // output channels [0, n0)    -> out0[pixel*ld0 + off0 + c]
+    T *out1; int ld1, off1;               // output channels [n0, cout) -> out1[pixel*ld1 + off1 + c - n0]
+    int n, h, w_, cin, cout;
+};
+template <typename T> void launch_conv3x3(hipStream_t s, const Conv3Params<T> &p);
+
+// ---- K_d: the three 1x1 heads of one stride as one 64->32 GEMM + 2-class softmax + anchor decode +
+//      bbox / landmark regression + clip + threshold compaction (RetinaFace.cpp:666-724, 378-432, 179-199).
+template <typename T>
+struct HeadParams {
+    const T *in;                          // [n][h][w][64] = rf_cX_det_concat_relu
+    const T *w; const float *b;           // packed 32x64, bias[32]: cls 0..3, bbox 4..11, landmark 12..31
+    int n, h, w_, stride, anchor_offset;  // anchor_offset = global index of (a=0, iy=0, ix=0) of this stride
+    float base[2][4];                     // the 2 base anchors of this stride (RetinaFace.cpp:34-103)
+    int net_h, net_w;
+    const RunParams *params;
+    Candidate *cand; int *cand_count; int cap;
+    float *dump_prob, *dump_bbox, *dump_lmk;   // optional NCHW fp32 copies of the 3 blobs (nullptr = off)
+};
+template <typename T> void launch_head(hipStream_t s, const HeadParams<T> &p);
+
+// ---- K_e: per-image sort (score desc, anchor index asc) + greedy NMS (RetinaFace.cpp:434-492); one
+//      workgroup per image, everything in LDS.
+struct NmsParams {
+    const Candidate *cand; const int *cand_count; int cap;   // cap: power of two <= 4096
+    const RunParams *params;
+    Candidate *out; int *out_count; int max_det;             // out[img*max_det + k], out_count = true count
+    int n;
+};
+void launch_nms(hipStream_t s, const NmsParams &p);
+
+// Area-average downscale of an over-size frame onto the net-size u8 canvas (NPPI_INTER_SUPER stand-in,
+// resizeconvertion.cu:298-311; closed-source NPP semantics -> "parity unpinned").
+void launch_resize_area(hipStream_t s, const FrameDesc *src, uint8_t *dst, int n, int net_h, int net_w);
+
+void launch_fill_u32(hipStream_t s, uint32_t *dst, uint32_t value, size_t count);
+
+// LDS bytes / tile geometry chosen for a layer (exposed for tests and DESIGN.md tables)
+struct TileInfo { int th, tw; size_t lds_bytes; int blocks_per_image; };
+template <typename T> TileInfo dwpw_tile_info(int cin, int cout, int stride, bool has_dw, int hout, int wout);
+template <typename T> TileInfo conv3x3_tile_info(int cin, int cout, int h, int w);
+
+}  // namespace rf

@@ -1,0 +1,862 @@
+// kernels.hip -- hand-written gfx950 (CDNA4) kernels of the RetinaFace detect() hot path.
+//
+// Layout: activations NHWC (channels innermost: one pixel = one contiguous 16..512-byte run, every global
+// access is a 16-byte-per-lane vector), weights pre-packed on the host in MFMA A-fragment order (pack.h).
+// Every dense contraction (1x1 pointwise / lateral / head, 3x3 FPN-aggr / SSH) runs on the matrix cores as
+// D[cout][pixel] += W[cout][k] * X[k][pixel] with 64-wide wavefronts; depthwise 3x3 and conv0 (Cin = 3) are
+// VALU stencils over LDS-staged halo tiles.  BN/Scale/ReLU/bias/concat/eltwise/upsample/softmax/decode are
+// fused into the producing or consuming kernel, so one kernel = one row of SURVEY.md App. A "fusion groups".
+//
+// What each kernel replaces in the reference is cited at its definition.
+#include "kernels.h"
+#include "pack.h"
+
+namespace rf {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+template <typename T> struct Vec;
+template <> struct Vec<half_t> { static constexpr int N = 8; typedef f16x8 type; };
+template <> struct Vec<float> { static constexpr int N = 4; typedef f32x4 type; };
+
+template <typename T> struct Mma;
+template <> struct Mma<half_t> {
+    static constexpr int K = 32, KPL = 8;
+    typedef f16x8 Frag;
+    static __device__ __forceinline__ Frag zero() { Frag f; for (int e = 0; e < 8; e++) f[e] = (half_t)0; return f; }
+    static __device__ __forceinline__ f32x4 mma(Frag a, Frag b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+    }
+};
+template <> struct Mma<float> {
+    static constexpr int K = 4, KPL = 1;
+    typedef float Frag;
+    static __device__ __forceinline__ Frag zero() { return 0.f; }
+    static __device__ __forceinline__ f32x4 mma(Frag a, Frag b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+    }
+};
+
+template <typename V, int N> __device__ __forceinline__ V vzero() {
+    V v;
+#pragma unroll
+    for (int e = 0; e < N; e++) v[e] = 0;
+    return v;
+}
+
+constexpr int kThreads = 256;   // 4 wavefronts
+
+template <typename F>
+static void set_max_lds(F func, size_t bytes) {
+    if (bytes > 48 * 1024) (void)hipFuncSetAttribute((const void *)func, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+
+// =============================================================================================
+// K_a  preprocess + conv0
+//   reference: cudaMemset + imageROIResize8U3C (factor 1 = top-left copy) + convertBGR2RGBfloatKernel +
+//   imageSplitKernel (RetinaFace.cpp:598-608, resizeconvertion.cu:46-63,165-185,279-316) and the first
+//   TensorRT layer mobilenet0_conv0_fwd + BN + ReLU (prototxt :11-53).
+//   One thread = one output pixel x 8 channels; the 33x33x3 u8 input patch of a 16x16 output tile is staged
+//   in LDS; fp32 accumulate on raw 0..255 pixels (pre-BN magnitudes ~1e3, SURVEY.md App. A hazards).
+// =============================================================================================
+constexpr int C0_T = 16;                       // output tile edge
+constexpr int C0_IN = 2 * C0_T + 1;            // 33 input rows / cols
+constexpr int C0_ROWB = C0_IN * 3 + 1;         // 100 bytes per staged row (+1 pad)
+
+template <typename T>
+__global__ __launch_bounds__(kThreads) void conv0_kernel(const FrameDesc *__restrict__ frames, T *__restrict__ out,
+                                                         const float *__restrict__ w, const float *__restrict__ b,
+                                                         int ho, int wo, int tiles_x, int tiles_y, int nblk) {
+    __shared__ uint8_t s_in[C0_IN * C0_ROWB];
+    const int tid = threadIdx.x;
+    const int bid = xcd_remap(blockIdx.x, nblk);
+    const int tx = bid % tiles_x;
+    const int ty = (bid / tiles_x) % tiles_y;
+    const int img = bid / (tiles_x * tiles_y);
+    const FrameDesc fd = frames[img];
+    const int iy0 = 2 * ty * C0_T - 1, ix0 = 2 * tx * C0_T - 1;
+    for (int i = tid; i < C0_IN * C0_IN * 3; i += kThreads) {
+        int r = i / (C0_IN * 3), cb = i % (C0_IN * 3);
+        int iy = iy0 + r, ix = ix0 + cb / 3;
+        uint8_t v = 0;
+        if (iy >= 0 && iy < fd.rows && ix >= 0 && ix < fd.cols) v = fd.ptr[(size_t)iy * fd.step + ix * 3 + cb % 3];
+        s_in[r * C0_ROWB + cb] = v;
+    }
+    __syncthreads();
+    const int py = tid / C0_T, px = tid % C0_T;
+    const int oy = ty * C0_T + py, ox = tx * C0_T + px;
+    float acc[8];
+#pragma unroll
+    for (int o = 0; o < 8; o++) acc[o] = b[o];
+#pragma unroll
+    for (int ky = 0; ky < 3; ky++)
+#pragma unroll
+        for (int kx = 0; kx < 3; kx++) {
+            const uint8_t *p = &s_in[(2 * py + ky) * C0_ROWB + (2 * px + kx) * 3];
+            // frame is BGR, the network's input channel 0 is R (convertBGR2RGBfloat): net channel c = frame channel 2-c
+            float v[3] = {(float)p[2], (float)p[1], (float)p[0]};
+#pragma unroll
+            for (int c = 0; c < 3; c++)
+#pragma unroll
+                for (int o = 0; o < 8; o++) acc[o] = fmaf(w[o * 27 + (ky * 3 + kx) * 3 + c], v[c], acc[o]);
+        }
+    if (oy < ho && ox < wo) {
+        T *dst = out + (((size_t)img * ho + oy) * wo + ox) * 8;
+        if constexpr (sizeof(T) == 2) {
+            f16x8 r;
+#pragma unroll
+            for (int o = 0; o < 8; o++) r[o] = (half_t)fmaxf(acc[o], 0.f);
+            *(f16x8 *)dst = r;
+        } else {
+            f32x4 r0, r1;
+#pragma unroll
+            for (int o = 0; o < 4; o++) { r0[o] = fmaxf(acc[o], 0.f); r1[o] = fmaxf(acc[o + 4], 0.f); }
+            *(f32x4 *)dst = r0;
+            *(f32x4 *)(dst + 4) = r1;
+        }
+    }
+}
+
+template <typename T>
+void launch_conv0(hipStream_t s, const FrameDesc *frames, T *out, const float *w, const float *b, int n, int net_h,
+                  int net_w) {
+    int ho = net_h / 2, wo = net_w / 2;
+    int tiles_x = (wo + C0_T - 1) / C0_T, tiles_y = (ho + C0_T - 1) / C0_T;
+    int nblk = n * tiles_x * tiles_y;
+    hipLaunchKernelGGL(conv0_kernel<T>, dim3(nblk), dim3(kThreads), 0, s, frames, out, w, b, ho, wo, tiles_x, tiles_y, nblk);
+}
+template void launch_conv0<half_t>(hipStream_t, const FrameDesc *, half_t *, const float *, const float *, int, int, int);
+template void launch_conv0<float>(hipStream_t, const FrameDesc *, float *, const float *, const float *, int, int, int);
+
+// =============================================================================================
+// GEMM core shared by K_b / K_c / K_d:  acc[i][j] += W-fragment(ct_i, kc) x X-fragment(pt_j, kc)
+// 4 waves split the output-channel tiles first (WN), the pixel tiles second (WP).
+// =============================================================================================
+template <int NT, int PT> struct WaveSplit {
+    static constexpr int WN = NT % 4 == 0 ? 4 : (NT % 2 == 0 ? 2 : 1);
+    static constexpr int WP = 4 / WN;
+    static constexpr int NI = NT / WN;
+    static constexpr int NJ = PT / WP;
+    static_assert(NT % WN == 0 && PT % WP == 0 && NJ >= 1, "tile does not split over 4 waves");
+};
+
+// epilogue: bias (+ReLU), convert, 4 consecutive output channels of one pixel -> LDS tile s_out[pixel][LDO]
+template <typename T, int LDO>
+__device__ __forceinline__ void store_acc(T *s_out, const float *__restrict__ bias, f32x4 acc, int ct, int pt, int lane,
+                                          bool relu) {
+    const int c0 = acc_cout(ct, lane, 0);
+    const int p = acc_pixel(pt, lane);
+    const f32x4 bv = *(const f32x4 *)(bias + c0);
+    float v[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        v[r] = acc[r] + bv[r];
+        if (relu) v[r] = fmaxf(v[r], 0.f);
+    }
+    if constexpr (sizeof(T) == 2) {
+        typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+        f16x4 h;
+#pragma unroll
+        for (int r = 0; r < 4; r++) h[r] = (half_t)v[r];
+        *(f16x4 *)(s_out + p * LDO + c0) = h;
+    } else {
+        f32x4 f;
+#pragma unroll
+        for (int r = 0; r < 4; r++) f[r] = v[r];
+        *(f32x4 *)(s_out + p * LDO + c0) = f;
+    }
+}
+
+// =============================================================================================
+// K_b  depthwise 3x3 + BN + ReLU  ->  pointwise 1x1 + BN + ReLU   (13 backbone pairs, prototxt :55-1193)
+//      HAS_DW = false: plain 1x1 + bias + ReLU (rf_c3_lateral / rf_c2_lateral / rf_c1_red_conv,
+//      prototxt :1199-1237, :1513-1551, :1908-1946).
+//   phase 1  halo tile ((TH-1)*S+3) x ((TW-1)*S+3) x CIN -> LDS, 16 B per lane, zero padding resolved here
+//   phase 2  depthwise stencil on the VALU, fp32 accumulate, result (as T) -> LDS tile s_a[pixel][CIN]
+//   phase 3  pointwise as MFMA GEMM, weights straight from L2 in fragment order (one coalesced 1 KiB
+//            load per wave per fragment), activations by ds_read_b128 from s_a
+//   phase 4  bias + ReLU, through LDS so the NHWC store is 16 B per lane and fully coalesced
+// =============================================================================================
+template <typename T, int CIN, int COUT, int STRIDE, bool HAS_DW, int TH, int TW> struct DwPwCfg {
+    static constexpr int VEC = Vec<T>::N;
+    static constexpr int P = TH * TW;
+    static constexpr int HR = HAS_DW ? (TH - 1) * STRIDE + 3 : 0;
+    static constexpr int HC = HAS_DW ? (TW - 1) * STRIDE + 3 : 0;
+    static constexpr int LDA = CIN + VEC;
+    static constexpr int LDO = COUT + VEC;
+    static constexpr int IN_ELEMS = HR * HC * CIN + (HAS_DW ? 9 * CIN : 0);
+    static constexpr int A_ELEMS = P * LDA;
+    static constexpr int O_ELEMS = P * LDO;
+    static constexpr bool ALIAS_OUT = HAS_DW && IN_ELEMS >= O_ELEMS;   // s_out reuses the dead halo region
+    static constexpr size_t LDS_BYTES = sizeof(T) * (size_t)(IN_ELEMS + A_ELEMS + (ALIAS_OUT ? 0 : O_ELEMS));
+    static_assert(P % 16 == 0 && CIN % VEC == 0 && COUT % 16 == 0, "bad tile");
+};
+
+template <typename T>
+struct DwPwArgs {
+    const T *in; T *out; const T *dw_w; const float *dw_b; const T *pw_w; const float *pw_b;
+    int hin, win, hout, wout, tiles_x, tiles_y, nblk;
+};
+
+template <typename T, int CIN, int COUT, int STRIDE, bool HAS_DW, int TH, int TW>
+__global__ __launch_bounds__(kThreads) void dwpw_kernel(DwPwArgs<T> a) {
+    typedef DwPwCfg<T, CIN, COUT, STRIDE, HAS_DW, TH, TW> C;
+    typedef typename Vec<T>::type V;
+    typedef Mma<T> M;
+    constexpr int VEC = C::VEC, P = C::P, HC = C::HC, HR = C::HR, LDA = C::LDA, LDO = C::LDO;
+    constexpr int CPV = CIN / VEC;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    T *s_in = (T *)smem;
+    T *s_dw = s_in + HR * HC * CIN;
+    T *s_a = s_in + C::IN_ELEMS;
+    T *s_out = C::ALIAS_OUT ? s_in : s_a + C::A_ELEMS;
+
+    const int tid = threadIdx.x;
+    const int bid = xcd_remap(blockIdx.x, a.nblk);
+    const int tx = bid % a.tiles_x;
+    const int ty = (bid / a.tiles_x) % a.tiles_y;
+    const int img = bid / (a.tiles_x * a.tiles_y);
+    const int oy0 = ty * TH, ox0 = tx * TW;
+    const T *inb = a.in + (size_t)img * a.hin * a.win * CIN;
+
+    if constexpr (HAS_DW) {
+        const int iy0 = oy0 * STRIDE - 1, ix0 = ox0 * STRIDE - 1;
+        for (int i = tid; i < HR * HC * CPV; i += kThreads) {
+            int pix = i / CPV, cv = i % CPV;
+            int iy = iy0 + pix / HC, ix = ix0 + pix % HC;
+            V v = vzero<V, VEC>();
+            if (iy >= 0 && iy < a.hin && ix >= 0 && ix < a.win)
+                v = *(const V *)(inb + ((size_t)iy * a.win + ix) * CIN + cv * VEC);
+            *(V *)(s_in + pix * CIN + cv * VEC) = v;
+        }
+        for (int i = tid; i < 9 * CPV; i += kThreads) *(V *)(s_dw + i * VEC) = *(const V *)(a.dw_w + i * VEC);
+        __syncthreads();
+        for (int i = tid; i < P * CPV; i += kThreads) {
+            int p = i / CPV, cv = i % CPV;
+            int py = p / TW, px = p % TW;
+            float acc[VEC];
+#pragma unroll
+            for (int e = 0; e < VEC; e++) acc[e] = a.dw_b[cv * VEC + e];
+#pragma unroll
+            for (int ky = 0; ky < 3; ky++)
+#pragma unroll
+                for (int kx = 0; kx < 3; kx++) {
+                    V x = *(const V *)(s_in + ((py * STRIDE + ky) * HC + px * STRIDE + kx) * CIN + cv * VEC);
+                    V wv = *(const V *)(s_dw + (ky * 3 + kx) * CIN + cv * VEC);
+#pragma unroll
+                    for (int e = 0; e < VEC; e++) acc[e] = fmaf((float)x[e], (float)wv[e], acc[e]);
+                }
+            V r;
+#pragma unroll
+            for (int e = 0; e < VEC; e++) r[e] = (T)fmaxf(acc[e], 0.f);
+            *(V *)(s_a + p * LDA + cv * VEC) = r;
+        }
+    } else {
+        for (int i = tid; i < P * CPV; i += kThreads) {
+            int p = i / CPV, cv = i % CPV;
+            int oy = oy0 + p / TW, ox = ox0 + p % TW;
+            V v = vzero<V, VEC>();
+            if (oy < a.hin && ox < a.win) v = *(const V *)(inb + ((size_t)oy * a.win + ox) * CIN + cv * VEC);
+            *(V *)(s_a + p * LDA + cv * VEC) = v;
+        }
+    }
+    __syncthreads();
+
+    // ---- pointwise GEMM: D[cout][pixel], K = CIN
+    constexpr int NT = COUT / 16, PT = P / 16;
+    typedef WaveSplit<NT, PT> WS;
+    constexpr int KCH = (CIN + M::K - 1) / M::K;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wn = wave % WS::WN, wp = wave / WS::WN;
+    f32x4 acc[WS::NI][WS::NJ];
+#pragma unroll
+    for (int i = 0; i < WS::NI; i++)
+#pragma unroll
+        for (int j = 0; j < WS::NJ; j++) acc[i][j] = vzero<f32x4, 4>();
+    const typename M::Frag *wfrag = (const typename M::Frag *)a.pw_w;
+#pragma unroll 4
+    for (int kc = 0; kc < KCH; kc++) {
+        typename M::Frag wf[WS::NI], xf[WS::NJ];
+#pragma unroll
+        for (int i = 0; i < WS::NI; i++) wf[i] = wfrag[((wn + i * WS::WN) * KCH + kc) * 64 + lane];
+        const int kb = kc * M::K + (lane >> 4) * M::KPL;
+#pragma unroll
+        for (int j = 0; j < WS::NJ; j++) {
+            const int p = acc_pixel(wp + j * WS::WP, lane);
+            xf[j] = kb < CIN ? *(const typename M::Frag *)(s_a + p * LDA + kb) : M::zero();
+        }
+#pragma unroll
+        for (int i = 0; i < WS::NI; i++)
+#pragma unroll
+            for (int j = 0; j < WS::NJ; j++) acc[i][j] = M::mma(wf[i], xf[j], acc[i][j]);
+    }
+#pragma unroll
+    for (int i = 0; i < WS::NI; i++)
+#pragma unroll
+        for (int j = 0; j < WS::NJ; j++)
+            store_acc<T, LDO>(s_out, a.pw_b, acc[i][j], wn + i * WS::WN, wp + j * WS::WP, lane, true);
+    __syncthreads();
+
+    constexpr int OPV = COUT / VEC;
+    T *outb = a.out + (size_t)img * a.hout * a.wout * COUT;
+    for (int i = tid; i < P * OPV; i += kThreads) {
+        int p = i / OPV, cv = i % OPV;
+        int oy = oy0 + p / TW, ox = ox0 + p % TW;
+        if (oy < a.hout && ox < a.wout)
+            *(V *)(outb + ((size_t)oy * a.wout + ox) * COUT + cv * VEC) = *(const V *)(s_out + p * LDO + cv * VEC);
+    }
+}
+
+template <typename T, int CIN, int COUT, int STRIDE, bool HAS_DW, int TH, int TW>
+static TileInfo dwpw_dispatch(hipStream_t s, const DwPwParams<T> *p, int hout, int wout) {
+    typedef DwPwCfg<T, CIN, COUT, STRIDE, HAS_DW, TH, TW> C;
+    int tiles_x = (wout + TW - 1) / TW, tiles_y = (hout + TH - 1) / TH;
+    TileInfo ti{TH, TW, C::LDS_BYTES, tiles_x * tiles_y};
+    if (!p) return ti;
+    auto kern = dwpw_kernel<T, CIN, COUT, STRIDE, HAS_DW, TH, TW>;
+    static bool attr_set = false;
+    if (!attr_set) { set_max_lds(kern, C::LDS_BYTES); attr_set = true; }
+    DwPwArgs<T> a{p->in, p->out, p->dw_w, p->dw_b, p->pw_w, p->pw_b, p->hin, p->win, p->hout, p->wout,
+                  tiles_x, tiles_y, p->n * tiles_x * tiles_y};
+    hipLaunchKernelGGL(kern, dim3(a.nblk), dim3(kThreads), C::LDS_BYTES, s, a);
+    return ti;
+}
+
+// the layer table of SURVEY.md App. A -> tile geometry
+template <typename T>
+static TileInfo dwpw_select(hipStream_t s, const DwPwParams<T> *p, int cin, int cout, int stride, bool has_dw, int hout,
+                            int wout) {
+#define RF_DWPW(CI, CO, ST, DW, TH_, TW_) \
+    if (cin == CI && cout == CO && stride == ST && has_dw == DW) return dwpw_dispatch<T, CI, CO, ST, DW, TH_, TW_>(s, p, hout, wout);
+    RF_DWPW(8, 16, 1, true, 8, 32)
+    RF_DWPW(16, 32, 2, true, 8, 16)
+    RF_DWPW(32, 32, 1, true, 8, 16)
+    RF_DWPW(32, 64, 2, true, 8, 8)
+    RF_DWPW(64, 64, 1, true, 8, 8)
+    RF_DWPW(64, 128, 2, true, 4, 8)
+    RF_DWPW(128, 128, 1, true, 4, 8)
+    RF_DWPW(128, 256, 2, true, 4, 8)
+    RF_DWPW(256, 256, 1, true, 4, 8)
+    RF_DWPW(256, 64, 1, false, 4, 8)
+    RF_DWPW(128, 64, 1, false, 4, 8)
+    RF_DWPW(64, 64, 1, false, 8, 8)
+#undef RF_DWPW
+    return TileInfo{0, 0, 0, 0};
+}
+
+template <typename T> void launch_dwpw(hipStream_t s, const DwPwParams<T> &p) {
+    TileInfo ti = dwpw_select<T>(s, &p, p.cin, p.cout, p.stride, p.has_dw, p.hout, p.wout);
+    if (ti.th == 0) abort();   // engine validates the layer table up front (plan.cpp), unreachable
+}
+template <typename T> TileInfo dwpw_tile_info(int cin, int cout, int stride, bool has_dw, int hout, int wout) {
+    return dwpw_select<T>(nullptr, nullptr, cin, cout, stride, has_dw, hout, wout);
+}
+template void launch_dwpw<half_t>(hipStream_t, const DwPwParams<half_t> &);
+template void launch_dwpw<float>(hipStream_t, const DwPwParams<float> &);
+template TileInfo dwpw_tile_info<half_t>(int, int, int, bool, int, int);
+template TileInfo dwpw_tile_info<float>(int, int, int, bool, int, int);
+
+// =============================================================================================
+// K_c  dense 3x3 p1 s1 convolution + BN + ReLU as implicit GEMM (K = 9*CIN) on MFMA
+//   rf_c2_aggr / rf_c1_aggr (UPADD: input = lateral + bilinear x2 upsample of the coarser level, i.e.
+//   Deconvolution k4 s2 p1 g64 + Crop + Eltwise SUM, prototxt :1553-1592 / :1948-1987, closed form
+//   SURVEY.md App. B.6) and the merged SSH convs 64->48, 16->32, 16->16 (prototxt :1239-1432 etc.).
+//   The (TH+2)x(TW+2) halo tile is staged once in LDS; the B fragment of tap (ky,kx) is just the same
+//   tile read at a shifted pixel offset, so no im2col buffer exists anywhere.
+// =============================================================================================
+template <typename T, int CIN, int COUT, int TH, int TW> struct Conv3Cfg {
+    static constexpr int VEC = Vec<T>::N;
+    static constexpr int P = TH * TW;
+    static constexpr int HR = TH + 2, HC = TW + 2;
+    static constexpr int LDI = CIN + VEC;
+    static constexpr int LDO = COUT + VEC;
+    static constexpr int IN_ELEMS = HR * HC * LDI;
+    static constexpr int O_ELEMS = P * LDO;
+    static constexpr size_t LDS_BYTES = sizeof(T) * (size_t)(IN_ELEMS > O_ELEMS ? IN_ELEMS : O_ELEMS);
+};
+
+template <typename T>
+struct Conv3Args {
+    const T *in; int in_ld, in_off; const T *up; const T *w; const float *b;
+    T *out0; int ld0, off0, n0; T *out1; int ld1, off1;
+    int h, w_, tiles_x, tiles_y, nblk;
+};
+
+template <typename T, int CIN, int COUT, int TH, int TW, bool UPADD>
+__global__ __launch_bounds__(kThreads) void conv3x3_kernel(Conv3Args<T> a) {
+    typedef Conv3Cfg<T, CIN, COUT, TH, TW> C;
+    typedef typename Vec<T>::type V;
+    typedef Mma<T> M;
+    constexpr int VEC = C::VEC, P = C::P, HC = C::HC, HR = C::HR, LDI = C::LDI, LDO = C::LDO;
+    constexpr int CPV = CIN / VEC;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    T *s_in = (T *)smem;
+    T *s_out = (T *)smem;     // reused after the GEMM (barrier in between)
+
+    const int tid = threadIdx.x;
+    const int bid = xcd_remap(blockIdx.x, a.nblk);
+    const int tx = bid % a.tiles_x;
+    const int ty = (bid / a.tiles_x) % a.tiles_y;
+    const int img = bid / (a.tiles_x * a.tiles_y);
+    const int oy0 = ty * TH, ox0 = tx * TW;
+    const size_t img_pix = (size_t)img * a.h * a.w_;
+
+    for (int i = tid; i < HR * HC * CPV; i += kThreads) {
+        int pix = i / CPV, cv = i % CPV;
+        int iy = oy0 - 1 + pix / HC, ix = ox0 - 1 + pix % HC;
+        V v = vzero<V, VEC>();
+        if (iy >= 0 && iy < a.h && ix >= 0 && ix < a.w_) {
+            v = *(const V *)(a.in + (img_pix + (size_t)iy * a.w_ + ix) * a.in_ld + a.in_off + cv * VEC);
+            if constexpr (UPADD) {
+                // out[2m] = .75 in[m] + .25 in[m-1];  out[2m+1] = .75 in[m] + .25 in[m+1];  taps outside = 0
+                const int hh = a.h >> 1, wh = a.w_ >> 1;
+                const int my = iy >> 1, mx = ix >> 1;
+                const int my2 = (iy & 1) ? my + 1 : my - 1, mx2 = (ix & 1) ? mx + 1 : mx - 1;
+                const T *ub = a.up + (size_t)img * hh * wh * CIN + cv * VEC;
+                float s[VEC];
+#pragma unroll
+                for (int e = 0; e < VEC; e++) s[e] = 0.f;
+                auto tap = [&](int yy, int xx, float wgt) {
+                    if (yy >= 0 && yy < hh && xx >= 0 && xx < wh) {
+                        V u = *(const V *)(ub + ((size_t)yy * wh + xx) * CIN);
+#pragma unroll
+                        for (int e = 0; e < VEC; e++) s[e] = fmaf(wgt, (float)u[e], s[e]);
+                    }
+                };
+                tap(my, mx, 0.5625f);
+                tap(my, mx2, 0.1875f);
+                tap(my2, mx, 0.1875f);
+                tap(my2, mx2, 0.0625f);
+#pragma unroll
+                for (int e = 0; e < VEC; e++) v[e] = (T)((float)v[e] + s[e]);
+            }
+        }
+        *(V *)(s_in + pix * LDI + cv * VEC) = v;
+    }
+    __syncthreads();
+
+    constexpr int NT = COUT / 16, PT = P / 16;
+    typedef WaveSplit<NT, PT> WS;
+    constexpr int KTOT = 9 * CIN;
+    constexpr int KCH = (KTOT + M::K - 1) / M::K;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wn = wave % WS::WN, wp = wave / WS::WN;
+    int pbase[WS::NJ];
+#pragma unroll
+    for (int j = 0; j < WS::NJ; j++) {
+        const int p = acc_pixel(wp + j * WS::WP, lane);
+        pbase[j] = ((p / TW) * HC + p % TW) * LDI;
+    }
+    f32x4 acc[WS::NI][WS::NJ];
+#pragma unroll
+    for (int i = 0; i < WS::NI; i++)
+#pragma unroll
+        for (int j = 0; j < WS::NJ; j++) acc[i][j] = vzero<f32x4, 4>();
+    const typename M::Frag *wfrag = (const typename M::Frag *)a.w;
+#pragma unroll 2
+    for (int kc = 0; kc < KCH; kc++) {
+        typename M::Frag wf[WS::NI], xf[WS::NJ];
+#pragma unroll
+        for (int i = 0; i < WS::NI; i++) wf[i] = wfrag[((wn + i * WS::WN) * KCH + kc) * 64 + lane];
+        const int kb = kc * M::K + (lane >> 4) * M::KPL;      // k = tap*CIN + c, KPL consecutive c of one tap
+        const int tap = kb / CIN, c = kb % CIN;
+        const int koff = ((tap / 3) * HC + tap % 3) * LDI + c;
+#pragma unroll
+        for (int j = 0; j < WS::NJ; j++)
+            xf[j] = kb < KTOT ? *(const typename M::Frag *)(s_in + pbase[j] + koff) : M::zero();
+#pragma unroll
+        for (int i = 0; i < WS::NI; i++)
+#pragma unroll
+            for (int j = 0; j < WS::NJ; j++) acc[i][j] = M::mma(wf[i], xf[j], acc[i][j]);
+    }
+    __syncthreads();      // every wave is done reading s_in before it is overwritten as s_out
+#pragma unroll
+    for (int i = 0; i < WS::NI; i++)
+#pragma unroll
+        for (int j = 0; j < WS::NJ; j++)
+            store_acc<T, LDO>(s_out, a.b, acc[i][j], wn + i * WS::WN, wp + j * WS::WP, lane, true);
+    __syncthreads();
+
+    constexpr int OPV = COUT / VEC;
+    for (int i = tid; i < P * OPV; i += kThreads) {
+        int p = i / OPV, cv = i % OPV;
+        int oy = oy0 + p / TW, ox = ox0 + p % TW;
+        if (oy < a.h && ox < a.w_) {
+            const size_t pix = img_pix + (size_t)oy * a.w_ + ox;
+            const int c = cv * VEC;
+            T *dst = c < a.n0 ? a.out0 + pix * a.ld0 + a.off0 + c : a.out1 + pix * a.ld1 + a.off1 + (c - a.n0);
+            *(V *)dst = *(const V *)(s_out + p * LDO + c);
+        }
+    }
+}
+
+template <typename T, int CIN, int COUT, int TH, int TW>
+static TileInfo conv3_dispatch(hipStream_t s, const Conv3Params<T> *p, int h, int w) {
+    typedef Conv3Cfg<T, CIN, COUT, TH, TW> C;
+    int tiles_x = (w + TW - 1) / TW, tiles_y = (h + TH - 1) / TH;
+    TileInfo ti{TH, TW, C::LDS_BYTES, tiles_x * tiles_y};
+    if (!p) return ti;
+    Conv3Args<T> a{p->in, p->in_ld, p->in_off, p->up, p->w, p->b, p->out0, p->ld0, p->off0, p->n0,
+                   p->out1, p->ld1, p->off1, p->h, p->w_, tiles_x, tiles_y, p->n * tiles_x * tiles_y};
+    if (p->up) {
+        if constexpr (CIN == 64 && COUT == 64) {
+            auto kern = conv3x3_kernel<T, CIN, COUT, TH, TW, true>;
+            static bool attr_set = false;
+            if (!attr_set) { set_max_lds(kern, C::LDS_BYTES); attr_set = true; }
+            hipLaunchKernelGGL(kern, dim3(a.nblk), dim3(kThreads), C::LDS_BYTES, s, a);
+        } else {
+            abort();
+        }
+    } else {
+        auto kern = conv3x3_kernel<T, CIN, COUT, TH, TW, false>;
+        static bool attr_set = false;
+        if (!attr_set) { set_max_lds(kern, C::LDS_BYTES); attr_set = true; }
+        hipLaunchKernelGGL(kern, dim3(a.nblk), dim3(kThreads), C::LDS_BYTES, s, a);
+    }
+    return ti;
+}
+
+template <typename T>
+static TileInfo conv3_select(hipStream_t s, const Conv3Params<T> *p, int cin, int cout, int h, int w) {
+    // small maps (stride 32 / 16 at 448^2: 14x14, 28x28) get 4x8 tiles for more workgroups where the channel
+    // tiles still split over 4 waves (COUT % 32 == 0); larger maps 8x8
+    const bool small = (size_t)h * w <= 32 * 32;
+    if (cin == 64 && cout == 64)
+        return small ? conv3_dispatch<T, 64, 64, 4, 8>(s, p, h, w) : conv3_dispatch<T, 64, 64, 8, 8>(s, p, h, w);
+    if (cin == 16 && cout == 32)
+        return small ? conv3_dispatch<T, 16, 32, 4, 8>(s, p, h, w) : conv3_dispatch<T, 16, 32, 8, 8>(s, p, h, w);
+    if (cin == 64 && cout == 48) return conv3_dispatch<T, 64, 48, 8, 8>(s, p, h, w);
+    if (cin == 16 && cout == 16) return conv3_dispatch<T, 16, 16, 8, 8>(s, p, h, w);
+    return TileInfo{0, 0, 0, 0};
+}
+
+template <typename T> void launch_conv3x3(hipStream_t s, const Conv3Params<T> &p) {
+    TileInfo ti = conv3_select<T>(s, &p, p.cin, p.cout, p.h, p.w_);
+    if (ti.th == 0) abort();
+}
+template <typename T> TileInfo conv3x3_tile_info(int cin, int cout, int h, int w) {
+    return conv3_select<T>(nullptr, nullptr, cin, cout, h, w);
+}
+template void launch_conv3x3<half_t>(hipStream_t, const Conv3Params<half_t> &);
+template void launch_conv3x3<float>(hipStream_t, const Conv3Params<float> &);
+template TileInfo conv3x3_tile_info<half_t>(int, int, int, int);
+template TileInfo conv3x3_tile_info<float>(int, int, int, int);
+
+// =============================================================================================
+// K_d  heads + softmax + decode + threshold compaction
+//   reference: 3 x 1x1 Convolution + Reshape/Softmax/Reshape on the GPU (prototxt :1434-1511), 9 D2H copies
+//   (trtretinafacenet.cpp:63-72) and the CPU loop RetinaFace.cpp:666-724 with bbox_pred (:378-398),
+//   clip_boxes (:179-199) and landmark_pred (:418-432).  Here only above-threshold candidates leave the chip.
+//   The float/double rounding points of the reference are reproduced (fp contraction off in decode_anchor).
+// =============================================================================================
+constexpr int HEAD_P = 64;          // pixels per workgroup (flat, row-major)
+constexpr int HEAD_LDO = 33;        // fp32 result tile row stride (32 + 1: conflict-free column reads)
+
+__device__ __forceinline__ void decode_anchor(const float *__restrict__ o /*32 head outputs of this pixel*/, int a,
+                                              float ax1, float ay1, float ax2, float ay2, int net_w, int net_h,
+                                              float conf, int anchor_index, Candidate *dst) {
+#pragma clang fp contract(off)
+    // bbox_pred, RetinaFace.cpp:378-398: "0.5 * (w - 1.0)" is double arithmetic, results stored as float
+    const float width = ax2 - ax1 + 1.f;
+    const float height = ay2 - ay1 + 1.f;
+    const float ctr_x = (float)((double)ax1 + 0.5 * ((double)width - 1.0));
+    const float ctr_y = (float)((double)ay1 + 0.5 * ((double)height - 1.0));
+    const float *d = o + 4 + a * 4;
+    const float pred_ctr_x = d[0] * width + ctr_x;
+    const float pred_ctr_y = d[1] * height + ctr_y;
+    const float pred_w = expf(d[2]) * width;
+    const float pred_h = expf(d[3]) * height;
+    float x1 = (float)((double)pred_ctr_x - 0.5 * ((double)pred_w - 1.0));
+    float y1 = (float)((double)pred_ctr_y - 0.5 * ((double)pred_h - 1.0));
+    float x2 = (float)((double)pred_ctr_x + 0.5 * ((double)pred_w - 1.0));
+    float y2 = (float)((double)pred_ctr_y + 0.5 * ((double)pred_h - 1.0));
+    // clip_boxes, RetinaFace.cpp:179-199 (one-sided)
+    if (x1 < 0) x1 = 0;
+    if (y1 < 0) y1 = 0;
+    if (x2 > (float)(net_w - 1)) x2 = (float)(net_w - 1);
+    if (y2 > (float)(net_h - 1)) y2 = (float)(net_h - 1);
+    dst->score = conf;
+    dst->x1 = x1; dst->y1 = y1; dst->x2 = x2; dst->y2 = y2;
+    // landmark_pred, RetinaFace.cpp:418-432 (not clipped)
+    const float *l = o + 12 + a * 10;
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+        dst->px[k] = l[2 * k] * width + ctr_x;
+        dst->py[k] = l[2 * k + 1] * height + ctr_y;
+    }
+    dst->anchor = anchor_index;
+}
+
+template <typename T>
+struct HeadArgs {
+    const T *in; const T *w; const float *b;
+    int hw, w_, stride, anchor_offset;
+    float base[2][4];
+    int net_h, net_w;
+    const RunParams *params;
+    Candidate *cand; int *cand_count; int cap;
+    float *dump_prob, *dump_bbox, *dump_lmk;
+    int blocks_per_image, nblk;
+};
+
+template <typename T>
+__global__ __launch_bounds__(kThreads) void head_kernel(HeadArgs<T> a) {
+    typedef typename Vec<T>::type V;
+    typedef Mma<T> M;
+    constexpr int VEC = Vec<T>::N, CIN = 64, COUT = 32, P = HEAD_P, LDA = CIN + VEC;
+    constexpr int CPV = CIN / VEC;
+    __shared__ __attribute__((aligned(16))) T s_a[P * LDA];
+    __shared__ float s_o[P * HEAD_LDO];
+
+    const int tid = threadIdx.x;
+    const int bid = xcd_remap(blockIdx.x, a.nblk);
+    const int img = bid / a.blocks_per_image;
+    const int p0 = (bid % a.blocks_per_image) * P;
+    const T *inb = a.in + (size_t)img * a.hw * CIN;
+    for (int i = tid; i < P * CPV; i += kThreads) {
+        int p = i / CPV, cv = i % CPV;
+        V v = vzero<V, VEC>();
+        if (p0 + p < a.hw) v = *(const V *)(inb + (size_t)(p0 + p) * CIN + cv * VEC);
+        *(V *)(s_a + p * LDA + cv * VEC) = v;
+    }
+    __syncthreads();
+
+    constexpr int NT = COUT / 16, PT = P / 16;       // 2 x 4 tiles: waves = 2 (cout) x 2 (pixel halves)
+    typedef WaveSplit<NT, PT> WS;
+    constexpr int KCH = CIN / M::K;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wn = wave % WS::WN, wp = wave / WS::WN;
+    f32x4 acc[WS::NJ];
+#pragma unroll
+    for (int j = 0; j < WS::NJ; j++) acc[j] = vzero<f32x4, 4>();
+    const typename M::Frag *wfrag = (const typename M::Frag *)a.w;
+#pragma unroll
+    for (int kc = 0; kc < KCH; kc++) {
+        const typename M::Frag wf = wfrag[(wn * KCH + kc) * 64 + lane];
+        const int kb = kc * M::K + (lane >> 4) * M::KPL;
+#pragma unroll
+        for (int j = 0; j < WS::NJ; j++) {
+            const int p = acc_pixel(wp + j * WS::WP, lane);
+            acc[j] = M::mma(wf, *(const typename M::Frag *)(s_a + p * LDA + kb), acc[j]);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < WS::NJ; j++) {
+        const int p = acc_pixel(wp + j * WS::WP, lane);
+        const int c0 = acc_cout(wn, lane, 0);
+#pragma unroll
+        for (int r = 0; r < 4; r++) s_o[p * HEAD_LDO + c0 + r] = acc[j][r] + a.b[c0 + r];
+    }
+    __syncthreads();
+
+    if (tid < 2 * P) {
+        const int p = tid % P, an = tid / P;          // anchor index a is wave-uniform
+        const int gp = p0 + p;
+        if (gp < a.hw) {
+            const float *o = s_o + p * HEAD_LDO;
+            // Softmax over the pair (channel a, channel 2+a): Caffe subtracts the max, exponentiates, normalises
+            const float s0 = o[an], s1 = o[2 + an];
+            const float m = fmaxf(s0, s1);
+            const float e0 = expf(s0 - m), e1 = expf(s1 - m);
+            const float sum = e0 + e1;
+            const float conf = e1 / sum;
+            if (a.dump_prob) {
+                const size_t hw = (size_t)a.hw;
+                a.dump_prob[((size_t)img * 4 + an) * hw + gp] = e0 / sum;
+                a.dump_prob[((size_t)img * 4 + 2 + an) * hw + gp] = conf;
+#pragma unroll
+                for (int c = 0; c < 4; c++) a.dump_bbox[((size_t)img * 8 + an * 4 + c) * hw + gp] = o[4 + an * 4 + c];
+#pragma unroll
+                for (int c = 0; c < 10; c++) a.dump_lmk[((size_t)img * 20 + an * 10 + c) * hw + gp] = o[12 + an * 10 + c];
+            }
+            if (conf > a.params->threshold) {          // "if (conf <= threshold) continue", RetinaFace.cpp:693
+                const int iy = gp / a.w_, ix = gp % a.w_;
+                const float sx = (float)(ix * a.stride), sy = (float)(iy * a.stride);
+                const int slot = atomicAdd(&a.cand_count[img], 1);
+                if (slot < a.cap)
+                    decode_anchor(o, an, a.base[an][0] + sx, a.base[an][1] + sy, a.base[an][2] + sx, a.base[an][3] + sy,
+                                  a.net_w, a.net_h, conf, a.anchor_offset + an * a.hw + gp,
+                                  a.cand + (size_t)img * a.cap + slot);
+            }
+        }
+    }
+}
+
+template <typename T> void launch_head(hipStream_t s, const HeadParams<T> &p) {
+    HeadArgs<T> a;
+    a.in = p.in; a.w = p.w; a.b = p.b;
+    a.hw = p.h * p.w_; a.w_ = p.w_; a.stride = p.stride; a.anchor_offset = p.anchor_offset;
+    for (int i = 0; i < 2; i++) for (int j = 0; j < 4; j++) a.base[i][j] = p.base[i][j];
+    a.net_h = p.net_h; a.net_w = p.net_w; a.params = p.params;
+    a.cand = p.cand; a.cand_count = p.cand_count; a.cap = p.cap;
+    a.dump_prob = p.dump_prob; a.dump_bbox = p.dump_bbox; a.dump_lmk = p.dump_lmk;
+    a.blocks_per_image = (a.hw + HEAD_P - 1) / HEAD_P;
+    a.nblk = p.n * a.blocks_per_image;
+    hipLaunchKernelGGL(head_kernel<T>, dim3(a.nblk), dim3(kThreads), 0, s, a);
+}
+template void launch_head<half_t>(hipStream_t, const HeadParams<half_t> &);
+template void launch_head<float>(hipStream_t, const HeadParams<float> &);
+
+// =============================================================================================
+// K_e  per-image NMS: total order (score desc, anchor index asc), greedy suppression with the reference's
+//      +1-pixel IoU and strict ">" (RetinaFace.cpp:434-492).  One 1024-thread workgroup per image:
+//      bitonic sort of 64-bit keys in LDS, then a serial walk over survivors where each survivor's
+//      suppression sweep is data-parallel.  fp contraction off: same roundings as the scalar CPU loop.
+// =============================================================================================
+constexpr int NMS_THREADS = 1024;
+
+__global__ __launch_bounds__(NMS_THREADS) void nms_kernel(NmsParams a) {
+#pragma clang fp contract(off)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int cap = a.cap;
+    unsigned long long *s_key = (unsigned long long *)smem;                 // [cap]
+    float4 *s_box = (float4 *)(s_key + cap);                                 // [cap]
+    int *s_slot = (int *)(s_box + cap);                                      // [cap]
+    int *s_kept = s_slot + cap;                                              // [max_det]
+    unsigned char *s_alive = (unsigned char *)(s_kept + a.max_det);          // [cap]
+
+    const int tid = threadIdx.x;
+    const int img = blockIdx.x;
+    const Candidate *cand = a.cand + (size_t)img * cap;
+    int n = a.cand_count[img];
+    if (n > cap) n = cap;
+    int npow = 64;
+    while (npow < n) npow <<= 1;
+
+    for (int i = tid; i < npow; i += NMS_THREADS) {
+        unsigned long long key = ~0ull;
+        if (i < n) {
+            const unsigned int sbits = __float_as_uint(cand[i].score);      // scores are positive: bit order = value order
+            key = ((unsigned long long)(~sbits) << 32) | (unsigned int)cand[i].anchor;
+        }
+        s_key[i] = key;
+        s_slot[i] = i;
+    }
+    __syncthreads();
+    for (int k = 2; k <= npow; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = tid; i < npow; i += NMS_THREADS) {
+                const int l = i ^ j;
+                if (l > i) {
+                    const unsigned long long ki = s_key[i], kl = s_key[l];
+                    const bool up = (i & k) == 0;
+                    if ((ki > kl) == up) {
+                        s_key[i] = kl; s_key[l] = ki;
+                        const int t = s_slot[i]; s_slot[i] = s_slot[l]; s_slot[l] = t;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    for (int i = tid; i < n; i += NMS_THREADS) {
+        const Candidate *c = cand + s_slot[i];
+        s_box[i] = make_float4(c->x1, c->y1, c->x2, c->y2);
+        s_alive[i] = 1;
+    }
+    __syncthreads();
+
+    const float thr = a.params->nms_threshold;
+    const int lane = tid & 63;
+    int kept = 0;
+    for (int base = 0; base < n; base += 64) {
+        const int idx = base + lane;
+        unsigned long long mask = __ballot(idx < n && s_alive[idx]);
+        while (mask) {
+            const int sel = base + __ffsll((long long)mask) - 1;
+            if (tid == 0 && kept < a.max_det) s_kept[kept] = sel;
+            kept++;
+            const float4 sb = s_box[sel];
+            const float area1 = (sb.z - sb.x + 1) * (sb.w - sb.y + 1);
+            for (int i = sel + 1 + tid; i < n; i += NMS_THREADS) {
+                if (!s_alive[i]) continue;
+                const float4 bi = s_box[i];
+                const float x = fmaxf(sb.x, bi.x);
+                const float y = fmaxf(sb.y, bi.y);
+                const float w = fminf(sb.z, bi.z) - x + 1;
+                const float h = fminf(sb.w, bi.w) - y + 1;
+                if (w <= 0 || h <= 0) continue;
+                const float area2 = (bi.z - bi.x + 1) * (bi.w - bi.y + 1);
+                const float inter = w * h;
+                if (inter / (area1 + area2 - inter) > thr) s_alive[i] = 0;
+            }
+            __syncthreads();
+            const unsigned long long later = (sel - base) >= 63 ? 0ull : (~0ull << (sel - base + 1));
+            mask = __ballot(idx < n && s_alive[idx]) & later;
+        }
+    }
+    __syncthreads();
+    const int nout = kept < a.max_det ? kept : a.max_det;
+    for (int i = tid; i < nout * 16; i += NMS_THREADS) {
+        const int k = i >> 4, f = i & 15;
+        const uint32_t *src = (const uint32_t *)(cand + s_slot[s_kept[k]]);
+        ((uint32_t *)(a.out + (size_t)img * a.max_det + k))[f] = src[f];
+    }
+    if (tid == 0) a.out_count[img] = kept;
+}
+
+void launch_nms(hipStream_t s, const NmsParams &p) {
+    size_t lds = (size_t)p.cap * (8 + 16 + 4 + 1) + (size_t)p.max_det * 4 + 16;
+    static size_t attr_bytes = 0;
+    if (lds > attr_bytes) { set_max_lds(nms_kernel, lds); attr_bytes = lds; }
+    hipLaunchKernelGGL(nms_kernel, dim3(p.n), dim3(NMS_THREADS), lds, s, p);
+}
+
+// =============================================================================================
+// Area-average downscale for frames larger than the net (TRT+NPP variant, factor < 1:
+// resizeconvertion.cu:298-311 uses NPPI_INTER_SUPER, a closed-source box filter).  Each destination pixel
+// averages the source rectangle it covers with fractional edge weights; aspect preserved, top-left
+// anchored, the rest of the canvas stays zero (cudaMemset, RetinaFace.cpp:598).  "parity unpinned".
+// =============================================================================================
+__global__ __launch_bounds__(kThreads) void resize_area_kernel(const FrameDesc *__restrict__ src, uint8_t *__restrict__ dst,
+                                                               int net_h, int net_w) {
+    const int img = blockIdx.z;
+    const FrameDesc fd = src[img];
+    const int x = blockIdx.x * 32 + (threadIdx.x & 31);
+    const int y = blockIdx.y * 8 + (threadIdx.x >> 5);
+    if (x >= net_w || y >= net_h) return;
+    uint8_t *d = dst + ((size_t)img * net_h * net_w + (size_t)y * net_w + x) * 3;
+    float f = fminf((float)net_w / (float)fd.cols, (float)net_h / (float)fd.rows);
+    if (f > 1.f) f = 1.f;
+    const int dw = (int)((float)fd.cols * f), dh = (int)((float)fd.rows * f);
+    if (x >= dw || y >= dh || fd.ptr == nullptr) { d[0] = d[1] = d[2] = 0; return; }
+    if (f == 1.f) {
+        const uint8_t *sp = fd.ptr + (size_t)y * fd.step + x * 3;
+        d[0] = sp[0]; d[1] = sp[1]; d[2] = sp[2];
+        return;
+    }
+    const float inv = 1.f / f;
+    const float sx0 = x * inv, sx1 = fminf((x + 1) * inv, (float)fd.cols);
+    const float sy0 = y * inv, sy1 = fminf((y + 1) * inv, (float)fd.rows);
+    float acc[3] = {0.f, 0.f, 0.f}, wsum = 0.f;
+    for (int yy = (int)sy0; yy < fd.rows && (float)yy < sy1; yy++) {
+        const float wy = fminf((float)(yy + 1), sy1) - fmaxf((float)yy, sy0);
+        for (int xx = (int)sx0; xx < fd.cols && (float)xx < sx1; xx++) {
+            const float wgt = wy * (fminf((float)(xx + 1), sx1) - fmaxf((float)xx, sx0));
+            const uint8_t *sp = fd.ptr + (size_t)yy * fd.step + xx * 3;
+            acc[0] += wgt * sp[0]; acc[1] += wgt * sp[1]; acc[2] += wgt * sp[2];
+            wsum += wgt;
+        }
+    }
+    for (int c = 0; c < 3; c++) {
+        float v = wsum > 0.f ? acc[c] / wsum : 0.f;
+        d[c] = (uint8_t)fminf(fmaxf(rintf(v), 0.f), 255.f);
+    }
+}
+
+void launch_resize_area(hipStream_t s, const FrameDesc *src, uint8_t *dst, int n, int net_h, int net_w) {
+    dim3 grid((net_w + 31) / 32, (net_h + 7) / 8, n);
+    hipLaunchKernelGGL(resize_area_kernel, grid, dim3(kThreads), 0, s, src, dst, net_h, net_w);
+}
+
+__global__ void fill_u32_kernel(uint32_t *dst, uint32_t v, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = v;
+}
+void launch_fill_u32(hipStream_t s, uint32_t *dst, uint32_t value, size_t count) {
+    if (!count) return;
+    hipLaunchKernelGGL(fill_u32_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, s, dst, value, count);
+}
+
+}  // namespace rf

@@ -1,0 +1,52 @@
+// pack.h -- index math shared by the host packers (engine.cpp), the HIP kernels and the host unit
+// tests (tests/csrc/test_pack.cpp): where element W[cout][k] of a GEMM-shaped weight lives in the
+// MFMA-fragment-ordered buffer, and which (cout, pixel) a lane's accumulator register holds.
+//
+// All GEMMs in this engine are computed "swapped": D[cout][pixel] = sum_k W[cout][k] * X[k][pixel],
+// weights as the MFMA A operand (rows = output channels), NHWC activations as the B operand
+// (columns = pixels).  With the gfx950 16x16 layouts (cdna_hip_programming.md section 3):
+//   A operand: lane l holds A[row = l & 15][k = (l >> 4) * KPL + e], e < KPL
+//   B operand: lane l holds B[k = (l >> 4) * KPL + e][col = l & 15]
+//   C / D    : lane l, register r holds D[row = (l >> 4) * 4 + r][col = l & 15]
+// so a lane ends up with 4 *consecutive output channels* of one pixel -- an 8-byte (fp16) NHWC store --
+// and the B fragment is KPL consecutive channels of one pixel -- a single ds_read_b128 from an NHWC tile.
+//   fp16: v_mfma_f32_16x16x32_f16  K = 32, KPL = 8      fp32: v_mfma_f32_16x16x4_f32  K = 4, KPL = 1
+#pragma once
+#include <cstddef>
+
+#if defined(__HIPCC__) || defined(__CUDACC__)
+#define RF_HD __host__ __device__
+#else
+#define RF_HD
+#endif
+
+namespace rf {
+
+// Packed weight buffer: [cout_tile = cout/16][k_chunk = k/K][lane 0..63][KPL] elements.
+// One (cout_tile, k_chunk) = one wave-wide A fragment = 64 * KPL contiguous elements, so a wave loads it with
+// one fully coalesced 16-byte-per-lane (fp16) global load.
+RF_HD inline size_t packed_weight_index(int cout, int k, int k_chunks, int K, int KPL) {
+    int ct = cout >> 4, row = cout & 15;
+    int kc = k / K, kk = k % K;
+    int lane = (kk / KPL) * 16 + row;
+    return ((size_t)(ct * k_chunks + kc) * 64 + lane) * KPL + (kk % KPL);
+}
+
+RF_HD inline int k_chunks_for(int k_total, int K) { return (k_total + K - 1) / K; }
+
+// accumulator register r of lane l in tile (ct, pt): which output channel / which pixel of the block tile
+RF_HD inline int acc_cout(int ct, int lane, int r) { return ct * 16 + (lane >> 4) * 4 + r; }
+RF_HD inline int acc_pixel(int pt, int lane) { return pt * 16 + (lane & 15); }
+
+// Workgroups are dispatched round-robin over the 8 XCDs (block b -> XCD b % 8, observed, speed only).
+// Give every XCD one contiguous range of logical tile ids so that (a) neighbouring tiles, which share
+// halo rows, and (b) the same image's tiles in consecutive layers land on the same XCD and hit its 4 MiB L2.
+// Bijective for any nblk (cdna_hip_programming.md section 5, "XCD swizzle must be bijective").
+RF_HD inline int xcd_remap(int bid, int nblk) {
+    int q = nblk >> 3, r = nblk & 7;
+    int xcd = bid & 7, i = bid >> 3;
+    int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + i;
+}
+
+}  // namespace rf

@@ -1,0 +1,79 @@
+#!/usr/bin/env python3
+"""Freeze golden vectors from the CPU oracle into tests/golden/ (run in the dev container).
+
+The reference ships no golden vectors (it has no tests at all), so these are minted from the
+oracle after it has been pinned by its own cross-checks (tests/test_oracle.py).  They are what the `-m gpu`
+parity tests compare the HIP path with on the GPU box, where /root/reference does not exist.
+
+  fixture_<stem>.npz      the reference's one image (data/img.jpg, padded to 1280x896, Caffe path):
+                          pre-NMS candidates, final detections, global anchor indices, stride-32/16 head blobs,
+                          checksums of the stride-8 blobs
+  crop448_<stem>.npz      448x448 crop of it (x0=440, y0=30): all 9 head blobs + candidates + detections
+  synth448_<stem>.npz     8 seeded synthetic frames (retinaface_amd.frames.synth_frames(448,448,8,config=1)):
+                          detections + anchor indices + candidate counts at thr 0.5 and 0.9
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle.caffe_forward import HEAD_STRIDES, head_names  # noqa: E402
+from oracle.caffe_io import read_rfw  # noqa: E402
+from oracle.pipeline import OracleDetector  # noqa: E402
+from retinaface_amd.frames import padded_base_frame, synth_frames  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+
+
+def rows(dets):
+    return np.stack([d.as_row() for d in dets]).astype(np.float32) if dets else np.zeros((0, 15), np.float32)
+
+
+def idx(dets):
+    return np.array([d.anchor_index for d in dets], np.int32)
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    frame = padded_base_frame()
+    crop = np.ascontiguousarray(frame[30:478, 440:888])
+    synth = synth_frames(448, 448, 8, config=1)
+    for stem in ("mnet-deconv-0517", "mnet25"):
+        det = OracleDetector(read_rfw(os.path.join(ROOT, "assets", stem + ".rfw")))
+        r = det.detect(frame, 0.5, 0.4)
+        r9 = det.detect(frame, 0.9, 0.4)
+        d = {"cand": rows(r.candidates), "cand_idx": idx(r.candidates), "det": rows(r.detections),
+             "det_idx": idx(r.detections), "det09": rows(r9.detections), "det09_idx": idx(r9.detections),
+             "ncand09": np.int32(len(r9.candidates))}
+        for s in (32, 16):
+            for n in head_names(s):
+                d[n] = r.heads[n][0]
+        for n in head_names(8):
+            d[n + "_sum"] = np.float64(r.heads[n].astype(np.float64).sum())
+            d[n + "_abs"] = np.float64(np.abs(r.heads[n].astype(np.float64)).sum())
+        np.savez_compressed(os.path.join(OUT, f"fixture_{stem}.npz"), **d)
+        print(stem, "fixture:", len(r.candidates), "cand", len(r.detections), "det")
+
+        c = det.detect(crop, 0.5, 0.4, net_hw=(448, 448))
+        d = {"cand": rows(c.candidates), "cand_idx": idx(c.candidates), "det": rows(c.detections), "det_idx": idx(c.detections)}
+        for s in HEAD_STRIDES:
+            for n in head_names(s):
+                d[n] = c.heads[n][0]
+        np.savez_compressed(os.path.join(OUT, f"crop448_{stem}.npz"), **d)
+        print(stem, "crop448:", len(c.candidates), "cand", len(c.detections), "det")
+
+        d = {}
+        for i, f in enumerate(synth):
+            for thr, tag in ((0.5, "05"), (0.9, "09")):
+                s_ = det.detect(f, thr, 0.4, net_hw=(448, 448))
+                d[f"det{tag}_{i}"] = rows(s_.detections)
+                d[f"idx{tag}_{i}"] = idx(s_.detections)
+                d[f"ncand{tag}_{i}"] = np.int32(len(s_.candidates))
+        np.savez_compressed(os.path.join(OUT, f"synth448_{stem}.npz"), **d)
+        print(stem, "synth448:", [len(d[f'det05_{i}']) for i in range(8)])
+
+
+if __name__ == "__main__":
+    main()
