@@ -1,0 +1,213 @@
+#!/usr/bin/env python3
+"""bench.py -- the RetinaFace::detect() hot path on N MI355X GPUs (one process per GPU).
+
+A "step" = one pass of the whole hot path (fused preprocess+conv0 -> backbone -> FPN -> SSH -> heads+decode -> NMS
+-> result D2H) over one batch of synthetic face-bearing frames already resident in HBM.  Workload at N = 1 is
+BASELINE.json configs[1]: mnet25, fp16, 448x448, batch 8 on one MI355X.  With N > 1 every rank runs the same batch
+size on its own frames (images are independent: no data-path collective; "scaling": "weak"); timing is
+barrier + synchronize on both sides, MAX over ranks (one RCCL all_reduce outside the timed region).
+
+Prints ONE JSON line (rank 0): metric faces/sec (BASELINE.json), images/sec and ms/frame beside it, the
+pre/infer/post split, `roofline` for the dominant kernel (HIP-event timed inside this process, algorithmic bytes
+per SURVEY.md 8d) and `cpu_baseline` (the CPU oracle = restatement of the reference's Caffe path, timed on the
+host cores on a bounded sample of the same frames; N = 1, rank 0 only).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+MFMA_F16_PEAK_TFLOPS = 2500.0  # dense fp16/bf16 MFMA
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=400)
+    ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--batch", type=int, default=8, help="images per GPU per step")
+    ap.add_argument("--height", type=int, default=448)
+    ap.add_argument("--width", type=int, default=448)
+    ap.add_argument("--precision", choices=["fp16", "fp32"], default="fp16")
+    ap.add_argument("--model", default="mnet25")
+    ap.add_argument("--threshold", type=float, default=0.5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--profile-iters", type=int, default=50)
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device: the product path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl")          # RCCL on ROCm
+
+    import retinaface_amd
+    from retinaface_amd.frames import synth_frames
+
+    B, H, W = args.batch, args.height, args.width
+    prec = retinaface_amd.PRECISION_FP16 if args.precision == "fp16" else retinaface_amd.PRECISION_FP32
+    det = retinaface_amd.RetinaFace(os.path.join(ROOT, "assets"), "net3", 0.4, precision=prec, net_hw=(H, W), max_batch=B,
+                                    model_stem=args.model)
+    frames_np = synth_frames(H, W, B, config=1 + rank)
+    frames = torch.from_numpy(np.stack(frames_np)).cuda()
+    torch.cuda.synchronize()
+    ptrs = [frames[i].data_ptr() for i in range(B)]
+    rows, cols = [H] * B, [W] * B
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    slots = det.num_slots()
+
+    def run(steps: int) -> int:
+        """Keep the engine's stream full: up to `slots` batches in flight, results of every step are collected."""
+        faces = 0
+        inflight = []
+        for _ in range(steps):
+            if len(inflight) == slots:
+                faces += sum(det.wait_counts(inflight.pop(0), B))
+            inflight.append(det.enqueue_device(ptrs, rows, cols, args.threshold))
+        while inflight:
+            faces += sum(det.wait_counts(inflight.pop(0), B))
+        return faces
+
+    run(max(args.warmup, 1))
+    barrier()
+    t0 = time.perf_counter()
+    faces = run(args.steps)
+    barrier()
+    dt = time.perf_counter() - t0
+
+    # synchronous latency of one call (what the reference's loop measures: main.cpp:40-52)
+    lat = []
+    for _ in range(30):
+        t = time.perf_counter()
+        det.detect_device(ptrs, rows, cols, args.threshold)
+        lat.append(time.perf_counter() - t)
+    sync_ms = float(np.median(lat) * 1e3)
+
+    tt = torch.tensor([dt, float(faces)], dtype=torch.float64, device="cuda")
+    if world > 1:
+        tmax = tt.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        tsum = tt.clone()
+        dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        dt_max, faces_total = float(tmax[0]), float(tsum[1])
+    else:
+        dt_max, faces_total = dt, float(faces)
+
+    if rank == 0:
+        images_total = args.steps * B * world
+        # pre / infer / post split (eager engine with HIP events between the stages)
+        eager = retinaface_amd.RetinaFace(os.path.join(ROOT, "assets"), "net3", 0.4, precision=prec, net_hw=(H, W),
+                                          max_batch=B, model_stem=args.model, use_graph=False)
+        split = []
+        for _ in range(20):
+            eager.detect_device(ptrs, rows, cols, args.threshold)
+            split.append(eager.last_timings())
+        med = {k: float(np.median([s[k] for s in split])) for k in split[0]}
+        # per-kernel HIP-event timing on the engine's own stream
+        prof = eager.profile(ptrs, iters=args.profile_iters)
+        eager.close()
+        dom = max(prof, key=lambda p: p["ms"])
+        kernel_ms = sum(p["ms"] for p in prof)
+        alg_total = sum(p["alg_bytes"] for p in prof)
+        elem = 2 if args.precision == "fp16" else 4
+        roofline = {
+            "bound": "hbm", "kernel": dom["name"],
+            "achieved": dom["alg_bytes"] / (dom["ms"] * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": dom["alg_bytes"] / (dom["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+            "kernel_ms": dom["ms"], "kernel_alg_bytes": dom["alg_bytes"],
+            "kernel_share_of_gpu_time": dom["ms"] / kernel_ms,
+            "all_kernels_ms": kernel_ms, "all_kernels_alg_bytes": alg_total,
+            "all_kernels_frac": alg_total / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "end_to_end_frac": (alg_total / B) * (images_total / world / dt_max) / 1e9 / HBM_PEAK_GBS,
+            "mfma_frac_all_kernels": 2 * sum(p["macs"] for p in prof) / (kernel_ms * 1e-3) / 1e12 / MFMA_F16_PEAK_TFLOPS,
+            "elem_bytes": elem,
+        }
+        out = {
+            "metric": "faces/sec", "value": faces_total / dt_max, "unit": "faces/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt_max / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f16" if args.precision == "fp16" else "f32", "data": "synthetic",
+            "config": {"workload": f"{args.model} {args.precision} HIP, {W}x{H}, batch {B} per GPU (BASELINE.json configs[1] at 448x448 b=8)",
+                       "global_batch": B * world, "frame": [H, W], "threshold": args.threshold, "nms": 0.4,
+                       "parallelism": f"dp{world} (image sharding, no data-path collective)"},
+            "images_per_sec": images_total / dt_max, "ms_per_frame": dt_max / (args.steps * B) * 1e3,
+            "faces_per_step": faces_total / args.steps / world,
+            "sync_call_ms": sync_ms,
+            "split_ms_per_batch": {"pre": med["pre_ms"], "infer": med["infer_ms"], "post": med["post_ms"], "all": med["total_ms"]},
+            "roofline": roofline,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(frames_np, args, det)
+        print(json.dumps(out), flush=True)
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(ROOT, "gpurun_out", "bench_kernels.json"), "w") as f:
+            json.dump(prof, f, indent=1)
+    det.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(frames_np, args, det):
+    """The CPU oracle (layer-by-layer unfused fp32 restatement of the reference's Caffe path on PyTorch-CPU/oneDNN +
+    the literal decode/NMS) on the same frames, all host cores, bounded to ~cpu-seconds; also cross-checks that the
+    GPU path found the same faces."""
+    import numpy as np
+    import torch
+    from oracle.caffe_io import read_rfw
+    from oracle.pipeline import OracleDetector
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    orc = OracleDetector(read_rfw(os.path.join(ROOT, "assets", args.model + ".rfw")))
+    H, W = args.height, args.width
+    orc.detect(frames_np[0], args.threshold, 0.4, net_hw=(H, W))         # warm-up (oneDNN primitive creation)
+    n_img = n_faces = 0
+    ref_idx = []
+    t0 = time.perf_counter()
+    while True:
+        for f in frames_np:
+            r = orc.detect(f, args.threshold, 0.4, net_hw=(H, W))
+            if len(ref_idx) < len(frames_np):
+                ref_idx.append([d.anchor_index for d in r.detections])
+            n_img += 1
+            n_faces += len(r.detections)
+        if time.perf_counter() - t0 > args.cpu_seconds:
+            break
+    dt = time.perf_counter() - t0
+    gpu = det.detectBatchImages(frames_np, args.threshold)
+    same = [[d.anchor_index for d in r] for r in gpu] == ref_idx
+    try:
+        model = [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
+    except Exception:  # noqa: BLE001
+        model = "unknown"
+    return {"value": n_faces / dt, "unit": "faces/s", "cores": cores, "kind": "port",
+            "sample": f"{n_img} frames ({n_img // len(frames_np)} passes over the bench batch), {dt:.1f} s, "
+                      f"PyTorch-CPU oneDNN fp32 unfused Caffe restatement + literal decode/NMS, torch threads = {cores}",
+            "images_per_sec": n_img / dt, "ms_per_frame": dt / n_img * 1e3, "cpu_model": model,
+            "gpu_faces_identical_to_oracle": bool(same)}
+
+
+if __name__ == "__main__":
+    main()

@@ -643,10 +643,11 @@ std::unique_ptr<Engine> Engine::create(const std::string &model_dir, const std::
     // Only "net3" has an anchor configuration in the reference (RetinaFace.cpp:215-217, 245-271); the other
     // presets print "please reconfig anchor_cfg" and leave cfg empty.
     if (network != "net3") throw Unsupported("network preset '" + network + "' has no anchor configuration (only net3)");
+    Model model = load_model_dir(model_dir, opt.model_stem);      // host-only steps first: their errors do not need a GPU
+    Plan plan = compile_plan(model);
+    if (opt.precision == RF_PRECISION_INT8) throw Unsupported("int8 precision is not implemented yet");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) throw HipError("no HIP device available");
-    Model model = load_model_dir(model_dir, opt.model_stem);
-    Plan plan = compile_plan(model);
     switch (opt.precision) {
         case RF_PRECISION_FP16: return std::unique_ptr<Engine>(new EngineImpl<half_t>(plan, nms, opt));
         case RF_PRECISION_FP32: return std::unique_ptr<Engine>(new EngineImpl<float>(plan, nms, opt));

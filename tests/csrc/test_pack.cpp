@@ -1,0 +1,94 @@
+// Host emulation of one wavefront executing the swapped MFMA GEMM exactly as kernels.hip indexes it
+// (weights = A operand in the packed fragment order of pack.h, NHWC activations = B operand, accumulator
+// register r of lane l = D[cout = (l>>4)*4 + r][pixel = l&15]) and of the 3x3 implicit-GEMM k -> (tap, channel)
+// mapping, against a direct convolution.  Validates pack.h's index math for both MMA shapes
+// (fp16: K=32, KPL=8; fp32: K=4, KPL=1) and the XCD remap's bijectivity.  Exit code 0 = pass.
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "../../retinaface_amd/csrc/pack.h"
+
+using namespace rf;
+
+static float frand() { return (float)(rand() % 2001 - 1000) / 500.f; }
+
+// one 16(cout) x 16(pixel) x K MFMA on operands laid out per lane
+static void mfma_emul(const std::vector<float> &a_frag /*[64][KPL]*/, const std::vector<float> &b_frag, float acc[64][4], int KPL) {
+    const int kgroups = 4;
+    for (int lane = 0; lane < 64; lane++)
+        for (int r = 0; r < 4; r++) {
+            int row = (lane >> 4) * 4 + r, col = lane & 15;
+            float s = 0;
+            for (int g = 0; g < kgroups; g++)
+                for (int e = 0; e < KPL; e++) s += a_frag[(g * 16 + row) * KPL + e] * b_frag[(g * 16 + col) * KPL + e];
+            acc[lane][r] += s;
+        }
+}
+
+static int test_conv(int K, int KPL, int cin, int cout, int ksz) {
+    const int TH = 4, TW = 8, P = TH * TW, HC = TW + 2, HR = TH + 2;
+    const int ktot = ksz * ksz * cin, kch = k_chunks_for(ktot, K);
+    std::vector<float> w((size_t)cout * ktot), x((size_t)HR * HC * cin);
+    for (auto &v : w) v = frand();
+    for (auto &v : x) v = frand();
+    std::vector<float> packed((size_t)(cout / 16) * kch * 64 * KPL, 0.f);
+    for (int o = 0; o < cout; o++)
+        for (int k = 0; k < ktot; k++) packed[packed_weight_index(o, k, kch, K, KPL)] = w[(size_t)o * ktot + k];
+    int bad = 0;
+    for (int ct = 0; ct < cout / 16; ct++)
+        for (int pt = 0; pt < P / 16; pt++) {
+            float acc[64][4] = {};
+            for (int kc = 0; kc < kch; kc++) {
+                std::vector<float> af((size_t)64 * KPL), bf((size_t)64 * KPL, 0.f);
+                for (int lane = 0; lane < 64; lane++)
+                    for (int e = 0; e < KPL; e++) af[lane * KPL + e] = packed[((size_t)(ct * kch + kc) * 64 + lane) * KPL + e];
+                for (int lane = 0; lane < 64; lane++) {
+                    int kb = kc * K + (lane >> 4) * KPL;
+                    if (kb >= ktot) continue;
+                    int p = acc_pixel(pt, lane), py = p / TW, px = p % TW;
+                    int tap = kb / cin, c = kb % cin;
+                    int ky = ksz == 3 ? tap / 3 : 1, kx = ksz == 3 ? tap % 3 : 1;     // 1x1: centre of the halo tile
+                    for (int e = 0; e < KPL; e++) bf[lane * KPL + e] = x[((size_t)(py + ky) * HC + px + kx) * cin + c + e];
+                }
+                mfma_emul(af, bf, acc, KPL);
+            }
+            for (int lane = 0; lane < 64; lane++)
+                for (int r = 0; r < 4; r++) {
+                    int o = acc_cout(ct, lane, r), p = acc_pixel(pt, lane), py = p / TW, px = p % TW;
+                    double ref = 0;
+                    for (int ky = 0; ky < ksz; ky++)
+                        for (int kx = 0; kx < ksz; kx++)
+                            for (int c = 0; c < cin; c++) {
+                                int yy = ksz == 3 ? py + ky : py + 1, xx = ksz == 3 ? px + kx : px + 1;
+                                ref += (double)w[(size_t)o * ktot + (ky * ksz + kx) * cin + c] * x[((size_t)yy * HC + xx) * cin + c];
+                            }
+                    if (std::fabs(ref - acc[lane][r]) > 1e-3 * (1 + std::fabs(ref))) bad++;
+                }
+        }
+    if (bad) printf("FAIL K=%d KPL=%d cin=%d cout=%d k=%d: %d mismatches\n", K, KPL, cin, cout, ksz, bad);
+    return bad;
+}
+
+int main() {
+    int bad = 0;
+    for (int shape = 0; shape < 2; shape++) {
+        int K = shape ? 4 : 32, KPL = shape ? 1 : 8;
+        bad += test_conv(K, KPL, 8, 16, 1);
+        bad += test_conv(K, KPL, 64, 32, 1);
+        bad += test_conv(K, KPL, 256, 64, 1);
+        bad += test_conv(K, KPL, 16, 16, 3);     // K chunk straddles taps, tail chunk half empty (fp16)
+        bad += test_conv(K, KPL, 16, 32, 3);
+        bad += test_conv(K, KPL, 64, 48, 3);
+    }
+    for (int nblk : {1, 7, 8, 9, 15, 64, 100, 3136}) {
+        std::vector<int> seen(nblk, 0);
+        for (int b = 0; b < nblk; b++) {
+            int m = xcd_remap(b, nblk);
+            if (m < 0 || m >= nblk || seen[m]++) { printf("FAIL xcd_remap nblk=%d\n", nblk); bad++; break; }
+        }
+    }
+    printf(bad ? "test_pack: FAILED\n" : "test_pack: ok\n");
+    return bad ? 1 : 0;
+}

@@ -1,0 +1,302 @@
+"""Parity tests proper (`-m gpu`, run on the MI355X box): the HIP path, called through the C ABI, against the CPU
+oracle on the same inputs, against the committed golden vectors, and -- at BASELINE.json's full sizes -- through
+size-independent properties (batch-composition invariance, determinism, graph == eager).
+
+Tolerances (stated once, used everywhere):
+  fp32 engine : anchor indices identical, candidate counts identical, box IoU >= 1 - 1e-5, |score| <= 1e-5
+  fp16 engine : anchor indices identical, box IoU >= 1 - 1e-3 (north_star's bound), |score| <= 2e-3,
+                landmarks within 0.15 px, candidate count within +-4 of the oracle (threshold margin band:
+                an fp16 logit can move a borderline candidate across `conf <= thr`)
+  post-processing alone (decode + NMS given the GPU's own head blobs, vs the plain-C restatement):
+                anchor indices and scores bit-exact, coordinates within 1e-4 px (expf ulp)
+"""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ASSETS, ROOT, STEMS, golden
+from oracle import build as obuild
+from oracle.caffe_forward import HEAD_STRIDES, head_names
+from oracle.retinaface_post import iou_plus1, preprocess_trt_identity
+
+pytestmark = pytest.mark.gpu
+
+FP32, FP16 = 0, 1
+TOL = {FP32: dict(iou=1e-5, score=1e-5, lm=2e-3, ncand=0), FP16: dict(iou=1e-3, score=2e-3, lm=0.15, ncand=4)}
+
+
+@pytest.fixture(scope="module")
+def rfa(built_lib):
+    import retinaface_amd
+    import torch
+    assert torch.cuda.is_available(), "the -m gpu tests need the GPU box"
+    return retinaface_amd
+
+
+_engines = {}
+
+
+def engine(rfa, stem, prec, hw, **kw):
+    key = (stem, prec, hw, tuple(sorted(kw.items())))
+    if key not in _engines:
+        _engines[key] = rfa.RetinaFace(ASSETS, "net3", 0.4, precision=prec, net_hw=hw, model_stem=stem, **kw)
+    return _engines[key]
+
+
+def compare(got, ref_rows, ref_idx, prec):
+    t = TOL[prec]
+    assert [d.anchor_index for d in got] == list(ref_idx), ([d.anchor_index for d in got], list(ref_idx))
+    for g, r in zip(got, ref_rows):
+        assert iou_plus1(g.rect, r[1:5]) >= 1 - t["iou"], (g.rect, r[1:5])
+        assert abs(g.score - r[0]) <= t["score"]
+        assert np.abs(g.as_row()[5:] - r[5:]).max() <= t["lm"]
+
+
+# --------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("prec", [FP32, FP16])
+def test_every_fused_op_against_the_oracle_blob(rfa, oracles, crop448, prec):
+    """Layer by layer: each fused kernel's NHWC output vs the reference blob it stands for."""
+    det = engine(rfa, "mnet-deconv-0517", prec, (448, 448), keep_outputs=True, use_graph=False)
+    det.detect(crop448, 0.5)
+    blobs = oracles["mnet-deconv-0517"].forward(preprocess_trt_identity(crop448, 448, 448), keep_all=True)
+    names = ["mobilenet0_relu0_fwd"] + [f"mobilenet0_relu{i}_fwd" for i in range(2, 27, 2)]
+    names += ["rf_c3_lateral_relu", "rf_c2_lateral_relu", "rf_c2_aggr_relu", "rf_c1_red_conv_relu", "rf_c1_aggr_relu"]
+    for c in (3, 2, 1):
+        names += [f"rf_c{c}_det_context_conv1_relu", f"rf_c{c}_det_context_conv3_1_relu", f"rf_c{c}_det_concat_relu"]
+    rel_max, rel_mean = (1e-4, 1e-5) if prec == FP32 else (3e-2, 2e-3)
+    for n in names:
+        a = det.debug_activation(n)
+        r = blobs[n][0].transpose(1, 2, 0)
+        assert a.shape == r.shape, n
+        scale = max(1.0, float(np.abs(r).max()))
+        d = np.abs(a - r)
+        assert d.max() <= rel_max * scale and d.mean() <= rel_mean * scale, (n, float(d.max()), float(d.mean()), scale)
+
+
+@pytest.mark.parametrize("prec", [FP32, FP16])
+@pytest.mark.parametrize("stem", STEMS)
+def test_head_blobs_against_golden(rfa, crop448, stem, prec):
+    """blob_by_name() equivalents vs the frozen oracle blobs (golden: tests/golden/crop448_*.npz)."""
+    det = engine(rfa, stem, prec, (448, 448), keep_outputs=True, use_graph=False)
+    got = det.detect(crop448, 0.5)
+    g = golden(f"crop448_{stem}.npz")
+    atol = 5e-5 if prec == FP32 else 3e-2
+    for s in HEAD_STRIDES:
+        for n in head_names(s):
+            assert np.abs(det.get_output(n) - g[n]).max() <= atol, n
+    compare(got, g["det"], g["det_idx"], prec)
+    assert abs(det.last_candidate_counts(1)[0] - len(g["cand_idx"])) <= TOL[prec]["ncand"]
+
+
+@pytest.mark.parametrize("prec", [FP32, FP16])
+@pytest.mark.parametrize("stem", STEMS)
+def test_reference_fixture_image_1280x896(rfa, base_frame, stem, prec):
+    """The reference's only image at BASELINE config 4's size: 6 faces, identical anchors, IoU within tolerance."""
+    det = engine(rfa, stem, prec, (896, 1280), max_batch=2)
+    g = golden(f"fixture_{stem}.npz")
+    got = det.detect(base_frame, 0.5)
+    assert len(got) == 6
+    compare(got, g["det"], g["det_idx"], prec)
+    assert abs(det.last_candidate_counts(1)[0] - len(g["cand_idx"])) <= TOL[prec]["ncand"]
+    got9 = det.detect(base_frame, 0.9)                   # main.cpp:43 uses 0.9
+    compare(got9, g["det09"], g["det09_idx"], prec)
+    assert abs(det.last_candidate_counts(1)[0] - int(g["ncand09"])) <= TOL[prec]["ncand"]
+    # the unpadded 886-row frame is placed top-left on the zero canvas: same result as the padded one
+    got_u = det.detect(np.ascontiguousarray(base_frame[:886]), 0.5)
+    assert [d.anchor_index for d in got_u] == [d.anchor_index for d in got]
+    assert all(a.rect == b.rect for a, b in zip(got_u, got))
+
+
+@pytest.mark.parametrize("prec", [FP32, FP16])
+@pytest.mark.parametrize("stem", STEMS)
+def test_synthetic_batch8_against_golden(rfa, stem, prec):
+    """BASELINE config 2's shape (448x448, batch 8) on the seeded face-bearing frames."""
+    from retinaface_amd.frames import synth_frames
+    frames = synth_frames(448, 448, 8, config=1)
+    det = engine(rfa, stem, prec, (448, 448))
+    g = golden(f"synth448_{stem}.npz")
+    for thr, tag in ((0.5, "05"), (0.9, "09")):
+        res = det.detectBatchImages(frames, thr)
+        ncand = det.last_candidate_counts(8)
+        for i in range(8):
+            compare(res[i], g[f"det{tag}_{i}"], g[f"idx{tag}_{i}"], prec)
+            assert abs(ncand[i] - int(g[f"ncand{tag}_{i}"])) <= TOL[prec]["ncand"]
+
+
+@pytest.mark.parametrize("thr", [0.5, 0.1, 0.02])
+def test_postprocessing_is_exact_given_the_gpu_head_blobs(rfa, crop448, thr):
+    """Decode + regression + clip + NMS on the device vs the plain-C restatement fed the device's own head blobs:
+    anchor indices and scores bit-exact, coordinates to expf-ulp -- also with hundreds of candidates (thr 0.02)."""
+    det = engine(rfa, "mnet25", FP32, (448, 448), keep_outputs=True, use_graph=False)
+    got = det.detect(crop448, thr)
+    heads9 = [det.get_output(n) for s in HEAD_STRIDES for n in head_names(s)]
+    cand, cidx, kept, kidx = obuild.decode_nms(heads9, 448, 448, thr, 0.4)
+    assert det.last_candidate_counts(1)[0] == len(cidx)
+    assert [d.anchor_index for d in got] == kidx.tolist()
+    rows = np.stack([d.as_row() for d in got]) if got else np.zeros((0, 15), np.float32)
+    assert np.array_equal(rows[:, 0], kept[:, 0])
+    assert np.abs(rows - kept).max(initial=0.0) <= 1e-4
+    if thr == 0.02:
+        assert len(cidx) > 150
+
+
+def test_candidate_overflow_is_reported(rfa, crop448):
+    det = engine(rfa, "mnet25", FP16, (448, 448), max_candidates=64, max_detections=4)
+    got = det.detect(crop448, 0.001)
+    assert det.truncated and det.last_candidate_counts(1)[0] > 64 and len(got) <= 4
+    got = det.detect(crop448, 0.999999)
+    assert not det.truncated and got == []
+
+
+@pytest.mark.parametrize("prec", [FP32, FP16])
+def test_edge_cases_empty_small_strided_and_chunked(rfa, oracles, crop448, prec):
+    from retinaface_amd.frames import synth_frames
+    det = engine(rfa, "mnet-deconv-0517", prec, (448, 448))
+    frames = synth_frames(448, 448, 11, config=5)
+    single = [det.detect(f, 0.5) for f in frames]
+    # 11 images with max_batch 8 -> chunked 8 + 3 (the reference overruns its buffers here, trtretinafacenet.cpp:21)
+    batch = det.detectBatchImages(frames, 0.5)
+    assert [[d.anchor_index for d in r] for r in batch] == [[d.anchor_index for d in r] for r in single]
+    assert all(a.rect == b.rect and a.score == b.score for ra, rb in zip(batch, single) for a, b in zip(ra, rb))
+    # empty Mat inside a batch: count 0, neighbours untouched (img.empty() early-out, RetinaFace.cpp:578-580)
+    mixed = det.detectBatchImages([frames[0], np.zeros((0, 0, 3), np.uint8), None, frames[1]], 0.5)
+    assert mixed[1] == [] and mixed[2] == []
+    assert [d.anchor_index for d in mixed[0]] == [d.anchor_index for d in single[0]]
+    assert [d.anchor_index for d in mixed[3]] == [d.anchor_index for d in single[1]]
+    assert det.detect(None) == [] and det.detectBatchImages([]) == []
+    # a frame smaller than the net sits top-left on a zero canvas (scale factor clamps to 1)
+    small = np.ascontiguousarray(crop448[:300, :400])
+    ref = oracles["mnet-deconv-0517"].detect(small, 0.5, 0.4, net_hw=(448, 448))
+    compare(det.detect(small, 0.5), ref.rows(), ref.anchor_indices(), prec)
+    # non-contiguous rows (cv::Mat ROI: step > cols*3)
+    wide = np.zeros((448, 600, 3), np.uint8)
+    wide[:, :448] = crop448
+    view = wide[:, :448]
+    assert view.strides[0] == 1800
+    a, b = det.detect(view, 0.5), det.detect(crop448, 0.5)
+    assert [d.anchor_index for d in a] == [d.anchor_index for d in b] and all(x.rect == y.rect for x, y in zip(a, b))
+
+
+def test_device_resident_and_async_entry_points(rfa):
+    import torch
+    from retinaface_amd.frames import synth_frames
+    det = engine(rfa, "mnet25", FP16, (448, 448))
+    frames = synth_frames(448, 448, 8, config=1)
+    host = det.detectBatchImages(frames, 0.5)
+    dev = [torch.from_numpy(f).cuda() for f in frames]
+    torch.cuda.synchronize()
+    ptrs = [t.data_ptr() for t in dev]
+    res = det.detect_device(ptrs, [448] * 8, [448] * 8, 0.5)
+    assert [[(d.anchor_index, d.rect, d.score) for d in r] for r in res] == [[(d.anchor_index, d.rect, d.score) for d in r] for r in host]
+    # asynchronous ring: more batches in flight than slots
+    tickets = []
+    outs = []
+    for k in range(2 * det.num_slots() + 1):
+        if len(tickets) == det.num_slots():
+            t, n = tickets.pop(0)
+            outs.append(det.wait(t, n))
+        n = 1 + k % 8
+        tickets.append((det.enqueue_device(ptrs[:n], [448] * n, [448] * n, 0.5), n))
+    while tickets:
+        t, n = tickets.pop(0)
+        outs.append(det.wait(t, n))
+    for k, o in enumerate(outs):
+        n = 1 + k % 8
+        assert [[d.anchor_index for d in r] for r in o] == [[d.anchor_index for d in r] for r in host[:n]]
+
+
+@pytest.mark.parametrize("prec", [FP32, FP16])
+def test_determinism_and_graph_equals_eager(rfa, prec):
+    from retinaface_amd.frames import synth_frames
+    frames = synth_frames(448, 448, 8, config=2)
+    g = engine(rfa, "mnet25", prec, (448, 448))
+    e = engine(rfa, "mnet25", prec, (448, 448), use_graph=False)
+    first = g.detectBatchImages(frames, 0.5)       # first call of a batch size is eager, later ones replay the graph
+    for _ in range(3):
+        again = g.detectBatchImages(frames, 0.5)
+        assert [[d.as_row().tobytes() for d in r] for r in again] == [[d.as_row().tobytes() for d in r] for r in first]
+    eager = e.detectBatchImages(frames, 0.5)
+    assert [[d.as_row().tobytes() for d in r] for r in eager] == [[d.as_row().tobytes() for d in r] for r in first]
+    t = e.last_timings()
+    assert t["pre_ms"] >= 0 and t["infer_ms"] > 0 and t["post_ms"] > 0
+
+
+def test_full_size_batch32_is_batch_composition_invariant(rfa):
+    """BASELINE config 3's size (448x448, batch 32): each image's result is independent of what else is in the batch
+    and of its position -- compared with the batch-8 engine and with a permuted batch."""
+    from retinaface_amd.frames import synth_frames
+    frames = synth_frames(448, 448, 32, config=7)
+    big = engine(rfa, "mnet-deconv-0517", FP16, (448, 448), max_batch=32)
+    small = engine(rfa, "mnet-deconv-0517", FP16, (448, 448))
+    a = big.detectBatchImages(frames, 0.5)
+    b = small.detectBatchImages(frames, 0.5)
+    key = lambda res: [[(d.anchor_index, d.as_row().tobytes()) for d in r] for r in res]  # noqa: E731
+    assert key(a) == key(b)
+    perm = np.random.default_rng(0).permutation(32)
+    c = big.detectBatchImages([frames[i] for i in perm], 0.5)
+    assert key(c) == [key(a)[i] for i in perm]
+    assert sum(len(r) for r in a) >= 32
+
+
+def test_oversize_frame_is_area_averaged_down(rfa, base_frame):
+    """Frames larger than the net (factor < 1, resizeconvertion.cu:298-311).  NPP's SUPER filter is closed source
+    ("parity unpinned"); this checks the kernel against its own definition: an exact 2x downscale = 2x2 box mean,
+    so detecting on the 2x nearest-upsampled frame must equal detecting on the original."""
+    det = engine(rfa, "mnet-deconv-0517", FP32, (448, 448))
+    from retinaface_amd.frames import synth_frames
+    f = synth_frames(448, 448, 1, config=9)[0]
+    up = np.repeat(np.repeat(f, 2, axis=0), 2, axis=1)
+    a, b = det.detect(up, 0.5), det.detect(f, 0.5)
+    assert len(a) == len(b) > 0 and [d.anchor_index for d in a] == [d.anchor_index for d in b]
+    assert all(x.rect == y.rect for x, y in zip(a, b))
+    # aspect-preserving, top-left anchored: a wide 2:1 frame only fills the top half of the canvas
+    wide = np.concatenate([up, up], axis=1)                     # 896 x 1792 -> factor 0.25 -> 224 x 448
+    c = det.detect(wide, 0.3)
+    assert all(d.rect[3] <= 224 + 16 for d in c)
+
+
+def test_cxx_class_drop_in(rfa, tmp_path):
+    """The reference's class surface (include/RetinaFace.h) driven from C++ like retinaface/main.cpp does."""
+    from retinaface_amd.frames import synth_frames
+    exe = os.path.join(ROOT, "retinaface_amd", "lib", "rf_demo")
+    assert os.path.exists(exe), "rf_demo is built by __graft_entry__.build()"
+    frames = synth_frames(448, 448, 3, config=1)
+    paths = []
+    for i, f in enumerate(frames):
+        p = str(tmp_path / f"f{i}.bgr")
+        f.tofile(p)
+        paths.append(p)
+    out = subprocess.run([exe, ASSETS, "mnet25", "448", "448", "fp16", "0.5", "448", "448"] + paths, capture_output=True,
+                         text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    det = engine(rfa, "mnet25", FP16, (448, 448))
+    ref = det.detectBatchImages(frames, 0.5)
+    lines = [l.split() for l in out.stdout.strip().splitlines()]
+    batch = [l for l in lines if l[0] == "batch"]
+    assert len(batch) == sum(len(r) for r in ref)
+    k = 0
+    for i, r in enumerate(ref):
+        for d in r:
+            l = batch[k]
+            k += 1
+            assert int(l[1]) == i and abs(float(l[2]) - d.score) < 1e-5
+            assert np.allclose([float(v) for v in l[3:7]], d.rect, atol=2e-3)
+            assert abs(float(l[7]) - d.xs[0]) < 2e-3 and abs(float(l[8]) - d.ys[4]) < 2e-3
+    single = [l for l in lines if l[0] == "detect"]
+    assert len(single) == len(ref[0])
+    assert lines[-1] == ["empty", "0"]
+
+
+def test_profile_accounting_matches_baseline_md(rfa):
+    """rf_profile's per-launch algorithmic bytes / MACs sum to BASELINE.md section 2's per-image figures:
+    B = 3P + 2(E - 3P) = 27 615 616 B (fp16, 448^2), MACs = 481 764 864."""
+    import torch
+    det = engine(rfa, "mnet25", FP16, (448, 448))
+    frames = torch.zeros((8, 448, 448, 3), dtype=torch.uint8, device="cuda")
+    prof = det.profile([frames[i].data_ptr() for i in range(8)], iters=2)
+    assert len(prof) == 1 + 13 + 5 + 9 + 3 + 1
+    assert abs(sum(p["alg_bytes"] for p in prof) / 8 - 27615616) < 1
+    assert abs(sum(p["macs"] for p in prof) / 8 - 481764864) / 481764864 < 2.5e-3     # + the 4-tap upsample MACs
+    assert all(p["ms"] > 0 for p in prof)

@@ -1,0 +1,241 @@
+"""Host-side logic of the product, no GPU: the C-ABI library loads and exports every declared symbol, the C++
+model loader / graph compiler agree with the oracle's readers and an independent numpy BN fold, error paths,
+packing index math, frame synthesis, batch sharding over a 2-process gloo group."""
+import ctypes as C
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ASSETS, REFERENCE, ROOT, STEMS, needs_reference
+from retinaface_amd import _lib
+
+
+def _header_functions():
+    text = open(os.path.join(ROOT, "include", "retinaface_amd.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(rf_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol(built_lib):
+    names = _header_functions()
+    assert len(names) >= 18
+    assert set(names) == set(_lib.SYMBOLS), set(names) ^ set(_lib.SYMBOLS)
+    for n in names:
+        assert getattr(built_lib, n) is not None
+    assert built_lib.rf_abi_version() == 1
+    assert C.sizeof(_lib.rf_face) == 60          # FaceDetectInfo, RetinaFace.h:37-42
+
+
+def test_class_header_keeps_reference_signatures():
+    h = open(os.path.join(ROOT, "include", "RetinaFace.h")).read()
+    for sig in ('RetinaFace(string &model, string network = "net3", float nms = 0.4);',
+                "void detectBatchImages(vector<cv::Mat> imgs, float threshold = 0.5);",
+                "void detect(const Mat &img, float threshold = 0.5, float scales = 1.0);"):
+        assert sig in h, sig
+
+
+def _folded(lib, model_dir, stem, op):
+    dims = (C.c_int * 4)()
+    st = lib.rf_plan_folded(model_dir.encode(), stem.encode(), op.encode(), None, 0, None, 0, dims)
+    assert st == 0, lib.rf_last_error(None)
+    n = dims[0] * dims[1] * dims[2] * dims[3]
+    w = np.empty(n, np.float32)
+    b = np.empty(dims[0], np.float32)
+    st = lib.rf_plan_folded(model_dir.encode(), stem.encode(), op.encode(), w.ctypes.data_as(C.POINTER(C.c_float)), n,
+                            b.ctypes.data_as(C.POINTER(C.c_float)), dims[0], dims)
+    assert st == 0
+    return w.reshape(dims[0], dims[1], dims[2], dims[3]), b
+
+
+def _np_fold(net, conv, bn=None):
+    l = net.layer(conv)
+    W = l.blobs[0].astype(np.float64)
+    b = l.blobs[1].reshape(-1).astype(np.float64) if l.bias_term else np.zeros(W.shape[0])
+    if bn:
+        B, S = net.layer(bn), net.layer(bn + "_scale")
+        sf = B.blobs[2].reshape(-1)[0]
+        inv = np.float32(0) if sf == 0 else np.float32(1) / np.float32(sf)
+        mean = (B.blobs[0].reshape(-1) * inv).astype(np.float64)
+        var = (B.blobs[1].reshape(-1) * inv).astype(np.float64)
+        k = S.blobs[0].reshape(-1).astype(np.float64) / np.sqrt(var + np.float64(np.float32(B.eps)))
+        W = W * k[:, None, None, None]
+        b = (b - mean) * k + S.blobs[1].reshape(-1).astype(np.float64)
+    return W.transpose(0, 2, 3, 1).astype(np.float32), b.astype(np.float32)
+
+
+@pytest.mark.parametrize("stem", STEMS)
+def test_graph_compiler_fold_matches_numpy(stem, built_lib, nets):
+    net = nets[stem]
+    w, b = _folded(built_lib, ASSETS, stem, "conv0")
+    rw, rb = _np_fold(net, "mobilenet0_conv0_fwd", "mobilenet0_batchnorm0_fwd")
+    assert w.shape == (8, 3, 3, 3) and np.array_equal(w, rw) and np.array_equal(b, rb)
+    for i in (0, 5, 12):
+        for kind, idx in (("dw", 2 * i + 1), ("pw", 2 * i + 2)):
+            w, b = _folded(built_lib, ASSETS, stem, f"{kind}{i}")
+            rw, rb = _np_fold(net, f"mobilenet0_conv{idx}_fwd", f"mobilenet0_batchnorm{idx}_fwd")
+            assert np.array_equal(w, rw) and np.array_equal(b, rb), (kind, i)
+    w, b = _folded(built_lib, ASSETS, stem, "lateral0")
+    rw, rb = _np_fold(net, "rf_c3_lateral", "rf_c3_lateral_bn")
+    assert w.shape == (64, 1, 1, 256) and np.array_equal(w, rw) and np.array_equal(b, rb)
+    w, b = _folded(built_lib, ASSETS, stem, "aggr1")
+    rw, rb = _np_fold(net, "rf_c1_aggr", "rf_c1_aggr_bn")
+    assert np.array_equal(w, rw) and np.array_equal(b, rb)
+    # merged siblings: 64->48 = det_conv1 (32) || context_conv1 (16); heads 64->32 = cls 4 || bbox 8 || landmark 20
+    w, b = _folded(built_lib, ASSETS, stem, "ssh1.a")
+    w1, b1 = _np_fold(net, "rf_c2_det_conv1", "rf_c2_det_conv1_bn")
+    w2, b2 = _np_fold(net, "rf_c2_det_context_conv1", "rf_c2_det_context_conv1_bn")
+    assert w.shape == (48, 3, 3, 64) and np.array_equal(w, np.concatenate([w1, w2])) and np.array_equal(b, np.concatenate([b1, b2]))
+    w, b = _folded(built_lib, ASSETS, stem, "ssh2.head")
+    parts = [_np_fold(net, f"face_rpn_{k}_stride8") for k in ("cls_score", "bbox_pred", "landmark_pred")]
+    assert w.shape == (32, 1, 1, 64) and np.array_equal(w, np.concatenate([p[0] for p in parts]))
+    assert np.array_equal(b, np.concatenate([p[1] for p in parts]))
+
+
+@needs_reference
+@pytest.mark.parametrize("stem", STEMS)
+def test_cxx_loader_reads_the_reference_files(stem, built_lib, tmp_path):
+    """prototxt + caffemodel + int8 table parsed by the C++ loader and re-packed must equal the committed .rfw byte
+    for byte (the Python writer produced that one), and the plan compiled straight from the Caffe files must equal
+    the plan compiled from the .rfw."""
+    m = os.path.join(REFERENCE, "model")
+    out = str(tmp_path / (stem + ".rfw"))
+    st = built_lib.rf_convert_model(os.path.join(m, stem + ".prototxt").encode(), os.path.join(m, stem + ".caffemodel").encode(),
+                                    os.path.join(m, "mnet-deconv-0517.table.int8").encode(), out.encode())
+    assert st == 0, built_lib.rf_last_error(None)
+    assert open(out, "rb").read() == open(os.path.join(ASSETS, stem + ".rfw"), "rb").read()
+    a = _folded(built_lib, m, stem, "ssh0.b")
+    b = _folded(built_lib, ASSETS, stem, "ssh0.b")
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+
+
+def _create(lib, model_dir, network=b"net3", **kw):
+    o = _lib.rf_options()
+    o.struct_size = C.sizeof(_lib.rf_options)
+    for k, v in kw.items():
+        setattr(o, k, v)
+    h = C.c_void_p()
+    st = lib.rf_create(model_dir, network, 0.4, C.byref(o), C.byref(h))
+    msg = lib.rf_last_error(None).decode()
+    if st == 0:
+        lib.rf_destroy(h)
+    return st, msg
+
+
+def test_error_paths_without_a_gpu(built_lib, tmp_path):
+    st, msg = _create(built_lib, str(tmp_path).encode())
+    assert st == _lib.RF_ERR_IO and "mnet-deconv-0517" in msg
+    st, msg = _create(built_lib, ASSETS.encode(), network=b"net5")
+    assert st == _lib.RF_ERR_UNSUPPORTED
+    st, msg = _create(built_lib, ASSETS.encode(), precision=7)
+    assert st == _lib.RF_ERR_INVALID_ARG
+    bad = tmp_path / "mnet-deconv-0517.rfw"
+    bad.write_bytes(b"RFW1" + b"\x01\0\0\0" + b"\xff" * 64)
+    st, msg = _create(built_lib, str(tmp_path).encode())
+    assert st == _lib.RF_ERR_MODEL
+    o = _lib.rf_options()
+    o.struct_size = 4
+    h = C.c_void_p()
+    assert built_lib.rf_create(ASSETS.encode(), b"net3", 0.4, C.byref(o), C.byref(h)) == _lib.RF_ERR_INVALID_ARG
+    assert built_lib.rf_detect_batch(None, None, None, None, None, 0, 0.5, None, 0, None) == _lib.RF_ERR_INVALID_ARG
+
+
+def test_truncated_graph_is_rejected(built_lib, nets, tmp_path):
+    """A model whose topology is not mnet0.25+FPN+SSH must fail loudly at load (RF_ERR_MODEL), not mis-run."""
+    from oracle.caffe_io import write_rfw
+    import copy
+    net = copy.deepcopy(nets["mnet25"])
+    net.layer("rf_c2_det_context_conv2").num_output = 8
+    net.layer("rf_c2_det_context_conv2").blobs[0] = net.layer("rf_c2_det_context_conv2").blobs[0][:8]
+    write_rfw(net, str(tmp_path / "mnet25.rfw"))
+    st, msg = _create(built_lib, str(tmp_path).encode(), model_stem=b"mnet25")
+    assert st == _lib.RF_ERR_MODEL and "context_conv2" in msg
+    net = copy.deepcopy(nets["mnet25"])
+    net.layer("rf_c3_upsampling").blobs[0][3, 0, 1, 1] += 0.01       # no longer the fixed bilinear kernel
+    write_rfw(net, str(tmp_path / "mnet25.rfw"))
+    st, msg = _create(built_lib, str(tmp_path).encode(), model_stem=b"mnet25")
+    assert st == _lib.RF_ERR_MODEL and "bilinear" in msg
+
+
+def test_no_gpu_means_loud_failure(built_lib):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    st, msg = _create(built_lib, ASSETS.encode())
+    assert st == _lib.RF_ERR_HIP and "HIP device" in msg
+    import retinaface_amd
+    with pytest.raises(retinaface_amd.RFError):
+        retinaface_amd.RetinaFace(ASSETS)
+
+
+def test_pack_index_math_host_emulation(tmp_path):
+    exe = str(tmp_path / "test_pack")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-o", exe, os.path.join(ROOT, "tests", "csrc", "test_pack.cpp")])
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0 and "ok" in out.stdout, out.stdout
+
+
+def test_synthetic_frames_are_seeded_and_net_sized():
+    from retinaface_amd.frames import FACE_BOXES, load_base_frame, synth_frames
+    base = load_base_frame()
+    assert base.shape == (886, 1280, 3) and base.dtype == np.uint8 and len(FACE_BOXES) == 6
+    a = synth_frames(448, 448, 3, config=1, base=base)
+    b = synth_frames(448, 448, 3, config=1, base=base)
+    c = synth_frames(448, 448, 1, config=2, base=base)
+    assert all(x.shape == (448, 448, 3) and x.flags["C_CONTIGUOUS"] for x in a)
+    assert all(np.array_equal(x, y) for x, y in zip(a, b)) and not np.array_equal(a[0], c[0])
+    big = synth_frames(896, 1280, 1, config=3, base=base)[0]
+    assert big.shape == (896, 1280, 3)
+
+
+def test_shard_ranges_cover_the_batch():
+    from retinaface_amd.shard import shard_range
+    for n in (0, 1, 7, 8, 9, 256, 257):
+        for world in (1, 2, 3, 4, 8):
+            got = []
+            for r in range(world):
+                lo, hi = shard_range(n, r, world)
+                assert 0 <= lo <= hi <= n and hi - lo <= -(-n // world) if n else hi == lo
+                got += list(range(lo, hi))
+            assert got == list(range(n))
+    assert shard_range(256, 3, 8) == (96, 128)
+
+
+def _gloo_worker(rank, world, port, q):
+    import torch.distributed as dist
+    from retinaface_amd.shard import gather_records, pack_records, shard_range, unpack_records
+    from oracle.retinaface_post import Detection
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    n, cap = 5, 4
+    lo, hi = shard_range(n, rank, world)
+    f = np.float32
+    dets = [[Detection(f(0.5 + 0.01 * img + 0.001 * k), (f(img), f(k), f(img + 10), f(k + 10)), [f(img)] * 5, [f(k)] * 5,
+                       1000 * img + k) for k in range(img % 3 + 1)] for img in range(lo, hi)]
+    full = gather_records(pack_records(dets, cap), n)
+    res = unpack_records(full, cap)
+    ok = len(res) == n
+    for img in range(n):
+        ok &= len(res[img]) == img % 3 + 1
+        for k, (row, idx) in enumerate(res[img]):
+            ok &= idx == 1000 * img + k and abs(row[0] - (0.5 + 0.01 * img + 0.001 * k)) < 1e-6 and row[1] == img
+    dist.barrier()
+    dist.destroy_process_group()
+    q.put((rank, bool(ok)))
+
+
+def test_result_gather_over_gloo_world2():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_gloo_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(60)
+    assert res == [(0, True), (1, True)]
