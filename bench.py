@@ -178,22 +178,32 @@ def cpu_baseline(frames_np, args, det):
     import torch
     from oracle.caffe_io import read_rfw
     from oracle.pipeline import OracleDetector
-    cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
+    ncpu = os.cpu_count() or 1
     orc = OracleDetector(read_rfw(os.path.join(ROOT, "assets", args.model + ".rfw")))
     H, W = args.height, args.width
-    orc.detect(frames_np[0], args.threshold, 0.4, net_hw=(H, W))         # warm-up (oneDNN primitive creation)
+    # oneDNN on these tiny convolutions gets SLOWER with very many threads; pick the best thread count from a short
+    # calibration (one frame each) and report the one actually used as `cores`.
+    best = None
+    for th in sorted({min(ncpu, t) for t in (8, 16, 32, 64)}):
+        torch.set_num_threads(th)
+        orc.detect(frames_np[0], args.threshold, 0.4, net_hw=(H, W))     # warm-up (oneDNN primitive creation)
+        t = time.perf_counter()
+        orc.detect(frames_np[0], args.threshold, 0.4, net_hw=(H, W))
+        t = time.perf_counter() - t
+        if best is None or t < best[1]:
+            best = (th, t)
+    cores = best[0]
+    torch.set_num_threads(cores)
     n_img = n_faces = 0
-    ref_idx = []
+    ref_idx = [None] * len(frames_np)
     t0 = time.perf_counter()
-    while True:
-        for f in frames_np:
-            r = orc.detect(f, args.threshold, 0.4, net_hw=(H, W))
-            if len(ref_idx) < len(frames_np):
-                ref_idx.append([d.anchor_index for d in r.detections])
-            n_img += 1
-            n_faces += len(r.detections)
-        if time.perf_counter() - t0 > args.cpu_seconds:
+    while n_img < len(frames_np) or time.perf_counter() - t0 < args.cpu_seconds:
+        i = n_img % len(frames_np)
+        r = orc.detect(frames_np[i], args.threshold, 0.4, net_hw=(H, W))
+        ref_idx[i] = [d.anchor_index for d in r.detections]
+        n_img += 1
+        n_faces += len(r.detections)
+        if n_img >= len(frames_np) and time.perf_counter() - t0 > 4 * args.cpu_seconds:
             break
     dt = time.perf_counter() - t0
     gpu = det.detectBatchImages(frames_np, args.threshold)
@@ -203,8 +213,8 @@ def cpu_baseline(frames_np, args, det):
     except Exception:  # noqa: BLE001
         model = "unknown"
     return {"value": n_faces / dt, "unit": "faces/s", "cores": cores, "kind": "port",
-            "sample": f"{n_img} frames ({n_img // len(frames_np)} passes over the bench batch), {dt:.1f} s, "
-                      f"PyTorch-CPU oneDNN fp32 unfused Caffe restatement + literal decode/NMS, torch threads = {cores}",
+            "sample": f"{n_img} frames (cycling over the bench batch), {dt:.1f} s, PyTorch-CPU oneDNN fp32 unfused Caffe "
+                      f"restatement + literal decode/NMS, torch threads = {cores} of {ncpu} logical CPUs (best of 8/16/32/64)",
             "images_per_sec": n_img / dt, "ms_per_frame": dt / n_img * 1e3, "cpu_model": model,
             "gpu_faces_identical_to_oracle": bool(same)}
 

@@ -68,6 +68,13 @@ def load_library() -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
+    # PyTorch-ROCm wheels bundle their own libamdhip64.so / libhsa-runtime64.so (same SONAME as /opt/rocm's).  If this
+    # library were loaded first it would pull in /opt/rocm's copy and a later `import torch` would bring a SECOND HIP
+    # runtime into the process (the second one then finds no device).  Importing torch first makes both share one.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     path = lib_path()
     if not os.path.exists(path):
         raise RuntimeError(f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
