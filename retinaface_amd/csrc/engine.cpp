@@ -78,8 +78,9 @@ void base_anchor(int scale, float out[4]) {
     out[2] = xc + 0.5 * (w - 1); out[3] = yc + 0.5 * (h - 1);
 }
 
-constexpr int kSlots = 4;
-
+// One lane = one independent copy of everything a batch touches while in flight: stream(s), activation buffers,
+// candidate buffers, pinned host descriptor / result blocks and the captured hipGraphs.  Batches on different
+// lanes overlap on the GPU (most kernels of a batch-8 pass fill only a fraction of the 256 CUs); weights are shared.
 template <typename T>
 class EngineImpl final : public Engine {
 public:
@@ -95,24 +96,29 @@ public:
         int mc = opt_.max_candidates;
         if (mc < 64 || mc > 4096 || (mc & (mc - 1))) throw ArgError("max_candidates must be a power of two in [64, 4096]");
         if (opt_.max_detections < 1 || opt_.max_detections > 4096) throw ArgError("max_detections must be in [1, 4096]");
+        if (opt_.lanes < 1 || opt_.lanes > 16) throw ArgError("lanes must be in [1, 16]");
         if (opt_.device >= 0) RF_HIP(hipSetDevice(opt_.device));
         RF_HIP(hipGetDevice(&device_));
-        RF_HIP(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
-        for (auto &e : ev_) RF_HIP(hipEventCreate(&e));
-        build(plan);
+        upload_weights(plan);
+        lanes_.resize(opt_.lanes);
+        for (auto &l : lanes_) build_lane(l, plan);
     }
 
     ~EngineImpl() override {
-        (void)hipStreamSynchronize(stream_);
-        for (auto &kv : graphs_) (void)hipGraphExecDestroy(kv.second);
+        for (auto &l : lanes_) {
+            if (l.stream) (void)hipStreamSynchronize(l.stream);
+            for (auto &kv : l.graphs) (void)hipGraphExecDestroy(kv.second);
+            for (hipStream_t s : l.side) if (s) (void)hipStreamDestroy(s);
+            for (hipEvent_t e : l.sync_ev) (void)hipEventDestroy(e);
+            for (hipEvent_t e : l.time_ev) (void)hipEventDestroy(e);
+            if (l.done) (void)hipEventDestroy(l.done);
+            if (l.d_raw) (void)hipFree(l.d_raw);
+            if (l.stream) (void)hipStreamDestroy(l.stream);
+        }
         for (void *p : dev_allocs_) (void)hipFree(p);
         for (void *p : host_allocs_) (void)hipHostFree(p);
-        if (d_raw_) (void)hipFree(d_raw_);
         arena_.release();
-        for (auto &s : slots_) (void)hipEventDestroy(s.done);
-        for (auto &e : ev_) (void)hipEventDestroy(e);
         for (auto &e : prof_ev_) (void)hipEventDestroy(e);
-        (void)hipStreamDestroy(stream_);
     }
 
     // ------------------------------------------------------------------------------------------ API
@@ -121,6 +127,8 @@ public:
         if (n < 0 || (n > 0 && (!frames || !rows || !cols || !counts))) throw ArgError("null argument");
         if (cap_per_image < 0 || (cap_per_image > 0 && !out)) throw ArgError("out is null");
         *truncated = false;
+        std::vector<int> all_cand;
+        std::vector<std::vector<int32_t>> all_anchor;
         for (int base = 0; base < n; base += opt_.max_batch) {
             int m = std::min(opt_.max_batch, n - base);
             std::vector<int> st(m);
@@ -129,7 +137,12 @@ public:
             bool tr = false;
             wait(ticket, out ? out + (size_t)base * cap_per_image : nullptr, cap_per_image, counts + base, &tr);
             *truncated = *truncated || tr;
+            all_cand.insert(all_cand.end(), last_cand_counts_.begin(), last_cand_counts_.end());
+            for (auto &v : last_anchor_) all_anchor.push_back(std::move(v));
         }
+        last_n_ = n;                         // the "most recent completed batch" of a chunked call is the whole call
+        last_cand_counts_.swap(all_cand);
+        last_anchor_.swap(all_anchor);
     }
 
     int enqueue(const void *const *d_frames, const int *rows, const int *cols, const int *steps, int n,
@@ -142,17 +155,19 @@ public:
     }
 
     void wait(int ticket, rf_face *out, int cap_per_image, int *counts, bool *truncated) override {
-        if (ticket < 0 || ticket >= kSlots || !slots_[ticket].busy) throw ArgError("wait: invalid ticket");
-        Slot &s = slots_[ticket];
+        if (ticket < 0 || ticket >= (int)lanes_.size() || !lanes_[ticket].busy) throw ArgError("wait: invalid ticket");
+        Lane &s = lanes_[ticket];
         RF_HIP(hipEventSynchronize(s.done));
         s.busy = false;
+        last_lane_ = ticket;
         bool tr = false;
         last_n_ = s.n;
         last_cand_counts_.assign(s.n, 0);
         last_anchor_.assign(s.n, std::vector<int32_t>());
+        const int mb = opt_.max_batch;
         for (int i = 0; i < s.n; i++) {
             int kept = s.empty[i] ? 0 : s.h_counts[i];
-            int ncand = s.empty[i] ? 0 : s.h_counts[opt_.max_batch + i];
+            int ncand = s.empty[i] ? 0 : s.h_counts[mb + i];
             last_cand_counts_[i] = ncand;
             if (ncand > opt_.max_candidates) tr = true;
             int avail = std::min(kept, opt_.max_detections);
@@ -167,16 +182,16 @@ public:
         }
         if (s.timed) {
             float a = 0, b = 0, c = 0;
-            (void)hipEventElapsedTime(&a, ev_[0], ev_[1]);
-            (void)hipEventElapsedTime(&b, ev_[1], ev_[2]);
-            (void)hipEventElapsedTime(&c, ev_[2], ev_[3]);
+            (void)hipEventElapsedTime(&a, s.time_ev[0], s.time_ev[1]);
+            (void)hipEventElapsedTime(&b, s.time_ev[1], s.time_ev[2]);
+            (void)hipEventElapsedTime(&c, s.time_ev[2], s.time_ev[3]);
             t_pre_ = a; t_infer_ = b; t_post_ = c; t_total_ = a + b + c;
             have_split_ = true;
         }
         if (truncated) *truncated = tr;
     }
 
-    int num_slots() const override { return kSlots; }
+    int num_slots() const override { return (int)lanes_.size(); }
 
     int last_anchor_indices(int image, int32_t *out, int cap) const override {
         if (image < 0 || image >= last_n_) throw ArgError("image index out of range");
@@ -200,6 +215,7 @@ public:
         static const char *kinds[3] = {"face_rpn_cls_prob_reshape_stride", "face_rpn_bbox_pred_stride",
                                        "face_rpn_landmark_pred_stride"};
         static const int chans[3] = {4, 8, 20};
+        Lane &l = lanes_[last_lane_];
         for (int si = 0; si < 3; si++)
             for (int k = 0; k < 3; k++) {
                 if (blob != std::string(kinds[k]) + std::to_string(strides_[si])) continue;
@@ -208,23 +224,24 @@ public:
                 size_t cnt = hw * chans[k];
                 if (!dst) return (long)cnt;
                 if (cap < cnt) throw ArgError("destination too small");
-                RF_HIP(hipStreamSynchronize(stream_));
-                RF_HIP(hipMemcpy(dst, d_dump_[si][k] + (size_t)image * cnt, cnt * sizeof(float), hipMemcpyDeviceToHost));
+                RF_HIP(hipStreamSynchronize(l.stream));
+                RF_HIP(hipMemcpy(dst, l.d_dump[si][k] + (size_t)image * cnt, cnt * sizeof(float), hipMemcpyDeviceToHost));
                 return (long)cnt;
             }
         throw ArgError("unknown output blob '" + blob + "'");
     }
 
     long debug_activation(const std::string &blob, int image, float *dst, size_t cap, int dims[3]) override {
-        auto it = acts_.find(blob);
-        if (it == acts_.end()) throw ArgError("unknown activation '" + blob + "'");
+        Lane &l = lanes_[last_lane_];
+        auto it = l.acts.find(blob);
+        if (it == l.acts.end()) throw ArgError("unknown activation '" + blob + "'");
         const ActInfo &ai = it->second;
         if (image < 0 || image >= opt_.max_batch) throw ArgError("image index out of range");
         size_t cnt = (size_t)ai.h * ai.w * ai.c;
         if (dims) { dims[0] = ai.h; dims[1] = ai.w; dims[2] = ai.c; }
         if (!dst) return (long)cnt;
         if (cap < cnt) throw ArgError("destination too small");
-        RF_HIP(hipStreamSynchronize(stream_));
+        RF_HIP(hipStreamSynchronize(l.stream));
         std::vector<T> tmp(cnt);
         RF_HIP(hipMemcpy(tmp.data(), (const T *)ai.ptr + (size_t)image * cnt, cnt * sizeof(T), hipMemcpyDeviceToHost));
         for (size_t i = 0; i < cnt; i++) dst[i] = Cast<T>::to(tmp[i]);
@@ -234,23 +251,22 @@ public:
     int profile(const void *const *d_frames, int n, int iters, int cap, const char **names, float *avg_ms,
                 double *alg_bytes, double *macs) override {
         if (n < 1 || n > opt_.max_batch || iters < 1) throw ArgError("profile: bad n / iters");
-        RF_HIP(hipStreamSynchronize(stream_));
-        std::vector<FrameDesc> fd(2 * opt_.max_batch);
-        for (int i = 0; i < n; i++) fd[opt_.max_batch + i] = FrameDesc{(const uint8_t *)d_frames[i], net_h_, net_w_, net_w_ * 3, 0};
-        RunParams rp{0.5f, nms_threshold_, n, 0};
-        RF_HIP(hipMemcpy(d_frames_, fd.data(), fd.size() * sizeof(FrameDesc), hipMemcpyHostToDevice));
-        RF_HIP(hipMemcpy(d_params_, &rp, sizeof(rp), hipMemcpyHostToDevice));
-        size_t nops = ops_.size();
+        Lane &l = lanes_[0];
+        if (l.busy) { RF_HIP(hipEventSynchronize(l.done)); }
+        RF_HIP(hipStreamSynchronize(l.stream));
+        const int mb = opt_.max_batch;
+        for (int i = 0; i < n; i++) l.h_frames[mb + i] = FrameDesc{(const uint8_t *)d_frames[i], net_h_, net_w_, net_w_ * 3, 0};
+        *l.h_params = RunParams{0.5f, nms_threshold_, n, 0};
+        size_t nops = l.ops.size();
         while (prof_ev_.size() < 2 * nops) { hipEvent_t e; RF_HIP(hipEventCreate(&e)); prof_ev_.push_back(e); }
         std::vector<double> sum(nops, 0.0);
         for (int it = -2; it < iters; it++) {      // two untimed warm-up passes
-            RF_HIP(hipMemsetAsync(d_counts_, 0, 2 * opt_.max_batch * sizeof(int), stream_));
             for (size_t k = 0; k < nops; k++) {
-                RF_HIP(hipEventRecord(prof_ev_[2 * k], stream_));
-                ops_[k].launch(stream_, n);
-                RF_HIP(hipEventRecord(prof_ev_[2 * k + 1], stream_));
+                RF_HIP(hipEventRecord(prof_ev_[2 * k], l.stream));
+                l.ops[k].launch(l.stream, n);
+                RF_HIP(hipEventRecord(prof_ev_[2 * k + 1], l.stream));
             }
-            RF_HIP(hipStreamSynchronize(stream_));
+            RF_HIP(hipStreamSynchronize(l.stream));
             RF_HIP(hipGetLastError());
             if (it < 0) continue;
             for (size_t k = 0; k < nops; k++) {
@@ -260,21 +276,42 @@ public:
             }
         }
         for (size_t k = 0; k < nops && (int)k < cap; k++) {
-            if (names) names[k] = ops_[k].name.c_str();
+            if (names) names[k] = l.ops[k].name.c_str();
             if (avg_ms) avg_ms[k] = (float)(sum[k] / iters);
-            if (alg_bytes) alg_bytes[k] = n * (ops_[k].alg_u8_in + sizeof(T) * (ops_[k].alg_elems_in + ops_[k].alg_elems_out));
-            if (macs) macs[k] = n * ops_[k].macs;
+            if (alg_bytes) alg_bytes[k] = n * (l.ops[k].alg_u8_in + sizeof(T) * (l.ops[k].alg_elems_in + l.ops[k].alg_elems_out));
+            if (macs) macs[k] = n * l.ops[k].macs;
         }
         return (int)nops;
     }
 
 private:
-    struct Slot {
-        FrameDesc *h_frames = nullptr;   // [2*max_batch]: [0,mb) source frames, [mb,2mb) what conv0 reads
+    struct GemmW { size_t w, b; };
+    struct DwW { size_t w, b; };
+
+    struct Lane {
+        hipStream_t stream = nullptr;
+        hipStream_t side[3] = {nullptr, nullptr, nullptr};
+        std::vector<hipEvent_t> sync_ev;      // fork / join edges between stream and side[]
+        hipEvent_t time_ev[4] = {nullptr, nullptr, nullptr, nullptr};
+        hipEvent_t done = nullptr;
+        std::map<int, hipGraphExec_t> graphs;
+        std::set<int> warmed;
+        std::map<std::string, ActInfo> acts;
+        std::vector<OpInfo> ops;              // serial (topological) order; indices below pick ops for the branch schedule
+        size_t i_conv0 = 0, i_blocks = 0, i_lat[3] = {0, 0, 0}, i_aggr[2] = {0, 0}, i_ssh[3] = {0, 0, 0}, i_head[3] = {0, 0, 0},
+               i_nms = 0, first_post = 0;
+        // pinned host, read / written by the GPU directly
+        FrameDesc *h_frames = nullptr;        // [2*max_batch]: [0,mb) source frames, [mb,2mb) what conv0 reads
         RunParams *h_params = nullptr;
-        int *h_counts = nullptr;         // [2*max_batch]: kept counts, candidate counts
-        Candidate *h_out = nullptr;      // [max_batch*max_det]
-        hipEvent_t done;
+        int *h_counts = nullptr;              // [2*max_batch]: kept counts, candidate counts
+        Candidate *h_out = nullptr;           // [max_batch*max_det]
+        // device
+        RunParams *d_params = nullptr;
+        int *d_cand_count = nullptr;
+        Candidate *d_cand = nullptr;
+        uint8_t *d_canvas = nullptr, *d_raw = nullptr;
+        size_t raw_stride = 0;
+        float *d_dump[3][3] = {};
         bool busy = false, timed = false;
         int n = 0;
         std::vector<char> empty;
@@ -291,91 +328,89 @@ private:
         void *p = nullptr;
         RF_HIP(hipHostMalloc(&p, std::max<size_t>(count * sizeof(U), 256), hipHostMallocDefault));
         host_allocs_.push_back(p);
+        memset(p, 0, std::max<size_t>(count * sizeof(U), 256));
         return (U *)p;
     }
-    T *act(const std::string &name, int h, int w, int c) {
-        T *p = dalloc<T>((size_t)opt_.max_batch * h * w * c);
-        acts_[name] = ActInfo{p, h, w, c};
-        return p;
+
+    GemmW put_gemm(const FoldedConv &f) {
+        int ktot = f.k * f.k * (f.cin / f.group);
+        GemmW g;
+        g.w = arena_.put(pack_gemm<T>(f.w, f.cout, ktot, mma_k<T>(), mma_kpl<T>()));
+        g.b = arena_.put(f.b);
+        return g;
     }
 
-    void build(const Plan &plan) {
-        const int mb = opt_.max_batch;
-        const int K = mma_k<T>(), KPL = mma_kpl<T>();
-        const int H = net_h_, W = net_w_;
-        const double P = (double)H * W;
-
-        // ---- run-time tables
-        d_frames_ = dalloc<FrameDesc>(2 * mb);
-        d_params_ = dalloc<RunParams>(1);
-        const size_t hdr = ((2 * mb * sizeof(int) + 255) / 256) * 256;
-        result_bytes_ = hdr + (size_t)mb * opt_.max_detections * sizeof(Candidate);
-        d_result_ = dalloc<unsigned char>(result_bytes_);
-        d_counts_ = (int *)d_result_;
-        d_out_ = (Candidate *)(d_result_ + hdr);
-        result_hdr_ = hdr;
-        d_cand_ = dalloc<Candidate>((size_t)mb * opt_.max_candidates);
-        d_canvas_ = dalloc<uint8_t>((size_t)mb * H * W * 3);
-        slots_.resize(kSlots);
-        for (auto &s : slots_) {
-            s.h_frames = halloc<FrameDesc>(2 * mb);
-            s.h_params = halloc<RunParams>(1);
-            unsigned char *res = halloc<unsigned char>(result_bytes_);
-            s.h_counts = (int *)res;
-            s.h_out = (Candidate *)(res + hdr);
-            RF_HIP(hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
-        }
-
-        // ---- weights -> arena (offsets first, pointers after upload)
-        struct GemmW { size_t w, b; };
-        auto put_gemm = [&](const FoldedConv &f) {
-            int ktot = f.k * f.k * (f.cin / f.group);
-            GemmW g;
-            g.w = arena_.put(pack_gemm<T>(f.w, f.cout, ktot, K, KPL));
-            g.b = arena_.put(f.b);
-            return g;
-        };
-        size_t c0_w = arena_.put(plan.conv0.w), c0_b = arena_.put(plan.conv0.b);
-        struct DwW { size_t w, b; };
-        std::vector<DwW> dw_w;
-        std::vector<GemmW> pw_w;
+    void upload_weights(const Plan &plan) {
+        c0_w_ = arena_.put(plan.conv0.w);
+        c0_b_ = arena_.put(plan.conv0.b);
         for (const auto &blk : plan.blocks) {
-            // depthwise weights [c][3][3][1] -> [tap][c]
-            int c = blk.dw.cout;
+            int c = blk.dw.cout;                       // depthwise weights [c][3][3][1] -> [tap][c]
             std::vector<T> w((size_t)9 * c);
             for (int ch = 0; ch < c; ch++)
                 for (int t = 0; t < 9; t++) w[(size_t)t * c + ch] = Cast<T>::from(blk.dw.w[(size_t)ch * 9 + t]);
-            dw_w.push_back(DwW{arena_.put(w), arena_.put(blk.dw.b)});
-            pw_w.push_back(put_gemm(blk.pw));
+            dw_w_.push_back(DwW{arena_.put(w), arena_.put(blk.dw.b)});
+            pw_w_.push_back(put_gemm(blk.pw));
         }
-        GemmW lat_w[3] = {put_gemm(plan.lateral[0]), put_gemm(plan.lateral[1]), put_gemm(plan.lateral[2])};
-        GemmW aggr_w[2] = {put_gemm(plan.aggr[0]), put_gemm(plan.aggr[1])};
-        GemmW ssh_w[3][4];
+        for (int i = 0; i < 3; i++) lat_w_[i] = put_gemm(plan.lateral[i]);
+        for (int i = 0; i < 2; i++) aggr_w_[i] = put_gemm(plan.aggr[i]);
         for (int i = 0; i < 3; i++) {
-            ssh_w[i][0] = put_gemm(plan.ssh[i].conv_a);
-            ssh_w[i][1] = put_gemm(plan.ssh[i].conv_b);
-            ssh_w[i][2] = put_gemm(plan.ssh[i].conv_c);
-            ssh_w[i][3] = put_gemm(plan.ssh[i].head);
+            ssh_w_[i][0] = put_gemm(plan.ssh[i].conv_a);
+            ssh_w_[i][1] = put_gemm(plan.ssh[i].conv_b);
+            ssh_w_[i][2] = put_gemm(plan.ssh[i].conv_c);
+            ssh_w_[i][3] = put_gemm(plan.ssh[i].head);
         }
         arena_.upload();
+    }
 
-        // ---- activations (one buffer per reference blob that survives fusion; 288 GB of HBM: nothing is recycled)
+    void build_lane(Lane &L, const Plan &plan) {
+        const int mb = opt_.max_batch;
+        const int H = net_h_, W = net_w_;
+        const double P = (double)H * W;
+        RF_HIP(hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking));
+        for (auto &s : L.side) RF_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+        L.sync_ev.resize(12);
+        for (auto &e : L.sync_ev) RF_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        for (auto &e : L.time_ev) RF_HIP(hipEventCreate(&e));
+        RF_HIP(hipEventCreateWithFlags(&L.done, hipEventDisableTiming));
+
+        L.h_frames = halloc<FrameDesc>(2 * mb);
+        L.h_params = halloc<RunParams>(1);
+        const size_t hdr = ((2 * mb * sizeof(int) + 255) / 256) * 256;
+        unsigned char *res = halloc<unsigned char>(hdr + (size_t)mb * opt_.max_detections * sizeof(Candidate));
+        L.h_counts = (int *)res;
+        L.h_out = (Candidate *)(res + hdr);
+        L.d_params = dalloc<RunParams>(1);
+        L.d_cand_count = dalloc<int>(mb);
+        RF_HIP(hipMemset(L.d_cand_count, 0, mb * sizeof(int)));
+        L.d_cand = dalloc<Candidate>((size_t)mb * opt_.max_candidates);
+        L.d_canvas = dalloc<uint8_t>((size_t)mb * H * W * 3);
+
+        auto act = [&](const std::string &name, int h, int w, int c) {
+            T *p = dalloc<T>((size_t)mb * h * w * c);
+            L.acts[name] = ActInfo{p, h, w, c};
+            return p;
+        };
+        // activations: one buffer per reference blob that survives fusion (288 GB of HBM: nothing is recycled)
         int h = H / 2, w = W / 2;
         T *cur = act(plan.conv0.out_blob, h, w, 8);
-        T *conv0_out = cur;
         {
             OpInfo op;
             op.name = "pre+" + plan.conv0.name;
             op.alg_u8_in = 3.0 * P;
             op.alg_elems_out = 8.0 * h * w;
             op.macs = plan.conv0.macs_per_out_pixel() * h * w;
-            const float *wp = arena_.ptr<float>(c0_w), *bp = arena_.ptr<float>(c0_b);
-            const FrameDesc *fr = d_frames_ + mb;
-            op.launch = [fr, conv0_out, wp, bp, H, W](hipStream_t s, int n) { launch_conv0<T>(s, fr, conv0_out, wp, bp, n, H, W); };
-            ops_.push_back(op);
+            const float *wp = arena_.ptr<float>(c0_w_), *bp = arena_.ptr<float>(c0_b_);
+            const FrameDesc *fr = L.h_frames + mb;
+            const RunParams *pin = L.h_params;
+            RunParams *pout = L.d_params;
+            T *o = cur;
+            op.launch = [=](hipStream_t s, int n) { launch_conv0<T>(s, fr, o, wp, bp, pin, pout, n, H, W); };
+            L.i_conv0 = L.ops.size();
+            L.ops.push_back(op);
         }
         int c = 8;
         T *taps[3] = {nullptr, nullptr, nullptr};   // c3 (stride 32), c2 (16), c1 (8)
+        L.i_blocks = L.ops.size();
         for (size_t i = 0; i < plan.blocks.size(); i++) {
             const auto &blk = plan.blocks[i];
             int ho = h / blk.dw.stride, wo = w / blk.dw.stride;
@@ -384,8 +419,8 @@ private:
                 throw ModelError("no kernel instance for depthwise/pointwise block " + blk.dw.name);
             DwPwParams<T> p;
             p.in = cur; p.out = out;
-            p.dw_w = arena_.ptr<T>(dw_w[i].w); p.dw_b = arena_.ptr<float>(dw_w[i].b);
-            p.pw_w = arena_.ptr<T>(pw_w[i].w); p.pw_b = arena_.ptr<float>(pw_w[i].b);
+            p.dw_w = arena_.ptr<T>(dw_w_[i].w); p.dw_b = arena_.ptr<float>(dw_w_[i].b);
+            p.pw_w = arena_.ptr<T>(pw_w_[i].w); p.pw_b = arena_.ptr<float>(pw_w_[i].b);
             p.n = 0; p.hin = h; p.win = w; p.hout = ho; p.wout = wo;
             p.cin = c; p.cout = blk.pw.cout; p.stride = blk.dw.stride; p.has_dw = true;
             OpInfo op;
@@ -394,22 +429,22 @@ private:
             op.alg_elems_out = (double)c * ho * wo + (double)blk.pw.cout * ho * wo;
             op.macs = (blk.dw.macs_per_out_pixel() + blk.pw.macs_per_out_pixel()) * ho * wo;
             op.launch = [p](hipStream_t s, int n) { DwPwParams<T> q = p; q.n = n; launch_dwpw<T>(s, q); };
-            ops_.push_back(op);
+            L.ops.push_back(op);
             cur = out; h = ho; w = wo; c = blk.pw.cout;
             if (i == 4) taps[2] = out;
             if (i == 10) taps[1] = out;
             if (i == 12) taps[0] = out;
         }
         // FPN: laterals (1x1), then aggr convs with the upsample+add fused into their input staging
-        T *feat[3];
+        T *feat[3], *lat[3];
         const int tap_c[3] = {256, 128, 64};
-        T *lat[3];
+        OpInfo lat_ops[3];
         for (int i = 0; i < 3; i++) {
             int fh = H / strides_[i], fw = W / strides_[i];
             lat[i] = act(plan.lateral[i].out_blob, fh, fw, 64);
             DwPwParams<T> p;
             p.in = taps[i]; p.out = lat[i]; p.dw_w = nullptr; p.dw_b = nullptr;
-            p.pw_w = arena_.ptr<T>(lat_w[i].w); p.pw_b = arena_.ptr<float>(lat_w[i].b);
+            p.pw_w = arena_.ptr<T>(lat_w_[i].w); p.pw_b = arena_.ptr<float>(lat_w_[i].b);
             p.n = 0; p.hin = fh; p.win = fw; p.hout = fh; p.wout = fw;
             p.cin = tap_c[i]; p.cout = 64; p.stride = 1; p.has_dw = false;
             OpInfo op;
@@ -418,18 +453,20 @@ private:
             op.alg_elems_out = 64.0 * fh * fw;
             op.macs = plan.lateral[i].macs_per_out_pixel() * fh * fw;
             op.launch = [p](hipStream_t s, int n) { DwPwParams<T> q = p; q.n = n; launch_dwpw<T>(s, q); };
-            lat_ops_[i] = op;
+            lat_ops[i] = op;
         }
         feat[0] = lat[0];
-        // order: c3 lateral, c2 lateral, c2 aggr, c1 lateral, c1 aggr (dependencies of the prototxt order)
-        ops_.push_back(lat_ops_[0]);
+        // serial order: c3 lateral, c2 lateral, c2 aggr, c1 lateral, c1 aggr (the prototxt's order)
+        L.i_lat[0] = L.ops.size();
+        L.ops.push_back(lat_ops[0]);
         for (int i = 0; i < 2; i++) {
-            ops_.push_back(lat_ops_[i + 1]);
+            L.i_lat[i + 1] = L.ops.size();
+            L.ops.push_back(lat_ops[i + 1]);
             int fh = H / strides_[i + 1], fw = W / strides_[i + 1];
             feat[i + 1] = act(plan.aggr[i].out_blob, fh, fw, 64);
             Conv3Params<T> p;
             p.in = lat[i + 1]; p.in_ld = 64; p.in_off = 0; p.up = feat[i];
-            p.w = arena_.ptr<T>(aggr_w[i].w); p.b = arena_.ptr<float>(aggr_w[i].b);
+            p.w = arena_.ptr<T>(aggr_w_[i].w); p.b = arena_.ptr<float>(aggr_w_[i].b);
             p.out0 = feat[i + 1]; p.ld0 = 64; p.off0 = 0; p.n0 = 64; p.out1 = nullptr; p.ld1 = 0; p.off1 = 0;
             p.n = 0; p.h = fh; p.w_ = fw; p.cin = 64; p.cout = 64;
             OpInfo op;
@@ -438,10 +475,10 @@ private:
             op.alg_elems_out = 64.0 * fh * fw + 64.0 * fh * fw;               // deconv output + conv output
             op.macs = plan.aggr[i].macs_per_out_pixel() * fh * fw + 16.0 * 64 * (fh / 2) * (fw / 2);
             op.launch = [p](hipStream_t s, int n) { Conv3Params<T> q = p; q.n = n; launch_conv3x3<T>(s, q); };
-            ops_.push_back(op);
+            L.i_aggr[i] = L.ops.size();
+            L.ops.push_back(op);
         }
-        // SSH modules + heads
-        first_post_op_ = 0;
+        // SSH modules, then the heads, then NMS
         int anchor_off = 0;
         std::vector<OpInfo> head_ops;
         for (int i = 0; i < 3; i++) {
@@ -464,24 +501,25 @@ private:
                 op.alg_elems_out = (double)f.cout * fh * fw;
                 op.macs = f.macs_per_out_pixel() * fh * fw;
                 op.launch = [p](hipStream_t s, int n) { Conv3Params<T> q = p; q.n = n; launch_conv3x3<T>(s, q); };
-                ops_.push_back(op);
+                L.ops.push_back(op);
             };
-            conv_op(m.conv_a, ssh_w[i][0], feat[i], 64, cat, 64, 0, 32, ctx1, 16, 0, 2);
-            conv_op(m.conv_b, ssh_w[i][1], ctx1, 16, cat, 64, 32, 16, ctx31, 16, 0, 2);
-            conv_op(m.conv_c, ssh_w[i][2], ctx31, 16, cat, 64, 48, 16, nullptr, 0, 0, 1);
+            L.i_ssh[i] = L.ops.size();
+            conv_op(m.conv_a, ssh_w_[i][0], feat[i], 64, cat, 64, 0, 32, ctx1, 16, 0, 2);
+            conv_op(m.conv_b, ssh_w_[i][1], ctx1, 16, cat, 64, 32, 16, ctx31, 16, 0, 2);
+            conv_op(m.conv_c, ssh_w_[i][2], ctx31, 16, cat, 64, 48, 16, nullptr, 0, 0, 1);
             HeadParams<T> hp;
-            hp.in = cat; hp.w = arena_.ptr<T>(ssh_w[i][3].w); hp.b = arena_.ptr<float>(ssh_w[i][3].b);
+            hp.in = cat; hp.w = arena_.ptr<T>(ssh_w_[i][3].w); hp.b = arena_.ptr<float>(ssh_w_[i][3].b);
             hp.n = 0; hp.h = fh; hp.w_ = fw; hp.stride = strides_[i]; hp.anchor_offset = anchor_off;
             static const int scales[3][2] = {{32, 16}, {8, 4}, {2, 1}};
             base_anchor(scales[i][0], hp.base[0]);
             base_anchor(scales[i][1], hp.base[1]);
-            hp.net_h = H; hp.net_w = W; hp.params = d_params_;
-            hp.cand = d_cand_; hp.cand_count = d_counts_ + mb; hp.cap = opt_.max_candidates;
+            hp.net_h = H; hp.net_w = W; hp.params = L.d_params;
+            hp.cand = L.d_cand; hp.cand_count = L.d_cand_count; hp.cap = opt_.max_candidates;
             hp.dump_prob = hp.dump_bbox = hp.dump_lmk = nullptr;
             if (opt_.keep_outputs) {
                 static const int chans[3] = {4, 8, 20};
-                for (int k = 0; k < 3; k++) d_dump_[i][k] = dalloc<float>((size_t)mb * chans[k] * fh * fw);
-                hp.dump_prob = d_dump_[i][0]; hp.dump_bbox = d_dump_[i][1]; hp.dump_lmk = d_dump_[i][2];
+                for (int k = 0; k < 3; k++) L.d_dump[i][k] = dalloc<float>((size_t)mb * chans[k] * fh * fw);
+                hp.dump_prob = L.d_dump[i][0]; hp.dump_bbox = L.d_dump[i][1]; hp.dump_lmk = L.d_dump[i][2];
             }
             OpInfo op;
             op.name = m.head.name + "+softmax+decode";
@@ -492,36 +530,72 @@ private:
             head_ops.push_back(op);
             anchor_off += 2 * fh * fw;
         }
-        total_anchors_ = anchor_off;
-        first_post_op_ = ops_.size();
-        for (auto &op : head_ops) ops_.push_back(op);
+        L.first_post = L.ops.size();
+        for (int i = 0; i < 3; i++) { L.i_head[i] = L.ops.size(); L.ops.push_back(head_ops[i]); }
         {
             NmsParams np;
-            np.cand = d_cand_; np.cand_count = d_counts_ + mb; np.cap = opt_.max_candidates; np.params = d_params_;
-            np.out = d_out_; np.out_count = d_counts_; np.max_det = opt_.max_detections; np.n = 0;
+            np.cand = L.d_cand; np.cand_count = L.d_cand_count; np.cap = opt_.max_candidates; np.params = L.d_params;
+            np.out = L.h_out; np.out_count = L.h_counts; np.out_cand_count = L.h_counts + mb;
+            np.max_det = opt_.max_detections; np.n = 0;
             OpInfo op;
             op.name = "sort+nms";
             op.launch = [np](hipStream_t s, int n) { NmsParams q = np; q.n = n; launch_nms(s, q); };
-            ops_.push_back(op);
+            L.i_nms = L.ops.size();
+            L.ops.push_back(op);
         }
     }
 
     // ------------------------------------------------------------------------------------------ run
-    void ensure_raw(size_t per_image) {
-        if (per_image <= raw_stride_) return;
-        RF_HIP(hipStreamSynchronize(stream_));
-        if (d_raw_) RF_HIP(hipFree(d_raw_));
-        d_raw_ = nullptr;
-        raw_stride_ = ((per_image + 255) / 256) * 256;
-        RF_HIP(hipMalloc((void **)&d_raw_, raw_stride_ * opt_.max_batch));
+    void ensure_raw(Lane &L, size_t per_image) {
+        if (per_image <= L.raw_stride) return;
+        RF_HIP(hipStreamSynchronize(L.stream));
+        if (L.d_raw) RF_HIP(hipFree(L.d_raw));
+        L.d_raw = nullptr;
+        L.raw_stride = ((per_image + 255) / 256) * 256;
+        RF_HIP(hipMalloc((void **)&L.d_raw, L.raw_stride * opt_.max_batch));
+    }
+
+    // Branch schedule (used for graph capture and for un-timed eager runs): the three laterals and the stride-32 /
+    // stride-16 SSH+head chains run on side streams next to the critical path
+    //   conv0 -> 13 dw/pw blocks -> c3 lateral -> c2 aggr -> c1 aggr -> SSH(stride 8) -> head -> NMS      (22 launches deep
+    // instead of 32).  fork/join are event edges; under capture they become graph dependencies.
+    void issue_parallel(Lane &L, int n) {
+        hipStream_t S0 = L.stream, S1 = L.side[0], S2 = L.side[1], S3 = L.side[2];
+        int ev = 0;
+        auto edge = [&](hipStream_t from, hipStream_t to) {
+            hipEvent_t e = L.sync_ev[ev++];
+            RF_HIP(hipEventRecord(e, from));
+            RF_HIP(hipStreamWaitEvent(to, e, 0));
+        };
+        auto run = [&](size_t i, hipStream_t s) { L.ops[i].launch(s, n); };
+        run(L.i_conv0, S0);
+        for (size_t i = 0; i < 5; i++) run(L.i_blocks + i, S0);
+        edge(S0, S1); run(L.i_lat[2], S1);                                  // c1 lateral (stride 8 tap = block 4)
+        for (size_t i = 5; i < 11; i++) run(L.i_blocks + i, S0);
+        edge(S0, S2); run(L.i_lat[1], S2);                                  // c2 lateral (stride 16 tap = block 10)
+        for (size_t i = 11; i < 13; i++) run(L.i_blocks + i, S0);
+        run(L.i_lat[0], S0);                                                // c3 lateral = P3
+        edge(S0, S3);
+        for (size_t k = 0; k < 3; k++) run(L.i_ssh[0] + k, S3);             // SSH + head of stride 32
+        run(L.i_head[0], S3);
+        edge(S2, S0); run(L.i_aggr[0], S0);                                 // P2 = aggr(c2 lateral + up(P3))
+        edge(S0, S2);
+        for (size_t k = 0; k < 3; k++) run(L.i_ssh[1] + k, S2);             // SSH + head of stride 16
+        run(L.i_head[1], S2);
+        edge(S1, S0); run(L.i_aggr[1], S0);                                 // P1 = aggr(c1 lateral + up(P2))
+        for (size_t k = 0; k < 3; k++) run(L.i_ssh[2] + k, S0);
+        run(L.i_head[2], S0);
+        edge(S3, S0);
+        edge(S2, S0);
+        run(L.i_nms, S0);
     }
 
     int submit(const uint8_t *const *frames, const int *rows, const int *cols, const int *steps, int n, bool on_device,
                float threshold, bool timed) {
         const int mb = opt_.max_batch;
-        int ticket = next_slot_;
-        next_slot_ = (next_slot_ + 1) % kSlots;
-        Slot &s = slots_[ticket];
+        int ticket = next_lane_;
+        next_lane_ = (next_lane_ + 1) % (int)lanes_.size();
+        Lane &s = lanes_[ticket];
         if (s.busy) { RF_HIP(hipEventSynchronize(s.done)); s.busy = false; }
         s.n = n;
         s.empty.assign(n, 0);
@@ -536,62 +610,63 @@ private:
             if (rows[i] > net_h_ || cols[i] > net_w_) need_resize = true;
             max_raw = std::max(max_raw, (size_t)rows[i] * cols[i] * 3);
         }
-        const bool eager = timed && !opt_.use_graph;
-        s.timed = eager;
-        if (eager) RF_HIP(hipEventRecord(ev_[0], stream_));
-        if (!on_device) ensure_raw(max_raw);
+        const bool eager_timed = timed && !opt_.use_graph;
+        s.timed = eager_timed;
+        if (eager_timed) RF_HIP(hipEventRecord(s.time_ev[0], s.stream));
+        if (!on_device) ensure_raw(s, max_raw);
         for (int i = 0; i < n; i++) {
             FrameDesc src{nullptr, 0, 0, 0, 0};
             if (!s.empty[i]) {
                 if (on_device) {
                     src = FrameDesc{frames[i], rows[i], cols[i], steps[i], 0};
                 } else {
-                    uint8_t *dst = d_raw_ + (size_t)i * raw_stride_;
+                    uint8_t *dst = s.d_raw + (size_t)i * s.raw_stride;
                     RF_HIP(hipMemcpy2DAsync(dst, (size_t)cols[i] * 3, frames[i], (size_t)steps[i], (size_t)cols[i] * 3,
-                                            (size_t)rows[i], hipMemcpyHostToDevice, stream_));
+                                            (size_t)rows[i], hipMemcpyHostToDevice, s.stream));
                     src = FrameDesc{dst, rows[i], cols[i], cols[i] * 3, 0};
                 }
             }
             s.h_frames[i] = src;
             s.h_frames[mb + i] = need_resize
-                                     ? FrameDesc{d_canvas_ + (size_t)i * net_h_ * net_w_ * 3, net_h_, net_w_, net_w_ * 3, 0}
+                                     ? FrameDesc{s.d_canvas + (size_t)i * net_h_ * net_w_ * 3, net_h_, net_w_, net_w_ * 3, 0}
                                      : src;
         }
         *s.h_params = RunParams{threshold, nms_threshold_, n, 0};
-        RF_HIP(hipMemcpyAsync(d_frames_, s.h_frames, 2 * mb * sizeof(FrameDesc), hipMemcpyHostToDevice, stream_));
-        RF_HIP(hipMemcpyAsync(d_params_, s.h_params, sizeof(RunParams), hipMemcpyHostToDevice, stream_));
-        if (need_resize) launch_resize_area(stream_, d_frames_, d_canvas_, n, net_h_, net_w_);
-        if (eager) RF_HIP(hipEventRecord(ev_[1], stream_));
-        if (opt_.use_graph && warmed_.count(n)) {
-            auto it = graphs_.find(n);
-            if (it == graphs_.end()) it = graphs_.emplace(n, capture(n)).first;
-            RF_HIP(hipGraphLaunch(it->second, stream_));
-        } else {
-            RF_HIP(hipMemsetAsync(d_counts_, 0, 2 * mb * sizeof(int), stream_));
-            for (size_t k = 0; k < ops_.size(); k++) {
-                if (eager && k == first_post_op_) RF_HIP(hipEventRecord(ev_[2], stream_));
-                ops_[k].launch(stream_, n);
+        if (need_resize) launch_resize_area(s.stream, s.h_frames, s.d_canvas, n, net_h_, net_w_);
+        if (eager_timed) RF_HIP(hipEventRecord(s.time_ev[1], s.stream));
+        if (opt_.use_graph && s.warmed.count(n)) {
+            auto it = s.graphs.find(n);
+            if (it == s.graphs.end()) it = s.graphs.emplace(n, capture(s, n)).first;
+            RF_HIP(hipGraphLaunch(it->second, s.stream));
+        } else if (eager_timed || !opt_.parallel_branches) {
+            for (size_t k = 0; k < s.ops.size(); k++) {
+                if (eager_timed && k == s.first_post) RF_HIP(hipEventRecord(s.time_ev[2], s.stream));
+                s.ops[k].launch(s.stream, n);
             }
-            warmed_.insert(n);     // first run of a batch size is always eager: function attributes get set outside capture
+            s.warmed.insert(n);    // first run of a batch size is always eager: function attributes get set outside capture
+        } else {
+            issue_parallel(s, n);
+            s.warmed.insert(n);
         }
         RF_HIP(hipGetLastError());
-        RF_HIP(hipMemcpyAsync(s.h_counts, d_result_, result_hdr_ + (size_t)n * opt_.max_detections * sizeof(Candidate),
-                              hipMemcpyDeviceToHost, stream_));
-        if (eager) RF_HIP(hipEventRecord(ev_[3], stream_));
-        RF_HIP(hipEventRecord(s.done, stream_));
+        if (eager_timed) RF_HIP(hipEventRecord(s.time_ev[3], s.stream));
+        RF_HIP(hipEventRecord(s.done, s.stream));
         s.busy = true;
         return ticket;
     }
 
-    hipGraphExec_t capture(int n) {
+    hipGraphExec_t capture(Lane &L, int n) {
         hipGraph_t g = nullptr;
         hipGraphExec_t ge = nullptr;
-        RF_HIP(hipStreamBeginCapture(stream_, hipStreamCaptureModeThreadLocal));
-        hipError_t err = hipMemsetAsync(d_counts_, 0, 2 * opt_.max_batch * sizeof(int), stream_);
-        for (size_t k = 0; k < ops_.size() && err == hipSuccess; k++) ops_[k].launch(stream_, n);
-        hipError_t end = hipStreamEndCapture(stream_, &g);
-        if (err != hipSuccess || end != hipSuccess || !g)
-            throw HipError(std::string("hipGraph capture failed: ") + hipGetErrorString(err != hipSuccess ? err : end));
+        RF_HIP(hipStreamBeginCapture(L.stream, hipStreamCaptureModeThreadLocal));
+        std::string err;
+        try {
+            if (opt_.parallel_branches) issue_parallel(L, n);
+            else for (size_t k = 0; k < L.ops.size(); k++) L.ops[k].launch(L.stream, n);
+        } catch (const std::exception &e) { err = e.what(); }
+        hipError_t end = hipStreamEndCapture(L.stream, &g);
+        if (!err.empty() || end != hipSuccess || !g)
+            throw HipError("hipGraph capture failed: " + (err.empty() ? std::string(hipGetErrorString(end)) : err));
         hipError_t inst = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
         (void)hipGraphDestroy(g);
         if (inst != hipSuccess) throw HipError(std::string("hipGraphInstantiate failed: ") + hipGetErrorString(inst));
@@ -600,34 +675,17 @@ private:
 
     // ------------------------------------------------------------------------------------------ state
     int device_ = 0;
-    hipStream_t stream_ = nullptr;
-    hipEvent_t ev_[4];
     std::vector<hipEvent_t> prof_ev_;
     Arena arena_;
+    size_t c0_w_ = 0, c0_b_ = 0;
+    std::vector<DwW> dw_w_;
+    std::vector<GemmW> pw_w_;
+    GemmW lat_w_[3], aggr_w_[2], ssh_w_[3][4];
     std::vector<void *> dev_allocs_, host_allocs_;
-    std::map<std::string, ActInfo> acts_;
-    std::vector<OpInfo> ops_;
-    OpInfo lat_ops_[3];
-    size_t first_post_op_ = 0;
     const int strides_[3] = {32, 16, 8};
-    int total_anchors_ = 0;
 
-    FrameDesc *d_frames_ = nullptr;
-    RunParams *d_params_ = nullptr;
-    unsigned char *d_result_ = nullptr;
-    size_t result_bytes_ = 0, result_hdr_ = 0;
-    int *d_counts_ = nullptr;         // [0,mb) kept counts, [mb,2mb) candidate counts
-    Candidate *d_out_ = nullptr;
-    Candidate *d_cand_ = nullptr;
-    uint8_t *d_canvas_ = nullptr;
-    uint8_t *d_raw_ = nullptr;
-    size_t raw_stride_ = 0;
-    float *d_dump_[3][3] = {};
-
-    std::vector<Slot> slots_;
-    int next_slot_ = 0;
-    std::map<int, hipGraphExec_t> graphs_;
-    std::set<int> warmed_;
+    std::vector<Lane> lanes_;
+    int next_lane_ = 0, last_lane_ = 0;
 
     int last_n_ = 0;
     std::vector<int> last_cand_counts_;

@@ -36,7 +36,7 @@ struct RunParams {
 //      165-185, 279-316 with factor 1) fused with mobilenet0_conv0 (3x3 s2 p1 3->8) + BN + ReLU.
 template <typename T>
 void launch_conv0(hipStream_t s, const FrameDesc *frames, T *out, const float *w, const float *b,
-                  int n, int net_h, int net_w);
+                  const RunParams *params_in, RunParams *params_out, int n, int net_h, int net_w);
 
 // ---- K_b: depthwise 3x3 (+BN+ReLU) -> pointwise 1x1 (+BN+ReLU), the intermediate never leaves LDS.
 //      has_dw = false gives a plain 1x1 conv (+bias, +ReLU): the FPN laterals.
@@ -85,9 +85,10 @@ template <typename T> void launch_head(hipStream_t s, const HeadParams<T> &p);
 // ---- K_e: per-image sort (score desc, anchor index asc) + greedy NMS (RetinaFace.cpp:434-492); one
 //      workgroup per image, everything in LDS.
 struct NmsParams {
-    const Candidate *cand; const int *cand_count; int cap;   // cap: power of two <= 4096
+    const Candidate *cand; int *cand_count; int cap;         // cap: power of two <= 4096; counter is reset to 0 at the end
     const RunParams *params;
-    Candidate *out; int *out_count; int max_det;             // out[img*max_det + k], out_count = true count
+    Candidate *out; int *out_count; int *out_cand_count;     // out[img*max_det + k]; true kept / candidate counts
+    int max_det;                                             // (out* may be pinned host memory: written over PCIe)
     int n;
 };
 void launch_nms(hipStream_t s, const NmsParams &p);

@@ -67,9 +67,13 @@ constexpr int C0_ROWB = C0_IN * 3 + 1;         // 100 bytes per staged row (+1 p
 template <typename T>
 __global__ __launch_bounds__(kThreads) void conv0_kernel(const FrameDesc *__restrict__ frames, T *__restrict__ out,
                                                          const float *__restrict__ w, const float *__restrict__ b,
+                                                         const RunParams *__restrict__ params_in, RunParams *params_out,
                                                          int ho, int wo, int tiles_x, int tiles_y, int nblk) {
     __shared__ uint8_t s_in[C0_IN * C0_ROWB];
     const int tid = threadIdx.x;
+    // `frames` / `params_in` sit in pinned host memory (written by the CPU just before the launch, read here over
+    // PCIe: no H2D copy kernel per call).  One thread re-publishes the scalars in HBM for the head / NMS kernels.
+    if (blockIdx.x == 0 && tid == 0 && params_out) *params_out = *params_in;
     const int bid = xcd_remap(blockIdx.x, nblk);
     const int tx = bid % tiles_x;
     const int ty = (bid / tiles_x) % tiles_y;
@@ -119,15 +123,18 @@ __global__ __launch_bounds__(kThreads) void conv0_kernel(const FrameDesc *__rest
 }
 
 template <typename T>
-void launch_conv0(hipStream_t s, const FrameDesc *frames, T *out, const float *w, const float *b, int n, int net_h,
-                  int net_w) {
+void launch_conv0(hipStream_t s, const FrameDesc *frames, T *out, const float *w, const float *b,
+                  const RunParams *params_in, RunParams *params_out, int n, int net_h, int net_w) {
     int ho = net_h / 2, wo = net_w / 2;
     int tiles_x = (wo + C0_T - 1) / C0_T, tiles_y = (ho + C0_T - 1) / C0_T;
     int nblk = n * tiles_x * tiles_y;
-    hipLaunchKernelGGL(conv0_kernel<T>, dim3(nblk), dim3(kThreads), 0, s, frames, out, w, b, ho, wo, tiles_x, tiles_y, nblk);
+    hipLaunchKernelGGL(conv0_kernel<T>, dim3(nblk), dim3(kThreads), 0, s, frames, out, w, b, params_in, params_out, ho, wo, tiles_x,
+                       tiles_y, nblk);
 }
-template void launch_conv0<half_t>(hipStream_t, const FrameDesc *, half_t *, const float *, const float *, int, int, int);
-template void launch_conv0<float>(hipStream_t, const FrameDesc *, float *, const float *, const float *, int, int, int);
+template void launch_conv0<half_t>(hipStream_t, const FrameDesc *, half_t *, const float *, const float *, const RunParams *,
+                                   RunParams *, int, int, int);
+template void launch_conv0<float>(hipStream_t, const FrameDesc *, float *, const float *, const float *, const RunParams *,
+                                  RunParams *, int, int, int);
 
 // =============================================================================================
 // GEMM core shared by K_b / K_c / K_d:  acc[i][j] += W-fragment(ct_i, kc) x X-fragment(pt_j, kc)
@@ -719,7 +726,8 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(NmsParams a) {
     const int tid = threadIdx.x;
     const int img = blockIdx.x;
     const Candidate *cand = a.cand + (size_t)img * cap;
-    int n = a.cand_count[img];
+    const int n_found = a.cand_count[img];
+    int n = n_found;
     if (n > cap) n = cap;
     int npow = 64;
     while (npow < n) npow <<= 1;
@@ -793,7 +801,11 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(NmsParams a) {
         const uint32_t *src = (const uint32_t *)(cand + s_slot[s_kept[k]]);
         ((uint32_t *)(a.out + (size_t)img * a.max_det + k))[f] = src[f];
     }
-    if (tid == 0) a.out_count[img] = kept;
+    if (tid == 0) {
+        a.out_count[img] = kept;
+        a.out_cand_count[img] = n_found;
+        a.cand_count[img] = 0;        // re-arm the head kernels' counter for the next batch on this lane
+    }
 }
 
 void launch_nms(hipStream_t s, const NmsParams &p) {

@@ -40,7 +40,8 @@ class RetinaFace:
     def __init__(self, model: str, network: str = "net3", nms: float = 0.4, *, precision: int = PRECISION_FP16,
                  net_hw: Optional[tuple] = None, max_batch: int = 8, model_stem: Optional[str] = None,
                  max_candidates: int = 0, max_detections: int = 0, use_graph: bool = True,
-                 keep_outputs: bool = False, device: Optional[int] = None):
+                 keep_outputs: bool = False, device: Optional[int] = None, lanes: int = 0,
+                 parallel_branches: bool = True):
         self._lib = _lib.load_library()
         o = rf_options()
         o.struct_size = C.sizeof(rf_options)
@@ -53,6 +54,8 @@ class RetinaFace:
         o.max_detections = max_detections
         o.use_graph = 1 if use_graph else 2
         o.keep_outputs = 1 if keep_outputs else 0
+        o.lanes = lanes
+        o.parallel_branches = 1 if parallel_branches else 2
         self._stem = model_stem.encode() if model_stem else None
         o.model_stem = self._stem
         h = C.c_void_p()
@@ -194,7 +197,7 @@ class RetinaFace:
         counts = (C.c_int * n)()
         st = _lib.check(fn(self._h, ptrs, rows, cols, steps, n, float(threshold), out, cap, counts), self._h)
         self.truncated = st == _lib.RF_ERR_TRUNCATED
-        return self._collect(out, counts, n, cap, anchors=n <= self.max_batch)
+        return self._collect(out, counts, n, cap)
 
     def _collect(self, out, counts, n, cap, anchors=True):
         rows = _faces_to_array(out, n * cap)
