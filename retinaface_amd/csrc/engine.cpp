@@ -108,8 +108,6 @@ public:
         for (auto &l : lanes_) {
             if (l.stream) (void)hipStreamSynchronize(l.stream);
             for (auto &kv : l.graphs) (void)hipGraphExecDestroy(kv.second);
-            for (hipStream_t s : l.side) if (s) (void)hipStreamDestroy(s);
-            for (hipEvent_t e : l.sync_ev) (void)hipEventDestroy(e);
             for (hipEvent_t e : l.time_ev) (void)hipEventDestroy(e);
             if (l.done) (void)hipEventDestroy(l.done);
             if (l.d_raw) (void)hipFree(l.d_raw);
@@ -290,16 +288,13 @@ private:
 
     struct Lane {
         hipStream_t stream = nullptr;
-        hipStream_t side[3] = {nullptr, nullptr, nullptr};
-        std::vector<hipEvent_t> sync_ev;      // fork / join edges between stream and side[]
         hipEvent_t time_ev[4] = {nullptr, nullptr, nullptr, nullptr};
         hipEvent_t done = nullptr;
         std::map<int, hipGraphExec_t> graphs;
         std::set<int> warmed;
         std::map<std::string, ActInfo> acts;
-        std::vector<OpInfo> ops;              // serial (topological) order; indices below pick ops for the branch schedule
-        size_t i_conv0 = 0, i_blocks = 0, i_lat[3] = {0, 0, 0}, i_aggr[2] = {0, 0}, i_ssh[3] = {0, 0, 0}, i_head[3] = {0, 0, 0},
-               i_nms = 0, first_post = 0;
+        std::vector<OpInfo> ops;              // launch order
+        size_t first_post = 0;                // index of the first post-processing launch (heads)
         // pinned host, read / written by the GPU directly
         FrameDesc *h_frames = nullptr;        // [2*max_batch]: [0,mb) source frames, [mb,2mb) what conv0 reads
         RunParams *h_params = nullptr;
@@ -367,9 +362,6 @@ private:
         const int H = net_h_, W = net_w_;
         const double P = (double)H * W;
         RF_HIP(hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking));
-        for (auto &s : L.side) RF_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
-        L.sync_ev.resize(12);
-        for (auto &e : L.sync_ev) RF_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         for (auto &e : L.time_ev) RF_HIP(hipEventCreate(&e));
         RF_HIP(hipEventCreateWithFlags(&L.done, hipEventDisableTiming));
 
@@ -405,12 +397,11 @@ private:
             RunParams *pout = L.d_params;
             T *o = cur;
             op.launch = [=](hipStream_t s, int n) { launch_conv0<T>(s, fr, o, wp, bp, pin, pout, n, H, W); };
-            L.i_conv0 = L.ops.size();
             L.ops.push_back(op);
         }
         int c = 8;
-        T *taps[3] = {nullptr, nullptr, nullptr};   // c3 (stride 32), c2 (16), c1 (8)
-        L.i_blocks = L.ops.size();
+        // FPN tap -> lateral index: block 4 (stride 8) -> lateral[2], block 10 (stride 16) -> [1], block 12 (stride 32) -> [0]
+        T *lat[3] = {nullptr, nullptr, nullptr};
         for (size_t i = 0; i < plan.blocks.size(); i++) {
             const auto &blk = plan.blocks[i];
             int ho = h / blk.dw.stride, wo = w / blk.dw.stride;
@@ -428,40 +419,24 @@ private:
             op.alg_elems_in = (double)c * h * w + (double)c * ho * wo;
             op.alg_elems_out = (double)c * ho * wo + (double)blk.pw.cout * ho * wo;
             op.macs = (blk.dw.macs_per_out_pixel() + blk.pw.macs_per_out_pixel()) * ho * wo;
+            const int li = i == 4 ? 2 : i == 10 ? 1 : i == 12 ? 0 : -1;
+            if (li >= 0) {          // the lateral 1x1 is computed from this block's output tile while it is in LDS
+                const FoldedConv &lf = plan.lateral[li];
+                lat[li] = act(lf.out_blob, ho, wo, 64);
+                p.lat_w = arena_.ptr<T>(lat_w_[li].w); p.lat_b = arena_.ptr<float>(lat_w_[li].b); p.lat_out = lat[li];
+                op.name += "+" + lf.name;
+                op.alg_elems_in += (double)blk.pw.cout * ho * wo;
+                op.alg_elems_out += 64.0 * ho * wo;
+                op.macs += lf.macs_per_out_pixel() * ho * wo;
+            }
             op.launch = [p](hipStream_t s, int n) { DwPwParams<T> q = p; q.n = n; launch_dwpw<T>(s, q); };
             L.ops.push_back(op);
             cur = out; h = ho; w = wo; c = blk.pw.cout;
-            if (i == 4) taps[2] = out;
-            if (i == 10) taps[1] = out;
-            if (i == 12) taps[0] = out;
         }
-        // FPN: laterals (1x1), then aggr convs with the upsample+add fused into their input staging
-        T *feat[3], *lat[3];
-        const int tap_c[3] = {256, 128, 64};
-        OpInfo lat_ops[3];
-        for (int i = 0; i < 3; i++) {
-            int fh = H / strides_[i], fw = W / strides_[i];
-            lat[i] = act(plan.lateral[i].out_blob, fh, fw, 64);
-            DwPwParams<T> p;
-            p.in = taps[i]; p.out = lat[i]; p.dw_w = nullptr; p.dw_b = nullptr;
-            p.pw_w = arena_.ptr<T>(lat_w_[i].w); p.pw_b = arena_.ptr<float>(lat_w_[i].b);
-            p.n = 0; p.hin = fh; p.win = fw; p.hout = fh; p.wout = fw;
-            p.cin = tap_c[i]; p.cout = 64; p.stride = 1; p.has_dw = false;
-            OpInfo op;
-            op.name = plan.lateral[i].name;
-            op.alg_elems_in = (double)tap_c[i] * fh * fw;
-            op.alg_elems_out = 64.0 * fh * fw;
-            op.macs = plan.lateral[i].macs_per_out_pixel() * fh * fw;
-            op.launch = [p](hipStream_t s, int n) { DwPwParams<T> q = p; q.n = n; launch_dwpw<T>(s, q); };
-            lat_ops[i] = op;
-        }
+        // FPN: P3 = c3 lateral; P2 / P1 = aggr conv with "lateral + bilinear x2 upsample(coarser)" fused into its input staging
+        T *feat[3];
         feat[0] = lat[0];
-        // serial order: c3 lateral, c2 lateral, c2 aggr, c1 lateral, c1 aggr (the prototxt's order)
-        L.i_lat[0] = L.ops.size();
-        L.ops.push_back(lat_ops[0]);
         for (int i = 0; i < 2; i++) {
-            L.i_lat[i + 1] = L.ops.size();
-            L.ops.push_back(lat_ops[i + 1]);
             int fh = H / strides_[i + 1], fw = W / strides_[i + 1];
             feat[i + 1] = act(plan.aggr[i].out_blob, fh, fw, 64);
             Conv3Params<T> p;
@@ -474,13 +449,15 @@ private:
             op.alg_elems_in = 64.0 * (fh / 2) * (fw / 2) + 64.0 * fh * fw;     // deconv input + conv input
             op.alg_elems_out = 64.0 * fh * fw + 64.0 * fh * fw;               // deconv output + conv output
             op.macs = plan.aggr[i].macs_per_out_pixel() * fh * fw + 16.0 * 64 * (fh / 2) * (fw / 2);
-            op.launch = [p](hipStream_t s, int n) { Conv3Params<T> q = p; q.n = n; launch_conv3x3<T>(s, q); };
-            L.i_aggr[i] = L.ops.size();
+            op.launch = [p](hipStream_t s, int n) { Conv3Params<T> q = p; q.n = n; launch_conv3x3<T>(s, &q, 1); };
             L.ops.push_back(op);
         }
-        // SSH modules, then the heads, then NMS
+        // SSH context modules: each of the three merged convs is ONE launch covering strides 32, 16 and 8
+        struct Level3 { Conv3Params<T> p[3]; };
+        Level3 lv_a, lv_b, lv_c;
+        OpInfo op_a, op_b, op_c, op_h;
+        struct HeadLevels { HeadParams<T> p[3]; } hl;
         int anchor_off = 0;
-        std::vector<OpInfo> head_ops;
         for (int i = 0; i < 3; i++) {
             const SshModule &m = plan.ssh[i];
             int fh = H / strides_[i], fw = W / strides_[i];
@@ -488,26 +465,21 @@ private:
             T *cat = act(pre + "concat_relu", fh, fw, 64);
             T *ctx1 = act(pre + "context_conv1_relu", fh, fw, 16);
             T *ctx31 = act(pre + "context_conv3_1_relu", fh, fw, 16);
-            auto conv_op = [&](const FoldedConv &f, const GemmW &gw, const T *in, int cin, T *o0, int ld0, int off0, int n0,
-                               T *o1, int ld1, int off1, int nlayers) {
-                Conv3Params<T> p;
+            auto fill = [&](Conv3Params<T> &p, OpInfo &op, const FoldedConv &f, const GemmW &gw, const T *in, int cin, T *o0,
+                            int ld0, int off0, int n0, T *o1, int ld1, int off1, int nlayers) {
                 p.in = in; p.in_ld = cin; p.in_off = 0; p.up = nullptr;
                 p.w = arena_.ptr<T>(gw.w); p.b = arena_.ptr<float>(gw.b);
                 p.out0 = o0; p.ld0 = ld0; p.off0 = off0; p.n0 = n0; p.out1 = o1; p.ld1 = ld1; p.off1 = off1;
                 p.n = 0; p.h = fh; p.w_ = fw; p.cin = cin; p.cout = f.cout;
-                OpInfo op;
-                op.name = f.name;
-                op.alg_elems_in = (double)nlayers * cin * fh * fw;    // each merged sibling reads the input once, layer-wise
-                op.alg_elems_out = (double)f.cout * fh * fw;
-                op.macs = f.macs_per_out_pixel() * fh * fw;
-                op.launch = [p](hipStream_t s, int n) { Conv3Params<T> q = p; q.n = n; launch_conv3x3<T>(s, q); };
-                L.ops.push_back(op);
+                op.name += (op.name.empty() ? "" : " | ") + f.name;
+                op.alg_elems_in += (double)nlayers * cin * fh * fw;   // each merged sibling reads the input once, layer-wise
+                op.alg_elems_out += (double)f.cout * fh * fw;
+                op.macs += f.macs_per_out_pixel() * fh * fw;
             };
-            L.i_ssh[i] = L.ops.size();
-            conv_op(m.conv_a, ssh_w_[i][0], feat[i], 64, cat, 64, 0, 32, ctx1, 16, 0, 2);
-            conv_op(m.conv_b, ssh_w_[i][1], ctx1, 16, cat, 64, 32, 16, ctx31, 16, 0, 2);
-            conv_op(m.conv_c, ssh_w_[i][2], ctx31, 16, cat, 64, 48, 16, nullptr, 0, 0, 1);
-            HeadParams<T> hp;
+            fill(lv_a.p[i], op_a, m.conv_a, ssh_w_[i][0], feat[i], 64, cat, 64, 0, 32, ctx1, 16, 0, 2);
+            fill(lv_b.p[i], op_b, m.conv_b, ssh_w_[i][1], ctx1, 16, cat, 64, 32, 16, ctx31, 16, 0, 2);
+            fill(lv_c.p[i], op_c, m.conv_c, ssh_w_[i][2], ctx31, 16, cat, 64, 48, 16, nullptr, 0, 0, 1);
+            HeadParams<T> &hp = hl.p[i];
             hp.in = cat; hp.w = arena_.ptr<T>(ssh_w_[i][3].w); hp.b = arena_.ptr<float>(ssh_w_[i][3].b);
             hp.n = 0; hp.h = fh; hp.w_ = fw; hp.stride = strides_[i]; hp.anchor_offset = anchor_off;
             static const int scales[3][2] = {{32, 16}, {8, 4}, {2, 1}};
@@ -521,17 +493,22 @@ private:
                 for (int k = 0; k < 3; k++) L.d_dump[i][k] = dalloc<float>((size_t)mb * chans[k] * fh * fw);
                 hp.dump_prob = L.d_dump[i][0]; hp.dump_bbox = L.d_dump[i][1]; hp.dump_lmk = L.d_dump[i][2];
             }
-            OpInfo op;
-            op.name = m.head.name + "+softmax+decode";
-            op.alg_elems_in = 3.0 * 64 * fh * fw;
-            op.alg_elems_out = 32.0 * fh * fw;
-            op.macs = m.head.macs_per_out_pixel() * fh * fw;
-            op.launch = [hp](hipStream_t s, int n) { HeadParams<T> q = hp; q.n = n; launch_head<T>(s, q); };
-            head_ops.push_back(op);
+            op_h.name += (op_h.name.empty() ? "" : " | ") + m.head.name;
+            op_h.alg_elems_in += 3.0 * 64 * fh * fw;
+            op_h.alg_elems_out += 32.0 * fh * fw;
+            op_h.macs += m.head.macs_per_out_pixel() * fh * fw;
             anchor_off += 2 * fh * fw;
         }
+        op_a.launch = [lv_a](hipStream_t s, int n) { Level3 q = lv_a; for (auto &p : q.p) p.n = n; launch_conv3x3<T>(s, q.p, 3); };
+        op_b.launch = [lv_b](hipStream_t s, int n) { Level3 q = lv_b; for (auto &p : q.p) p.n = n; launch_conv3x3<T>(s, q.p, 3); };
+        op_c.launch = [lv_c](hipStream_t s, int n) { Level3 q = lv_c; for (auto &p : q.p) p.n = n; launch_conv3x3<T>(s, q.p, 3); };
+        L.ops.push_back(op_a);
+        L.ops.push_back(op_b);
+        L.ops.push_back(op_c);
         L.first_post = L.ops.size();
-        for (int i = 0; i < 3; i++) { L.i_head[i] = L.ops.size(); L.ops.push_back(head_ops[i]); }
+        op_h.name += " +softmax+decode";
+        op_h.launch = [hl](hipStream_t s, int n) { HeadLevels q = hl; for (auto &p : q.p) p.n = n; launch_head<T>(s, q.p, 3); };
+        L.ops.push_back(op_h);
         {
             NmsParams np;
             np.cand = L.d_cand; np.cand_count = L.d_cand_count; np.cap = opt_.max_candidates; np.params = L.d_params;
@@ -540,7 +517,6 @@ private:
             OpInfo op;
             op.name = "sort+nms";
             op.launch = [np](hipStream_t s, int n) { NmsParams q = np; q.n = n; launch_nms(s, q); };
-            L.i_nms = L.ops.size();
             L.ops.push_back(op);
         }
     }
@@ -553,41 +529,6 @@ private:
         L.d_raw = nullptr;
         L.raw_stride = ((per_image + 255) / 256) * 256;
         RF_HIP(hipMalloc((void **)&L.d_raw, L.raw_stride * opt_.max_batch));
-    }
-
-    // Branch schedule (used for graph capture and for un-timed eager runs): the three laterals and the stride-32 /
-    // stride-16 SSH+head chains run on side streams next to the critical path
-    //   conv0 -> 13 dw/pw blocks -> c3 lateral -> c2 aggr -> c1 aggr -> SSH(stride 8) -> head -> NMS      (22 launches deep
-    // instead of 32).  fork/join are event edges; under capture they become graph dependencies.
-    void issue_parallel(Lane &L, int n) {
-        hipStream_t S0 = L.stream, S1 = L.side[0], S2 = L.side[1], S3 = L.side[2];
-        int ev = 0;
-        auto edge = [&](hipStream_t from, hipStream_t to) {
-            hipEvent_t e = L.sync_ev[ev++];
-            RF_HIP(hipEventRecord(e, from));
-            RF_HIP(hipStreamWaitEvent(to, e, 0));
-        };
-        auto run = [&](size_t i, hipStream_t s) { L.ops[i].launch(s, n); };
-        run(L.i_conv0, S0);
-        for (size_t i = 0; i < 5; i++) run(L.i_blocks + i, S0);
-        edge(S0, S1); run(L.i_lat[2], S1);                                  // c1 lateral (stride 8 tap = block 4)
-        for (size_t i = 5; i < 11; i++) run(L.i_blocks + i, S0);
-        edge(S0, S2); run(L.i_lat[1], S2);                                  // c2 lateral (stride 16 tap = block 10)
-        for (size_t i = 11; i < 13; i++) run(L.i_blocks + i, S0);
-        run(L.i_lat[0], S0);                                                // c3 lateral = P3
-        edge(S0, S3);
-        for (size_t k = 0; k < 3; k++) run(L.i_ssh[0] + k, S3);             // SSH + head of stride 32
-        run(L.i_head[0], S3);
-        edge(S2, S0); run(L.i_aggr[0], S0);                                 // P2 = aggr(c2 lateral + up(P3))
-        edge(S0, S2);
-        for (size_t k = 0; k < 3; k++) run(L.i_ssh[1] + k, S2);             // SSH + head of stride 16
-        run(L.i_head[1], S2);
-        edge(S1, S0); run(L.i_aggr[1], S0);                                 // P1 = aggr(c1 lateral + up(P2))
-        for (size_t k = 0; k < 3; k++) run(L.i_ssh[2] + k, S0);
-        run(L.i_head[2], S0);
-        edge(S3, S0);
-        edge(S2, S0);
-        run(L.i_nms, S0);
     }
 
     int submit(const uint8_t *const *frames, const int *rows, const int *cols, const int *steps, int n, bool on_device,
@@ -638,15 +579,12 @@ private:
             auto it = s.graphs.find(n);
             if (it == s.graphs.end()) it = s.graphs.emplace(n, capture(s, n)).first;
             RF_HIP(hipGraphLaunch(it->second, s.stream));
-        } else if (eager_timed || !opt_.parallel_branches) {
+        } else {
             for (size_t k = 0; k < s.ops.size(); k++) {
                 if (eager_timed && k == s.first_post) RF_HIP(hipEventRecord(s.time_ev[2], s.stream));
                 s.ops[k].launch(s.stream, n);
             }
             s.warmed.insert(n);    // first run of a batch size is always eager: function attributes get set outside capture
-        } else {
-            issue_parallel(s, n);
-            s.warmed.insert(n);
         }
         RF_HIP(hipGetLastError());
         if (eager_timed) RF_HIP(hipEventRecord(s.time_ev[3], s.stream));
@@ -661,8 +599,7 @@ private:
         RF_HIP(hipStreamBeginCapture(L.stream, hipStreamCaptureModeThreadLocal));
         std::string err;
         try {
-            if (opt_.parallel_branches) issue_parallel(L, n);
-            else for (size_t k = 0; k < L.ops.size(); k++) L.ops[k].launch(L.stream, n);
+            for (size_t k = 0; k < L.ops.size(); k++) L.ops[k].launch(L.stream, n);
         } catch (const std::exception &e) { err = e.what(); }
         hipError_t end = hipStreamEndCapture(L.stream, &g);
         if (!err.empty() || end != hipSuccess || !g)

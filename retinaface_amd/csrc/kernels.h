@@ -47,6 +47,7 @@ struct DwPwParams {
     const float *dw_b;    // [cin]
     const T *pw_w;        // MFMA-fragment packed (pack.h), k = cin
     const float *pw_b;    // [cout]
+    const T *lat_w = nullptr; const float *lat_b = nullptr; T *lat_out = nullptr;   // optional fused FPN lateral (cout -> 64)
     int n, hin, win, hout, wout;
     int cin, cout, stride;
     bool has_dw;
@@ -65,7 +66,8 @@ struct Conv3Params {
     T *out1; int ld1, off1;               // output channels [n0, cout) -> out1[pixel*ld1 + off1 + c - n0]
     int n, h, w_, cin, cout;
 };
-template <typename T> void launch_conv3x3(hipStream_t s, const Conv3Params<T> &p);
+// `levels`: 1..3 parameter sets of the same (cin, cout) covered by ONE launch (the FPN levels of the SSH module)
+template <typename T> void launch_conv3x3(hipStream_t s, const Conv3Params<T> *levels, int nlevels);
 
 // ---- K_d: the three 1x1 heads of one stride as one 64->32 GEMM + 2-class softmax + anchor decode +
 //      bbox / landmark regression + clip + threshold compaction (RetinaFace.cpp:666-724, 378-432, 179-199).
@@ -80,7 +82,7 @@ struct HeadParams {
     Candidate *cand; int *cand_count; int cap;
     float *dump_prob, *dump_bbox, *dump_lmk;   // optional NCHW fp32 copies of the 3 blobs (nullptr = off)
 };
-template <typename T> void launch_head(hipStream_t s, const HeadParams<T> &p);
+template <typename T> void launch_head(hipStream_t s, const HeadParams<T> *levels, int nlevels);   // 1..3 strides per launch
 
 // ---- K_e: per-image sort (score desc, anchor index asc) + greedy NMS (RetinaFace.cpp:434-492); one
 //      workgroup per image, everything in LDS.

@@ -62,14 +62,16 @@ static void set_max_lds(F func, size_t bytes) {
 // =============================================================================================
 constexpr int C0_T = 16;                       // output tile edge
 constexpr int C0_IN = 2 * C0_T + 1;            // 33 input rows / cols
-constexpr int C0_ROWB = C0_IN * 3 + 1;         // 100 bytes per staged row (+1 pad)
+constexpr int C0_LD = 26;                      // dwords fetched per staged row: 99 payload bytes + <= 3 bytes of misalignment
+constexpr int C0_ROWD = 27;                    // LDS row stride in dwords (+1: rows land on different banks)
 
 template <typename T>
 __global__ __launch_bounds__(kThreads) void conv0_kernel(const FrameDesc *__restrict__ frames, T *__restrict__ out,
                                                          const float *__restrict__ w, const float *__restrict__ b,
                                                          const RunParams *__restrict__ params_in, RunParams *params_out,
                                                          int ho, int wo, int tiles_x, int tiles_y, int nblk) {
-    __shared__ uint8_t s_in[C0_IN * C0_ROWB];
+    __shared__ uint32_t s_in32[C0_IN * C0_ROWD];
+    const uint8_t *s_in = (const uint8_t *)s_in32;
     const int tid = threadIdx.x;
     // `frames` / `params_in` sit in pinned host memory (written by the CPU just before the launch, read here over
     // PCIe: no H2D copy kernel per call).  One thread re-publishes the scalars in HBM for the head / NMS kernels.
@@ -79,13 +81,28 @@ __global__ __launch_bounds__(kThreads) void conv0_kernel(const FrameDesc *__rest
     const int ty = (bid / tiles_x) % tiles_y;
     const int img = bid / (tiles_x * tiles_y);
     const FrameDesc fd = frames[img];
-    const int iy0 = 2 * ty * C0_T - 1, ix0 = 2 * tx * C0_T - 1;
-    for (int i = tid; i < C0_IN * C0_IN * 3; i += kThreads) {
-        int r = i / (C0_IN * 3), cb = i % (C0_IN * 3);
-        int iy = iy0 + r, ix = ix0 + cb / 3;
-        uint8_t v = 0;
-        if (iy >= 0 && iy < fd.rows && ix >= 0 && ix < fd.cols) v = fd.ptr[(size_t)iy * fd.step + ix * 3 + cb % 3];
-        s_in[r * C0_ROWB + cb] = v;
+    const int iy0 = 2 * ty * C0_T - 1;
+    const int bx0 = (2 * tx * C0_T - 1) * 3;          // first byte column of the patch (-3 at the left edge)
+    const uintptr_t base = (uintptr_t)fd.ptr;
+    const size_t row_bytes = (size_t)fd.cols * 3;
+    // stage the 33 x 99-byte u8 patch with aligned 4-byte loads (the row start is arbitrary mod 4: each row keeps its
+    // own misalignment, re-derived in the compute phase); bytes outside the frame are the zero canvas / zero padding
+    for (int i = tid; i < C0_IN * C0_LD; i += kThreads) {
+        const int r = i / C0_LD, d = i % C0_LD;
+        const int iy = iy0 + r;
+        uint32_t v = 0;
+        if (iy >= 0 && iy < fd.rows) {
+            const uintptr_t lo = base + (size_t)iy * fd.step, hi = lo + row_bytes;
+            const uintptr_t a0 = ((lo + bx0) & ~(uintptr_t)3) + 4 * d;
+            if (a0 >= lo && a0 + 4 <= hi) {
+                v = *(const uint32_t *)a0;
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+                    if (a0 + k >= lo && a0 + k < hi) v |= (uint32_t)(*(const uint8_t *)(a0 + k)) << (8 * k);
+            }
+        }
+        s_in32[r * C0_ROWD + d] = v;
     }
     __syncthreads();
     const int py = tid / C0_T, px = tid % C0_T;
@@ -94,10 +111,12 @@ __global__ __launch_bounds__(kThreads) void conv0_kernel(const FrameDesc *__rest
 #pragma unroll
     for (int o = 0; o < 8; o++) acc[o] = b[o];
 #pragma unroll
-    for (int ky = 0; ky < 3; ky++)
+    for (int ky = 0; ky < 3; ky++) {
+        const int r = 2 * py + ky;
+        const int mis = (int)((base + (size_t)(iy0 + r) * fd.step + bx0) & 3);
 #pragma unroll
         for (int kx = 0; kx < 3; kx++) {
-            const uint8_t *p = &s_in[(2 * py + ky) * C0_ROWB + (2 * px + kx) * 3];
+            const uint8_t *p = s_in + r * (C0_ROWD * 4) + mis + (2 * px + kx) * 3;
             // frame is BGR, the network's input channel 0 is R (convertBGR2RGBfloat): net channel c = frame channel 2-c
             float v[3] = {(float)p[2], (float)p[1], (float)p[0]};
 #pragma unroll
@@ -105,6 +124,7 @@ __global__ __launch_bounds__(kThreads) void conv0_kernel(const FrameDesc *__rest
 #pragma unroll
                 for (int o = 0; o < 8; o++) acc[o] = fmaf(w[o * 27 + (ky * 3 + kx) * 3 + c], v[c], acc[o]);
         }
+    }
     if (oy < ho && ox < wo) {
         T *dst = out + (((size_t)img * ho + oy) * wo + ox) * 8;
         if constexpr (sizeof(T) == 2) {
@@ -148,13 +168,78 @@ template <int NT, int PT> struct WaveSplit {
     static_assert(NT % WN == 0 && PT % WP == 0 && NJ >= 1, "tile does not split over 4 waves");
 };
 
+// Weight-fragment stream of one wave: NI output-channel tiles x KCH K-chunks, read straight from L2 in MFMA A-fragment
+// order (one coalesced 16 B-per-lane load per fragment).  fp16 path: software pipelined through registers -- group 0
+// (<= 12 fragments) is issued at kernel entry, BEFORE the activation tile is staged, so the L2 round trip of the
+// weights overlaps the HBM round trip of the activations; group g+1 is issued before group g's MFMAs.
+// fp32 path (parity reference, speed irrelevant): plain loop.
+template <typename T, int NI, int NJ, int KCH, int WN>
+struct GemmPipe {
+    typedef Mma<T> M;
+    typedef typename M::Frag Frag;
+    static constexpr bool PIPE = sizeof(T) == 2;
+    static constexpr int GMAX = 12 / NI > 0 ? 12 / NI : 1;
+    static constexpr int G = PIPE ? (KCH < GMAX ? KCH : GMAX) : 1;
+    static constexpr int NG = (KCH + G - 1) / G;
+    Frag buf[PIPE ? 2 : 1][G][NI];
+    const Frag *wp;
+
+    __device__ __forceinline__ void load(int g, int slot) {
+#pragma unroll
+        for (int c = 0; c < G; c++) {
+            const int kc = g * G + c;
+            if (kc < KCH) {
+#pragma unroll
+                for (int i = 0; i < NI; i++) buf[slot][c][i] = wp[((i * WN) * KCH + kc) * 64];
+            }
+        }
+    }
+    __device__ __forceinline__ void init(const void *w, int wn, int lane) {
+        wp = (const Frag *)w + (size_t)wn * KCH * 64 + lane;
+        if constexpr (PIPE) load(0, 0);
+    }
+    // xf(j, kc) returns the activation (B) fragment of pixel tile j for K-chunk kc
+    template <typename XF> __device__ __forceinline__ void run(f32x4 (&acc)[NI][NJ], XF &&xf) {
+        if constexpr (PIPE) {
+#pragma unroll
+            for (int g = 0; g < NG; g++) {
+                if (g + 1 < NG) load(g + 1, (g + 1) & 1);
+#pragma unroll
+                for (int c = 0; c < G; c++) {
+                    const int kc = g * G + c;
+                    if (kc < KCH) {
+                        Frag x[NJ];
+#pragma unroll
+                        for (int j = 0; j < NJ; j++) x[j] = xf(j, kc);
+#pragma unroll
+                        for (int i = 0; i < NI; i++)
+#pragma unroll
+                            for (int j = 0; j < NJ; j++) acc[i][j] = M::mma(buf[g & 1][c][i], x[j], acc[i][j]);
+                    }
+                }
+            }
+        } else {
+#pragma unroll 2
+            for (int kc = 0; kc < KCH; kc++) {
+                Frag wf[NI], x[NJ];
+#pragma unroll
+                for (int i = 0; i < NI; i++) wf[i] = wp[((i * WN) * KCH + kc) * 64];
+#pragma unroll
+                for (int j = 0; j < NJ; j++) x[j] = xf(j, kc);
+#pragma unroll
+                for (int i = 0; i < NI; i++)
+#pragma unroll
+                    for (int j = 0; j < NJ; j++) acc[i][j] = M::mma(wf[i], x[j], acc[i][j]);
+            }
+        }
+    }
+};
+
 // epilogue: bias (+ReLU), convert, 4 consecutive output channels of one pixel -> LDS tile s_out[pixel][LDO]
 template <typename T, int LDO>
-__device__ __forceinline__ void store_acc(T *s_out, const float *__restrict__ bias, f32x4 acc, int ct, int pt, int lane,
-                                          bool relu) {
+__device__ __forceinline__ void store_acc(T *s_out, f32x4 bv, f32x4 acc, int ct, int pt, int lane, bool relu) {
     const int c0 = acc_cout(ct, lane, 0);
     const int p = acc_pixel(pt, lane);
-    const f32x4 bv = *(const f32x4 *)(bias + c0);
     float v[4];
 #pragma unroll
     for (int r = 0; r < 4; r++) {
@@ -177,13 +262,16 @@ __device__ __forceinline__ void store_acc(T *s_out, const float *__restrict__ bi
 
 // =============================================================================================
 // K_b  depthwise 3x3 + BN + ReLU  ->  pointwise 1x1 + BN + ReLU   (13 backbone pairs, prototxt :55-1193)
-//      HAS_DW = false: plain 1x1 + bias + ReLU (rf_c3_lateral / rf_c2_lateral / rf_c1_red_conv,
-//      prototxt :1199-1237, :1513-1551, :1908-1946).
+//      HAS_DW = false: plain 1x1 + bias + ReLU.
+//      LAT = true: the FPN lateral that taps this block's output (rf_c1_red_conv / rf_c2_lateral / rf_c3_lateral,
+//      1x1 -> 64 + BN + ReLU, prototxt :1199-1237, :1513-1551, :1908-1946) is computed from the output tile while it
+//      is still in LDS: one launch and one HBM re-read less per tap.
+//   phase 0  weight fragments (group 0), biases -> registers: their L2 round trip overlaps phase 1's HBM round trip
 //   phase 1  halo tile ((TH-1)*S+3) x ((TW-1)*S+3) x CIN -> LDS, 16 B per lane, zero padding resolved here
 //   phase 2  depthwise stencil on the VALU, fp32 accumulate, result (as T) -> LDS tile s_a[pixel][CIN]
-//   phase 3  pointwise as MFMA GEMM, weights straight from L2 in fragment order (one coalesced 1 KiB
-//            load per wave per fragment), activations by ds_read_b128 from s_a
+//   phase 3  pointwise as MFMA GEMM, activations by ds_read_b128 from s_a
 //   phase 4  bias + ReLU, through LDS so the NHWC store is 16 B per lane and fully coalesced
+//   phase 5  (LAT) second GEMM 64 x COUT on the LDS-resident output tile, same epilogue
 // =============================================================================================
 template <typename T, int CIN, int COUT, int STRIDE, bool HAS_DW, int TH, int TW> struct DwPwCfg {
     static constexpr int VEC = Vec<T>::N;
@@ -198,15 +286,17 @@ template <typename T, int CIN, int COUT, int STRIDE, bool HAS_DW, int TH, int TW
     static constexpr bool ALIAS_OUT = HAS_DW && IN_ELEMS >= O_ELEMS;   // s_out reuses the dead halo region
     static constexpr size_t LDS_BYTES = sizeof(T) * (size_t)(IN_ELEMS + A_ELEMS + (ALIAS_OUT ? 0 : O_ELEMS));
     static_assert(P % 16 == 0 && CIN % VEC == 0 && COUT % 16 == 0, "bad tile");
+    static_assert(kThreads % (CIN / VEC) == 0, "a thread must keep one channel group across its depthwise items");
 };
 
 template <typename T>
 struct DwPwArgs {
     const T *in; T *out; const T *dw_w; const float *dw_b; const T *pw_w; const float *pw_b;
+    const T *lat_w; const float *lat_b; T *lat_out;
     int hin, win, hout, wout, tiles_x, tiles_y, nblk;
 };
 
-template <typename T, int CIN, int COUT, int STRIDE, bool HAS_DW, int TH, int TW>
+template <typename T, int CIN, int COUT, int STRIDE, bool HAS_DW, int TH, int TW, bool LAT>
 __global__ __launch_bounds__(kThreads) void dwpw_kernel(DwPwArgs<T> a) {
     typedef DwPwCfg<T, CIN, COUT, STRIDE, HAS_DW, TH, TW> C;
     typedef typename Vec<T>::type V;
@@ -220,12 +310,37 @@ __global__ __launch_bounds__(kThreads) void dwpw_kernel(DwPwArgs<T> a) {
     T *s_out = C::ALIAS_OUT ? s_in : s_a + C::A_ELEMS;
 
     const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
     const int bid = xcd_remap(blockIdx.x, a.nblk);
     const int tx = bid % a.tiles_x;
     const int ty = (bid / a.tiles_x) % a.tiles_y;
     const int img = bid / (a.tiles_x * a.tiles_y);
     const int oy0 = ty * TH, ox0 = tx * TW;
     const T *inb = a.in + (size_t)img * a.hin * a.win * CIN;
+
+    // ---- phase 0: everything that only depends on kernel arguments is requested first
+    constexpr int NT = COUT / 16, PT = P / 16;
+    typedef WaveSplit<NT, PT> WS;
+    constexpr int KCH = (CIN + M::K - 1) / M::K;
+    const int wn = wave % WS::WN, wp = wave / WS::WN;
+    GemmPipe<T, WS::NI, WS::NJ, KCH, WS::WN> pipe;
+    pipe.init(a.pw_w, wn, lane);
+    f32x4 pw_bias[WS::NI];
+#pragma unroll
+    for (int i = 0; i < WS::NI; i++) pw_bias[i] = *(const f32x4 *)(a.pw_b + acc_cout(wn + i * WS::WN, lane, 0));
+    // lateral: 64 output channels = 4 tiles, one per wave, all pixel tiles
+    constexpr int LKCH = (COUT + M::K - 1) / M::K;
+    GemmPipe<T, 1, PT, LAT ? LKCH : 1, 4> lpipe;
+    f32x4 lat_bias = vzero<f32x4, 4>();
+    if constexpr (LAT) {
+        lpipe.init(a.lat_w, wave, lane);
+        lat_bias = *(const f32x4 *)(a.lat_b + acc_cout(wave, lane, 0));
+    }
+    float dw_bias[VEC];
+    if constexpr (HAS_DW) {
+#pragma unroll
+        for (int e = 0; e < VEC; e++) dw_bias[e] = a.dw_b[(tid % CPV) * VEC + e];
+    }
 
     if constexpr (HAS_DW) {
         const int iy0 = oy0 * STRIDE - 1, ix0 = ox0 * STRIDE - 1;
@@ -239,12 +354,13 @@ __global__ __launch_bounds__(kThreads) void dwpw_kernel(DwPwArgs<T> a) {
         }
         for (int i = tid; i < 9 * CPV; i += kThreads) *(V *)(s_dw + i * VEC) = *(const V *)(a.dw_w + i * VEC);
         __syncthreads();
+        const int cv = tid % CPV;                 // kThreads % CPV == 0: the channel group is fixed per thread
         for (int i = tid; i < P * CPV; i += kThreads) {
-            int p = i / CPV, cv = i % CPV;
+            int p = i / CPV;
             int py = p / TW, px = p % TW;
             float acc[VEC];
 #pragma unroll
-            for (int e = 0; e < VEC; e++) acc[e] = a.dw_b[cv * VEC + e];
+            for (int e = 0; e < VEC; e++) acc[e] = dw_bias[e];
 #pragma unroll
             for (int ky = 0; ky < 3; ky++)
 #pragma unroll
@@ -271,38 +387,21 @@ __global__ __launch_bounds__(kThreads) void dwpw_kernel(DwPwArgs<T> a) {
     __syncthreads();
 
     // ---- pointwise GEMM: D[cout][pixel], K = CIN
-    constexpr int NT = COUT / 16, PT = P / 16;
-    typedef WaveSplit<NT, PT> WS;
-    constexpr int KCH = (CIN + M::K - 1) / M::K;
-    const int lane = tid & 63, wave = tid >> 6;
-    const int wn = wave % WS::WN, wp = wave / WS::WN;
     f32x4 acc[WS::NI][WS::NJ];
 #pragma unroll
     for (int i = 0; i < WS::NI; i++)
 #pragma unroll
         for (int j = 0; j < WS::NJ; j++) acc[i][j] = vzero<f32x4, 4>();
-    const typename M::Frag *wfrag = (const typename M::Frag *)a.pw_w;
-#pragma unroll 4
-    for (int kc = 0; kc < KCH; kc++) {
-        typename M::Frag wf[WS::NI], xf[WS::NJ];
-#pragma unroll
-        for (int i = 0; i < WS::NI; i++) wf[i] = wfrag[((wn + i * WS::WN) * KCH + kc) * 64 + lane];
+    pipe.run(acc, [&](int j, int kc) -> typename M::Frag {
         const int kb = kc * M::K + (lane >> 4) * M::KPL;
-#pragma unroll
-        for (int j = 0; j < WS::NJ; j++) {
-            const int p = acc_pixel(wp + j * WS::WP, lane);
-            xf[j] = kb < CIN ? *(const typename M::Frag *)(s_a + p * LDA + kb) : M::zero();
-        }
-#pragma unroll
-        for (int i = 0; i < WS::NI; i++)
-#pragma unroll
-            for (int j = 0; j < WS::NJ; j++) acc[i][j] = M::mma(wf[i], xf[j], acc[i][j]);
-    }
+        const int p = acc_pixel(wp + j * WS::WP, lane);
+        return kb < CIN ? *(const typename M::Frag *)(s_a + p * LDA + kb) : M::zero();
+    });
 #pragma unroll
     for (int i = 0; i < WS::NI; i++)
 #pragma unroll
         for (int j = 0; j < WS::NJ; j++)
-            store_acc<T, LDO>(s_out, a.pw_b, acc[i][j], wn + i * WS::WN, wp + j * WS::WP, lane, true);
+            store_acc<T, LDO>(s_out, pw_bias[i], acc[i][j], wn + i * WS::WN, wp + j * WS::WP, lane, true);
     __syncthreads();
 
     constexpr int OPV = COUT / VEC;
@@ -313,6 +412,42 @@ __global__ __launch_bounds__(kThreads) void dwpw_kernel(DwPwArgs<T> a) {
         if (oy < a.hout && ox < a.wout)
             *(V *)(outb + ((size_t)oy * a.wout + ox) * COUT + cv * VEC) = *(const V *)(s_out + p * LDO + cv * VEC);
     }
+
+    if constexpr (LAT) {
+        // ---- fused lateral: D2[64][pixel] = Wlat[64][COUT] x out_tile; s_a (dead since the barrier above) takes the result
+        static_assert(LDA >= 64 + VEC, "lateral result tile must fit the depthwise tile");
+        constexpr int LDL = 64 + VEC;
+        T *s_lat = s_a;
+        f32x4 acc2[1][PT];
+#pragma unroll
+        for (int j = 0; j < PT; j++) acc2[0][j] = vzero<f32x4, 4>();
+        lpipe.run(acc2, [&](int j, int kc) -> typename M::Frag {
+            const int kb = kc * M::K + (lane >> 4) * M::KPL;
+            return *(const typename M::Frag *)(s_out + acc_pixel(j, lane) * LDO + kb);
+        });
+#pragma unroll
+        for (int j = 0; j < PT; j++) store_acc<T, LDL>(s_lat, lat_bias, acc2[0][j], wave, j, lane, true);
+        __syncthreads();
+        constexpr int LPV = 64 / VEC;
+        T *latb = a.lat_out + (size_t)img * a.hout * a.wout * 64;
+        for (int i = tid; i < P * LPV; i += kThreads) {
+            int p = i / LPV, cv = i % LPV;
+            int oy = oy0 + p / TW, ox = ox0 + p % TW;
+            if (oy < a.hout && ox < a.wout)
+                *(V *)(latb + ((size_t)oy * a.wout + ox) * 64 + cv * VEC) = *(const V *)(s_lat + p * LDL + cv * VEC);
+        }
+    }
+}
+
+template <typename T, int CIN, int COUT, int STRIDE, bool HAS_DW, int TH, int TW, bool LAT>
+static void dwpw_launch(hipStream_t s, const DwPwParams<T> *p, int tiles_x, int tiles_y) {
+    typedef DwPwCfg<T, CIN, COUT, STRIDE, HAS_DW, TH, TW> C;
+    auto kern = dwpw_kernel<T, CIN, COUT, STRIDE, HAS_DW, TH, TW, LAT>;
+    static bool attr_set = false;
+    if (!attr_set) { set_max_lds(kern, C::LDS_BYTES); attr_set = true; }
+    DwPwArgs<T> a{p->in, p->out, p->dw_w, p->dw_b, p->pw_w, p->pw_b, p->lat_w, p->lat_b, p->lat_out,
+                  p->hin, p->win, p->hout, p->wout, tiles_x, tiles_y, p->n * tiles_x * tiles_y};
+    hipLaunchKernelGGL(kern, dim3(a.nblk), dim3(kThreads), C::LDS_BYTES, s, a);
 }
 
 template <typename T, int CIN, int COUT, int STRIDE, bool HAS_DW, int TH, int TW>
@@ -321,12 +456,13 @@ static TileInfo dwpw_dispatch(hipStream_t s, const DwPwParams<T> *p, int hout, i
     int tiles_x = (wout + TW - 1) / TW, tiles_y = (hout + TH - 1) / TH;
     TileInfo ti{TH, TW, C::LDS_BYTES, tiles_x * tiles_y};
     if (!p) return ti;
-    auto kern = dwpw_kernel<T, CIN, COUT, STRIDE, HAS_DW, TH, TW>;
-    static bool attr_set = false;
-    if (!attr_set) { set_max_lds(kern, C::LDS_BYTES); attr_set = true; }
-    DwPwArgs<T> a{p->in, p->out, p->dw_w, p->dw_b, p->pw_w, p->pw_b, p->hin, p->win, p->hout, p->wout,
-                  tiles_x, tiles_y, p->n * tiles_x * tiles_y};
-    hipLaunchKernelGGL(kern, dim3(a.nblk), dim3(kThreads), C::LDS_BYTES, s, a);
+    if (p->lat_out) {
+        // laterals tap the outputs of blocks 4 (64ch), 10 (128ch) and 12 (256ch)
+        if constexpr (HAS_DW && STRIDE == 1 && CIN == COUT && COUT >= 64) dwpw_launch<T, CIN, COUT, STRIDE, HAS_DW, TH, TW, true>(s, p, tiles_x, tiles_y);
+        else abort();
+    } else {
+        dwpw_launch<T, CIN, COUT, STRIDE, HAS_DW, TH, TW, false>(s, p, tiles_x, tiles_y);
+    }
     return ti;
 }
 
@@ -371,6 +507,8 @@ template TileInfo dwpw_tile_info<float>(int, int, int, bool, int, int);
 //   SURVEY.md App. B.6) and the merged SSH convs 64->48, 16->32, 16->16 (prototxt :1239-1432 etc.).
 //   The (TH+2)x(TW+2) halo tile is staged once in LDS; the B fragment of tap (ky,kx) is just the same
 //   tile read at a shifted pixel offset, so no im2col buffer exists anywhere.
+//   One launch can cover up to 3 FPN levels (same conv shape, different maps / weights): the SSH module of
+//   strides 32, 16 and 8 is 3 launches, not 9.
 // =============================================================================================
 template <typename T, int CIN, int COUT, int TH, int TW> struct Conv3Cfg {
     static constexpr int VEC = Vec<T>::N;
@@ -384,10 +522,14 @@ template <typename T, int CIN, int COUT, int TH, int TW> struct Conv3Cfg {
 };
 
 template <typename T>
+struct Conv3Level {
+    const T *in; const T *up; const T *w; const float *b; T *out0; T *out1;
+    int in_ld, in_off, ld0, off0, n0, ld1, off1, h, w_, tiles_x, tiles_y, blk_begin;
+};
+template <typename T>
 struct Conv3Args {
-    const T *in; int in_ld, in_off; const T *up; const T *w; const float *b;
-    T *out0; int ld0, off0, n0; T *out1; int ld1, off1;
-    int h, w_, tiles_x, tiles_y, nblk;
+    Conv3Level<T> lv[3];
+    int nblk;
 };
 
 template <typename T, int CIN, int COUT, int TH, int TW, bool UPADD>
@@ -402,25 +544,43 @@ __global__ __launch_bounds__(kThreads) void conv3x3_kernel(Conv3Args<T> a) {
     T *s_out = (T *)smem;     // reused after the GEMM (barrier in between)
 
     const int tid = threadIdx.x;
-    const int bid = xcd_remap(blockIdx.x, a.nblk);
-    const int tx = bid % a.tiles_x;
-    const int ty = (bid / a.tiles_x) % a.tiles_y;
-    const int img = bid / (a.tiles_x * a.tiles_y);
+    const int lane = tid & 63, wave = tid >> 6;
+    const int gbid = xcd_remap(blockIdx.x, a.nblk);
+    const int lvl = (gbid >= a.lv[1].blk_begin ? 1 : 0) + (gbid >= a.lv[2].blk_begin ? 1 : 0);
+    const Conv3Level<T> &L = a.lv[lvl];
+    const int bid = gbid - L.blk_begin;
+    const int tx = bid % L.tiles_x;
+    const int ty = (bid / L.tiles_x) % L.tiles_y;
+    const int img = bid / (L.tiles_x * L.tiles_y);
     const int oy0 = ty * TH, ox0 = tx * TW;
-    const size_t img_pix = (size_t)img * a.h * a.w_;
+    const int lh = L.h, lw = L.w_;
+    const size_t img_pix = (size_t)img * lh * lw;
 
+    constexpr int NT = COUT / 16, PT = P / 16;
+    typedef WaveSplit<NT, PT> WS;
+    constexpr int KTOT = 9 * CIN;
+    constexpr int KCH = (KTOT + M::K - 1) / M::K;
+    const int wn = wave % WS::WN, wp = wave / WS::WN;
+    GemmPipe<T, WS::NI, WS::NJ, KCH, WS::WN> pipe;
+    pipe.init(L.w, wn, lane);
+    f32x4 bias[WS::NI];
+#pragma unroll
+    for (int i = 0; i < WS::NI; i++) bias[i] = *(const f32x4 *)(L.b + acc_cout(wn + i * WS::WN, lane, 0));
+
+    const T *in = L.in;
+    const int in_ld = L.in_ld, in_off = L.in_off;
     for (int i = tid; i < HR * HC * CPV; i += kThreads) {
         int pix = i / CPV, cv = i % CPV;
         int iy = oy0 - 1 + pix / HC, ix = ox0 - 1 + pix % HC;
         V v = vzero<V, VEC>();
-        if (iy >= 0 && iy < a.h && ix >= 0 && ix < a.w_) {
-            v = *(const V *)(a.in + (img_pix + (size_t)iy * a.w_ + ix) * a.in_ld + a.in_off + cv * VEC);
+        if (iy >= 0 && iy < lh && ix >= 0 && ix < lw) {
+            v = *(const V *)(in + (img_pix + (size_t)iy * lw + ix) * in_ld + in_off + cv * VEC);
             if constexpr (UPADD) {
                 // out[2m] = .75 in[m] + .25 in[m-1];  out[2m+1] = .75 in[m] + .25 in[m+1];  taps outside = 0
-                const int hh = a.h >> 1, wh = a.w_ >> 1;
+                const int hh = lh >> 1, wh = lw >> 1;
                 const int my = iy >> 1, mx = ix >> 1;
                 const int my2 = (iy & 1) ? my + 1 : my - 1, mx2 = (ix & 1) ? mx + 1 : mx - 1;
-                const T *ub = a.up + (size_t)img * hh * wh * CIN + cv * VEC;
+                const T *ub = L.up + (size_t)img * hh * wh * CIN + cv * VEC;
                 float s[VEC];
 #pragma unroll
                 for (int e = 0; e < VEC; e++) s[e] = 0.f;
@@ -443,12 +603,6 @@ __global__ __launch_bounds__(kThreads) void conv3x3_kernel(Conv3Args<T> a) {
     }
     __syncthreads();
 
-    constexpr int NT = COUT / 16, PT = P / 16;
-    typedef WaveSplit<NT, PT> WS;
-    constexpr int KTOT = 9 * CIN;
-    constexpr int KCH = (KTOT + M::K - 1) / M::K;
-    const int lane = tid & 63, wave = tid >> 6;
-    const int wn = wave % WS::WN, wp = wave / WS::WN;
     int pbase[WS::NJ];
 #pragma unroll
     for (int j = 0; j < WS::NJ; j++) {
@@ -460,53 +614,52 @@ __global__ __launch_bounds__(kThreads) void conv3x3_kernel(Conv3Args<T> a) {
     for (int i = 0; i < WS::NI; i++)
 #pragma unroll
         for (int j = 0; j < WS::NJ; j++) acc[i][j] = vzero<f32x4, 4>();
-    const typename M::Frag *wfrag = (const typename M::Frag *)a.w;
-#pragma unroll 2
-    for (int kc = 0; kc < KCH; kc++) {
-        typename M::Frag wf[WS::NI], xf[WS::NJ];
-#pragma unroll
-        for (int i = 0; i < WS::NI; i++) wf[i] = wfrag[((wn + i * WS::WN) * KCH + kc) * 64 + lane];
+    pipe.run(acc, [&](int j, int kc) -> typename M::Frag {
         const int kb = kc * M::K + (lane >> 4) * M::KPL;      // k = tap*CIN + c, KPL consecutive c of one tap
         const int tap = kb / CIN, c = kb % CIN;
         const int koff = ((tap / 3) * HC + tap % 3) * LDI + c;
-#pragma unroll
-        for (int j = 0; j < WS::NJ; j++)
-            xf[j] = kb < KTOT ? *(const typename M::Frag *)(s_in + pbase[j] + koff) : M::zero();
-#pragma unroll
-        for (int i = 0; i < WS::NI; i++)
-#pragma unroll
-            for (int j = 0; j < WS::NJ; j++) acc[i][j] = M::mma(wf[i], xf[j], acc[i][j]);
-    }
+        return kb < KTOT ? *(const typename M::Frag *)(s_in + pbase[j] + koff) : M::zero();
+    });
     __syncthreads();      // every wave is done reading s_in before it is overwritten as s_out
 #pragma unroll
     for (int i = 0; i < WS::NI; i++)
 #pragma unroll
         for (int j = 0; j < WS::NJ; j++)
-            store_acc<T, LDO>(s_out, a.b, acc[i][j], wn + i * WS::WN, wp + j * WS::WP, lane, true);
+            store_acc<T, LDO>(s_out, bias[i], acc[i][j], wn + i * WS::WN, wp + j * WS::WP, lane, true);
     __syncthreads();
 
     constexpr int OPV = COUT / VEC;
+    T *out0 = L.out0, *out1 = L.out1;
+    const int n0 = L.n0, ld0 = L.ld0, off0 = L.off0, ld1 = L.ld1, off1 = L.off1;
     for (int i = tid; i < P * OPV; i += kThreads) {
         int p = i / OPV, cv = i % OPV;
         int oy = oy0 + p / TW, ox = ox0 + p % TW;
-        if (oy < a.h && ox < a.w_) {
-            const size_t pix = img_pix + (size_t)oy * a.w_ + ox;
+        if (oy < lh && ox < lw) {
+            const size_t pix = img_pix + (size_t)oy * lw + ox;
             const int c = cv * VEC;
-            T *dst = c < a.n0 ? a.out0 + pix * a.ld0 + a.off0 + c : a.out1 + pix * a.ld1 + a.off1 + (c - a.n0);
+            T *dst = c < n0 ? out0 + pix * ld0 + off0 + c : out1 + pix * ld1 + off1 + (c - n0);
             *(V *)dst = *(const V *)(s_out + p * LDO + c);
         }
     }
 }
 
 template <typename T, int CIN, int COUT, int TH, int TW>
-static TileInfo conv3_dispatch(hipStream_t s, const Conv3Params<T> *p, int h, int w) {
+static TileInfo conv3_dispatch(hipStream_t s, const Conv3Params<T> *p, int nlv, int h, int w) {
     typedef Conv3Cfg<T, CIN, COUT, TH, TW> C;
-    int tiles_x = (w + TW - 1) / TW, tiles_y = (h + TH - 1) / TH;
-    TileInfo ti{TH, TW, C::LDS_BYTES, tiles_x * tiles_y};
+    TileInfo ti{TH, TW, C::LDS_BYTES, ((w + TW - 1) / TW) * ((h + TH - 1) / TH)};
     if (!p) return ti;
-    Conv3Args<T> a{p->in, p->in_ld, p->in_off, p->up, p->w, p->b, p->out0, p->ld0, p->off0, p->n0,
-                   p->out1, p->ld1, p->off1, p->h, p->w_, tiles_x, tiles_y, p->n * tiles_x * tiles_y};
-    if (p->up) {
+    Conv3Args<T> a;
+    int blk = 0;
+    for (int l = 0; l < 3; l++) {
+        const Conv3Params<T> &q = p[l < nlv ? l : nlv - 1];
+        int tiles_x = (q.w_ + TW - 1) / TW, tiles_y = (q.h + TH - 1) / TH;
+        a.lv[l] = Conv3Level<T>{q.in, q.up, q.w, q.b, q.out0, q.out1, q.in_ld, q.in_off, q.ld0, q.off0, q.n0, q.ld1, q.off1,
+                                q.h, q.w_, tiles_x, tiles_y, blk};
+        if (l < nlv) blk += q.n * tiles_x * tiles_y;
+        else a.lv[l].blk_begin = 0x7fffffff;
+    }
+    a.nblk = blk;
+    if (p[0].up) {
         if constexpr (CIN == 64 && COUT == 64) {
             auto kern = conv3x3_kernel<T, CIN, COUT, TH, TW, true>;
             static bool attr_set = false;
@@ -525,28 +678,31 @@ static TileInfo conv3_dispatch(hipStream_t s, const Conv3Params<T> *p, int h, in
 }
 
 template <typename T>
-static TileInfo conv3_select(hipStream_t s, const Conv3Params<T> *p, int cin, int cout, int h, int w) {
-    // small maps (stride 32 / 16 at 448^2: 14x14, 28x28) get 4x8 tiles for more workgroups where the channel
-    // tiles still split over 4 waves (COUT % 32 == 0); larger maps 8x8
-    const bool small = (size_t)h * w <= 32 * 32;
+static TileInfo conv3_select(hipStream_t s, const Conv3Params<T> *p, int nlv, int cin, int cout, int h, int w) {
+    // single-level small maps (stride 32 / 16 at 448^2: 14x14, 28x28) get 4x8 tiles for more workgroups where the
+    // channel tiles still split over 4 waves (COUT % 32 == 0); everything else 8x8
+    const bool small = nlv == 1 && (size_t)h * w <= 32 * 32;
     if (cin == 64 && cout == 64)
-        return small ? conv3_dispatch<T, 64, 64, 4, 8>(s, p, h, w) : conv3_dispatch<T, 64, 64, 8, 8>(s, p, h, w);
+        return small ? conv3_dispatch<T, 64, 64, 4, 8>(s, p, nlv, h, w) : conv3_dispatch<T, 64, 64, 8, 8>(s, p, nlv, h, w);
     if (cin == 16 && cout == 32)
-        return small ? conv3_dispatch<T, 16, 32, 4, 8>(s, p, h, w) : conv3_dispatch<T, 16, 32, 8, 8>(s, p, h, w);
-    if (cin == 64 && cout == 48) return conv3_dispatch<T, 64, 48, 8, 8>(s, p, h, w);
-    if (cin == 16 && cout == 16) return conv3_dispatch<T, 16, 16, 8, 8>(s, p, h, w);
+        return small ? conv3_dispatch<T, 16, 32, 4, 8>(s, p, nlv, h, w) : conv3_dispatch<T, 16, 32, 8, 8>(s, p, nlv, h, w);
+    if (cin == 64 && cout == 48) return conv3_dispatch<T, 64, 48, 8, 8>(s, p, nlv, h, w);
+    if (cin == 16 && cout == 16) return conv3_dispatch<T, 16, 16, 8, 8>(s, p, nlv, h, w);
     return TileInfo{0, 0, 0, 0};
 }
 
-template <typename T> void launch_conv3x3(hipStream_t s, const Conv3Params<T> &p) {
-    TileInfo ti = conv3_select<T>(s, &p, p.cin, p.cout, p.h, p.w_);
+template <typename T> void launch_conv3x3(hipStream_t s, const Conv3Params<T> *levels, int nlevels) {
+    if (nlevels < 1 || nlevels > 3) abort();
+    for (int l = 1; l < nlevels; l++)
+        if (levels[l].cin != levels[0].cin || levels[l].cout != levels[0].cout || levels[l].up) abort();
+    TileInfo ti = conv3_select<T>(s, levels, nlevels, levels[0].cin, levels[0].cout, levels[0].h, levels[0].w_);
     if (ti.th == 0) abort();
 }
 template <typename T> TileInfo conv3x3_tile_info(int cin, int cout, int h, int w) {
-    return conv3_select<T>(nullptr, nullptr, cin, cout, h, w);
+    return conv3_select<T>(nullptr, nullptr, 1, cin, cout, h, w);
 }
-template void launch_conv3x3<half_t>(hipStream_t, const Conv3Params<half_t> &);
-template void launch_conv3x3<float>(hipStream_t, const Conv3Params<float> &);
+template void launch_conv3x3<half_t>(hipStream_t, const Conv3Params<half_t> *, int);
+template void launch_conv3x3<float>(hipStream_t, const Conv3Params<float> *, int);
 template TileInfo conv3x3_tile_info<half_t>(int, int, int, int);
 template TileInfo conv3x3_tile_info<float>(int, int, int, int);
 
@@ -556,6 +712,7 @@ template TileInfo conv3x3_tile_info<float>(int, int, int, int);
 //   (trtretinafacenet.cpp:63-72) and the CPU loop RetinaFace.cpp:666-724 with bbox_pred (:378-398),
 //   clip_boxes (:179-199) and landmark_pred (:418-432).  Here only above-threshold candidates leave the chip.
 //   The float/double rounding points of the reference are reproduced (fp contraction off in decode_anchor).
+//   One launch covers the heads of all three strides.
 // =============================================================================================
 constexpr int HEAD_P = 64;          // pixels per workgroup (flat, row-major)
 constexpr int HEAD_LDO = 33;        // fp32 result tile row stride (32 + 1: conflict-free column reads)
@@ -596,15 +753,19 @@ __device__ __forceinline__ void decode_anchor(const float *__restrict__ o /*32 h
 }
 
 template <typename T>
-struct HeadArgs {
+struct HeadLevel {
     const T *in; const T *w; const float *b;
-    int hw, w_, stride, anchor_offset;
+    float *dump_prob, *dump_bbox, *dump_lmk;
     float base[2][4];
+    int hw, w_, stride, anchor_offset, blocks_per_image, blk_begin;
+};
+template <typename T>
+struct HeadArgs {
+    HeadLevel<T> lv[3];
     int net_h, net_w;
     const RunParams *params;
     Candidate *cand; int *cand_count; int cap;
-    float *dump_prob, *dump_bbox, *dump_lmk;
-    int blocks_per_image, nblk;
+    int nblk;
 };
 
 template <typename T>
@@ -617,50 +778,53 @@ __global__ __launch_bounds__(kThreads) void head_kernel(HeadArgs<T> a) {
     __shared__ float s_o[P * HEAD_LDO];
 
     const int tid = threadIdx.x;
-    const int bid = xcd_remap(blockIdx.x, a.nblk);
-    const int img = bid / a.blocks_per_image;
-    const int p0 = (bid % a.blocks_per_image) * P;
-    const T *inb = a.in + (size_t)img * a.hw * CIN;
-    for (int i = tid; i < P * CPV; i += kThreads) {
-        int p = i / CPV, cv = i % CPV;
-        V v = vzero<V, VEC>();
-        if (p0 + p < a.hw) v = *(const V *)(inb + (size_t)(p0 + p) * CIN + cv * VEC);
-        *(V *)(s_a + p * LDA + cv * VEC) = v;
-    }
-    __syncthreads();
+    const int lane = tid & 63, wave = tid >> 6;
+    const int gbid = xcd_remap(blockIdx.x, a.nblk);
+    const int lvl = (gbid >= a.lv[1].blk_begin ? 1 : 0) + (gbid >= a.lv[2].blk_begin ? 1 : 0);
+    const HeadLevel<T> &L = a.lv[lvl];
+    const int bid = gbid - L.blk_begin;
+    const int img = bid / L.blocks_per_image;
+    const int p0 = (bid % L.blocks_per_image) * P;
+    const int hw = L.hw;
 
     constexpr int NT = COUT / 16, PT = P / 16;       // 2 x 4 tiles: waves = 2 (cout) x 2 (pixel halves)
     typedef WaveSplit<NT, PT> WS;
     constexpr int KCH = CIN / M::K;
-    const int lane = tid & 63, wave = tid >> 6;
     const int wn = wave % WS::WN, wp = wave / WS::WN;
-    f32x4 acc[WS::NJ];
-#pragma unroll
-    for (int j = 0; j < WS::NJ; j++) acc[j] = vzero<f32x4, 4>();
-    const typename M::Frag *wfrag = (const typename M::Frag *)a.w;
-#pragma unroll
-    for (int kc = 0; kc < KCH; kc++) {
-        const typename M::Frag wf = wfrag[(wn * KCH + kc) * 64 + lane];
-        const int kb = kc * M::K + (lane >> 4) * M::KPL;
-#pragma unroll
-        for (int j = 0; j < WS::NJ; j++) {
-            const int p = acc_pixel(wp + j * WS::WP, lane);
-            acc[j] = M::mma(wf, *(const typename M::Frag *)(s_a + p * LDA + kb), acc[j]);
-        }
+    GemmPipe<T, 1, WS::NJ, KCH, WS::WN> pipe;
+    pipe.init(L.w, wn, lane);
+    const float threshold = a.params->threshold;
+    const f32x4 bias = *(const f32x4 *)(L.b + acc_cout(wn, lane, 0));
+
+    const T *inb = L.in + (size_t)img * hw * CIN;
+    for (int i = tid; i < P * CPV; i += kThreads) {
+        int p = i / CPV, cv = i % CPV;
+        V v = vzero<V, VEC>();
+        if (p0 + p < hw) v = *(const V *)(inb + (size_t)(p0 + p) * CIN + cv * VEC);
+        *(V *)(s_a + p * LDA + cv * VEC) = v;
     }
+    __syncthreads();
+
+    f32x4 acc[1][WS::NJ];
+#pragma unroll
+    for (int j = 0; j < WS::NJ; j++) acc[0][j] = vzero<f32x4, 4>();
+    pipe.run(acc, [&](int j, int kc) -> typename M::Frag {
+        const int kb = kc * M::K + (lane >> 4) * M::KPL;
+        return *(const typename M::Frag *)(s_a + acc_pixel(wp + j * WS::WP, lane) * LDA + kb);
+    });
 #pragma unroll
     for (int j = 0; j < WS::NJ; j++) {
         const int p = acc_pixel(wp + j * WS::WP, lane);
         const int c0 = acc_cout(wn, lane, 0);
 #pragma unroll
-        for (int r = 0; r < 4; r++) s_o[p * HEAD_LDO + c0 + r] = acc[j][r] + a.b[c0 + r];
+        for (int r = 0; r < 4; r++) s_o[p * HEAD_LDO + c0 + r] = acc[0][j][r] + bias[r];
     }
     __syncthreads();
 
     if (tid < 2 * P) {
         const int p = tid % P, an = tid / P;          // anchor index a is wave-uniform
         const int gp = p0 + p;
-        if (gp < a.hw) {
+        if (gp < hw) {
             const float *o = s_o + p * HEAD_LDO;
             // Softmax over the pair (channel a, channel 2+a): Caffe subtracts the max, exponentiates, normalises
             const float s0 = o[an], s1 = o[2 + an];
@@ -668,50 +832,60 @@ __global__ __launch_bounds__(kThreads) void head_kernel(HeadArgs<T> a) {
             const float e0 = expf(s0 - m), e1 = expf(s1 - m);
             const float sum = e0 + e1;
             const float conf = e1 / sum;
-            if (a.dump_prob) {
-                const size_t hw = (size_t)a.hw;
-                a.dump_prob[((size_t)img * 4 + an) * hw + gp] = e0 / sum;
-                a.dump_prob[((size_t)img * 4 + 2 + an) * hw + gp] = conf;
+            if (L.dump_prob) {
+                const size_t shw = (size_t)hw;
+                L.dump_prob[((size_t)img * 4 + an) * shw + gp] = e0 / sum;
+                L.dump_prob[((size_t)img * 4 + 2 + an) * shw + gp] = conf;
 #pragma unroll
-                for (int c = 0; c < 4; c++) a.dump_bbox[((size_t)img * 8 + an * 4 + c) * hw + gp] = o[4 + an * 4 + c];
+                for (int c = 0; c < 4; c++) L.dump_bbox[((size_t)img * 8 + an * 4 + c) * shw + gp] = o[4 + an * 4 + c];
 #pragma unroll
-                for (int c = 0; c < 10; c++) a.dump_lmk[((size_t)img * 20 + an * 10 + c) * hw + gp] = o[12 + an * 10 + c];
+                for (int c = 0; c < 10; c++) L.dump_lmk[((size_t)img * 20 + an * 10 + c) * shw + gp] = o[12 + an * 10 + c];
             }
-            if (conf > a.params->threshold) {          // "if (conf <= threshold) continue", RetinaFace.cpp:693
-                const int iy = gp / a.w_, ix = gp % a.w_;
-                const float sx = (float)(ix * a.stride), sy = (float)(iy * a.stride);
+            if (conf > threshold) {                    // "if (conf <= threshold) continue", RetinaFace.cpp:693
+                const int iy = gp / L.w_, ix = gp % L.w_;
+                const float sx = (float)(ix * L.stride), sy = (float)(iy * L.stride);
                 const int slot = atomicAdd(&a.cand_count[img], 1);
                 if (slot < a.cap)
-                    decode_anchor(o, an, a.base[an][0] + sx, a.base[an][1] + sy, a.base[an][2] + sx, a.base[an][3] + sy,
-                                  a.net_w, a.net_h, conf, a.anchor_offset + an * a.hw + gp,
+                    decode_anchor(o, an, L.base[an][0] + sx, L.base[an][1] + sy, L.base[an][2] + sx, L.base[an][3] + sy,
+                                  a.net_w, a.net_h, conf, L.anchor_offset + an * hw + gp,
                                   a.cand + (size_t)img * a.cap + slot);
             }
         }
     }
 }
 
-template <typename T> void launch_head(hipStream_t s, const HeadParams<T> &p) {
+template <typename T> void launch_head(hipStream_t s, const HeadParams<T> *levels, int nlevels) {
+    if (nlevels < 1 || nlevels > 3) abort();
     HeadArgs<T> a;
-    a.in = p.in; a.w = p.w; a.b = p.b;
-    a.hw = p.h * p.w_; a.w_ = p.w_; a.stride = p.stride; a.anchor_offset = p.anchor_offset;
-    for (int i = 0; i < 2; i++) for (int j = 0; j < 4; j++) a.base[i][j] = p.base[i][j];
-    a.net_h = p.net_h; a.net_w = p.net_w; a.params = p.params;
-    a.cand = p.cand; a.cand_count = p.cand_count; a.cap = p.cap;
-    a.dump_prob = p.dump_prob; a.dump_bbox = p.dump_bbox; a.dump_lmk = p.dump_lmk;
-    a.blocks_per_image = (a.hw + HEAD_P - 1) / HEAD_P;
-    a.nblk = p.n * a.blocks_per_image;
+    int blk = 0;
+    for (int l = 0; l < 3; l++) {
+        const HeadParams<T> &p = levels[l < nlevels ? l : nlevels - 1];
+        HeadLevel<T> &L = a.lv[l];
+        L.in = p.in; L.w = p.w; L.b = p.b;
+        L.dump_prob = p.dump_prob; L.dump_bbox = p.dump_bbox; L.dump_lmk = p.dump_lmk;
+        for (int i = 0; i < 2; i++) for (int j = 0; j < 4; j++) L.base[i][j] = p.base[i][j];
+        L.hw = p.h * p.w_; L.w_ = p.w_; L.stride = p.stride; L.anchor_offset = p.anchor_offset;
+        L.blocks_per_image = (L.hw + HEAD_P - 1) / HEAD_P;
+        L.blk_begin = l < nlevels ? blk : 0x7fffffff;
+        if (l < nlevels) blk += p.n * L.blocks_per_image;
+    }
+    const HeadParams<T> &p0 = levels[0];
+    a.net_h = p0.net_h; a.net_w = p0.net_w; a.params = p0.params;
+    a.cand = p0.cand; a.cand_count = p0.cand_count; a.cap = p0.cap;
+    a.nblk = blk;
     hipLaunchKernelGGL(head_kernel<T>, dim3(a.nblk), dim3(kThreads), 0, s, a);
 }
-template void launch_head<half_t>(hipStream_t, const HeadParams<half_t> &);
-template void launch_head<float>(hipStream_t, const HeadParams<float> &);
+template void launch_head<half_t>(hipStream_t, const HeadParams<half_t> *, int);
+template void launch_head<float>(hipStream_t, const HeadParams<float> *, int);
 
 // =============================================================================================
 // K_e  per-image NMS: total order (score desc, anchor index asc), greedy suppression with the reference's
-//      +1-pixel IoU and strict ">" (RetinaFace.cpp:434-492).  One 1024-thread workgroup per image:
+//      +1-pixel IoU and strict ">" (RetinaFace.cpp:434-492).  One 256-thread workgroup per image:
 //      bitonic sort of 64-bit keys in LDS, then a serial walk over survivors where each survivor's
 //      suppression sweep is data-parallel.  fp contraction off: same roundings as the scalar CPU loop.
+//      Results are written straight to the caller-visible (pinned host) result block.
 // =============================================================================================
-constexpr int NMS_THREADS = 1024;
+constexpr int NMS_THREADS = 256;
 
 __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(NmsParams a) {
 #pragma clang fp contract(off)
@@ -726,6 +900,7 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(NmsParams a) {
     const int tid = threadIdx.x;
     const int img = blockIdx.x;
     const Candidate *cand = a.cand + (size_t)img * cap;
+    const float thr = a.params->nms_threshold;
     const int n_found = a.cand_count[img];
     int n = n_found;
     if (n > cap) n = cap;
@@ -742,20 +917,22 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(NmsParams a) {
         s_slot[i] = i;
     }
     __syncthreads();
-    for (int k = 2; k <= npow; k <<= 1) {
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int i = tid; i < npow; i += NMS_THREADS) {
-                const int l = i ^ j;
-                if (l > i) {
-                    const unsigned long long ki = s_key[i], kl = s_key[l];
-                    const bool up = (i & k) == 0;
-                    if ((ki > kl) == up) {
-                        s_key[i] = kl; s_key[l] = ki;
-                        const int t = s_slot[i]; s_slot[i] = s_slot[l]; s_slot[l] = t;
+    if (n > 1) {
+        for (int k = 2; k <= npow; k <<= 1) {
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                for (int i = tid; i < npow; i += NMS_THREADS) {
+                    const int l = i ^ j;
+                    if (l > i) {
+                        const unsigned long long ki = s_key[i], kl = s_key[l];
+                        const bool up = (i & k) == 0;
+                        if ((ki > kl) == up) {
+                            s_key[i] = kl; s_key[l] = ki;
+                            const int t = s_slot[i]; s_slot[i] = s_slot[l]; s_slot[l] = t;
+                        }
                     }
                 }
+                __syncthreads();
             }
-            __syncthreads();
         }
     }
     for (int i = tid; i < n; i += NMS_THREADS) {
@@ -765,7 +942,6 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(NmsParams a) {
     }
     __syncthreads();
 
-    const float thr = a.params->nms_threshold;
     const int lane = tid & 63;
     int kept = 0;
     for (int base = 0; base < n; base += 64) {
