@@ -41,6 +41,7 @@ def main() -> None:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--profile-iters", type=int, default=50)
+    ap.add_argument("--lanes", type=int, default=0, help="batches in flight (0 = engine default)")
     args = ap.parse_args()
 
     import numpy as np
@@ -63,7 +64,7 @@ def main() -> None:
     B, H, W = args.batch, args.height, args.width
     prec = retinaface_amd.PRECISION_FP16 if args.precision == "fp16" else retinaface_amd.PRECISION_FP32
     det = retinaface_amd.RetinaFace(os.path.join(ROOT, "assets"), "net3", 0.4, precision=prec, net_hw=(H, W), max_batch=B,
-                                    model_stem=args.model)
+                                    model_stem=args.model, lanes=args.lanes)
     frames_np = synth_frames(H, W, B, config=1 + rank)
     frames = torch.from_numpy(np.stack(frames_np)).cuda()
     torch.cuda.synchronize()
@@ -151,7 +152,7 @@ def main() -> None:
             "dtype": "f16" if args.precision == "fp16" else "f32", "data": "synthetic",
             "config": {"workload": f"{args.model} {args.precision} HIP, {W}x{H}, batch {B} per GPU (BASELINE.json configs[1] at 448x448 b=8)",
                        "global_batch": B * world, "frame": [H, W], "threshold": args.threshold, "nms": 0.4,
-                       "parallelism": f"dp{world} (image sharding, no data-path collective)"},
+                       "parallelism": f"dp{world} (image sharding, no data-path collective)", "lanes_in_flight": slots},
             "images_per_sec": images_total / dt_max, "ms_per_frame": dt_max / (args.steps * B) * 1e3,
             "faces_per_step": faces_total / args.steps / world,
             "sync_call_ms": sync_ms,

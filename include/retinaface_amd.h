@@ -65,7 +65,7 @@ typedef struct rf_options {
     int32_t use_graph;          /* 1 (default) = replay a captured hipGraph per batch size; 2 = off */
     int32_t keep_outputs;       /* 1 = also materialise the 9 NCHW fp32 head blobs for rf_get_output() */
     const char *model_stem;     /* default "mnet-deconv-0517" (RetinaFace.cpp:276) */
-    int32_t lanes;              /* batches that may be in flight at once (default 2): each lane owns a stream, its
+    int32_t lanes;              /* batches that may be in flight at once (default 3): each lane owns a stream, its
                                    activation buffers and its hipGraphs; = rf_num_slots() */
 } rf_options;
 

@@ -257,11 +257,17 @@ public:
         *l.h_params = RunParams{0.5f, nms_threshold_, n, 0};
         size_t nops = l.ops.size();
         while (prof_ev_.size() < 2 * nops) { hipEvent_t e; RF_HIP(hipEventCreate(&e)); prof_ev_.push_back(e); }
+        // Every launch is timed on the engine's own stream as `kReps` back-to-back repetitions between one HIP event
+        // pair (a single launch between two events would mostly measure the ~6 us event/launch overhead); the result is
+        // the average duration per launch including its launch boundary.  A full pass runs first in launch order so
+        // every kernel sees the real producer's data.
+        constexpr int kReps = 8;
         std::vector<double> sum(nops, 0.0);
-        for (int it = -2; it < iters; it++) {      // two untimed warm-up passes
+        for (int it = -1; it < iters; it++) {      // one untimed warm-up pass
             for (size_t k = 0; k < nops; k++) {
+                l.ops[k].launch(l.stream, n);       // real predecessor state for op k+1 .. (and warm caches as in the pipeline)
                 RF_HIP(hipEventRecord(prof_ev_[2 * k], l.stream));
-                l.ops[k].launch(l.stream, n);
+                for (int r = 0; r < kReps; r++) l.ops[k].launch(l.stream, n);
                 RF_HIP(hipEventRecord(prof_ev_[2 * k + 1], l.stream));
             }
             RF_HIP(hipStreamSynchronize(l.stream));
@@ -270,7 +276,7 @@ public:
             for (size_t k = 0; k < nops; k++) {
                 float ms = 0;
                 RF_HIP(hipEventElapsedTime(&ms, prof_ev_[2 * k], prof_ev_[2 * k + 1]));
-                sum[k] += ms;
+                sum[k] += ms / kReps;
             }
         }
         for (size_t k = 0; k < nops && (int)k < cap; k++) {

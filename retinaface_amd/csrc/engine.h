@@ -30,7 +30,7 @@ struct EngineOptions {
     int max_candidates = 4096;
     int max_detections = 256;
     bool use_graph = true;
-    int lanes = 2;                   // batches in flight (each lane has its own stream + buffers + graphs)
+    int lanes = 3;                   // batches in flight (each lane has its own stream + buffers + graphs)
     bool keep_outputs = false;
     std::string model_stem = "mnet-deconv-0517";
 };
