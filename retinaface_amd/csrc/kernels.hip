@@ -904,23 +904,41 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(NmsParams a) {
     const int n_found = a.cand_count[img];
     int n = n_found;
     if (n > cap) n = cap;
-    int npow = 64;
-    while (npow < n) npow <<= 1;
-
-    for (int i = tid; i < npow; i += NMS_THREADS) {
-        unsigned long long key = ~0ull;
-        if (i < n) {
+    // Typical images carry a few dozen candidates: then ONE wavefront does everything (the other three retire, so
+    // every __syncthreads() below degenerates to a wave-local fence) and the order comes from a rank sort (one pass,
+    // no barrier ladder).  Larger sets fall back to a 256-thread bitonic network.
+    const bool small = n <= 64;
+    if (small && tid >= 64) return;
+    const int nthr = small ? 64 : NMS_THREADS;
+    if (n <= 256) {
+        for (int i = tid; i < n; i += nthr) {
             const unsigned int sbits = __float_as_uint(cand[i].score);      // scores are positive: bit order = value order
-            key = ((unsigned long long)(~sbits) << 32) | (unsigned int)cand[i].anchor;
+            s_key[i] = ((unsigned long long)(~sbits) << 32) | (unsigned int)cand[i].anchor;
         }
-        s_key[i] = key;
-        s_slot[i] = i;
-    }
-    __syncthreads();
-    if (n > 1) {
+        __syncthreads();
+        for (int i = tid; i < n; i += nthr) {
+            const unsigned long long ki = s_key[i];
+            int rank = 0;
+            for (int j = 0; j < n; j++) rank += s_key[j] < ki ? 1 : 0;      // keys are unique (anchor index)
+            s_slot[rank] = i;
+        }
+        __syncthreads();
+    } else {
+        int npow = 512;
+        while (npow < n) npow <<= 1;
+        for (int i = tid; i < npow; i += nthr) {
+            unsigned long long key = ~0ull;
+            if (i < n) {
+                const unsigned int sbits = __float_as_uint(cand[i].score);
+                key = ((unsigned long long)(~sbits) << 32) | (unsigned int)cand[i].anchor;
+            }
+            s_key[i] = key;
+            s_slot[i] = i;
+        }
+        __syncthreads();
         for (int k = 2; k <= npow; k <<= 1) {
             for (int j = k >> 1; j > 0; j >>= 1) {
-                for (int i = tid; i < npow; i += NMS_THREADS) {
+                for (int i = tid; i < npow; i += nthr) {
                     const int l = i ^ j;
                     if (l > i) {
                         const unsigned long long ki = s_key[i], kl = s_key[l];
@@ -935,7 +953,7 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(NmsParams a) {
             }
         }
     }
-    for (int i = tid; i < n; i += NMS_THREADS) {
+    for (int i = tid; i < n; i += nthr) {
         const Candidate *c = cand + s_slot[i];
         s_box[i] = make_float4(c->x1, c->y1, c->x2, c->y2);
         s_alive[i] = 1;
@@ -953,7 +971,7 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(NmsParams a) {
             kept++;
             const float4 sb = s_box[sel];
             const float area1 = (sb.z - sb.x + 1) * (sb.w - sb.y + 1);
-            for (int i = sel + 1 + tid; i < n; i += NMS_THREADS) {
+            for (int i = sel + 1 + tid; i < n; i += nthr) {
                 if (!s_alive[i]) continue;
                 const float4 bi = s_box[i];
                 const float x = fmaxf(sb.x, bi.x);
@@ -972,7 +990,7 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(NmsParams a) {
     }
     __syncthreads();
     const int nout = kept < a.max_det ? kept : a.max_det;
-    for (int i = tid; i < nout * 16; i += NMS_THREADS) {
+    for (int i = tid; i < nout * 16; i += nthr) {
         const int k = i >> 4, f = i & 15;
         const uint32_t *src = (const uint32_t *)(cand + s_slot[s_kept[k]]);
         ((uint32_t *)(a.out + (size_t)img * a.max_det + k))[f] = src[f];

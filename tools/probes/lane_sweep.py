@@ -11,7 +11,7 @@ frames = torch.from_numpy(np.stack(synth_frames(448, 448, B, config=1))).cuda()
 torch.cuda.synchronize()
 ptrs = [frames[i].data_ptr() for i in range(B)]
 rows = cols = [448] * B
-for lanes in (1, 2, 3, 4):
+for lanes in [int(x) for x in os.environ.get("LANES", "1,2,3,4").split(",")]:
     for par in (True, False):
         for graph in (True,):
             det = retinaface_amd.RetinaFace(os.path.join(ROOT, "assets"), "net3", 0.4, net_hw=(448, 448), max_batch=B,
