@@ -130,13 +130,23 @@ def main() -> None:
         prof = eager.profile(ptrs, iters=args.profile_iters)
         eager.close()
         dom = max(prof, key=lambda p: p["ms"])
+        # HBM bytes per launch of that kernel from the rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE, collected
+        # separately and corrected as MI355X_MICROARCH.md prescribes; tools/pmc_summary.py).  PMC collection cannot run
+        # inside this process, so the committed summary of the same workload (batch 8, 448x448, fp16) is joined by kernel
+        # instance; any other workload reports null.
+        traffic = None
+        pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic_b8_448_fp16.json")
+        if os.path.exists(pmc_path) and (B, H, W, args.precision) == (8, 448, 448, "fp16"):
+            for k in json.load(open(pmc_path))["kernels"]:
+                if k["kernel"] == dom["kernel"]:
+                    traffic = k["hbm_bytes_per_launch"]
         kernel_ms = sum(p["ms"] for p in prof)
         alg_total = sum(p["alg_bytes"] for p in prof)
         elem = 2 if args.precision == "fp16" else 4
         roofline = {
-            "bound": "hbm", "kernel": dom["name"],
+            "bound": "hbm", "kernel": dom["name"], "kernel_instance": dom["kernel"],
             "achieved": dom["alg_bytes"] / (dom["ms"] * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": dom["alg_bytes"] / (dom["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+            "frac": dom["alg_bytes"] / (dom["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
             "kernel_ms": dom["ms"], "kernel_alg_bytes": dom["alg_bytes"],
             "kernel_share_of_gpu_time": dom["ms"] / kernel_ms,
             "all_kernels_ms": kernel_ms, "all_kernels_alg_bytes": alg_total,

@@ -135,14 +135,15 @@ long rf_get_output(rf_handle h, const char *blob_name, int image, float *dst, si
  * rf_debug_activation: copy an internal NHWC activation of the last batch, converted to fp32, by the
  *   name of the reference blob it corresponds to (e.g. "mobilenet0_relu10_fwd", "rf_c2_aggr_relu").
  *   dims = {H, W, C}.  Returns floats written (or needed if dst == NULL), negative on error.
- * rf_profile: run the per-kernel launch sequence for a batch of n net-sized device frames `iters`
- *   times with a HIP event pair around every launch; returns the number of kernels, fills
- *   names (up to cap entries, pointers owned by the engine), avg_ms, and the algorithmic bytes /
- *   MACs each launch covers (layer-wise input+output elements x element size). */
+ * rf_profile: time every launch of the hot path on the engine's own stream with HIP events (each launch repeated
+ *   back to back between one event pair so the event overhead is amortised), `iters` passes over a batch of n
+ *   net-sized device frames; returns the number of launches, fills names (reference layers covered), kernels
+ *   (kernel instance, e.g. "dwpw<128,128,s1>"; both up to cap entries, pointers owned by the engine), avg_ms, and
+ *   the algorithmic bytes / MACs each launch covers (layer-wise input+output elements x element size). */
 long rf_debug_activation(rf_handle h, const char *blob_name, int image, float *dst, size_t cap_floats,
                          int dims[3]);
 int rf_profile(rf_handle h, const void *const *d_bgr, int n, int iters, int cap,
-               const char **names, float *avg_ms, double *alg_bytes, double *macs);
+               const char **names, const char **kernels, float *avg_ms, double *alg_bytes, double *macs);
 
 /* Offline: pack <prototxt, caffemodel[, int8 table]> into a .rfw file (the analogue of the reference's
  * first-run engine serialisation, trtnetbase.cpp:231-243).  int8_table may be NULL. */

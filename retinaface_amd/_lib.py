@@ -53,8 +53,8 @@ SYMBOLS = {
     "rf_last_timings": (C.c_int, [C.c_void_p, _PP(C.c_float), _PP(C.c_float), _PP(C.c_float), _PP(C.c_float)]),
     "rf_get_output": (C.c_long, [C.c_void_p, C.c_char_p, C.c_int, _PP(C.c_float), C.c_size_t]),
     "rf_debug_activation": (C.c_long, [C.c_void_p, C.c_char_p, C.c_int, _PP(C.c_float), C.c_size_t, _PP(C.c_int)]),
-    "rf_profile": (C.c_int, [C.c_void_p, _PP(C.c_void_p), C.c_int, C.c_int, C.c_int, _PP(C.c_char_p), _PP(C.c_float),
-                             _PP(C.c_double), _PP(C.c_double)]),
+    "rf_profile": (C.c_int, [C.c_void_p, _PP(C.c_void_p), C.c_int, C.c_int, C.c_int, _PP(C.c_char_p), _PP(C.c_char_p),
+                             _PP(C.c_float), _PP(C.c_double), _PP(C.c_double)]),
     "rf_convert_model": (C.c_int, [C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p]),
     "rf_plan_folded": (C.c_int, [C.c_char_p, C.c_char_p, C.c_char_p, _PP(C.c_float), C.c_size_t, _PP(C.c_float),
                                  C.c_size_t, _PP(C.c_int)]),

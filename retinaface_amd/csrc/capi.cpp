@@ -143,10 +143,10 @@ long rf_debug_activation(rf_handle h, const char *blob_name, int image, float *d
     return st == RF_OK ? r : st;
 }
 
-int rf_profile(rf_handle h, const void *const *d_bgr, int n, int iters, int cap, const char **names, float *avg_ms,
-               double *alg_bytes, double *macs) {
+int rf_profile(rf_handle h, const void *const *d_bgr, int n, int iters, int cap, const char **names, const char **kernels,
+               float *avg_ms, double *alg_bytes, double *macs) {
     if (!h || !d_bgr) return RF_ERR_INVALID_ARG;
-    return guarded(h, [&]() -> int { return h->eng->profile(d_bgr, n, iters, cap, names, avg_ms, alg_bytes, macs); });
+    return guarded(h, [&]() -> int { return h->eng->profile(d_bgr, n, iters, cap, names, kernels, avg_ms, alg_bytes, macs); });
 }
 
 int rf_convert_model(const char *prototxt, const char *caffemodel, const char *int8_table, const char *out_rfw) {

@@ -246,8 +246,8 @@ public:
         return (long)cnt;
     }
 
-    int profile(const void *const *d_frames, int n, int iters, int cap, const char **names, float *avg_ms,
-                double *alg_bytes, double *macs) override {
+    int profile(const void *const *d_frames, int n, int iters, int cap, const char **names, const char **kernels,
+                float *avg_ms, double *alg_bytes, double *macs) override {
         if (n < 1 || n > opt_.max_batch || iters < 1) throw ArgError("profile: bad n / iters");
         Lane &l = lanes_[0];
         if (l.busy) { RF_HIP(hipEventSynchronize(l.done)); }
@@ -294,6 +294,7 @@ public:
         sum[kn] = std::max(sum[kn] - sum[kh], 0.0);
         for (size_t k = 0; k < nops && (int)k < cap; k++) {
             if (names) names[k] = l.ops[k].name.c_str();
+            if (kernels) kernels[k] = l.ops[k].kernel.c_str();
             if (avg_ms) avg_ms[k] = (float)(sum[k] / iters);
             if (alg_bytes) alg_bytes[k] = n * (l.ops[k].alg_u8_in + sizeof(T) * (l.ops[k].alg_elems_in + l.ops[k].alg_elems_out));
             if (macs) macs[k] = n * l.ops[k].macs;
@@ -407,6 +408,7 @@ private:
         {
             OpInfo op;
             op.name = "pre+" + plan.conv0.name;
+            op.kernel = "conv0";
             op.alg_u8_in = 3.0 * P;
             op.alg_elems_out = 8.0 * h * w;
             op.macs = plan.conv0.macs_per_out_pixel() * h * w;
@@ -435,6 +437,7 @@ private:
             p.cin = c; p.cout = blk.pw.cout; p.stride = blk.dw.stride; p.has_dw = true;
             OpInfo op;
             op.name = blk.dw.name + "+" + blk.pw.name;
+            op.kernel = "dwpw<" + std::to_string(c) + "," + std::to_string(blk.pw.cout) + ",s" + std::to_string(blk.dw.stride) + ">";
             op.alg_elems_in = (double)c * h * w + (double)c * ho * wo;
             op.alg_elems_out = (double)c * ho * wo + (double)blk.pw.cout * ho * wo;
             op.macs = (blk.dw.macs_per_out_pixel() + blk.pw.macs_per_out_pixel()) * ho * wo;
@@ -444,6 +447,7 @@ private:
                 lat[li] = act(lf.out_blob, ho, wo, 64);
                 p.lat_w = arena_.ptr<T>(lat_w_[li].w); p.lat_b = arena_.ptr<float>(lat_w_[li].b); p.lat_out = lat[li];
                 op.name += "+" + lf.name;
+                op.kernel.insert(op.kernel.size() - 1, ",lat");
                 op.alg_elems_in += (double)blk.pw.cout * ho * wo;
                 op.alg_elems_out += 64.0 * ho * wo;
                 op.macs += lf.macs_per_out_pixel() * ho * wo;
@@ -465,6 +469,10 @@ private:
             p.n = 0; p.h = fh; p.w_ = fw; p.cin = 64; p.cout = 64;
             OpInfo op;
             op.name = std::string(i == 0 ? "rf_c3_upsampling" : "rf_c2_upsampling") + "+" + plan.aggr[i].name;
+            {
+                TileInfo ti = conv3x3_tile_info<T>(64, 64, fh, fw);
+                op.kernel = "conv3x3<64,64," + std::to_string(ti.th) + "x" + std::to_string(ti.tw) + ",up>";
+            }
             op.alg_elems_in = 64.0 * (fh / 2) * (fw / 2) + 64.0 * fh * fw;     // deconv input + conv input
             op.alg_elems_out = 64.0 * fh * fw + 64.0 * fh * fw;               // deconv output + conv output
             op.macs = plan.aggr[i].macs_per_out_pixel() * fh * fw + 16.0 * 64 * (fh / 2) * (fw / 2);
@@ -521,6 +529,10 @@ private:
         op_a.launch = [lv_a](hipStream_t s, int n) { Level3 q = lv_a; for (auto &p : q.p) p.n = n; launch_conv3x3<T>(s, q.p, 3); };
         op_b.launch = [lv_b](hipStream_t s, int n) { Level3 q = lv_b; for (auto &p : q.p) p.n = n; launch_conv3x3<T>(s, q.p, 3); };
         op_c.launch = [lv_c](hipStream_t s, int n) { Level3 q = lv_c; for (auto &p : q.p) p.n = n; launch_conv3x3<T>(s, q.p, 3); };
+        op_a.kernel = "conv3x3<64,48,8x8>";
+        op_b.kernel = "conv3x3<16,32,8x8>";
+        op_c.kernel = "conv3x3<16,16,8x8>";
+        op_h.kernel = "head";
         L.ops.push_back(op_a);
         L.ops.push_back(op_b);
         L.ops.push_back(op_c);
@@ -535,6 +547,7 @@ private:
             np.max_det = opt_.max_detections; np.n = 0;
             OpInfo op;
             op.name = "sort+nms";
+            op.kernel = "nms";
             op.launch = [np](hipStream_t s, int n) { NmsParams q = np; q.n = n; launch_nms(s, q); };
             L.ops.push_back(op);
         }

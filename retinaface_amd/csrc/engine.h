@@ -39,6 +39,7 @@ struct ActInfo { void *ptr; int h, w, c; };
 
 struct OpInfo {
     std::string name;            // reference layer name(s) the launch covers
+    std::string kernel;          // which kernel instance runs it, e.g. "dwpw<128,128,s1>" (joins profiles/*.json)
     double alg_elems_in = 0;     // per image: layer-wise input elements (SURVEY.md 8d "E")
     double alg_elems_out = 0;    // per image: layer-wise output elements
     double alg_u8_in = 0;        // per image: bytes read as u8 (the frame), not scaled by the element size
@@ -66,8 +67,8 @@ public:
     virtual void last_timings(float *pre, float *infer, float *post, float *total) const = 0;
     virtual long get_output(const std::string &blob, int image, float *dst, size_t cap) = 0;
     virtual long debug_activation(const std::string &blob, int image, float *dst, size_t cap, int dims[3]) = 0;
-    virtual int profile(const void *const *d_frames, int n, int iters, int cap, const char **names, float *avg_ms,
-                        double *alg_bytes, double *macs) = 0;
+    virtual int profile(const void *const *d_frames, int n, int iters, int cap, const char **names, const char **kernels,
+                        float *avg_ms, double *alg_bytes, double *macs) = 0;
 
     int net_h() const { return net_h_; }
     int net_w() const { return net_w_; }

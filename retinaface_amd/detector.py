@@ -177,16 +177,18 @@ class RetinaFace:
         return arr.reshape(dims[0], dims[1], dims[2])
 
     def profile(self, ptrs: Sequence[int], iters: int = 20):
-        """Per-kernel HIP-event timing: list of dicts {name, ms, alg_bytes, macs} in launch order."""
+        """Per-kernel HIP-event timing: list of dicts {name, kernel, ms, alg_bytes, macs} in launch order."""
         n = len(ptrs)
         p = (C.c_void_p * n)(*ptrs)
         cap = 128
         names = (C.c_char_p * cap)()
+        kernels = (C.c_char_p * cap)()
         ms = (C.c_float * cap)()
         ab = (C.c_double * cap)()
         mc = (C.c_double * cap)()
-        k = _lib.check(self._lib.rf_profile(self._h, p, n, iters, cap, names, ms, ab, mc), self._h)
-        return [{"name": names[i].decode(), "ms": ms[i], "alg_bytes": ab[i], "macs": mc[i]} for i in range(k)]
+        k = _lib.check(self._lib.rf_profile(self._h, p, n, iters, cap, names, kernels, ms, ab, mc), self._h)
+        return [{"name": names[i].decode(), "kernel": kernels[i].decode(), "ms": ms[i], "alg_bytes": ab[i], "macs": mc[i]}
+                for i in range(k)]
 
     # ------------------------------------------------------------------ internals
     def _run(self, fn, ptrs, rows, cols, steps, n, threshold):

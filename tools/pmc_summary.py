@@ -1,0 +1,56 @@
+#!/usr/bin/env python3
+"""Combine the two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE -- they do not fit one pass, MI355X_MICROARCH.md
+"rocprofv3 PMC slots") into per-kernel HBM bytes per launch.  gfx950 correction from the same guide: FETCH_SIZE
+reports exactly half the bytes of a wide coalesced read stream, so it is doubled; WRITE_SIZE is used as reported
+(uncalibrated per the guide).  Usage: pmc_summary.py fetch.db write.db out.json"""
+import json
+import re
+import sqlite3
+import sys
+
+
+def descriptor(mangled: str) -> str:
+    """Same kernel-instance string as rf_profile reports (engine.cpp OpInfo.kernel)."""
+    m = re.search(r"dwpw_kernelI(?:DF16_|f)Li(\d+)ELi(\d+)ELi(\d+)ELb(\d)ELi(\d+)ELi(\d+)ELb(\d)E", mangled)
+    if m:
+        cin, cout, st, dw, th, tw, lat = m.groups()
+        return f"dwpw<{cin},{cout},s{st}{',lat' if lat == '1' else ''}>"
+    m = re.search(r"conv3x3_kernelI(?:DF16_|f)Li(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELb(\d)E", mangled)
+    if m:
+        cin, cout, th, tw, up = m.groups()
+        return f"conv3x3<{cin},{cout},{th}x{tw}{',up' if up == '1' else ''}>"
+    for k in ("conv0", "head", "nms"):
+        if k + "_kernel" in mangled:
+            return k
+    return mangled
+
+
+def per_kernel(db_path, counter):
+    db = sqlite3.connect(db_path)
+    rows = db.execute("select kernel_name, grid_size, count(*), avg(value) from counters_collection where counter_name=? "
+                      "group by kernel_name, grid_size", (counter,)).fetchall()
+    return {(r[0], r[1]): (r[2], r[3]) for r in rows}
+
+
+def main(fetch_db, write_db, out):
+    f = per_kernel(fetch_db, "FETCH_SIZE")
+    w = per_kernel(write_db, "WRITE_SIZE")
+    res = []
+    for key in sorted(set(f) | set(w)):
+        name, grid = key
+        if not name.startswith("_ZN2rf") and "rf::" not in name:
+            continue
+        fk = f.get(key, (0, 0.0))[1] * 1024.0
+        wk = w.get(key, (0, 0.0))[1] * 1024.0
+        res.append({"kernel": descriptor(name), "symbol": name, "grid_threads": grid, "launches_sampled": f.get(key, (0, 0))[0],
+                    "fetch_size_bytes_raw": fk, "fetch_bytes_corrected_x2": 2 * fk, "write_size_bytes": wk,
+                    "hbm_bytes_per_launch": 2 * fk + wk})
+    json.dump({"note": "per launch at batch 8, 448x448, fp16, eager launches (PMC collection faults under hipGraph replay); "
+                       "FETCH_SIZE doubled per MI355X_MICROARCH.md section HBM", "kernels": res}, open(out, "w"), indent=1)
+    for r in res:
+        print(f"{r['kernel'][:90]:90s} grid {r['grid_threads']:8d}  fetch*2 {r['fetch_bytes_corrected_x2'] / 1e6:8.3f} MB  "
+              f"write {r['write_size_bytes'] / 1e6:8.3f} MB")
+
+
+if __name__ == "__main__":
+    main(*sys.argv[1:4])
