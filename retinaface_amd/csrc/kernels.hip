@@ -919,7 +919,9 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(NmsParams a) {
         for (int i = tid; i < n; i += nthr) {
             const unsigned long long ki = s_key[i];
             int rank = 0;
-            for (int j = 0; j < n; j++) rank += s_key[j] < ki ? 1 : 0;      // keys are unique (anchor index)
+            // keys are unique in normal operation (anchor index); the index tie-break keeps the ranks a permutation even
+            // if the same anchor was appended twice (rf_profile repeats the head launch)
+            for (int j = 0; j < n; j++) { const unsigned long long kj = s_key[j]; rank += (kj < ki || (kj == ki && j < i)) ? 1 : 0; }
             s_slot[rank] = i;
         }
         __syncthreads();
