@@ -65,8 +65,11 @@ typedef struct rf_options {
     int32_t use_graph;          /* 1 (default) = replay a captured hipGraph per batch size; 2 = off */
     int32_t keep_outputs;       /* 1 = also materialise the 9 NCHW fp32 head blobs for rf_get_output() */
     const char *model_stem;     /* default "mnet-deconv-0517" (RetinaFace.cpp:276) */
-    int32_t lanes;              /* batches that may be in flight at once (default 3): each lane owns a stream, its
-                                   activation buffers and its hipGraphs; = rf_num_slots() */
+    int32_t lanes;              /* launches that may be in flight at once (default 2): each lane owns a stream, its
+                                   activation buffers and its hipGraphs */
+    int32_t coalesce;           /* rf_enqueue_batch_device() batches merged into ONE launch of up to max_batch*coalesce
+                                   images (default 3; 1 = off).  A merged launch starts when it is full or when one of
+                                   its tickets is waited for.  rf_num_slots() = lanes * coalesce. */
 } rf_options;
 
 typedef struct rf_engine *rf_handle;
@@ -109,7 +112,8 @@ int rf_detect_batch_device(rf_handle h, const void *const *d_bgr, const int *row
 /* Asynchronous form of rf_detect_batch_device for serving loops: enqueue returns as soon as the
  * batch is queued on the engine's stream (n <= max_batch); `ticket` identifies one of
  * rf_num_slots() result slots.  rf_wait blocks until that batch has finished and copies its results.
- * Enqueueing into a slot that has not been waited for waits for it first. */
+ * Up to rf_num_slots() tickets may be outstanding; the engine merges consecutive enqueues into one launch
+ * (options.coalesce) and overlaps launches on options.lanes streams. */
 int rf_num_slots(rf_handle h);
 int rf_enqueue_batch_device(rf_handle h, const void *const *d_bgr, const int *rows, const int *cols,
                             const int *steps, int n, float threshold, int *ticket);

@@ -29,7 +29,7 @@ class rf_options(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("precision", C.c_int32), ("net_h", C.c_int32), ("net_w", C.c_int32),
                 ("max_batch", C.c_int32), ("device", C.c_int32), ("max_candidates", C.c_int32),
                 ("max_detections", C.c_int32), ("use_graph", C.c_int32), ("keep_outputs", C.c_int32),
-                ("model_stem", C.c_char_p), ("lanes", C.c_int32)]
+                ("model_stem", C.c_char_p), ("lanes", C.c_int32), ("coalesce", C.c_int32)]
 
 
 # every symbol include/retinaface_amd.h declares: name -> (restype, argtypes)

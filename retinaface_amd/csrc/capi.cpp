@@ -53,6 +53,7 @@ int rf_create(const char *model_dir, const char *network, float nms_threshold, c
             eo.keep_outputs = o->keep_outputs == 1;
             if (o->model_stem && *o->model_stem) eo.model_stem = o->model_stem;
             if (o->lanes) eo.lanes = o->lanes;
+            if (o->coalesce) eo.coalesce = o->coalesce;
         }
         auto eng = rf::Engine::create(model_dir, network ? network : "net3", nms_threshold, eo);
         rf_engine *h = new rf_engine;

@@ -97,6 +97,9 @@ public:
         if (mc < 64 || mc > 4096 || (mc & (mc - 1))) throw ArgError("max_candidates must be a power of two in [64, 4096]");
         if (opt_.max_detections < 1 || opt_.max_detections > 4096) throw ArgError("max_detections must be in [1, 4096]");
         if (opt_.lanes < 1 || opt_.lanes > 16) throw ArgError("lanes must be in [1, 16]");
+        if (opt_.coalesce < 1 || opt_.coalesce > 16) throw ArgError("coalesce must be in [1, 16]");
+        cap_images_ = opt_.max_batch * opt_.coalesce;
+        tickets_.resize(4 * opt_.lanes * opt_.coalesce + 8);
         if (opt_.device >= 0) RF_HIP(hipSetDevice(opt_.device));
         RF_HIP(hipGetDevice(&device_));
         upload_weights(plan);
@@ -127,17 +130,28 @@ public:
         *truncated = false;
         std::vector<int> all_cand;
         std::vector<std::vector<int32_t>> all_anchor;
-        for (int base = 0; base < n; base += opt_.max_batch) {
-            int m = std::min(opt_.max_batch, n - base);
-            std::vector<int> st(m);
-            for (int i = 0; i < m; i++) st[i] = steps ? steps[base + i] : cols[base + i] * 3;
-            int ticket = submit(frames + base, rows + base, cols + base, st.data(), m, on_device, threshold, true);
+        // a synchronous call keeps up to `lanes` chunks of max_batch images in flight and collects them in order
+        std::vector<std::pair<int, int>> inflight;      // (ticket, base)
+        auto collect = [&]() {
+            int ticket = inflight.front().first, base = inflight.front().second;
+            inflight.erase(inflight.begin());
             bool tr = false;
             wait(ticket, out ? out + (size_t)base * cap_per_image : nullptr, cap_per_image, counts + base, &tr);
             *truncated = *truncated || tr;
             all_cand.insert(all_cand.end(), last_cand_counts_.begin(), last_cand_counts_.end());
             for (auto &v : last_anchor_) all_anchor.push_back(std::move(v));
+        };
+        const bool timed = !opt_.use_graph;             // the eager engine measures the pre / infer / post split
+        for (int base = 0; base < n; base += opt_.max_batch) {
+            int m = std::min(opt_.max_batch, n - base);
+            std::vector<int> st(m);
+            for (int i = 0; i < m; i++) st[i] = steps ? steps[base + i] : cols[base + i] * 3;
+            if ((int)inflight.size() == (int)lanes_.size() || (timed && !inflight.empty())) collect();
+            int ticket = submit(frames + base, rows + base, cols + base, st.data(), m, on_device, threshold, true);
+            inflight.emplace_back(ticket, base);
         }
+        while (!inflight.empty()) collect();
+        if (n > opt_.max_batch) last_first_image_ = -1000000;   // blob accessors are per-launch: not valid for chunked calls
         last_n_ = n;                         // the "most recent completed batch" of a chunked call is the whole call
         last_cand_counts_.swap(all_cand);
         last_anchor_.swap(all_anchor);
@@ -153,19 +167,19 @@ public:
     }
 
     void wait(int ticket, rf_face *out, int cap_per_image, int *counts, bool *truncated) override {
-        if (ticket < 0 || ticket >= (int)lanes_.size() || !lanes_[ticket].busy) throw ArgError("wait: invalid ticket");
-        Lane &s = lanes_[ticket];
-        RF_HIP(hipEventSynchronize(s.done));
-        s.busy = false;
-        last_lane_ = ticket;
+        if (ticket < 0 || ticket >= (int)tickets_.size() || tickets_[ticket].state == Ticket::FREE)
+            throw ArgError("wait: invalid ticket");
+        Ticket &t = tickets_[ticket];
+        if (t.state == Ticket::PENDING) launch_pending();          // its super-batch has not been launched yet
+        if (t.state == Ticket::LAUNCHED) harvest(lanes_[t.lane]);  // first waiter of a super-batch collects all of it
         bool tr = false;
-        last_n_ = s.n;
-        last_cand_counts_.assign(s.n, 0);
-        last_anchor_.assign(s.n, std::vector<int32_t>());
-        const int mb = opt_.max_batch;
-        for (int i = 0; i < s.n; i++) {
-            int kept = s.empty[i] ? 0 : s.h_counts[i];
-            int ncand = s.empty[i] ? 0 : s.h_counts[mb + i];
+        last_lane_ = t.lane;
+        last_first_image_ = t.first_image;
+        last_n_ = t.n;
+        last_cand_counts_.assign(t.n, 0);
+        last_anchor_.assign(t.n, std::vector<int32_t>());
+        for (int i = 0; i < t.n; i++) {
+            int kept = t.kept[i], ncand = t.ncand[i];
             last_cand_counts_[i] = ncand;
             if (ncand > opt_.max_candidates) tr = true;
             int avail = std::min(kept, opt_.max_detections);
@@ -173,12 +187,13 @@ public:
             if (counts) counts[i] = kept;
             int ncopy = std::min(avail, cap_per_image);
             if (avail > cap_per_image) tr = true;
-            const Candidate *src = s.h_out + (size_t)i * opt_.max_detections;
+            const Candidate *src = t.records.data() + t.first_record[i];
             last_anchor_[i].resize(avail);
             for (int k = 0; k < avail; k++) last_anchor_[i][k] = src[k].anchor;
             for (int k = 0; k < ncopy; k++) memcpy(&out[(size_t)i * cap_per_image + k], &src[k], sizeof(rf_face));
         }
-        if (s.timed) {
+        if (t.timed) {
+            Lane &s = lanes_[t.lane];
             float a = 0, b = 0, c = 0;
             (void)hipEventElapsedTime(&a, s.time_ev[0], s.time_ev[1]);
             (void)hipEventElapsedTime(&b, s.time_ev[1], s.time_ev[2]);
@@ -186,10 +201,12 @@ public:
             t_pre_ = a; t_infer_ = b; t_post_ = c; t_total_ = a + b + c;
             have_split_ = true;
         }
+        t.state = Ticket::FREE;
         if (truncated) *truncated = tr;
     }
 
-    int num_slots() const override { return (int)lanes_.size(); }
+    // tickets the caller may keep outstanding before it has to wait: every lane can hold a full super-batch
+    int num_slots() const override { return (int)lanes_.size() * opt_.coalesce; }
 
     int last_anchor_indices(int image, int32_t *out, int cap) const override {
         if (image < 0 || image >= last_n_) throw ArgError("image index out of range");
@@ -217,13 +234,14 @@ public:
         for (int si = 0; si < 3; si++)
             for (int k = 0; k < 3; k++) {
                 if (blob != std::string(kinds[k]) + std::to_string(strides_[si])) continue;
-                if (image < 0 || image >= opt_.max_batch) throw ArgError("image index out of range");
+                if (image < 0 || image >= last_n_ || last_first_image_ < 0) throw ArgError("image index out of range");
                 size_t hw = (size_t)(net_h_ / strides_[si]) * (net_w_ / strides_[si]);
                 size_t cnt = hw * chans[k];
                 if (!dst) return (long)cnt;
                 if (cap < cnt) throw ArgError("destination too small");
                 RF_HIP(hipStreamSynchronize(l.stream));
-                RF_HIP(hipMemcpy(dst, l.d_dump[si][k] + (size_t)image * cnt, cnt * sizeof(float), hipMemcpyDeviceToHost));
+                RF_HIP(hipMemcpy(dst, l.d_dump[si][k] + (size_t)(last_first_image_ + image) * cnt, cnt * sizeof(float),
+                                 hipMemcpyDeviceToHost));
                 return (long)cnt;
             }
         throw ArgError("unknown output blob '" + blob + "'");
@@ -234,25 +252,27 @@ public:
         auto it = l.acts.find(blob);
         if (it == l.acts.end()) throw ArgError("unknown activation '" + blob + "'");
         const ActInfo &ai = it->second;
-        if (image < 0 || image >= opt_.max_batch) throw ArgError("image index out of range");
+        if (image < 0 || image >= last_n_ || last_first_image_ < 0) throw ArgError("image index out of range");
         size_t cnt = (size_t)ai.h * ai.w * ai.c;
         if (dims) { dims[0] = ai.h; dims[1] = ai.w; dims[2] = ai.c; }
         if (!dst) return (long)cnt;
         if (cap < cnt) throw ArgError("destination too small");
         RF_HIP(hipStreamSynchronize(l.stream));
         std::vector<T> tmp(cnt);
-        RF_HIP(hipMemcpy(tmp.data(), (const T *)ai.ptr + (size_t)image * cnt, cnt * sizeof(T), hipMemcpyDeviceToHost));
+        RF_HIP(hipMemcpy(tmp.data(), (const T *)ai.ptr + (size_t)(last_first_image_ + image) * cnt, cnt * sizeof(T),
+                         hipMemcpyDeviceToHost));
         for (size_t i = 0; i < cnt; i++) dst[i] = Cast<T>::to(tmp[i]);
         return (long)cnt;
     }
 
     int profile(const void *const *d_frames, int n, int iters, int cap, const char **names, const char **kernels,
                 float *avg_ms, double *alg_bytes, double *macs) override {
-        if (n < 1 || n > opt_.max_batch || iters < 1) throw ArgError("profile: bad n / iters");
+        if (n < 1 || n > cap_images_ || iters < 1) throw ArgError("profile: bad n / iters");
+        launch_pending();
         Lane &l = lanes_[0];
-        if (l.busy) { RF_HIP(hipEventSynchronize(l.done)); }
+        harvest(l);
         RF_HIP(hipStreamSynchronize(l.stream));
-        const int mb = opt_.max_batch;
+        const int mb = cap_images_;
         for (int i = 0; i < n; i++) l.h_frames[mb + i] = FrameDesc{(const uint8_t *)d_frames[i], net_h_, net_w_, net_w_ * 3, 0};
         *l.h_params = RunParams{0.5f, nms_threshold_, n, 0};
         size_t nops = l.ops.size();
@@ -327,9 +347,23 @@ private:
         uint8_t *d_canvas = nullptr, *d_raw = nullptr;
         size_t raw_stride = 0;
         float *d_dump[3][3] = {};
-        bool busy = false, timed = false;
-        int n = 0;
-        std::vector<char> empty;
+        bool busy = false;                    // a launched super-batch whose results have not been harvested yet
+        int n_images = 0;                     // images of the super-batch being assembled / in flight on this lane
+        float threshold = 0.f;
+        bool need_resize = false, timed = false;
+        std::vector<int> tickets;             // tickets riding on that super-batch
+        std::vector<char> empty;              // per image: img.empty() (count forced to 0)
+    };
+
+    // One enqueue() / detect chunk.  Several tickets are coalesced into one launch ("super-batch") of up to
+    // max_batch * coalesce images: the launch count per image -- what bounds throughput at batch 8 -- drops accordingly.
+    struct Ticket {
+        enum State { FREE, PENDING, LAUNCHED, DONE };
+        State state = FREE;
+        int lane = 0, first_image = 0, n = 0;
+        bool timed = false;
+        std::vector<int> kept, ncand, first_record;
+        std::vector<Candidate> records;
     };
 
     // ------------------------------------------------------------------------------------------ build
@@ -378,7 +412,7 @@ private:
     }
 
     void build_lane(Lane &L, const Plan &plan) {
-        const int mb = opt_.max_batch;
+        const int mb = cap_images_;           // images per launch: max_batch * coalesce
         const int H = net_h_, W = net_w_;
         const double P = (double)H * W;
         RF_HIP(hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking));
@@ -560,52 +594,56 @@ private:
         if (L.d_raw) RF_HIP(hipFree(L.d_raw));
         L.d_raw = nullptr;
         L.raw_stride = ((per_image + 255) / 256) * 256;
-        RF_HIP(hipMalloc((void **)&L.d_raw, L.raw_stride * opt_.max_batch));
+        RF_HIP(hipMalloc((void **)&L.d_raw, L.raw_stride * cap_images_));
     }
 
-    int submit(const uint8_t *const *frames, const int *rows, const int *cols, const int *steps, int n, bool on_device,
-               float threshold, bool timed) {
-        const int mb = opt_.max_batch;
-        int ticket = next_lane_;
-        next_lane_ = (next_lane_ + 1) % (int)lanes_.size();
-        Lane &s = lanes_[ticket];
-        if (s.busy) { RF_HIP(hipEventSynchronize(s.done)); s.busy = false; }
-        s.n = n;
-        s.empty.assign(n, 0);
-        bool need_resize = false;
-        size_t max_raw = 0;
-        for (int i = 0; i < n; i++) {
-            bool empty = !frames[i] || rows[i] <= 0 || cols[i] <= 0;      // img.empty(), RetinaFace.cpp:578-580
-            s.empty[i] = empty;
-            if (empty) continue;
-            if (rows[i] > 4096 * 3072 / std::max(cols[i], 1)) throw ArgError("frame larger than 4096x3072 (RetinaFace.cpp:325)");
-            if (steps[i] < cols[i] * 3) throw ArgError("row step smaller than cols*3");
-            if (rows[i] > net_h_ || cols[i] > net_w_) need_resize = true;
-            max_raw = std::max(max_raw, (size_t)rows[i] * cols[i] * 3);
+    int alloc_ticket() {
+        for (size_t k = 0; k < tickets_.size(); k++) {
+            int id = (int)((next_ticket_ + k) % tickets_.size());
+            if (tickets_[id].state == Ticket::FREE) { next_ticket_ = (id + 1) % (int)tickets_.size(); return id; }
         }
-        const bool eager_timed = timed && !opt_.use_graph;
-        s.timed = eager_timed;
-        if (eager_timed) RF_HIP(hipEventRecord(s.time_ev[0], s.stream));
-        if (!on_device) ensure_raw(s, max_raw);
-        for (int i = 0; i < n; i++) {
-            FrameDesc src{nullptr, 0, 0, 0, 0};
-            if (!s.empty[i]) {
-                if (on_device) {
-                    src = FrameDesc{frames[i], rows[i], cols[i], steps[i], 0};
-                } else {
-                    uint8_t *dst = s.d_raw + (size_t)i * s.raw_stride;
-                    RF_HIP(hipMemcpy2DAsync(dst, (size_t)cols[i] * 3, frames[i], (size_t)steps[i], (size_t)cols[i] * 3,
-                                            (size_t)rows[i], hipMemcpyHostToDevice, s.stream));
-                    src = FrameDesc{dst, rows[i], cols[i], cols[i] * 3, 0};
-                }
+        throw ArgError("too many outstanding tickets: call rf_wait before enqueueing more");
+    }
+
+    // copy a finished super-batch's results out of the lane's pinned block into its tickets, so the lane can be reused
+    void harvest(Lane &L) {
+        if (!L.busy) return;
+        RF_HIP(hipEventSynchronize(L.done));
+        const int mb = cap_images_;
+        for (int id : L.tickets) {
+            Ticket &t = tickets_[id];
+            t.kept.assign(t.n, 0); t.ncand.assign(t.n, 0); t.first_record.assign(t.n, 0);
+            t.records.clear();
+            for (int i = 0; i < t.n; i++) {
+                const int img = t.first_image + i;
+                if (L.empty[img]) continue;
+                t.kept[i] = L.h_counts[img];
+                t.ncand[i] = L.h_counts[mb + img];
+                t.first_record[i] = (int)t.records.size();
+                const int avail = std::min(t.kept[i], opt_.max_detections);
+                const Candidate *src = L.h_out + (size_t)img * opt_.max_detections;
+                t.records.insert(t.records.end(), src, src + avail);
             }
-            s.h_frames[i] = src;
-            s.h_frames[mb + i] = need_resize
-                                     ? FrameDesc{s.d_canvas + (size_t)i * net_h_ * net_w_ * 3, net_h_, net_w_, net_w_ * 3, 0}
-                                     : src;
+            t.state = Ticket::DONE;
         }
-        *s.h_params = RunParams{threshold, nms_threshold_, n, 0};
-        if (need_resize) launch_resize_area(s.stream, s.h_frames, s.d_canvas, n, net_h_, net_w_);
+        L.tickets.clear();
+        L.busy = false;
+        L.n_images = 0;
+    }
+
+    void launch_pending() {
+        if (pending_lane_ < 0) return;
+        Lane &s = lanes_[pending_lane_];
+        pending_lane_ = -1;
+        const int n = s.n_images;
+        *s.h_params = RunParams{s.threshold, nms_threshold_, n, 0};
+        if (s.need_resize) {
+            const int mb = cap_images_;
+            for (int i = 0; i < n; i++)
+                s.h_frames[mb + i] = FrameDesc{s.d_canvas + (size_t)i * net_h_ * net_w_ * 3, net_h_, net_w_, net_w_ * 3, 0};
+            launch_resize_area(s.stream, s.h_frames, s.d_canvas, n, net_h_, net_w_);
+        }
+        const bool eager_timed = s.timed;
         if (eager_timed) RF_HIP(hipEventRecord(s.time_ev[1], s.stream));
         if (opt_.use_graph && s.warmed.count(n)) {
             auto it = s.graphs.find(n);
@@ -622,7 +660,74 @@ private:
         if (eager_timed) RF_HIP(hipEventRecord(s.time_ev[3], s.stream));
         RF_HIP(hipEventRecord(s.done, s.stream));
         s.busy = true;
-        return ticket;
+        for (int id : s.tickets) tickets_[id].state = Ticket::LAUNCHED;
+    }
+
+    int submit(const uint8_t *const *frames, const int *rows, const int *cols, const int *steps, int n, bool on_device,
+               float threshold, bool sync_call) {
+        const int mb = cap_images_;
+        bool need_resize = false;
+        size_t max_raw = 0;
+        std::vector<char> empty(n, 0);
+        for (int i = 0; i < n; i++) {
+            empty[i] = !frames[i] || rows[i] <= 0 || cols[i] <= 0;      // img.empty(), RetinaFace.cpp:578-580
+            if (empty[i]) continue;
+            if (rows[i] > 4096 * 3072 / std::max(cols[i], 1)) throw ArgError("frame larger than 4096x3072 (RetinaFace.cpp:325)");
+            if (steps[i] < cols[i] * 3) throw ArgError("row step smaller than cols*3");
+            if (rows[i] > net_h_ || cols[i] > net_w_) need_resize = true;
+            max_raw = std::max(max_raw, (size_t)rows[i] * cols[i] * 3);
+        }
+        const bool eager_timed = sync_call && !opt_.use_graph;
+        // a pending super-batch is closed when this chunk does not fit, must not be mixed (different threshold, timed
+        // eager run), or needs a bigger host-frame staging buffer
+        if (pending_lane_ >= 0) {
+            Lane &p = lanes_[pending_lane_];
+            if (p.n_images + n > mb || p.threshold != threshold || eager_timed || p.timed ||
+                (!on_device && max_raw > p.raw_stride))
+                launch_pending();
+        }
+        if (pending_lane_ < 0) {
+            int lane = next_lane_;
+            next_lane_ = (next_lane_ + 1) % (int)lanes_.size();
+            Lane &s = lanes_[lane];
+            harvest(s);                       // waits for the previous super-batch on this lane, if any
+            s.n_images = 0;
+            s.threshold = threshold;
+            s.need_resize = false;
+            s.timed = eager_timed;
+            s.empty.assign(mb, 0);
+            s.tickets.clear();
+            pending_lane_ = lane;
+            if (eager_timed) RF_HIP(hipEventRecord(s.time_ev[0], s.stream));
+        }
+        Lane &s = lanes_[pending_lane_];
+        if (!on_device) ensure_raw(s, max_raw);
+        const int id = alloc_ticket();
+        Ticket &t = tickets_[id];
+        t.state = Ticket::PENDING; t.lane = pending_lane_; t.first_image = s.n_images; t.n = n; t.timed = eager_timed;
+        for (int i = 0; i < n; i++) {
+            const int img = s.n_images + i;
+            FrameDesc src{nullptr, 0, 0, 0, 0};
+            s.empty[img] = empty[i];
+            if (!empty[i]) {
+                if (on_device) {
+                    src = FrameDesc{frames[i], rows[i], cols[i], steps[i], 0};
+                } else {
+                    uint8_t *dst = s.d_raw + (size_t)img * s.raw_stride;
+                    RF_HIP(hipMemcpy2DAsync(dst, (size_t)cols[i] * 3, frames[i], (size_t)steps[i], (size_t)cols[i] * 3,
+                                            (size_t)rows[i], hipMemcpyHostToDevice, s.stream));
+                    src = FrameDesc{dst, rows[i], cols[i], cols[i] * 3, 0};
+                }
+            }
+            s.h_frames[img] = src;
+            s.h_frames[mb + img] = src;       // replaced by the canvas in launch_pending() when a resize is needed
+        }
+        s.need_resize = s.need_resize || need_resize;
+        s.n_images += n;
+        s.tickets.push_back(id);
+        // launch now when full, when the caller is synchronous, or when coalescing is off
+        if (s.n_images + 1 > mb || sync_call || opt_.coalesce == 1) launch_pending();
+        return id;
     }
 
     hipGraphExec_t capture(Lane &L, int n) {
@@ -654,7 +759,10 @@ private:
     const int strides_[3] = {32, 16, 8};
 
     std::vector<Lane> lanes_;
-    int next_lane_ = 0, last_lane_ = 0;
+    int next_lane_ = 0, last_lane_ = 0, last_first_image_ = 0, pending_lane_ = -1;
+    int cap_images_ = 0;                      // images per launch = max_batch * coalesce
+    std::vector<Ticket> tickets_;
+    int next_ticket_ = 0;
 
     int last_n_ = 0;
     std::vector<int> last_cand_counts_;

@@ -40,7 +40,7 @@ class RetinaFace:
     def __init__(self, model: str, network: str = "net3", nms: float = 0.4, *, precision: int = PRECISION_FP16,
                  net_hw: Optional[tuple] = None, max_batch: int = 8, model_stem: Optional[str] = None,
                  max_candidates: int = 0, max_detections: int = 0, use_graph: bool = True,
-                 keep_outputs: bool = False, device: Optional[int] = None, lanes: int = 0):
+                 keep_outputs: bool = False, device: Optional[int] = None, lanes: int = 0, coalesce: int = 0):
         self._lib = _lib.load_library()
         o = rf_options()
         o.struct_size = C.sizeof(rf_options)
@@ -54,6 +54,7 @@ class RetinaFace:
         o.use_graph = 1 if use_graph else 2
         o.keep_outputs = 1 if keep_outputs else 0
         o.lanes = lanes
+        o.coalesce = coalesce
         self._stem = model_stem.encode() if model_stem else None
         o.model_stem = self._stem
         h = C.c_void_p()
