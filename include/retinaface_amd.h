@@ -65,10 +65,10 @@ typedef struct rf_options {
     int32_t use_graph;          /* 1 (default) = replay a captured hipGraph per batch size; 2 = off */
     int32_t keep_outputs;       /* 1 = also materialise the 9 NCHW fp32 head blobs for rf_get_output() */
     const char *model_stem;     /* default "mnet-deconv-0517" (RetinaFace.cpp:276) */
-    int32_t lanes;              /* launches that may be in flight at once (default 2): each lane owns a stream, its
+    int32_t lanes;              /* launches that may be in flight at once (default 3): each lane owns a stream, its
                                    activation buffers and its hipGraphs */
     int32_t coalesce;           /* rf_enqueue_batch_device() batches merged into ONE launch of up to max_batch*coalesce
-                                   images (default 3; 1 = off).  A merged launch starts when it is full or when one of
+                                   images (default 4; 1 = off).  A merged launch starts when it is full or when one of
                                    its tickets is waited for.  rf_num_slots() = lanes * coalesce. */
 } rf_options;
 

@@ -30,8 +30,8 @@ struct EngineOptions {
     int max_candidates = 4096;
     int max_detections = 256;
     bool use_graph = true;
-    int lanes = 2;                   // launches in flight (each lane has its own stream + buffers + graphs)
-    int coalesce = 3;                // enqueued batches merged into one launch (max_batch * coalesce images)
+    int lanes = 3;                   // launches in flight (each lane has its own stream + buffers + graphs)
+    int coalesce = 4;                // enqueued batches merged into one launch (max_batch * coalesce images)
     bool keep_outputs = false;
     std::string model_stem = "mnet-deconv-0517";
 };

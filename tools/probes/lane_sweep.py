@@ -12,7 +12,7 @@ torch.cuda.synchronize()
 ptrs = [frames[i].data_ptr() for i in range(B)]
 rows = cols = [448] * B
 for lanes in [int(x) for x in os.environ.get("LANES", "1,2,3,4").split(",")]:
-    for par in (True, False):
+    for par in [int(x) for x in os.environ.get("COALESCE", "1,2,3,4").split(",")]:
         for graph in (True,):
             det = retinaface_amd.RetinaFace(os.path.join(ROOT, "assets"), "net3", 0.4, net_hw=(448, 448), max_batch=B,
                                             model_stem="mnet25", lanes=lanes, coalesce=par, use_graph=graph)
