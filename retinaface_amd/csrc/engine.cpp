@@ -392,6 +392,23 @@ private:
     void upload_weights(const Plan &plan) {
         c0_w_ = arena_.put(plan.conv0.w);
         c0_b_ = arena_.put(plan.conv0.b);
+        if constexpr (sizeof(T) == 2) {
+            // stem kernel: conv0 as a 16 x 32 A fragment, K = (ky, kx, c_bgr) (the frame's own byte order: net channel c is
+            // frame channel 2-c), fp16 hi + lo so the sum carries ~22 mantissa bits
+            std::vector<half_t> hi(64 * 8, (half_t)0), lo(64 * 8, (half_t)0);
+            for (int lane = 0; lane < 64; lane++)
+                for (int el = 0; el < 8; el++) {
+                    int row = lane & 15, k = (lane >> 4) * 8 + el;
+                    if (row >= 8 || k >= 27) continue;
+                    int tap = k / 3, cb = k % 3;
+                    float w = plan.conv0.w[(size_t)row * 27 + tap * 3 + (2 - cb)];
+                    half_t h = (half_t)w;
+                    hi[lane * 8 + el] = h;
+                    lo[lane * 8 + el] = (half_t)(w - (float)h);
+                }
+            c0_hi_ = arena_.put(hi);
+            c0_lo_ = arena_.put(lo);
+        }
         for (const auto &blk : plan.blocks) {
             int c = blk.dw.cout;                       // depthwise weights [c][3][3][1] -> [tap][c]
             std::vector<T> w((size_t)9 * c);
@@ -438,8 +455,32 @@ private:
         };
         // activations: one buffer per reference blob that survives fusion (288 GB of HBM: nothing is recycled)
         int h = H / 2, w = W / 2;
-        T *cur = act(plan.conv0.out_blob, h, w, 8);
-        {
+        T *cur = nullptr;
+        size_t first_block = 0;
+        int c = 8;
+        if constexpr (sizeof(T) == 2) {
+            // fp16 engine: preprocess + conv0 + the first depthwise/pointwise block are ONE launch (stem_kernel)
+            const auto &blk = plan.blocks[0];
+            T *out = act(blk.pw.out_blob, h, w, blk.pw.cout);
+            StemParams sp;
+            sp.frames = L.h_frames + mb; sp.out = out;
+            sp.w0_hi = arena_.ptr<half_t>(c0_hi_); sp.w0_lo = arena_.ptr<half_t>(c0_lo_); sp.b0 = arena_.ptr<float>(c0_b_);
+            sp.dw_w = arena_.ptr<half_t>(dw_w_[0].w); sp.dw_b = arena_.ptr<float>(dw_w_[0].b);
+            sp.pw_w = arena_.ptr<half_t>(pw_w_[0].w); sp.pw_b = arena_.ptr<float>(pw_w_[0].b);
+            sp.params_in = L.h_params; sp.params_out = L.d_params;
+            sp.n = 0; sp.net_h = H; sp.net_w = W;
+            OpInfo op;
+            op.name = "pre+" + plan.conv0.name + "+" + blk.dw.name + "+" + blk.pw.name;
+            op.kernel = "stem";
+            op.alg_u8_in = 3.0 * P;
+            op.alg_elems_in = 8.0 * h * w + 8.0 * h * w;                       // dw input, pw input
+            op.alg_elems_out = 8.0 * h * w + 8.0 * h * w + 16.0 * h * w;       // conv0, dw, pw outputs
+            op.macs = (plan.conv0.macs_per_out_pixel() + blk.dw.macs_per_out_pixel() + blk.pw.macs_per_out_pixel()) * h * w;
+            op.launch = [sp](hipStream_t s, int n) { StemParams q = sp; q.n = n; launch_stem(s, q); };
+            L.ops.push_back(op);
+            cur = out; c = blk.pw.cout; first_block = 1;
+        } else {
+            cur = act(plan.conv0.out_blob, h, w, 8);
             OpInfo op;
             op.name = "pre+" + plan.conv0.name;
             op.kernel = "conv0";
@@ -454,10 +495,9 @@ private:
             op.launch = [=](hipStream_t s, int n) { launch_conv0<T>(s, fr, o, wp, bp, pin, pout, n, H, W); };
             L.ops.push_back(op);
         }
-        int c = 8;
         // FPN tap -> lateral index: block 4 (stride 8) -> lateral[2], block 10 (stride 16) -> [1], block 12 (stride 32) -> [0]
         T *lat[3] = {nullptr, nullptr, nullptr};
-        for (size_t i = 0; i < plan.blocks.size(); i++) {
+        for (size_t i = first_block; i < plan.blocks.size(); i++) {
             const auto &blk = plan.blocks[i];
             int ho = h / blk.dw.stride, wo = w / blk.dw.stride;
             T *out = act(blk.pw.out_blob, ho, wo, blk.pw.cout);
@@ -751,7 +791,7 @@ private:
     int device_ = 0;
     std::vector<hipEvent_t> prof_ev_;
     Arena arena_;
-    size_t c0_w_ = 0, c0_b_ = 0;
+    size_t c0_w_ = 0, c0_b_ = 0, c0_hi_ = 0, c0_lo_ = 0;
     std::vector<DwW> dw_w_;
     std::vector<GemmW> pw_w_;
     GemmW lat_w_[3], aggr_w_[2], ssh_w_[3][4];

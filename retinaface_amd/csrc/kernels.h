@@ -38,6 +38,16 @@ template <typename T>
 void launch_conv0(hipStream_t s, const FrameDesc *frames, T *out, const float *w, const float *b,
                   const RunParams *params_in, RunParams *params_out, int n, int net_h, int net_w);
 
+// ---- K_a' (fp16 engine): K_a fused with the first depthwise/pointwise block; conv0 on MFMA (hi+lo split weights).
+struct StemParams {
+    const FrameDesc *frames; half_t *out;          // out: [n][net_h/2][net_w/2][16]
+    const half_t *w0_hi, *w0_lo; const float *b0;  // conv0 in A-fragment order, K = (ky,kx,c_bgr) -> 32
+    const half_t *dw_w; const float *dw_b; const half_t *pw_w; const float *pw_b;
+    const RunParams *params_in; RunParams *params_out;
+    int n, net_h, net_w;
+};
+void launch_stem(hipStream_t s, const StemParams &p);
+
 // ---- K_b: depthwise 3x3 (+BN+ReLU) -> pointwise 1x1 (+BN+ReLU), the intermediate never leaves LDS.
 //      has_dw = false gives a plain 1x1 conv (+bias, +ReLU): the FPN laterals.
 template <typename T>

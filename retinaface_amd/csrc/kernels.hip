@@ -261,6 +261,171 @@ __device__ __forceinline__ void store_acc(T *s_out, f32x4 bv, f32x4 acc, int ct,
 }
 
 // =============================================================================================
+// K_a' stem (fp16 engine): preprocess + conv0 + BN + ReLU + depthwise conv1 + BN + ReLU + pointwise conv2 + BN + ReLU
+//   = K_a fused with the first K_b block, so the 8-channel 224^2 map (the largest activation of the net per byte of
+//   useful work) never exists in HBM.  conv0 itself runs on the matrix cores: per output pixel the 27 taps are 3 runs of
+//   9 CONTIGUOUS bytes of the BGR frame (3 px x 3 ch per row), so with the weights' K axis ordered (ky, kx, c_bgr) an MFMA
+//   B fragment (8 consecutive k of one pixel) is 8 bytes gathered from at most two staged rows, converted u8 -> fp16
+//   exactly.  Weights are split hi + lo in fp16 (two MFMAs) so conv0 keeps fp32-grade weights on raw 0..255 inputs.
+//   Tile: 8 x 32 outputs of conv2 <- 10 x 34 conv0 pixels (halo recompute 1.33x) <- 21 x 69 input pixels.
+// =============================================================================================
+constexpr int ST_TH = 8, ST_TW = 32, ST_P = ST_TH * ST_TW;
+constexpr int ST_HR = ST_TH + 2, ST_HC = ST_TW + 2;            // conv0 pixels needed: 10 x 34 = 340
+constexpr int ST_NPIX = ST_HR * ST_HC;
+constexpr int ST_PTILES = (ST_NPIX + 15) / 16;                 // 22 MFMA pixel tiles
+constexpr int ST_IR = 2 * ST_HR + 1;                           // 21 input rows
+constexpr int ST_IB = (2 * ST_HC + 1) * 3;                     // 207 input bytes per row
+constexpr int ST_LD = (ST_IB + 3 + 3) / 4;                     // 53 dwords fetched per row (payload + misalignment)
+constexpr int ST_ROWD = ST_LD + 1;                             // LDS row stride in dwords
+
+struct StemArgs {
+    const FrameDesc *frames; half_t *out;
+    const half_t *w0_hi, *w0_lo;      // conv0 weights in A-fragment order [64 lanes][8], K = (ky,kx,c_bgr) padded to 32
+    const float *b0;                  // [8]
+    const half_t *dw_w; const float *dw_b; const half_t *pw_w; const float *pw_b;
+    const RunParams *params_in; RunParams *params_out;
+    int ho, wo, tiles_x, tiles_y, nblk;
+};
+
+__global__ __launch_bounds__(kThreads) void stem_kernel(StemArgs a) {
+    typedef half_t T;
+    typedef Mma<T> M;
+    constexpr int LDA = 16, LDO = 24;
+    __shared__ __attribute__((aligned(16))) uint32_t s_in32[ST_IR * ST_ROWD];
+    __shared__ __attribute__((aligned(16))) T s_c0[ST_PTILES * 16 * 8];
+    __shared__ __attribute__((aligned(16))) T s_dw[9 * 8];
+    __shared__ __attribute__((aligned(16))) T s_a[ST_P * LDA];
+    __shared__ __attribute__((aligned(16))) T s_out[ST_P * LDO];
+    const uint8_t *s_in = (const uint8_t *)s_in32;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (blockIdx.x == 0 && tid == 0 && a.params_out) *a.params_out = *a.params_in;
+    const int bid = xcd_remap(blockIdx.x, a.nblk);
+    const int tx = bid % a.tiles_x;
+    const int ty = (bid / a.tiles_x) % a.tiles_y;
+    const int img = bid / (a.tiles_x * a.tiles_y);
+    const int oy0 = ty * ST_TH, ox0 = tx * ST_TW;
+    const FrameDesc fd = a.frames[img];
+
+    // ---- phase 0: operands that depend only on kernel arguments
+    const f16x8 w_hi = ((const f16x8 *)a.w0_hi)[lane], w_lo = ((const f16x8 *)a.w0_lo)[lane];
+    const f32x4 b0 = lane < 32 ? *(const f32x4 *)(a.b0 + (lane >> 4) * 4) : vzero<f32x4, 4>();
+    GemmPipe<T, 1, 4, 1, 1> pipe;
+    pipe.init(a.pw_w, 0, lane);
+    const f32x4 pw_bias = *(const f32x4 *)(a.pw_b + acc_cout(0, lane, 0));
+    float dw_bias[8];
+#pragma unroll
+    for (int e = 0; e < 8; e++) dw_bias[e] = a.dw_b[e];
+
+    // ---- phase 1: stage the u8 patch (aligned dword loads, per-row misalignment kept; outside the frame = 0)
+    const int iy0 = 2 * oy0 - 3;                                  // input row of patch row 0
+    const int bx0 = (2 * ox0 - 3) * 3;                            // input byte column of patch byte 0
+    const uintptr_t base = (uintptr_t)fd.ptr;
+    const size_t row_bytes = (size_t)fd.cols * 3;
+    for (int i = tid; i < ST_IR * ST_LD; i += kThreads) {
+        const int r = i / ST_LD, d = i % ST_LD;
+        const int iy = iy0 + r;
+        uint32_t v = 0;
+        if (iy >= 0 && iy < fd.rows) {
+            const uintptr_t lo = base + (size_t)iy * fd.step, hi = lo + row_bytes;
+            const uintptr_t a0 = ((lo + bx0) & ~(uintptr_t)3) + 4 * d;
+            if (a0 >= lo && a0 + 4 <= hi) {
+                v = *(const uint32_t *)a0;
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+                    if (a0 + k >= lo && a0 + k < hi) v |= (uint32_t)(*(const uint8_t *)(a0 + k)) << (8 * k);
+            }
+        }
+        s_in32[r * ST_ROWD + d] = v;
+    }
+    if (tid < 9) *(f16x8 *)(s_dw + tid * 8) = *(const f16x8 *)(a.dw_w + tid * 8);
+    __syncthreads();
+
+    // ---- phase 2: conv0 on the 10 x 34 halo'd region, MFMA: D[cout 16 (8 real)][pixel 16] += W[16][32] x patch[32][16]
+    const int kb = lane >> 4;                                     // this lane supplies k = 8*kb .. 8*kb+7
+    for (int t = wave; t < ST_PTILES; t += 4) {
+        const int q = t * 16 + (lane & 15);
+        const int hy = q / ST_HC, hx = q % ST_HC;
+        f16x8 x;
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            const int k = 8 * kb + e;                             // (ky, byte j of the 9-byte run) = (k / 9, k % 9)
+            const int r = 2 * hy + k / 9;
+            const int mis = (int)((base + (size_t)(iy0 + r) * fd.step + bx0) & 3);
+            const uint8_t px = s_in[r * (ST_ROWD * 4) + mis + 6 * hx + k % 9];
+            x[e] = (k < 27 && q < ST_NPIX) ? (half_t)(float)px : (half_t)0;
+        }
+        f32x4 acc = vzero<f32x4, 4>();
+        acc = M::mma(w_hi, x, acc);
+        acc = M::mma(w_lo, x, acc);
+        if (lane < 32) {
+            // conv0 pixels outside its own map are the ZERO PADDING of the depthwise conv, not conv0(zero input)
+            const int cy = oy0 - 1 + hy, cx = ox0 - 1 + hx;
+            const bool inside = cy >= 0 && cy < a.ho && cx >= 0 && cx < a.wo;
+            typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+            f16x4 h;
+#pragma unroll
+            for (int r = 0; r < 4; r++) h[r] = inside ? (half_t)fmaxf(acc[r] + b0[r], 0.f) : (half_t)0;
+            *(f16x4 *)(s_c0 + q * 8 + kb * 4) = h;
+        }
+    }
+    __syncthreads();
+
+    // ---- phase 3: depthwise 3x3 (conv1), one output pixel x 8 channels per thread
+    {
+        const int py = tid / ST_TW, px = tid % ST_TW;
+        float acc[8];
+#pragma unroll
+        for (int e = 0; e < 8; e++) acc[e] = dw_bias[e];
+#pragma unroll
+        for (int ky = 0; ky < 3; ky++)
+#pragma unroll
+            for (int kx = 0; kx < 3; kx++) {
+                const f16x8 x = *(const f16x8 *)(s_c0 + ((py + ky) * ST_HC + px + kx) * 8);
+                const f16x8 wv = *(const f16x8 *)(s_dw + (ky * 3 + kx) * 8);
+#pragma unroll
+                for (int e = 0; e < 8; e++) acc[e] = fmaf((float)x[e], (float)wv[e], acc[e]);
+            }
+        f16x8 r;
+#pragma unroll
+        for (int e = 0; e < 8; e++) r[e] = (half_t)fmaxf(acc[e], 0.f);
+        *(f16x8 *)(s_a + tid * LDA) = r;
+    }
+    __syncthreads();
+
+    // ---- phase 4: pointwise 8 -> 16 (conv2) on MFMA, K padded to 32
+    f32x4 acc[1][4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) acc[0][j] = vzero<f32x4, 4>();
+    pipe.run(acc, [&](int j, int) -> M::Frag {
+        return kb == 0 ? *(const M::Frag *)(s_a + acc_pixel(wave + j * 4, lane) * LDA) : M::zero();
+    });
+#pragma unroll
+    for (int j = 0; j < 4; j++) store_acc<T, LDO>(s_out, pw_bias, acc[0][j], 0, wave + j * 4, lane, true);
+    __syncthreads();
+    T *outb = a.out + (size_t)img * a.ho * a.wo * 16;
+    for (int i = tid; i < ST_P * 2; i += kThreads) {
+        const int p = i >> 1, cv = i & 1;
+        const int oy = oy0 + p / ST_TW, ox = ox0 + p % ST_TW;
+        if (oy < a.ho && ox < a.wo)
+            *(f16x8 *)(outb + ((size_t)oy * a.wo + ox) * 16 + cv * 8) = *(const f16x8 *)(s_out + p * LDO + cv * 8);
+    }
+}
+
+void launch_stem(hipStream_t s, const StemParams &p) {
+    const int ho = p.net_h / 2, wo = p.net_w / 2;      // conv2 output = conv0 output size (stride-1 block)
+    StemArgs a;
+    a.frames = p.frames; a.out = p.out; a.w0_hi = p.w0_hi; a.w0_lo = p.w0_lo; a.b0 = p.b0;
+    a.dw_w = p.dw_w; a.dw_b = p.dw_b; a.pw_w = p.pw_w; a.pw_b = p.pw_b;
+    a.params_in = p.params_in; a.params_out = p.params_out;
+    a.ho = ho; a.wo = wo;
+    a.tiles_x = (wo + ST_TW - 1) / ST_TW; a.tiles_y = (ho + ST_TH - 1) / ST_TH;
+    a.nblk = p.n * a.tiles_x * a.tiles_y;
+    hipLaunchKernelGGL(stem_kernel, dim3(a.nblk), dim3(kThreads), 0, s, a);
+}
+
+// =============================================================================================
 // K_b  depthwise 3x3 + BN + ReLU  ->  pointwise 1x1 + BN + ReLU   (13 backbone pairs, prototxt :55-1193)
 //      HAS_DW = false: plain 1x1 + bias + ReLU.
 //      LAT = true: the FPN lateral that taps this block's output (rf_c1_red_conv / rf_c2_lateral / rf_c3_lateral,

@@ -19,7 +19,7 @@ def descriptor(mangled: str) -> str:
     if m:
         cin, cout, th, tw, up = m.groups()
         return f"conv3x3<{cin},{cout},{th}x{tw}{',up' if up == '1' else ''}>"
-    for k in ("conv0", "head", "nms"):
+    for k in ("stem", "conv0", "head", "nms"):
         if k + "_kernel" in mangled:
             return k
     return mangled
