@@ -343,18 +343,28 @@ __global__ __launch_bounds__(kThreads) void stem_kernel(StemArgs a) {
     __syncthreads();
 
     // ---- phase 2: conv0 on the 10 x 34 halo'd region, MFMA: D[cout 16 (8 real)][pixel 16] += W[16][32] x patch[32][16]
-    const int kb = lane >> 4;                                     // this lane supplies k = 8*kb .. 8*kb+7
+    // A lane supplies k = 8*kb .. 8*kb+7 of its pixel.  k = 9*ky + j (j = byte of the 9-byte run of patch row ky), so the 8
+    // bytes are a tail of one row's run (segment A: nA bytes from byte jA of row rA) followed by a head of the next row's
+    // run (segment B from byte 0 of row rA+1):  kb 0: row 0 bytes 0..7 | kb 1: row 0 byte 8 + row 1 bytes 0..6 |
+    // kb 2: row 1 bytes 7,8 + row 2 bytes 0..5 | kb 3: row 2 bytes 6..8, then K padding.
+    const int kb = lane >> 4;
+    const int rA = kb == 0 ? 0 : kb == 3 ? 2 : kb - 1;
+    const int jA = kb == 0 ? 0 : kb == 1 ? 8 : kb == 2 ? 7 : 6;
+    const int nA = kb == 0 ? 8 : kb;                              // 8, 1, 2, 3
+    const int nAB = kb == 3 ? 3 : 8;                              // valid k's of this lane (k < 27)
+    const int m0 = (int)((base + (size_t)((long long)iy0 * fd.step) + bx0) & 3);   // misalignment of patch row 0
+    const int stepm = fd.step & 3;
     for (int t = wave; t < ST_PTILES; t += 4) {
         const int q = t * 16 + (lane & 15);
         const int hy = q / ST_HC, hx = q % ST_HC;
+        const int rowA = 2 * hy + rA, rowB = rowA + 1;
+        const uint8_t *pA = s_in + rowA * (ST_ROWD * 4) + ((m0 + rowA * stepm) & 3) + 6 * hx + jA;
+        const uint8_t *pB = s_in + rowB * (ST_ROWD * 4) + ((m0 + rowB * stepm) & 3) + 6 * hx - nA;
         f16x8 x;
 #pragma unroll
         for (int e = 0; e < 8; e++) {
-            const int k = 8 * kb + e;                             // (ky, byte j of the 9-byte run) = (k / 9, k % 9)
-            const int r = 2 * hy + k / 9;
-            const int mis = (int)((base + (size_t)(iy0 + r) * fd.step + bx0) & 3);
-            const uint8_t px = s_in[r * (ST_ROWD * 4) + mis + 6 * hx + k % 9];
-            x[e] = (k < 27 && q < ST_NPIX) ? (half_t)(float)px : (half_t)0;
+            const uint8_t px = *(e < nA ? pA + e : pB + e);
+            x[e] = (e < nAB && q < ST_NPIX) ? (half_t)(float)px : (half_t)0;
         }
         f32x4 acc = vzero<f32x4, 4>();
         acc = M::mma(w_hi, x, acc);
