@@ -275,6 +275,7 @@ public:
         const int mb = cap_images_;
         for (int i = 0; i < n; i++) l.h_frames[mb + i] = FrameDesc{(const uint8_t *)d_frames[i], net_h_, net_w_, net_w_ * 3, 0};
         *l.h_params = RunParams{0.5f, nms_threshold_, n, 0};
+        RF_HIP(hipMemcpyAsync(l.d_frames, l.h_frames, l.table_bytes, hipMemcpyHostToDevice, l.stream));
         size_t nops = l.ops.size();
         while (prof_ev_.size() < 2 * nops) { hipEvent_t e; RF_HIP(hipEventCreate(&e)); prof_ev_.push_back(e); }
         // Every launch is timed on the engine's own stream as `kReps` back-to-back repetitions between one HIP event
@@ -335,9 +336,13 @@ private:
         std::map<std::string, ActInfo> acts;
         std::vector<OpInfo> ops;              // launch order
         size_t first_post = 0;                // index of the first post-processing launch (heads)
-        // pinned host, read / written by the GPU directly
-        FrameDesc *h_frames = nullptr;        // [2*max_batch]: [0,mb) source frames, [mb,2mb) what conv0 reads
+        // pinned host staging of the per-launch table: [0,mb) source frames, [mb,2mb) what the stem reads, then RunParams;
+        // ONE small H2D copy per launch puts it in HBM (a launch covers up to max_batch*coalesce images, so the copy is
+        // amortised; reading it from the kernels over PCIe instead cost every workgroup a PCIe round trip)
+        FrameDesc *h_frames = nullptr;
         RunParams *h_params = nullptr;
+        FrameDesc *d_frames = nullptr;
+        size_t table_bytes = 0;
         int *h_counts = nullptr;              // [2*max_batch]: kept counts, candidate counts
         Candidate *h_out = nullptr;           // [max_batch*max_det]
         // device
@@ -436,13 +441,17 @@ private:
         for (auto &e : L.time_ev) RF_HIP(hipEventCreate(&e));
         RF_HIP(hipEventCreateWithFlags(&L.done, hipEventDisableTiming));
 
-        L.h_frames = halloc<FrameDesc>(2 * mb);
-        L.h_params = halloc<RunParams>(1);
+        L.table_bytes = 2 * mb * sizeof(FrameDesc) + sizeof(RunParams);
+        unsigned char *htab = halloc<unsigned char>(L.table_bytes);
+        unsigned char *dtab = dalloc<unsigned char>(L.table_bytes);
+        L.h_frames = (FrameDesc *)htab;
+        L.h_params = (RunParams *)(htab + 2 * mb * sizeof(FrameDesc));
+        L.d_frames = (FrameDesc *)dtab;
+        L.d_params = (RunParams *)(dtab + 2 * mb * sizeof(FrameDesc));
         const size_t hdr = ((2 * mb * sizeof(int) + 255) / 256) * 256;
         unsigned char *res = halloc<unsigned char>(hdr + (size_t)mb * opt_.max_detections * sizeof(Candidate));
         L.h_counts = (int *)res;
         L.h_out = (Candidate *)(res + hdr);
-        L.d_params = dalloc<RunParams>(1);
         L.d_cand_count = dalloc<int>(mb);
         RF_HIP(hipMemset(L.d_cand_count, 0, mb * sizeof(int)));
         L.d_cand = dalloc<Candidate>((size_t)mb * opt_.max_candidates);
@@ -463,11 +472,10 @@ private:
             const auto &blk = plan.blocks[0];
             T *out = act(blk.pw.out_blob, h, w, blk.pw.cout);
             StemParams sp;
-            sp.frames = L.h_frames + mb; sp.out = out;
+            sp.frames = L.d_frames + mb; sp.out = out;
             sp.w0_hi = arena_.ptr<half_t>(c0_hi_); sp.w0_lo = arena_.ptr<half_t>(c0_lo_); sp.b0 = arena_.ptr<float>(c0_b_);
             sp.dw_w = arena_.ptr<half_t>(dw_w_[0].w); sp.dw_b = arena_.ptr<float>(dw_w_[0].b);
             sp.pw_w = arena_.ptr<half_t>(pw_w_[0].w); sp.pw_b = arena_.ptr<float>(pw_w_[0].b);
-            sp.params_in = L.h_params; sp.params_out = L.d_params;
             sp.n = 0; sp.net_h = H; sp.net_w = W;
             OpInfo op;
             op.name = "pre+" + plan.conv0.name + "+" + blk.dw.name + "+" + blk.pw.name;
@@ -488,11 +496,9 @@ private:
             op.alg_elems_out = 8.0 * h * w;
             op.macs = plan.conv0.macs_per_out_pixel() * h * w;
             const float *wp = arena_.ptr<float>(c0_w_), *bp = arena_.ptr<float>(c0_b_);
-            const FrameDesc *fr = L.h_frames + mb;
-            const RunParams *pin = L.h_params;
-            RunParams *pout = L.d_params;
+            const FrameDesc *fr = L.d_frames + mb;
             T *o = cur;
-            op.launch = [=](hipStream_t s, int n) { launch_conv0<T>(s, fr, o, wp, bp, pin, pout, n, H, W); };
+            op.launch = [=](hipStream_t s, int n) { launch_conv0<T>(s, fr, o, wp, bp, nullptr, nullptr, n, H, W); };
             L.ops.push_back(op);
         }
         // FPN tap -> lateral index: block 4 (stride 8) -> lateral[2], block 10 (stride 16) -> [1], block 12 (stride 32) -> [0]
@@ -681,8 +687,9 @@ private:
             const int mb = cap_images_;
             for (int i = 0; i < n; i++)
                 s.h_frames[mb + i] = FrameDesc{s.d_canvas + (size_t)i * net_h_ * net_w_ * 3, net_h_, net_w_, net_w_ * 3, 0};
-            launch_resize_area(s.stream, s.h_frames, s.d_canvas, n, net_h_, net_w_);
         }
+        RF_HIP(hipMemcpyAsync(s.d_frames, s.h_frames, s.table_bytes, hipMemcpyHostToDevice, s.stream));
+        if (s.need_resize) launch_resize_area(s.stream, s.d_frames, s.d_canvas, n, net_h_, net_w_);
         const bool eager_timed = s.timed;
         if (eager_timed) RF_HIP(hipEventRecord(s.time_ev[1], s.stream));
         if (opt_.use_graph && s.warmed.count(n)) {

@@ -43,7 +43,6 @@ struct StemParams {
     const FrameDesc *frames; half_t *out;          // out: [n][net_h/2][net_w/2][16]
     const half_t *w0_hi, *w0_lo; const float *b0;  // conv0 in A-fragment order, K = (ky,kx,c_bgr) -> 32
     const half_t *dw_w; const float *dw_b; const half_t *pw_w; const float *pw_b;
-    const RunParams *params_in; RunParams *params_out;
     int n, net_h, net_w;
 };
 void launch_stem(hipStream_t s, const StemParams &p);

@@ -46,6 +46,7 @@ template <typename V, int N> __device__ __forceinline__ V vzero() {
 }
 
 constexpr int kThreads = 256;   // 4 wavefronts
+constexpr int kPersistentBlocks = 256 * 5;   // MI355X: 256 CUs x resident workgroups per CU of the persistent kernels
 
 template <typename F>
 static void set_max_lds(F func, size_t bytes) {
@@ -283,14 +284,15 @@ struct StemArgs {
     const half_t *w0_hi, *w0_lo;      // conv0 weights in A-fragment order [64 lanes][8], K = (ky,kx,c_bgr) padded to 32
     const float *b0;                  // [8]
     const half_t *dw_w; const float *dw_b; const half_t *pw_w; const float *pw_b;
-    const RunParams *params_in; RunParams *params_out;
-    int ho, wo, tiles_x, tiles_y, nblk;
+    int ho, wo, tiles_x, tiles_y, ntiles;
 };
 
 __global__ __launch_bounds__(kThreads) void stem_kernel(StemArgs a) {
     typedef half_t T;
     typedef Mma<T> M;
     constexpr int LDA = 16, LDO = 24;
+    constexpr int NSTAGE = ST_IR * ST_LD;                               // dwords of one staged patch
+    constexpr int NPRE = (NSTAGE + kThreads - 1) / kThreads;            // prefetch registers per thread (5)
     __shared__ __attribute__((aligned(16))) uint32_t s_in32[ST_IR * ST_ROWD];
     __shared__ __attribute__((aligned(16))) T s_c0[ST_PTILES * 16 * 8];
     __shared__ __attribute__((aligned(16))) T s_dw[9 * 8];
@@ -299,15 +301,9 @@ __global__ __launch_bounds__(kThreads) void stem_kernel(StemArgs a) {
     const uint8_t *s_in = (const uint8_t *)s_in32;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (blockIdx.x == 0 && tid == 0 && a.params_out) *a.params_out = *a.params_in;
-    const int bid = xcd_remap(blockIdx.x, a.nblk);
-    const int tx = bid % a.tiles_x;
-    const int ty = (bid / a.tiles_x) % a.tiles_y;
-    const int img = bid / (a.tiles_x * a.tiles_y);
-    const int oy0 = ty * ST_TH, ox0 = tx * ST_TW;
-    const FrameDesc fd = a.frames[img];
+    const int tiles_per_img = a.tiles_x * a.tiles_y;
 
-    // ---- phase 0: operands that depend only on kernel arguments
+    // ---- phase 0: operands that depend only on kernel arguments (once per workgroup: the grid is persistent)
     const f16x8 w_hi = ((const f16x8 *)a.w0_hi)[lane], w_lo = ((const f16x8 *)a.w0_lo)[lane];
     const f32x4 b0 = lane < 32 ? *(const f32x4 *)(a.b0 + (lane >> 4) * 4) : vzero<f32x4, 4>();
     GemmPipe<T, 1, 4, 1, 1> pipe;
@@ -316,33 +312,39 @@ __global__ __launch_bounds__(kThreads) void stem_kernel(StemArgs a) {
     float dw_bias[8];
 #pragma unroll
     for (int e = 0; e < 8; e++) dw_bias[e] = a.dw_b[e];
-
-    // ---- phase 1: stage the u8 patch (aligned dword loads, per-row misalignment kept; outside the frame = 0)
-    const int iy0 = 2 * oy0 - 3;                                  // input row of patch row 0
-    const int bx0 = (2 * ox0 - 3) * 3;                            // input byte column of patch byte 0
-    const uintptr_t base = (uintptr_t)fd.ptr;
-    const size_t row_bytes = (size_t)fd.cols * 3;
-    for (int i = tid; i < ST_IR * ST_LD; i += kThreads) {
-        const int r = i / ST_LD, d = i % ST_LD;
-        const int iy = iy0 + r;
-        uint32_t v = 0;
-        if (iy >= 0 && iy < fd.rows) {
-            const uintptr_t lo = base + (size_t)iy * fd.step, hi = lo + row_bytes;
-            const uintptr_t a0 = ((lo + bx0) & ~(uintptr_t)3) + 4 * d;
-            if (a0 >= lo && a0 + 4 <= hi) {
-                v = *(const uint32_t *)a0;
-            } else {
-#pragma unroll
-                for (int k = 0; k < 4; k++)
-                    if (a0 + k >= lo && a0 + k < hi) v |= (uint32_t)(*(const uint8_t *)(a0 + k)) << (8 * k);
-            }
-        }
-        s_in32[r * ST_ROWD + d] = v;
-    }
     if (tid < 9) *(f16x8 *)(s_dw + tid * 8) = *(const f16x8 *)(a.dw_w + tid * 8);
-    __syncthreads();
 
-    // ---- phase 2: conv0 on the 10 x 34 halo'd region, MFMA: D[cout 16 (8 real)][pixel 16] += W[16][32] x patch[32][16]
+    // Issue the loads of one tile's u8 patch into registers (aligned dword loads, each row keeps its own misalignment;
+    // bytes outside the frame are the zero canvas / zero padding).  Called one tile AHEAD of the compute below, so the HBM
+    // round trip of tile t+1 overlaps conv0 / depthwise / pointwise of tile t.
+    auto fetch = [&](int tile, uint32_t (&pre)[NPRE]) {
+        const int img = tile / tiles_per_img, rem = tile % tiles_per_img;
+        const FrameDesc fd = a.frames[img];
+        const int iy0 = 2 * (rem / a.tiles_x) * ST_TH - 3;
+        const int bx0 = (2 * (rem % a.tiles_x) * ST_TW - 3) * 3;
+        const uintptr_t base = (uintptr_t)fd.ptr;
+        const size_t row_bytes = (size_t)fd.cols * 3;
+#pragma unroll
+        for (int u = 0; u < NPRE; u++) {
+            const int i = tid + u * kThreads;
+            const int r = i / ST_LD, d = i % ST_LD;
+            const int iy = iy0 + r;
+            uint32_t v = 0;
+            if (i < NSTAGE && iy >= 0 && iy < fd.rows) {
+                const uintptr_t lo = base + (size_t)iy * fd.step, hi = lo + row_bytes;
+                const uintptr_t a0 = ((lo + bx0) & ~(uintptr_t)3) + 4 * d;
+                if (a0 >= lo && a0 + 4 <= hi) {
+                    v = *(const uint32_t *)a0;
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 4; k++)
+                        if (a0 + k >= lo && a0 + k < hi) v |= (uint32_t)(*(const uint8_t *)(a0 + k)) << (8 * k);
+                }
+            }
+            pre[u] = v;
+        }
+    };
+
     // A lane supplies k = 8*kb .. 8*kb+7 of its pixel.  k = 9*ky + j (j = byte of the 9-byte run of patch row ky), so the 8
     // bytes are a tail of one row's run (segment A: nA bytes from byte jA of row rA) followed by a head of the next row's
     // run (segment B from byte 0 of row rA+1):  kb 0: row 0 bytes 0..7 | kb 1: row 0 byte 8 + row 1 bytes 0..6 |
@@ -352,74 +354,97 @@ __global__ __launch_bounds__(kThreads) void stem_kernel(StemArgs a) {
     const int jA = kb == 0 ? 0 : kb == 1 ? 8 : kb == 2 ? 7 : 6;
     const int nA = kb == 0 ? 8 : kb;                              // 8, 1, 2, 3
     const int nAB = kb == 3 ? 3 : 8;                              // valid k's of this lane (k < 27)
-    const int m0 = (int)((base + (size_t)((long long)iy0 * fd.step) + bx0) & 3);   // misalignment of patch row 0
-    const int stepm = fd.step & 3;
-    for (int t = wave; t < ST_PTILES; t += 4) {
-        const int q = t * 16 + (lane & 15);
-        const int hy = q / ST_HC, hx = q % ST_HC;
-        const int rowA = 2 * hy + rA, rowB = rowA + 1;
-        const uint8_t *pA = s_in + rowA * (ST_ROWD * 4) + ((m0 + rowA * stepm) & 3) + 6 * hx + jA;
-        const uint8_t *pB = s_in + rowB * (ST_ROWD * 4) + ((m0 + rowB * stepm) & 3) + 6 * hx - nA;
-        f16x8 x;
-#pragma unroll
-        for (int e = 0; e < 8; e++) {
-            const uint8_t px = *(e < nA ? pA + e : pB + e);
-            x[e] = (e < nAB && q < ST_NPIX) ? (half_t)(float)px : (half_t)0;
-        }
-        f32x4 acc = vzero<f32x4, 4>();
-        acc = M::mma(w_hi, x, acc);
-        acc = M::mma(w_lo, x, acc);
-        if (lane < 32) {
-            // conv0 pixels outside its own map are the ZERO PADDING of the depthwise conv, not conv0(zero input)
-            const int cy = oy0 - 1 + hy, cx = ox0 - 1 + hx;
-            const bool inside = cy >= 0 && cy < a.ho && cx >= 0 && cx < a.wo;
-            typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
-            f16x4 h;
-#pragma unroll
-            for (int r = 0; r < 4; r++) h[r] = inside ? (half_t)fmaxf(acc[r] + b0[r], 0.f) : (half_t)0;
-            *(f16x4 *)(s_c0 + q * 8 + kb * 4) = h;
-        }
-    }
-    __syncthreads();
 
-    // ---- phase 3: depthwise 3x3 (conv1), one output pixel x 8 channels per thread
-    {
-        const int py = tid / ST_TW, px = tid % ST_TW;
-        float acc[8];
+    uint32_t pre[NPRE];
+    int tile = xcd_remap(blockIdx.x, gridDim.x);
+    if (tile < a.ntiles) fetch(tile, pre);
+    for (; tile < a.ntiles; tile += gridDim.x) {
+        const int img = tile / tiles_per_img, rem = tile % tiles_per_img;
+        const int oy0 = (rem / a.tiles_x) * ST_TH, ox0 = (rem % a.tiles_x) * ST_TW;
+        const FrameDesc fd = a.frames[img];
+        const int iy0 = 2 * oy0 - 3;                                  // input row of patch row 0
+        const int bx0 = (2 * ox0 - 3) * 3;                            // input byte column of patch byte 0
+        const int m0 = (int)(((uintptr_t)fd.ptr + (size_t)((long long)iy0 * fd.step) + bx0) & 3);   // misalignment of patch row 0
+        const int stepm = fd.step & 3;
+
+        // ---- phase 1: registers -> LDS, then put the NEXT tile's loads in flight
 #pragma unroll
-        for (int e = 0; e < 8; e++) acc[e] = dw_bias[e];
+        for (int u = 0; u < NPRE; u++) {
+            const int i = tid + u * kThreads;
+            if (i < NSTAGE) s_in32[(i / ST_LD) * ST_ROWD + i % ST_LD] = pre[u];
+        }
+        if (tile + (int)gridDim.x < a.ntiles) fetch(tile + gridDim.x, pre);
+        __syncthreads();
+
+        // ---- phase 2: conv0 on the 10 x 34 halo'd region, MFMA: D[cout 16 (8 real)][pixel 16] += W[16][32] x patch[32][16]
+        for (int t = wave; t < ST_PTILES; t += 4) {
+            const int q = t * 16 + (lane & 15);
+            const int hy = q / ST_HC, hx = q % ST_HC;
+            const int rowA = 2 * hy + rA, rowB = rowA + 1;
+            const uint8_t *pA = s_in + rowA * (ST_ROWD * 4) + ((m0 + rowA * stepm) & 3) + 6 * hx + jA;
+            const uint8_t *pB = s_in + rowB * (ST_ROWD * 4) + ((m0 + rowB * stepm) & 3) + 6 * hx - nA;
+            f16x8 x;
 #pragma unroll
-        for (int ky = 0; ky < 3; ky++)
-#pragma unroll
-            for (int kx = 0; kx < 3; kx++) {
-                const f16x8 x = *(const f16x8 *)(s_c0 + ((py + ky) * ST_HC + px + kx) * 8);
-                const f16x8 wv = *(const f16x8 *)(s_dw + (ky * 3 + kx) * 8);
-#pragma unroll
-                for (int e = 0; e < 8; e++) acc[e] = fmaf((float)x[e], (float)wv[e], acc[e]);
+            for (int e = 0; e < 8; e++) {
+                const uint8_t px = *(e < nA ? pA + e : pB + e);
+                x[e] = (e < nAB && q < ST_NPIX) ? (half_t)(float)px : (half_t)0;
             }
-        f16x8 r;
+            f32x4 acc = vzero<f32x4, 4>();
+            acc = M::mma(w_hi, x, acc);
+            acc = M::mma(w_lo, x, acc);
+            if (lane < 32) {
+                // conv0 pixels outside its own map are the ZERO PADDING of the depthwise conv, not conv0(zero input)
+                const int cy = oy0 - 1 + hy, cx = ox0 - 1 + hx;
+                const bool inside = cy >= 0 && cy < a.ho && cx >= 0 && cx < a.wo;
+                typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+                f16x4 h;
 #pragma unroll
-        for (int e = 0; e < 8; e++) r[e] = (half_t)fmaxf(acc[e], 0.f);
-        *(f16x8 *)(s_a + tid * LDA) = r;
-    }
-    __syncthreads();
+                for (int r = 0; r < 4; r++) h[r] = inside ? (half_t)fmaxf(acc[r] + b0[r], 0.f) : (half_t)0;
+                *(f16x4 *)(s_c0 + q * 8 + kb * 4) = h;
+            }
+        }
+        __syncthreads();
 
-    // ---- phase 4: pointwise 8 -> 16 (conv2) on MFMA, K padded to 32
-    f32x4 acc[1][4];
+        // ---- phase 3: depthwise 3x3 (conv1), one output pixel x 8 channels per thread
+        {
+            const int py = tid / ST_TW, px = tid % ST_TW;
+            float acc[8];
 #pragma unroll
-    for (int j = 0; j < 4; j++) acc[0][j] = vzero<f32x4, 4>();
-    pipe.run(acc, [&](int j, int) -> M::Frag {
-        return kb == 0 ? *(const M::Frag *)(s_a + acc_pixel(wave + j * 4, lane) * LDA) : M::zero();
-    });
+            for (int e = 0; e < 8; e++) acc[e] = dw_bias[e];
 #pragma unroll
-    for (int j = 0; j < 4; j++) store_acc<T, LDO>(s_out, pw_bias, acc[0][j], 0, wave + j * 4, lane, true);
-    __syncthreads();
-    T *outb = a.out + (size_t)img * a.ho * a.wo * 16;
-    for (int i = tid; i < ST_P * 2; i += kThreads) {
-        const int p = i >> 1, cv = i & 1;
-        const int oy = oy0 + p / ST_TW, ox = ox0 + p % ST_TW;
-        if (oy < a.ho && ox < a.wo)
-            *(f16x8 *)(outb + ((size_t)oy * a.wo + ox) * 16 + cv * 8) = *(const f16x8 *)(s_out + p * LDO + cv * 8);
+            for (int ky = 0; ky < 3; ky++)
+#pragma unroll
+                for (int kx = 0; kx < 3; kx++) {
+                    const f16x8 x = *(const f16x8 *)(s_c0 + ((py + ky) * ST_HC + px + kx) * 8);
+                    const f16x8 wv = *(const f16x8 *)(s_dw + (ky * 3 + kx) * 8);
+#pragma unroll
+                    for (int e = 0; e < 8; e++) acc[e] = fmaf((float)x[e], (float)wv[e], acc[e]);
+                }
+            f16x8 r;
+#pragma unroll
+            for (int e = 0; e < 8; e++) r[e] = (half_t)fmaxf(acc[e], 0.f);
+            *(f16x8 *)(s_a + tid * LDA) = r;
+        }
+        __syncthreads();
+
+        // ---- phase 4: pointwise 8 -> 16 (conv2) on MFMA, K padded to 32
+        f32x4 acc[1][4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc[0][j] = vzero<f32x4, 4>();
+        pipe.run(acc, [&](int j, int) -> M::Frag {
+            return kb == 0 ? *(const M::Frag *)(s_a + acc_pixel(wave + j * 4, lane) * LDA) : M::zero();
+        });
+#pragma unroll
+        for (int j = 0; j < 4; j++) store_acc<T, LDO>(s_out, pw_bias, acc[0][j], 0, wave + j * 4, lane, true);
+        __syncthreads();
+        T *outb = a.out + (size_t)img * a.ho * a.wo * 16;
+        for (int i = tid; i < ST_P * 2; i += kThreads) {
+            const int p = i >> 1, cv = i & 1;
+            const int oy = oy0 + p / ST_TW, ox = ox0 + p % ST_TW;
+            if (oy < a.ho && ox < a.wo)
+                *(f16x8 *)(outb + ((size_t)oy * a.wo + ox) * 16 + cv * 8) = *(const f16x8 *)(s_out + p * LDO + cv * 8);
+        }
+        // the next iteration's first LDS writes (s_in32) were last read in phase 2, two barriers ago: no extra barrier
     }
 }
 
@@ -428,11 +453,12 @@ void launch_stem(hipStream_t s, const StemParams &p) {
     StemArgs a;
     a.frames = p.frames; a.out = p.out; a.w0_hi = p.w0_hi; a.w0_lo = p.w0_lo; a.b0 = p.b0;
     a.dw_w = p.dw_w; a.dw_b = p.dw_b; a.pw_w = p.pw_w; a.pw_b = p.pw_b;
-    a.params_in = p.params_in; a.params_out = p.params_out;
     a.ho = ho; a.wo = wo;
     a.tiles_x = (wo + ST_TW - 1) / ST_TW; a.tiles_y = (ho + ST_TH - 1) / ST_TH;
-    a.nblk = p.n * a.tiles_x * a.tiles_y;
-    hipLaunchKernelGGL(stem_kernel, dim3(a.nblk), dim3(kThreads), 0, s, a);
+    a.ntiles = p.n * a.tiles_x * a.tiles_y;
+    // persistent grid: as many workgroups as stay resident (5 per CU by LDS), each walks tiles with a one-tile prefetch
+    const int grid = a.ntiles < kPersistentBlocks ? a.ntiles : kPersistentBlocks;
+    hipLaunchKernelGGL(stem_kernel, dim3(grid), dim3(kThreads), 0, s, a);
 }
 
 // =============================================================================================
