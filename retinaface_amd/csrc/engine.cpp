@@ -398,21 +398,22 @@ private:
         c0_w_ = arena_.put(plan.conv0.w);
         c0_b_ = arena_.put(plan.conv0.b);
         if constexpr (sizeof(T) == 2) {
-            // stem kernel: conv0 as a 16 x 32 A fragment, K = (ky, kx, c_bgr) (the frame's own byte order: net channel c is
-            // frame channel 2-c), fp16 hi + lo so the sum carries ~22 mantissa bits
-            std::vector<half_t> hi(64 * 8, (half_t)0), lo(64 * 8, (half_t)0);
-            for (int lane = 0; lane < 64; lane++)
-                for (int el = 0; el < 8; el++) {
-                    int row = lane & 15, k = (lane >> 4) * 8 + el;
-                    if (row >= 8 || k >= 27) continue;
-                    int tap = k / 3, cb = k % 3;
-                    float w = plan.conv0.w[(size_t)row * 27 + tap * 3 + (2 - cb)];
-                    half_t h = (half_t)w;
-                    hi[lane * 8 + el] = h;
-                    lo[lane * 8 + el] = (half_t)(w - (float)h);
-                }
-            c0_hi_ = arena_.put(hi);
-            c0_lo_ = arena_.put(lo);
+            // stem kernel: conv0 as 16 x 64 A fragments, K = 4*(3*ky + kx) + c4 with c4 = B, G, R, pad (the frame's own
+            // byte order: net channel c is frame channel 2-c), fp16 hi + lo so the sum carries ~22 mantissa bits.
+            // Layout: [hi k<32 | lo k<32 | hi k>=32 | lo k>=32][lane 64][8]
+            std::vector<half_t> frag(4 * 64 * 8, (half_t)0);
+            for (int half = 0; half < 2; half++)
+                for (int lane = 0; lane < 64; lane++)
+                    for (int el = 0; el < 8; el++) {
+                        int row = lane & 15, k = half * 32 + (lane >> 4) * 8 + el;
+                        int tap = k / 4, c4 = k % 4;
+                        if (row >= 8 || tap >= 9 || c4 == 3) continue;
+                        float w = plan.conv0.w[(size_t)row * 27 + tap * 3 + (2 - c4)];
+                        half_t h = (half_t)w;
+                        frag[((half * 2 + 0) * 64 + lane) * 8 + el] = h;
+                        frag[((half * 2 + 1) * 64 + lane) * 8 + el] = (half_t)(w - (float)h);
+                    }
+            c0_hi_ = arena_.put(frag);
         }
         for (const auto &blk : plan.blocks) {
             int c = blk.dw.cout;                       // depthwise weights [c][3][3][1] -> [tap][c]
@@ -473,7 +474,7 @@ private:
             T *out = act(blk.pw.out_blob, h, w, blk.pw.cout);
             StemParams sp;
             sp.frames = L.d_frames + mb; sp.out = out;
-            sp.w0_hi = arena_.ptr<half_t>(c0_hi_); sp.w0_lo = arena_.ptr<half_t>(c0_lo_); sp.b0 = arena_.ptr<float>(c0_b_);
+            sp.w0 = arena_.ptr<half_t>(c0_hi_); sp.b0 = arena_.ptr<float>(c0_b_);
             sp.dw_w = arena_.ptr<half_t>(dw_w_[0].w); sp.dw_b = arena_.ptr<float>(dw_w_[0].b);
             sp.pw_w = arena_.ptr<half_t>(pw_w_[0].w); sp.pw_b = arena_.ptr<float>(pw_w_[0].b);
             sp.n = 0; sp.net_h = H; sp.net_w = W;

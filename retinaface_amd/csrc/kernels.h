@@ -41,7 +41,7 @@ void launch_conv0(hipStream_t s, const FrameDesc *frames, T *out, const float *w
 // ---- K_a' (fp16 engine): K_a fused with the first depthwise/pointwise block; conv0 on MFMA (hi+lo split weights).
 struct StemParams {
     const FrameDesc *frames; half_t *out;          // out: [n][net_h/2][net_w/2][16]
-    const half_t *w0_hi, *w0_lo; const float *b0;  // conv0 in A-fragment order, K = (ky,kx,c_bgr) -> 32
+    const half_t *w0; const float *b0;             // conv0: 4 A fragments (hi/lo x k<32/k>=32), K = (ky,kx,BGRX) 36 -> 64
     const half_t *dw_w; const float *dw_b; const half_t *pw_w; const float *pw_b;
     int n, net_h, net_w;
 };

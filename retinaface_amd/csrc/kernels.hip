@@ -46,7 +46,6 @@ template <typename V, int N> __device__ __forceinline__ V vzero() {
 }
 
 constexpr int kThreads = 256;   // 4 wavefronts
-constexpr int kPersistentBlocks = 256 * 5;   // MI355X: 256 CUs x resident workgroups per CU of the persistent kernels
 
 template <typename F>
 static void set_max_lds(F func, size_t bytes) {
@@ -264,10 +263,14 @@ __device__ __forceinline__ void store_acc(T *s_out, f32x4 bv, f32x4 acc, int ct,
 // =============================================================================================
 // K_a' stem (fp16 engine): preprocess + conv0 + BN + ReLU + depthwise conv1 + BN + ReLU + pointwise conv2 + BN + ReLU
 //   = K_a fused with the first K_b block, so the 8-channel 224^2 map (the largest activation of the net per byte of
-//   useful work) never exists in HBM.  conv0 itself runs on the matrix cores: per output pixel the 27 taps are 3 runs of
-//   9 CONTIGUOUS bytes of the BGR frame (3 px x 3 ch per row), so with the weights' K axis ordered (ky, kx, c_bgr) an MFMA
-//   B fragment (8 consecutive k of one pixel) is 8 bytes gathered from at most two staged rows, converted u8 -> fp16
-//   exactly.  Weights are split hi + lo in fp16 (two MFMAs) so conv0 keeps fp32-grade weights on raw 0..255 inputs.
+//   useful work) never exists in HBM.  The kernel is instruction-issue bound (few bytes per pixel, 300+ MACs), so the
+//   design minimises VALU work:
+//   * staging expands BGR (3 B) to BGRX (4 B) pixels: every later read is an aligned dword, and the zero X byte is the
+//     K padding of the MFMA;
+//   * conv0 runs on the matrix cores with K ordered (ky, kx, c4): 36 -> 64, two MFMAs; a lane's 8 k's are two whole
+//     pixels = two aligned ds_read_b32; u8 -> fp16 is exact and takes 1 instruction per byte
+//     (v_perm_b32 builds 0x6400|b = 1024 + b, v_pk_add_f16 subtracts 1024);
+//   * weights are split hi + lo in fp16 (two more MFMAs) so conv0 keeps fp32-grade weights on raw 0..255 inputs.
 //   Tile: 8 x 32 outputs of conv2 <- 10 x 34 conv0 pixels (halo recompute 1.33x) <- 21 x 69 input pixels.
 // =============================================================================================
 constexpr int ST_TH = 8, ST_TW = 32, ST_P = ST_TH * ST_TW;
@@ -275,36 +278,52 @@ constexpr int ST_HR = ST_TH + 2, ST_HC = ST_TW + 2;            // conv0 pixels n
 constexpr int ST_NPIX = ST_HR * ST_HC;
 constexpr int ST_PTILES = (ST_NPIX + 15) / 16;                 // 22 MFMA pixel tiles
 constexpr int ST_IR = 2 * ST_HR + 1;                           // 21 input rows
-constexpr int ST_IB = (2 * ST_HC + 1) * 3;                     // 207 input bytes per row
-constexpr int ST_LD = (ST_IB + 3 + 3) / 4;                     // 53 dwords fetched per row (payload + misalignment)
-constexpr int ST_ROWD = ST_LD + 1;                             // LDS row stride in dwords
+constexpr int ST_IPX = 2 * ST_HC + 1;                          // 69 input pixels per row
+constexpr int ST_GRP = (ST_IPX + 3) / 4;                       // 18 staging groups of 4 pixels (12 B in, 16 B out)
+constexpr int ST_ROWD = ST_GRP * 4;                            // 72 dwords (BGRX pixels) per staged row
 
 struct StemArgs {
     const FrameDesc *frames; half_t *out;
-    const half_t *w0_hi, *w0_lo;      // conv0 weights in A-fragment order [64 lanes][8], K = (ky,kx,c_bgr) padded to 32
+    const half_t *w0;                 // conv0 weights: 4 A fragments [hi k<32 | lo k<32 | hi k>=32 | lo k>=32][64 lanes][8]
     const float *b0;                  // [8]
     const half_t *dw_w; const float *dw_b; const half_t *pw_w; const float *pw_b;
-    int ho, wo, tiles_x, tiles_y, ntiles;
+    int ho, wo, tiles_x, tiles_y, nblk;
 };
+
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+
+// 4 u8 in a dword -> 4 fp16, exact: (0x6400 | b) is the fp16 number 1024 + b
+__device__ __forceinline__ void u8x4_to_f16(uint32_t v, f16x8 &dst, int at) {
+    union { uint32_t u; f16x2 h; } lo, hi;
+    lo.u = __builtin_amdgcn_perm(0x64646464u, v, 0x04010400u);     // {b0, 0x64, b1, 0x64}
+    hi.u = __builtin_amdgcn_perm(0x64646464u, v, 0x04030402u);     // {b2, 0x64, b3, 0x64}
+    const f16x2 k = {(half_t)1024, (half_t)1024};
+    lo.h -= k;
+    hi.h -= k;
+    dst[at] = lo.h[0]; dst[at + 1] = lo.h[1]; dst[at + 2] = hi.h[0]; dst[at + 3] = hi.h[1];
+}
 
 __global__ __launch_bounds__(kThreads) void stem_kernel(StemArgs a) {
     typedef half_t T;
     typedef Mma<T> M;
     constexpr int LDA = 16, LDO = 24;
-    constexpr int NSTAGE = ST_IR * ST_LD;                               // dwords of one staged patch
-    constexpr int NPRE = (NSTAGE + kThreads - 1) / kThreads;            // prefetch registers per thread (5)
-    __shared__ __attribute__((aligned(16))) uint32_t s_in32[ST_IR * ST_ROWD];
+    __shared__ __attribute__((aligned(16))) uint32_t s_in[ST_IR * ST_ROWD];       // BGRX pixels
     __shared__ __attribute__((aligned(16))) T s_c0[ST_PTILES * 16 * 8];
     __shared__ __attribute__((aligned(16))) T s_dw[9 * 8];
     __shared__ __attribute__((aligned(16))) T s_a[ST_P * LDA];
     __shared__ __attribute__((aligned(16))) T s_out[ST_P * LDO];
-    const uint8_t *s_in = (const uint8_t *)s_in32;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int tiles_per_img = a.tiles_x * a.tiles_y;
+    const int bid = xcd_remap(blockIdx.x, a.nblk);
+    const int tx = bid % a.tiles_x;
+    const int ty = (bid / a.tiles_x) % a.tiles_y;
+    const int img = bid / (a.tiles_x * a.tiles_y);
+    const int oy0 = ty * ST_TH, ox0 = tx * ST_TW;
+    const FrameDesc fd = a.frames[img];
 
-    // ---- phase 0: operands that depend only on kernel arguments (once per workgroup: the grid is persistent)
-    const f16x8 w_hi = ((const f16x8 *)a.w0_hi)[lane], w_lo = ((const f16x8 *)a.w0_lo)[lane];
+    // ---- phase 0: operands that depend only on kernel arguments
+    const f16x8 *wf = (const f16x8 *)a.w0 + lane;
+    const f16x8 w_hi1 = wf[0], w_lo1 = wf[64], w_hi2 = wf[128], w_lo2 = wf[192];
     const f32x4 b0 = lane < 32 ? *(const f32x4 *)(a.b0 + (lane >> 4) * 4) : vzero<f32x4, 4>();
     GemmPipe<T, 1, 4, 1, 1> pipe;
     pipe.init(a.pw_w, 0, lane);
@@ -312,153 +331,135 @@ __global__ __launch_bounds__(kThreads) void stem_kernel(StemArgs a) {
     float dw_bias[8];
 #pragma unroll
     for (int e = 0; e < 8; e++) dw_bias[e] = a.dw_b[e];
+
+    // ---- phase 1: stage the u8 patch as BGRX dwords.  One item = 4 pixels = 12 consecutive frame bytes at an arbitrary
+    //      alignment: 4 aligned dword loads, realigned with v_alignbyte, expanded 3 -> 4 bytes, one 16-byte LDS store.
+    //      Bytes outside the frame are the zero canvas / conv padding.
+    const int iy0 = 2 * oy0 - 3;                                  // input row of patch row 0
+    const int bx0 = (2 * ox0 - 3) * 3;                            // input byte column of patch pixel 0
+    const uintptr_t base = (uintptr_t)fd.ptr;
+    const long long row_bytes = (long long)fd.cols * 3;
+    for (int i = tid; i < ST_IR * ST_GRP; i += kThreads) {
+        const int r = i / ST_GRP, g = i % ST_GRP;
+        const int iy = iy0 + r;
+        uint32_t w0 = 0, w1 = 0, w2 = 0;                          // the 12 bytes
+        if (iy >= 0 && iy < fd.rows) {
+            const long long off = (long long)bx0 + 12 * g;         // byte offset in the row
+            const uintptr_t lo = base + (size_t)iy * fd.step;
+            if (off >= 0 && off + 16 <= row_bytes) {               // interior: may over-read up to 3 bytes, still inside the row
+                const uintptr_t A = lo + off, a0 = A & ~(uintptr_t)3;
+                const uint32_t sh = (uint32_t)(A & 3);
+                const uint32_t *p = (const uint32_t *)a0;
+                const uint32_t d0 = p[0], d1 = p[1], d2 = p[2], d3 = p[3];
+                w0 = __builtin_amdgcn_alignbyte(d1, d0, sh);
+                w1 = __builtin_amdgcn_alignbyte(d2, d1, sh);
+                w2 = __builtin_amdgcn_alignbyte(d3, d2, sh);
+            } else {
+                const uint8_t *q = (const uint8_t *)lo;
+#pragma unroll
+                for (int k = 0; k < 12; k++) {
+                    const long long o = off + k;
+                    const uint32_t byte = (o >= 0 && o < row_bytes) ? q[o] : 0u;
+                    if (k < 4) w0 |= byte << (8 * k);
+                    else if (k < 8) w1 |= byte << (8 * (k - 4));
+                    else w2 |= byte << (8 * (k - 8));
+                }
+            }
+        }
+        uint4 o4;
+        o4.x = w0 & 0x00ffffffu;
+        o4.y = ((w0 >> 24) | (w1 << 8)) & 0x00ffffffu;
+        o4.z = ((w1 >> 16) | (w2 << 16)) & 0x00ffffffu;
+        o4.w = w2 >> 8;
+        *(uint4 *)(s_in + r * ST_ROWD + g * 4) = o4;
+    }
     if (tid < 9) *(f16x8 *)(s_dw + tid * 8) = *(const f16x8 *)(a.dw_w + tid * 8);
+    __syncthreads();
 
-    // Issue the loads of one tile's u8 patch into registers (aligned dword loads, each row keeps its own misalignment;
-    // bytes outside the frame are the zero canvas / zero padding).  Called one tile AHEAD of the compute below, so the HBM
-    // round trip of tile t+1 overlaps conv0 / depthwise / pointwise of tile t.
-    auto fetch = [&](int tile, uint32_t (&pre)[NPRE]) {
-        const int img = tile / tiles_per_img, rem = tile % tiles_per_img;
-        const FrameDesc fd = a.frames[img];
-        const int iy0 = 2 * (rem / a.tiles_x) * ST_TH - 3;
-        const int bx0 = (2 * (rem % a.tiles_x) * ST_TW - 3) * 3;
-        const uintptr_t base = (uintptr_t)fd.ptr;
-        const size_t row_bytes = (size_t)fd.cols * 3;
-#pragma unroll
-        for (int u = 0; u < NPRE; u++) {
-            const int i = tid + u * kThreads;
-            const int r = i / ST_LD, d = i % ST_LD;
-            const int iy = iy0 + r;
-            uint32_t v = 0;
-            if (i < NSTAGE && iy >= 0 && iy < fd.rows) {
-                const uintptr_t lo = base + (size_t)iy * fd.step, hi = lo + row_bytes;
-                const uintptr_t a0 = ((lo + bx0) & ~(uintptr_t)3) + 4 * d;
-                if (a0 >= lo && a0 + 4 <= hi) {
-                    v = *(const uint32_t *)a0;
-                } else {
-#pragma unroll
-                    for (int k = 0; k < 4; k++)
-                        if (a0 + k >= lo && a0 + k < hi) v |= (uint32_t)(*(const uint8_t *)(a0 + k)) << (8 * k);
-                }
-            }
-            pre[u] = v;
-        }
-    };
-
-    // A lane supplies k = 8*kb .. 8*kb+7 of its pixel.  k = 9*ky + j (j = byte of the 9-byte run of patch row ky), so the 8
-    // bytes are a tail of one row's run (segment A: nA bytes from byte jA of row rA) followed by a head of the next row's
-    // run (segment B from byte 0 of row rA+1):  kb 0: row 0 bytes 0..7 | kb 1: row 0 byte 8 + row 1 bytes 0..6 |
-    // kb 2: row 1 bytes 7,8 + row 2 bytes 0..5 | kb 3: row 2 bytes 6..8, then K padding.
+    // ---- phase 2: conv0 on the 10 x 34 halo'd region: D[cout 16 (8 real)][pixel 16] += W[16][64] x patch[64][16]
+    //      k = 4*(3*ky + kx) + c4.  Lane group kb supplies window pixels 2kb, 2kb+1 (MFMA 1) and pixel 8 (MFMA 2, kb 0 only).
     const int kb = lane >> 4;
-    const int rA = kb == 0 ? 0 : kb == 3 ? 2 : kb - 1;
-    const int jA = kb == 0 ? 0 : kb == 1 ? 8 : kb == 2 ? 7 : 6;
-    const int nA = kb == 0 ? 8 : kb;                              // 8, 1, 2, 3
-    const int nAB = kb == 3 ? 3 : 8;                              // valid k's of this lane (k < 27)
-
-    uint32_t pre[NPRE];
-    int tile = xcd_remap(blockIdx.x, gridDim.x);
-    if (tile < a.ntiles) fetch(tile, pre);
-    for (; tile < a.ntiles; tile += gridDim.x) {
-        const int img = tile / tiles_per_img, rem = tile % tiles_per_img;
-        const int oy0 = (rem / a.tiles_x) * ST_TH, ox0 = (rem % a.tiles_x) * ST_TW;
-        const FrameDesc fd = a.frames[img];
-        const int iy0 = 2 * oy0 - 3;                                  // input row of patch row 0
-        const int bx0 = (2 * ox0 - 3) * 3;                            // input byte column of patch byte 0
-        const int m0 = (int)(((uintptr_t)fd.ptr + (size_t)((long long)iy0 * fd.step) + bx0) & 3);   // misalignment of patch row 0
-        const int stepm = fd.step & 3;
-
-        // ---- phase 1: registers -> LDS, then put the NEXT tile's loads in flight
+    const int ppA = 2 * kb, ppB = 2 * kb + 1;
+    const int offA = (ppA / 3) * ST_ROWD + ppA % 3, offB = (ppB / 3) * ST_ROWD + ppB % 3, offC = 2 * ST_ROWD + 2;
+    for (int t = wave; t < ST_PTILES; t += 4) {
+        const int q = t * 16 + (lane & 15);
+        const int hy = q / ST_HC, hx = q % ST_HC;
+        const uint32_t *pp = s_in + (2 * hy) * ST_ROWD + 2 * hx;
+        const bool valid = q < ST_NPIX;
+        const uint32_t vA = valid ? pp[offA] : 0u, vB = valid ? pp[offB] : 0u;
+        const uint32_t vC = (valid && kb == 0) ? pp[offC] : 0u;
+        f16x8 x1, x2 = vzero<f16x8, 8>();
+        u8x4_to_f16(vA, x1, 0);
+        u8x4_to_f16(vB, x1, 4);
+        u8x4_to_f16(vC, x2, 0);
+        f32x4 acc = vzero<f32x4, 4>();
+        acc = M::mma(w_hi1, x1, acc);
+        acc = M::mma(w_lo1, x1, acc);
+        acc = M::mma(w_hi2, x2, acc);
+        acc = M::mma(w_lo2, x2, acc);
+        if (lane < 32) {
+            // conv0 pixels outside its own map are the ZERO PADDING of the depthwise conv, not conv0(zero input)
+            const int cy = oy0 - 1 + hy, cx = ox0 - 1 + hx;
+            const bool inside = cy >= 0 && cy < a.ho && cx >= 0 && cx < a.wo;
+            typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+            f16x4 h;
 #pragma unroll
-        for (int u = 0; u < NPRE; u++) {
-            const int i = tid + u * kThreads;
-            if (i < NSTAGE) s_in32[(i / ST_LD) * ST_ROWD + i % ST_LD] = pre[u];
+            for (int r = 0; r < 4; r++) h[r] = inside ? (half_t)fmaxf(acc[r] + b0[r], 0.f) : (half_t)0;
+            *(f16x4 *)(s_c0 + q * 8 + kb * 4) = h;
         }
-        if (tile + (int)gridDim.x < a.ntiles) fetch(tile + gridDim.x, pre);
-        __syncthreads();
+    }
+    __syncthreads();
 
-        // ---- phase 2: conv0 on the 10 x 34 halo'd region, MFMA: D[cout 16 (8 real)][pixel 16] += W[16][32] x patch[32][16]
-        for (int t = wave; t < ST_PTILES; t += 4) {
-            const int q = t * 16 + (lane & 15);
-            const int hy = q / ST_HC, hx = q % ST_HC;
-            const int rowA = 2 * hy + rA, rowB = rowA + 1;
-            const uint8_t *pA = s_in + rowA * (ST_ROWD * 4) + ((m0 + rowA * stepm) & 3) + 6 * hx + jA;
-            const uint8_t *pB = s_in + rowB * (ST_ROWD * 4) + ((m0 + rowB * stepm) & 3) + 6 * hx - nA;
-            f16x8 x;
+    // ---- phase 3: depthwise 3x3 (conv1), one output pixel x 8 channels per thread
+    {
+        const int py = tid / ST_TW, px = tid % ST_TW;
+        float acc[8];
 #pragma unroll
-            for (int e = 0; e < 8; e++) {
-                const uint8_t px = *(e < nA ? pA + e : pB + e);
-                x[e] = (e < nAB && q < ST_NPIX) ? (half_t)(float)px : (half_t)0;
+        for (int e = 0; e < 8; e++) acc[e] = dw_bias[e];
+#pragma unroll
+        for (int ky = 0; ky < 3; ky++)
+#pragma unroll
+            for (int kx = 0; kx < 3; kx++) {
+                const f16x8 x = *(const f16x8 *)(s_c0 + ((py + ky) * ST_HC + px + kx) * 8);
+                const f16x8 wv = *(const f16x8 *)(s_dw + (ky * 3 + kx) * 8);
+#pragma unroll
+                for (int e = 0; e < 8; e++) acc[e] = fmaf((float)x[e], (float)wv[e], acc[e]);
             }
-            f32x4 acc = vzero<f32x4, 4>();
-            acc = M::mma(w_hi, x, acc);
-            acc = M::mma(w_lo, x, acc);
-            if (lane < 32) {
-                // conv0 pixels outside its own map are the ZERO PADDING of the depthwise conv, not conv0(zero input)
-                const int cy = oy0 - 1 + hy, cx = ox0 - 1 + hx;
-                const bool inside = cy >= 0 && cy < a.ho && cx >= 0 && cx < a.wo;
-                typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
-                f16x4 h;
+        f16x8 r;
 #pragma unroll
-                for (int r = 0; r < 4; r++) h[r] = inside ? (half_t)fmaxf(acc[r] + b0[r], 0.f) : (half_t)0;
-                *(f16x4 *)(s_c0 + q * 8 + kb * 4) = h;
-            }
-        }
-        __syncthreads();
+        for (int e = 0; e < 8; e++) r[e] = (half_t)fmaxf(acc[e], 0.f);
+        *(f16x8 *)(s_a + tid * LDA) = r;
+    }
+    __syncthreads();
 
-        // ---- phase 3: depthwise 3x3 (conv1), one output pixel x 8 channels per thread
-        {
-            const int py = tid / ST_TW, px = tid % ST_TW;
-            float acc[8];
+    // ---- phase 4: pointwise 8 -> 16 (conv2) on MFMA, K padded to 32
+    f32x4 acc[1][4];
 #pragma unroll
-            for (int e = 0; e < 8; e++) acc[e] = dw_bias[e];
+    for (int j = 0; j < 4; j++) acc[0][j] = vzero<f32x4, 4>();
+    pipe.run(acc, [&](int j, int) -> M::Frag {
+        return kb == 0 ? *(const M::Frag *)(s_a + acc_pixel(wave + j * 4, lane) * LDA) : M::zero();
+    });
 #pragma unroll
-            for (int ky = 0; ky < 3; ky++)
-#pragma unroll
-                for (int kx = 0; kx < 3; kx++) {
-                    const f16x8 x = *(const f16x8 *)(s_c0 + ((py + ky) * ST_HC + px + kx) * 8);
-                    const f16x8 wv = *(const f16x8 *)(s_dw + (ky * 3 + kx) * 8);
-#pragma unroll
-                    for (int e = 0; e < 8; e++) acc[e] = fmaf((float)x[e], (float)wv[e], acc[e]);
-                }
-            f16x8 r;
-#pragma unroll
-            for (int e = 0; e < 8; e++) r[e] = (half_t)fmaxf(acc[e], 0.f);
-            *(f16x8 *)(s_a + tid * LDA) = r;
-        }
-        __syncthreads();
-
-        // ---- phase 4: pointwise 8 -> 16 (conv2) on MFMA, K padded to 32
-        f32x4 acc[1][4];
-#pragma unroll
-        for (int j = 0; j < 4; j++) acc[0][j] = vzero<f32x4, 4>();
-        pipe.run(acc, [&](int j, int) -> M::Frag {
-            return kb == 0 ? *(const M::Frag *)(s_a + acc_pixel(wave + j * 4, lane) * LDA) : M::zero();
-        });
-#pragma unroll
-        for (int j = 0; j < 4; j++) store_acc<T, LDO>(s_out, pw_bias, acc[0][j], 0, wave + j * 4, lane, true);
-        __syncthreads();
-        T *outb = a.out + (size_t)img * a.ho * a.wo * 16;
-        for (int i = tid; i < ST_P * 2; i += kThreads) {
-            const int p = i >> 1, cv = i & 1;
-            const int oy = oy0 + p / ST_TW, ox = ox0 + p % ST_TW;
-            if (oy < a.ho && ox < a.wo)
-                *(f16x8 *)(outb + ((size_t)oy * a.wo + ox) * 16 + cv * 8) = *(const f16x8 *)(s_out + p * LDO + cv * 8);
-        }
-        // the next iteration's first LDS writes (s_in32) were last read in phase 2, two barriers ago: no extra barrier
+    for (int j = 0; j < 4; j++) store_acc<T, LDO>(s_out, pw_bias, acc[0][j], 0, wave + j * 4, lane, true);
+    __syncthreads();
+    T *outb = a.out + (size_t)img * a.ho * a.wo * 16;
+    for (int i = tid; i < ST_P * 2; i += kThreads) {
+        const int p = i >> 1, cv = i & 1;
+        const int oy = oy0 + p / ST_TW, ox = ox0 + p % ST_TW;
+        if (oy < a.ho && ox < a.wo)
+            *(f16x8 *)(outb + ((size_t)oy * a.wo + ox) * 16 + cv * 8) = *(const f16x8 *)(s_out + p * LDO + cv * 8);
     }
 }
 
 void launch_stem(hipStream_t s, const StemParams &p) {
     const int ho = p.net_h / 2, wo = p.net_w / 2;      // conv2 output = conv0 output size (stride-1 block)
     StemArgs a;
-    a.frames = p.frames; a.out = p.out; a.w0_hi = p.w0_hi; a.w0_lo = p.w0_lo; a.b0 = p.b0;
+    a.frames = p.frames; a.out = p.out; a.w0 = p.w0; a.b0 = p.b0;
     a.dw_w = p.dw_w; a.dw_b = p.dw_b; a.pw_w = p.pw_w; a.pw_b = p.pw_b;
     a.ho = ho; a.wo = wo;
     a.tiles_x = (wo + ST_TW - 1) / ST_TW; a.tiles_y = (ho + ST_TH - 1) / ST_TH;
-    a.ntiles = p.n * a.tiles_x * a.tiles_y;
-    // persistent grid: as many workgroups as stay resident (5 per CU by LDS), each walks tiles with a one-tile prefetch
-    const int grid = a.ntiles < kPersistentBlocks ? a.ntiles : kPersistentBlocks;
-    hipLaunchKernelGGL(stem_kernel, dim3(grid), dim3(kThreads), 0, s, a);
+    a.nblk = p.n * a.tiles_x * a.tiles_y;
+    hipLaunchKernelGGL(stem_kernel, dim3(a.nblk), dim3(kThreads), 0, s, a);
 }
 
 // =============================================================================================
