@@ -173,12 +173,12 @@ template <int NT, int PT> struct WaveSplit {
 // (<= 12 fragments) is issued at kernel entry, BEFORE the activation tile is staged, so the L2 round trip of the
 // weights overlaps the HBM round trip of the activations; group g+1 is issued before group g's MFMAs.
 // fp32 path (parity reference, speed irrelevant): plain loop.
-template <typename T, int NI, int NJ, int KCH, int WN>
+template <typename T, int NI, int NJ, int KCH, int WN, int GFRAGS = 12>
 struct GemmPipe {
     typedef Mma<T> M;
     typedef typename M::Frag Frag;
     static constexpr bool PIPE = sizeof(T) == 2;
-    static constexpr int GMAX = 12 / NI > 0 ? 12 / NI : 1;
+    static constexpr int GMAX = GFRAGS / NI > 0 ? GFRAGS / NI : 1;      // K-chunks per prefetch group (GFRAGS fragments)
     static constexpr int G = PIPE ? (KCH < GMAX ? KCH : GMAX) : 1;
     static constexpr int NG = (KCH + G - 1) / G;
     Frag buf[PIPE ? 2 : 1][G][NI];
@@ -303,15 +303,19 @@ __device__ __forceinline__ void u8x4_to_f16(uint32_t v, f16x8 &dst, int at) {
     dst[at] = lo.h[0]; dst[at + 1] = lo.h[1]; dst[at + 2] = hi.h[0]; dst[at + 3] = hi.h[1];
 }
 
-__global__ __launch_bounds__(kThreads) void stem_kernel(StemArgs a) {
+__global__ __launch_bounds__(kThreads, 7) void stem_kernel(StemArgs a) {
     typedef half_t T;
     typedef Mma<T> M;
     constexpr int LDA = 16, LDO = 24;
-    __shared__ __attribute__((aligned(16))) uint32_t s_in[ST_IR * ST_ROWD];       // BGRX pixels
-    __shared__ __attribute__((aligned(16))) T s_c0[ST_PTILES * 16 * 8];
-    __shared__ __attribute__((aligned(16))) T s_dw[9 * 8];
-    __shared__ __attribute__((aligned(16))) T s_a[ST_P * LDA];
-    __shared__ __attribute__((aligned(16))) T s_out[ST_P * LDO];
+    // LDS (20.6 KB -> 7 workgroups per CU): s_out reuses the staged patch + conv0 tile, both dead after phase 3
+    constexpr int IN_BYTES = ST_IR * ST_ROWD * 4, C0_BYTES = ST_PTILES * 16 * 8 * 2, OUT_BYTES = ST_P * LDO * 2;
+    constexpr int REGION_B = IN_BYTES + C0_BYTES > OUT_BYTES ? IN_BYTES + C0_BYTES : OUT_BYTES;
+    __shared__ __attribute__((aligned(16))) unsigned char s_raw[ST_P * LDA * 2 + 9 * 8 * 2 + REGION_B];
+    T *s_a = (T *)s_raw;
+    T *s_dw = s_a + ST_P * LDA;
+    uint32_t *s_in = (uint32_t *)(s_raw + ST_P * LDA * 2 + 9 * 8 * 2);              // BGRX pixels
+    T *s_c0 = (T *)((unsigned char *)s_in + IN_BYTES);
+    T *s_out = (T *)s_in;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int bid = xcd_remap(blockIdx.x, a.nblk);
@@ -489,6 +493,14 @@ template <typename T, int CIN, int COUT, int STRIDE, bool HAS_DW, int TH, int TW
     static constexpr size_t LDS_BYTES = sizeof(T) * (size_t)(IN_ELEMS + A_ELEMS + (ALIAS_OUT ? 0 : O_ELEMS));
     static_assert(P % 16 == 0 && CIN % VEC == 0 && COUT % 16 == 0, "bad tile");
     static_assert(kThreads % (CIN / VEC) == 0, "a thread must keep one channel group across its depthwise items");
+    // These kernels are latency chains (load -> stencil -> GEMM -> store) hidden only by other resident workgroups, and
+    // their time is (grid / resident workgroups) rounds x chain latency.  The big-map layers (CIN <= 64: thousands of
+    // workgroups per launch) are therefore compiled for as many workgroups per CU as LDS allows (1 wave per SIMD each)
+    // with a shallow weight prefetch; the small-map layers (<= 1 round) keep the deep prefetch instead.
+    static constexpr int LDS_OCC = (int)(160 * 1024 / LDS_BYTES) > 8 ? 8 : (int)(160 * 1024 / LDS_BYTES);
+    static constexpr bool BIG_MAP = CIN <= 64 && HAS_DW && sizeof(T) == 2;
+    static constexpr int OCC = BIG_MAP ? (LDS_OCC < 1 ? 1 : LDS_OCC) : 1;
+    static constexpr int GFRAGS = BIG_MAP ? 4 : 12;
 };
 
 template <typename T>
@@ -499,7 +511,7 @@ struct DwPwArgs {
 };
 
 template <typename T, int CIN, int COUT, int STRIDE, bool HAS_DW, int TH, int TW, bool LAT>
-__global__ __launch_bounds__(kThreads) void dwpw_kernel(DwPwArgs<T> a) {
+__global__ __launch_bounds__(kThreads, (DwPwCfg<T, CIN, COUT, STRIDE, HAS_DW, TH, TW>::OCC)) void dwpw_kernel(DwPwArgs<T> a) {
     typedef DwPwCfg<T, CIN, COUT, STRIDE, HAS_DW, TH, TW> C;
     typedef typename Vec<T>::type V;
     typedef Mma<T> M;
@@ -525,14 +537,14 @@ __global__ __launch_bounds__(kThreads) void dwpw_kernel(DwPwArgs<T> a) {
     typedef WaveSplit<NT, PT> WS;
     constexpr int KCH = (CIN + M::K - 1) / M::K;
     const int wn = wave % WS::WN, wp = wave / WS::WN;
-    GemmPipe<T, WS::NI, WS::NJ, KCH, WS::WN> pipe;
+    GemmPipe<T, WS::NI, WS::NJ, KCH, WS::WN, C::GFRAGS> pipe;
     pipe.init(a.pw_w, wn, lane);
     f32x4 pw_bias[WS::NI];
 #pragma unroll
     for (int i = 0; i < WS::NI; i++) pw_bias[i] = *(const f32x4 *)(a.pw_b + acc_cout(wn + i * WS::WN, lane, 0));
     // lateral: 64 output channels = 4 tiles, one per wave, all pixel tiles
     constexpr int LKCH = (COUT + M::K - 1) / M::K;
-    GemmPipe<T, 1, PT, LAT ? LKCH : 1, 4> lpipe;
+    GemmPipe<T, 1, PT, LAT ? LKCH : 1, 4, C::GFRAGS> lpipe;
     f32x4 lat_bias = vzero<f32x4, 4>();
     if constexpr (LAT) {
         lpipe.init(a.lat_w, wave, lane);
@@ -721,6 +733,8 @@ template <typename T, int CIN, int COUT, int TH, int TW> struct Conv3Cfg {
     static constexpr int IN_ELEMS = HR * HC * LDI;
     static constexpr int O_ELEMS = P * LDO;
     static constexpr size_t LDS_BYTES = sizeof(T) * (size_t)(IN_ELEMS > O_ELEMS ? IN_ELEMS : O_ELEMS);
+    static constexpr int OCC = sizeof(T) == 2 ? 6 : 1;          // see DwPwCfg: rounds x chain latency
+    static constexpr int GFRAGS = sizeof(T) == 2 ? 4 : 12;
 };
 
 template <typename T>
@@ -735,7 +749,7 @@ struct Conv3Args {
 };
 
 template <typename T, int CIN, int COUT, int TH, int TW, bool UPADD>
-__global__ __launch_bounds__(kThreads) void conv3x3_kernel(Conv3Args<T> a) {
+__global__ __launch_bounds__(kThreads, (Conv3Cfg<T, CIN, COUT, TH, TW>::OCC)) void conv3x3_kernel(Conv3Args<T> a) {
     typedef Conv3Cfg<T, CIN, COUT, TH, TW> C;
     typedef typename Vec<T>::type V;
     typedef Mma<T> M;
@@ -763,7 +777,7 @@ __global__ __launch_bounds__(kThreads) void conv3x3_kernel(Conv3Args<T> a) {
     constexpr int KTOT = 9 * CIN;
     constexpr int KCH = (KTOT + M::K - 1) / M::K;
     const int wn = wave % WS::WN, wp = wave / WS::WN;
-    GemmPipe<T, WS::NI, WS::NJ, KCH, WS::WN> pipe;
+    GemmPipe<T, WS::NI, WS::NJ, KCH, WS::WN, C::GFRAGS> pipe;
     pipe.init(L.w, wn, lane);
     f32x4 bias[WS::NI];
 #pragma unroll
