@@ -35,7 +35,7 @@ def main() -> None:
     ap.add_argument("--batch", type=int, default=8, help="images per GPU per step")
     ap.add_argument("--height", type=int, default=448)
     ap.add_argument("--width", type=int, default=448)
-    ap.add_argument("--precision", choices=["fp16", "fp32"], default="fp16")
+    ap.add_argument("--precision", choices=["fp16", "fp32", "int8"], default="fp16")
     ap.add_argument("--model", default="mnet25")
     ap.add_argument("--threshold", type=float, default=0.5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -63,7 +63,7 @@ def main() -> None:
     from retinaface_amd.frames import synth_frames
 
     B, H, W = args.batch, args.height, args.width
-    prec = retinaface_amd.PRECISION_FP16 if args.precision == "fp16" else retinaface_amd.PRECISION_FP32
+    prec = {"fp16": retinaface_amd.PRECISION_FP16, "fp32": retinaface_amd.PRECISION_FP32, "int8": 2}[args.precision]
     det = retinaface_amd.RetinaFace(os.path.join(ROOT, "assets"), "net3", 0.4, precision=prec, net_hw=(H, W), max_batch=B,
                                     model_stem=args.model, lanes=args.lanes, coalesce=args.coalesce)
     frames_np = synth_frames(H, W, B, config=1 + rank)
@@ -155,7 +155,7 @@ def main() -> None:
                     traffic = k["hbm_bytes_per_launch"] * per_launch
         kernel_ms = sum(p["ms"] for p in prof)
         alg_total = sum(p["alg_bytes"] for p in prof)
-        elem = 2 if args.precision == "fp16" else 4
+        elem = {"fp16": 2, "fp32": 4, "int8": 1}[args.precision]
         roofline = {
             "bound": "hbm", "kernel": dom["name"], "kernel_instance": dom["kernel"],
             "achieved": dom["alg_bytes"] / (dom["ms"] * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -176,7 +176,7 @@ def main() -> None:
             "metric": "faces/sec", "value": faces_total / dt_max, "unit": "faces/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt_max / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f16" if args.precision == "fp16" else "f32", "data": "synthetic",
+            "dtype": {"fp16": "f16", "fp32": "f32", "int8": "i8"}[args.precision], "data": "synthetic",
             "config": {"workload": f"{args.model} {args.precision} HIP, {W}x{H}, batch {B} per GPU (BASELINE.json configs[1] at 448x448 b=8)",
                        "global_batch": B * world, "frame": [H, W], "threshold": args.threshold, "nms": 0.4,
                        "parallelism": f"dp{world} (image sharding, no data-path collective)",

@@ -38,7 +38,8 @@ typedef enum rf_status {
 typedef enum rf_precision {
     RF_PRECISION_FP32 = 0,      /* fp32 storage, exact-f32 MFMA (parity reference path)            */
     RF_PRECISION_FP16 = 1,      /* fp16 storage, fp32 accumulate (reference: kHALF, trtnetbase.cpp:268-274) */
-    RF_PRECISION_INT8 = 2       /* reserved: int8 via the TensorRT calibration table (trtnetbase.cpp:295-311) */
+    RF_PRECISION_INT8 = 2       /* int8 storage + v_mfma_i32_16x16x64_i8 with the per-tensor activation scales of the
+                                   TensorRT calibration table (trtnetbase.cpp:295-311), per-channel weight scales */
 } rf_precision;
 
 /* Result record: byte-identical to the reference's FaceDetectInfo (RetinaFace.h:15-42):

@@ -8,4 +8,4 @@ There is no CPU fallback: importing works anywhere, but creating a detector with
 without a HIP device raises.
 """
 from ._lib import RFError, abi_version, lib_path, load_library  # noqa: F401
-from .detector import PRECISION_FP16, PRECISION_FP32, Detection, RetinaFace  # noqa: F401
+from .detector import PRECISION_FP16, PRECISION_FP32, PRECISION_INT8, Detection, RetinaFace  # noqa: F401

@@ -25,6 +25,10 @@ template <> struct Cast<half_t> {
     static half_t from(float v) { return (half_t)v; }
     static float to(half_t v) { return (float)v; }
 };
+template <> struct Cast<int8_t> {            // values are already integers in [-127, 127] (quantised on the host)
+    static int8_t from(float v) { return (int8_t)std::lrintf(v); }
+    static float to(int8_t v) { return (float)v; }
+};
 
 // Device memory arena for the read-only weights: one allocation, 256-byte aligned sub-buffers.
 class Arena {
@@ -61,8 +65,8 @@ template <typename T> std::vector<T> pack_gemm(const std::vector<float> &w, int 
     return out;
 }
 
-template <typename T> constexpr int mma_k() { return sizeof(T) == 2 ? 32 : 4; }
-template <typename T> constexpr int mma_kpl() { return sizeof(T) == 2 ? 8 : 1; }
+template <typename T> constexpr int mma_k() { return sizeof(T) == 1 ? 64 : sizeof(T) == 2 ? 32 : 4; }
+template <typename T> constexpr int mma_kpl() { return sizeof(T) == 1 ? 16 : sizeof(T) == 2 ? 8 : 1; }
 
 // base anchor of generate_anchors(base_size 16, ratios {1.0}, scales {scale}) -- RetinaFace.cpp:34-103
 void base_anchor(int scale, float out[4]) {
@@ -261,7 +265,7 @@ public:
         std::vector<T> tmp(cnt);
         RF_HIP(hipMemcpy(tmp.data(), (const T *)ai.ptr + (size_t)(last_first_image_ + image) * cnt, cnt * sizeof(T),
                          hipMemcpyDeviceToHost));
-        for (size_t i = 0; i < cnt; i++) dst[i] = Cast<T>::to(tmp[i]);
+        for (size_t i = 0; i < cnt; i++) dst[i] = Cast<T>::to(tmp[i]) * ai.scale;
         return (long)cnt;
     }
 
@@ -324,7 +328,8 @@ public:
     }
 
 private:
-    struct GemmW { size_t w, b; };
+    static constexpr size_t kNone = (size_t)-1;
+    struct GemmW { size_t w, b, m = kNone; };          // m: int8 requantisation multipliers (absent otherwise)
     struct DwW { size_t w, b; };
 
     struct Lane {
@@ -386,21 +391,71 @@ private:
         return (U *)p;
     }
 
-    GemmW put_gemm(const FoldedConv &f) {
-        int ktot = f.k * f.k * (f.cin / f.group);
+    static constexpr bool kInt8 = sizeof(T) == 1;
+    typedef typename DwWeightT<T>::type DWT;
+
+    // per-tensor activation scale of a reference blob (TensorRT calibration cache)
+    float scale_of(const Plan &plan, const std::string &blob) const {
+        for (const auto &kv : plan.int8_scales)
+            if (kv.first == blob) return kv.second;
+        throw Unsupported("int8: the calibration table has no scale for tensor '" + blob + "'");
+    }
+    const float *mult_ptr(const GemmW &g) const { return g.m == kNone ? nullptr : arena_.ptr<float>(g.m); }
+
+    // fp16 / fp32: weights as they are.  int8: per-output-channel symmetric weight quantisation (w_scale = amax / 127, what
+    // TensorRT does with a per-tensor activation table); the epilogue computes acc * mult + bias with
+    //   mult[c] = w_scale[c] * in_scale / out_scale[c],  bias[c] = b[c] / out_scale[c]     (out_scale = 1: real output)
+    GemmW put_gemm(const FoldedConv &f, float in_scale = 1.f, const std::vector<float> &out_scale = {}) {
+        const int ktot = f.k * f.k * (f.cin / f.group);
         GemmW g;
-        g.w = arena_.put(pack_gemm<T>(f.w, f.cout, ktot, mma_k<T>(), mma_kpl<T>()));
-        g.b = arena_.put(f.b);
+        if constexpr (!kInt8) {
+            g.w = arena_.put(pack_gemm<T>(f.w, f.cout, ktot, mma_k<T>(), mma_kpl<T>()));
+            g.b = arena_.put(f.b);
+        } else {
+            std::vector<float> q(f.w.size()), mult(f.cout), bias(f.cout);
+            for (int o = 0; o < f.cout; o++) {
+                float amax = 0.f;
+                for (int k = 0; k < ktot; k++) amax = std::max(amax, std::fabs(f.w[(size_t)o * ktot + k]));
+                const float ws = amax > 0.f ? amax / 127.f : 1.f;
+                for (int k = 0; k < ktot; k++)
+                    q[(size_t)o * ktot + k] = std::min(127.f, std::max(-127.f, std::nearbyintf(f.w[(size_t)o * ktot + k] / ws)));
+                const float os = out_scale.empty() ? 1.f : out_scale[out_scale.size() == 1 ? 0 : o];
+                mult[o] = ws * in_scale / os;
+                bias[o] = f.b[o] / os;
+            }
+            g.w = arena_.put(pack_gemm<T>(q, f.cout, ktot, mma_k<T>(), mma_kpl<T>()));
+            g.b = arena_.put(bias);
+            g.m = arena_.put(mult);
+        }
         return g;
     }
 
+    // depthwise weights [c][3][3][1] -> [tap][c].  int8: fp32 weights pre-scaled so the stencil maps input quanta straight to
+    // output quanta: w * in_scale / mid_scale, b / mid_scale
+    DwW put_dw(const FoldedConv &dw, float in_scale = 1.f, float mid_scale = 1.f) {
+        const int c = dw.cout;
+        std::vector<DWT> w((size_t)9 * c);
+        std::vector<float> b(dw.b);
+        for (int ch = 0; ch < c; ch++)
+            for (int t = 0; t < 9; t++) {
+                float v = dw.w[(size_t)ch * 9 + t];
+                if constexpr (kInt8) w[(size_t)t * c + ch] = v * in_scale / mid_scale;
+                else w[(size_t)t * c + ch] = Cast<DWT>::from(v);
+            }
+        if constexpr (kInt8) for (auto &v : b) v /= mid_scale;
+        return DwW{arena_.put(w), arena_.put(b)};
+    }
+
     void upload_weights(const Plan &plan) {
+        if constexpr (kInt8)
+            if (plan.int8_scales.empty()) throw Unsupported("int8 precision needs a calibration table (<stem>.table.int8)");
         c0_w_ = arena_.put(plan.conv0.w);
         c0_b_ = arena_.put(plan.conv0.b);
-        if constexpr (sizeof(T) == 2) {
-            // stem kernel: conv0 as 16 x 64 A fragments, K = 4*(3*ky + kx) + c4 with c4 = B, G, R, pad (the frame's own
-            // byte order: net channel c is frame channel 2-c), fp16 hi + lo so the sum carries ~22 mantissa bits.
-            // Layout: [hi k<32 | lo k<32 | hi k>=32 | lo k>=32][lane 64][8]
+        size_t first_block = 0;
+        if constexpr (sizeof(T) <= 2) {
+            // stem kernel (fp16 and int8 engines): conv0 as 16 x 64 A fragments, K = 4*(3*ky + kx) + c4 with c4 = B, G, R, pad
+            // (the frame's own byte order: net channel c is frame channel 2-c), fp16 hi + lo so the sum carries ~22 mantissa
+            // bits.  Layout: [hi k<32 | lo k<32 | hi k>=32 | lo k>=32][lane 64][8]
             std::vector<half_t> frag(4 * 64 * 8, (half_t)0);
             for (int half = 0; half < 2; half++)
                 for (int lane = 0; lane < 64; lane++)
@@ -414,22 +469,81 @@ private:
                         frag[((half * 2 + 1) * 64 + lane) * 8 + el] = (half_t)(w - (float)h);
                     }
             c0_hi_ = arena_.put(frag);
+            // the stem computes its depthwise + pointwise block in fp16 whatever the storage type of its OUTPUT
+            const auto &b0 = plan.blocks[0];
+            std::vector<half_t> dw((size_t)9 * 8);
+            for (int ch = 0; ch < 8; ch++)
+                for (int t = 0; t < 9; t++) dw[(size_t)t * 8 + ch] = (half_t)b0.dw.w[(size_t)ch * 9 + t];
+            stem_dw_ = DwW{arena_.put(dw), arena_.put(b0.dw.b)};
+            stem_pw_.w = arena_.put(pack_gemm<half_t>(b0.pw.w, b0.pw.cout, 8, 32, 8));
+            if constexpr (kInt8) {
+                const float os = scale_of(plan, b0.pw.out_blob);
+                std::vector<float> b(b0.pw.b), m(b0.pw.cout, 1.f / os);
+                for (auto &v : b) v /= os;
+                stem_pw_.b = arena_.put(b);
+                stem_pw_.m = arena_.put(m);
+            } else {
+                stem_pw_.b = arena_.put(b0.pw.b);
+            }
+            first_block = 1;
+            dw_w_.push_back(DwW{0, 0});
+            pw_w_.push_back(GemmW{0, 0});
         }
-        for (const auto &blk : plan.blocks) {
-            int c = blk.dw.cout;                       // depthwise weights [c][3][3][1] -> [tap][c]
-            std::vector<T> w((size_t)9 * c);
-            for (int ch = 0; ch < c; ch++)
-                for (int t = 0; t < 9; t++) w[(size_t)t * c + ch] = Cast<T>::from(blk.dw.w[(size_t)ch * 9 + t]);
-            dw_w_.push_back(DwW{arena_.put(w), arena_.put(blk.dw.b)});
-            pw_w_.push_back(put_gemm(blk.pw));
+        float s_prev = 1.f;
+        if constexpr (kInt8) s_prev = scale_of(plan, plan.blocks[0].pw.out_blob);
+        float s_tap[3] = {1.f, 1.f, 1.f};            // scale of the block outputs the laterals tap (blocks 12, 10, 4)
+        for (size_t i = first_block; i < plan.blocks.size(); i++) {
+            const auto &blk = plan.blocks[i];
+            float s_mid = 1.f, s_out = 1.f;
+            if constexpr (kInt8) { s_mid = scale_of(plan, blk.dw.out_blob); s_out = scale_of(plan, blk.pw.out_blob); }
+            dw_w_.push_back(put_dw(blk.dw, s_prev, s_mid));
+            pw_w_.push_back(put_gemm(blk.pw, s_mid, {s_out}));
+            s_prev = s_out;
+            if (i == 12) s_tap[0] = s_out;
+            if (i == 10) s_tap[1] = s_out;
+            if (i == 4) s_tap[2] = s_out;
         }
-        for (int i = 0; i < 3; i++) lat_w_[i] = put_gemm(plan.lateral[i]);
-        for (int i = 0; i < 2; i++) aggr_w_[i] = put_gemm(plan.aggr[i]);
+        float s_lat[3] = {1.f, 1.f, 1.f}, s_feat[3] = {1.f, 1.f, 1.f};
         for (int i = 0; i < 3; i++) {
-            ssh_w_[i][0] = put_gemm(plan.ssh[i].conv_a);
-            ssh_w_[i][1] = put_gemm(plan.ssh[i].conv_b);
-            ssh_w_[i][2] = put_gemm(plan.ssh[i].conv_c);
-            ssh_w_[i][3] = put_gemm(plan.ssh[i].head);
+            if constexpr (kInt8) s_lat[i] = scale_of(plan, plan.lateral[i].out_blob);
+            lat_w_[i] = put_gemm(plan.lateral[i], s_tap[i], {s_lat[i]});
+        }
+        s_feat[0] = s_lat[0];
+        for (int i = 0; i < 2; i++) {
+            float s_plus = 1.f, s_out = 1.f;
+            if constexpr (kInt8) {
+                s_plus = scale_of(plan, i == 0 ? "_plus0" : "_plus1");
+                s_out = scale_of(plan, plan.aggr[i].out_blob);
+                aggr_a_lat_[i] = s_lat[i + 1] / s_plus;
+                aggr_a_up_[i] = s_feat[i] / s_plus;
+            }
+            aggr_w_[i] = put_gemm(plan.aggr[i], s_plus, {s_out});
+            s_feat[i + 1] = s_out;
+        }
+        for (int i = 0; i < 3; i++) {
+            const SshModule &m = plan.ssh[i];
+            std::string pre = "rf_c" + std::to_string(3 - i) + "_det_";
+            float s_cat = 1.f, s_c1 = 1.f, s_c31 = 1.f;
+            if constexpr (kInt8) {
+                s_cat = scale_of(plan, pre + "concat_relu");          // the three concat inputs share one scale
+                s_c1 = scale_of(plan, pre + "context_conv1_relu");
+                s_c31 = scale_of(plan, pre + "context_conv3_1_relu");
+            }
+            std::vector<float> oa(48, s_cat), ob(32, s_cat);
+            for (int c = 32; c < 48; c++) oa[c] = s_c1;
+            for (int c = 16; c < 32; c++) ob[c] = s_c31;
+            ssh_w_[i][0] = put_gemm(m.conv_a, s_feat[i], oa);
+            ssh_w_[i][1] = put_gemm(m.conv_b, s_c1, ob);
+            ssh_w_[i][2] = put_gemm(m.conv_c, s_c31, {s_cat});
+            ssh_w_[i][3] = put_gemm(m.head, s_cat, {});              // heads are dequantised to real logits / deltas
+            act_scale_[pre + "concat_relu"] = s_cat;
+            act_scale_[pre + "context_conv1_relu"] = s_c1;
+            act_scale_[pre + "context_conv3_1_relu"] = s_c31;
+        }
+        if constexpr (kInt8) {
+            for (const auto &blk : plan.blocks) act_scale_[blk.pw.out_blob] = scale_of(plan, blk.pw.out_blob);
+            for (int i = 0; i < 3; i++) act_scale_[plan.lateral[i].out_blob] = s_lat[i];
+            for (int i = 0; i < 2; i++) act_scale_[plan.aggr[i].out_blob] = s_feat[i + 1];
         }
         arena_.upload();
     }
@@ -460,7 +574,8 @@ private:
 
         auto act = [&](const std::string &name, int h, int w, int c) {
             T *p = dalloc<T>((size_t)mb * h * w * c);
-            L.acts[name] = ActInfo{p, h, w, c};
+            auto sc = act_scale_.find(name);
+            L.acts[name] = ActInfo{p, h, w, c, sc == act_scale_.end() ? 1.f : sc->second};
             return p;
         };
         // activations: one buffer per reference blob that survives fusion (288 GB of HBM: nothing is recycled)
@@ -468,15 +583,17 @@ private:
         T *cur = nullptr;
         size_t first_block = 0;
         int c = 8;
-        if constexpr (sizeof(T) == 2) {
-            // fp16 engine: preprocess + conv0 + the first depthwise/pointwise block are ONE launch (stem_kernel)
+        if constexpr (sizeof(T) <= 2) {
+            // fp16 / int8 engines: preprocess + conv0 + the first depthwise/pointwise block are ONE launch (stem_kernel);
+            // it computes in fp16 and stores its 16-channel output in the engine's storage type
             const auto &blk = plan.blocks[0];
             T *out = act(blk.pw.out_blob, h, w, blk.pw.cout);
-            StemParams sp;
+            StemParams<T> sp;
             sp.frames = L.d_frames + mb; sp.out = out;
             sp.w0 = arena_.ptr<half_t>(c0_hi_); sp.b0 = arena_.ptr<float>(c0_b_);
-            sp.dw_w = arena_.ptr<half_t>(dw_w_[0].w); sp.dw_b = arena_.ptr<float>(dw_w_[0].b);
-            sp.pw_w = arena_.ptr<half_t>(pw_w_[0].w); sp.pw_b = arena_.ptr<float>(pw_w_[0].b);
+            sp.dw_w = arena_.ptr<half_t>(stem_dw_.w); sp.dw_b = arena_.ptr<float>(stem_dw_.b);
+            sp.pw_w = arena_.ptr<half_t>(stem_pw_.w); sp.pw_b = arena_.ptr<float>(stem_pw_.b);
+            sp.pw_m = mult_ptr(stem_pw_);
             sp.n = 0; sp.net_h = H; sp.net_w = W;
             OpInfo op;
             op.name = "pre+" + plan.conv0.name + "+" + blk.dw.name + "+" + blk.pw.name;
@@ -485,7 +602,7 @@ private:
             op.alg_elems_in = 8.0 * h * w + 8.0 * h * w;                       // dw input, pw input
             op.alg_elems_out = 8.0 * h * w + 8.0 * h * w + 16.0 * h * w;       // conv0, dw, pw outputs
             op.macs = (plan.conv0.macs_per_out_pixel() + blk.dw.macs_per_out_pixel() + blk.pw.macs_per_out_pixel()) * h * w;
-            op.launch = [sp](hipStream_t s, int n) { StemParams q = sp; q.n = n; launch_stem(s, q); };
+            op.launch = [sp](hipStream_t s, int n) { StemParams<T> q = sp; q.n = n; launch_stem<T>(s, q); };
             L.ops.push_back(op);
             cur = out; c = blk.pw.cout; first_block = 1;
         } else {
@@ -512,8 +629,8 @@ private:
                 throw ModelError("no kernel instance for depthwise/pointwise block " + blk.dw.name);
             DwPwParams<T> p;
             p.in = cur; p.out = out;
-            p.dw_w = arena_.ptr<T>(dw_w_[i].w); p.dw_b = arena_.ptr<float>(dw_w_[i].b);
-            p.pw_w = arena_.ptr<T>(pw_w_[i].w); p.pw_b = arena_.ptr<float>(pw_w_[i].b);
+            p.dw_w = arena_.ptr<DWT>(dw_w_[i].w); p.dw_b = arena_.ptr<float>(dw_w_[i].b);
+            p.pw_w = arena_.ptr<T>(pw_w_[i].w); p.pw_b = arena_.ptr<float>(pw_w_[i].b); p.pw_m = mult_ptr(pw_w_[i]);
             p.n = 0; p.hin = h; p.win = w; p.hout = ho; p.wout = wo;
             p.cin = c; p.cout = blk.pw.cout; p.stride = blk.dw.stride; p.has_dw = true;
             OpInfo op;
@@ -527,6 +644,7 @@ private:
                 const FoldedConv &lf = plan.lateral[li];
                 lat[li] = act(lf.out_blob, ho, wo, 64);
                 p.lat_w = arena_.ptr<T>(lat_w_[li].w); p.lat_b = arena_.ptr<float>(lat_w_[li].b); p.lat_out = lat[li];
+                p.lat_m = mult_ptr(lat_w_[li]);
                 op.name += "+" + lf.name;
                 op.kernel.insert(op.kernel.size() - 1, ",lat");
                 op.alg_elems_in += (double)blk.pw.cout * ho * wo;
@@ -545,7 +663,8 @@ private:
             feat[i + 1] = act(plan.aggr[i].out_blob, fh, fw, 64);
             Conv3Params<T> p;
             p.in = lat[i + 1]; p.in_ld = 64; p.in_off = 0; p.up = feat[i];
-            p.w = arena_.ptr<T>(aggr_w_[i].w); p.b = arena_.ptr<float>(aggr_w_[i].b);
+            p.w = arena_.ptr<T>(aggr_w_[i].w); p.b = arena_.ptr<float>(aggr_w_[i].b); p.m = mult_ptr(aggr_w_[i]);
+            p.a_lat = aggr_a_lat_[i]; p.a_up = aggr_a_up_[i];
             p.out0 = feat[i + 1]; p.ld0 = 64; p.off0 = 0; p.n0 = 64; p.out1 = nullptr; p.ld1 = 0; p.off1 = 0;
             p.n = 0; p.h = fh; p.w_ = fw; p.cin = 64; p.cout = 64;
             OpInfo op;
@@ -576,7 +695,7 @@ private:
             auto fill = [&](Conv3Params<T> &p, OpInfo &op, const FoldedConv &f, const GemmW &gw, const T *in, int cin, T *o0,
                             int ld0, int off0, int n0, T *o1, int ld1, int off1, int nlayers) {
                 p.in = in; p.in_ld = cin; p.in_off = 0; p.up = nullptr;
-                p.w = arena_.ptr<T>(gw.w); p.b = arena_.ptr<float>(gw.b);
+                p.w = arena_.ptr<T>(gw.w); p.b = arena_.ptr<float>(gw.b); p.m = mult_ptr(gw);
                 p.out0 = o0; p.ld0 = ld0; p.off0 = off0; p.n0 = n0; p.out1 = o1; p.ld1 = ld1; p.off1 = off1;
                 p.n = 0; p.h = fh; p.w_ = fw; p.cin = cin; p.cout = f.cout;
                 op.name += (op.name.empty() ? "" : " | ") + f.name;
@@ -589,6 +708,7 @@ private:
             fill(lv_c.p[i], op_c, m.conv_c, ssh_w_[i][2], ctx31, 16, cat, 64, 48, 16, nullptr, 0, 0, 1);
             HeadParams<T> &hp = hl.p[i];
             hp.in = cat; hp.w = arena_.ptr<T>(ssh_w_[i][3].w); hp.b = arena_.ptr<float>(ssh_w_[i][3].b);
+            hp.m = mult_ptr(ssh_w_[i][3]);
             hp.n = 0; hp.h = fh; hp.w_ = fw; hp.stride = strides_[i]; hp.anchor_offset = anchor_off;
             static const int scales[3][2] = {{32, 16}, {8, 4}, {2, 1}};
             base_anchor(scales[i][0], hp.base[0]);
@@ -799,7 +919,11 @@ private:
     int device_ = 0;
     std::vector<hipEvent_t> prof_ev_;
     Arena arena_;
-    size_t c0_w_ = 0, c0_b_ = 0, c0_hi_ = 0, c0_lo_ = 0;
+    size_t c0_w_ = 0, c0_b_ = 0, c0_hi_ = 0;
+    DwW stem_dw_{0, 0};
+    GemmW stem_pw_{0, 0};
+    float aggr_a_lat_[2] = {1.f, 1.f}, aggr_a_up_[2] = {1.f, 1.f};
+    std::map<std::string, float> act_scale_;    // int8: blob -> scale (debug accessors dequantise)
     std::vector<DwW> dw_w_;
     std::vector<GemmW> pw_w_;
     GemmW lat_w_[3], aggr_w_[2], ssh_w_[3][4];
@@ -828,13 +952,14 @@ std::unique_ptr<Engine> Engine::create(const std::string &model_dir, const std::
     if (network != "net3") throw Unsupported("network preset '" + network + "' has no anchor configuration (only net3)");
     Model model = load_model_dir(model_dir, opt.model_stem);      // host-only steps first: their errors do not need a GPU
     Plan plan = compile_plan(model);
-    if (opt.precision == RF_PRECISION_INT8) throw Unsupported("int8 precision is not implemented yet");
+    if (opt.precision == RF_PRECISION_INT8 && plan.int8_scales.empty())
+        throw Unsupported("int8 precision needs a calibration table (<stem>.table.int8, or scales inside the .rfw)");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) throw HipError("no HIP device available");
     switch (opt.precision) {
         case RF_PRECISION_FP16: return std::unique_ptr<Engine>(new EngineImpl<half_t>(plan, nms, opt));
         case RF_PRECISION_FP32: return std::unique_ptr<Engine>(new EngineImpl<float>(plan, nms, opt));
-        case RF_PRECISION_INT8: throw Unsupported("int8 precision is not implemented yet");
+        case RF_PRECISION_INT8: return std::unique_ptr<Engine>(new EngineImpl<int8_t>(plan, nms, opt));
         default: throw ArgError("unknown precision");
     }
 }

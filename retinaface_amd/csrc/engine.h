@@ -36,7 +36,7 @@ struct EngineOptions {
     std::string model_stem = "mnet-deconv-0517";
 };
 
-struct ActInfo { void *ptr; int h, w, c; };
+struct ActInfo { void *ptr; int h, w, c; float scale = 1.f; };
 
 struct OpInfo {
     std::string name;            // reference layer name(s) the launch covers

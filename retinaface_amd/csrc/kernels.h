@@ -9,6 +9,10 @@ namespace rf {
 
 typedef _Float16 half_t;
 
+// depthwise weights are stored in the activation type, except fp32 for int8 activations
+template <typename T> struct DwWeightT { typedef T type; };
+template <> struct DwWeightT<int8_t> { typedef float type; };
+
 // One input frame: CV_8UC3 BGR, row y at ptr + y*step (cv::Mat data/step; RetinaFace.cpp:594).
 struct FrameDesc {
     const uint8_t *ptr;
@@ -39,24 +43,27 @@ void launch_conv0(hipStream_t s, const FrameDesc *frames, T *out, const float *w
                   const RunParams *params_in, RunParams *params_out, int n, int net_h, int net_w);
 
 // ---- K_a' (fp16 engine): K_a fused with the first depthwise/pointwise block; conv0 on MFMA (hi+lo split weights).
+template <typename TO>
 struct StemParams {
-    const FrameDesc *frames; half_t *out;          // out: [n][net_h/2][net_w/2][16]
+    const FrameDesc *frames; TO *out;              // out: [n][net_h/2][net_w/2][16], fp16 or int8
     const half_t *w0; const float *b0;             // conv0: 4 A fragments (hi/lo x k<32/k>=32), K = (ky,kx,BGRX) 36 -> 64
     const half_t *dw_w; const float *dw_b; const half_t *pw_w; const float *pw_b;
+    const float *pw_m = nullptr;                   // int8 output: 1 / out_scale per channel (pw_b pre-divided)
     int n, net_h, net_w;
 };
-void launch_stem(hipStream_t s, const StemParams &p);
+template <typename TO> void launch_stem(hipStream_t s, const StemParams<TO> &p);
 
 // ---- K_b: depthwise 3x3 (+BN+ReLU) -> pointwise 1x1 (+BN+ReLU), the intermediate never leaves LDS.
 //      has_dw = false gives a plain 1x1 conv (+bias, +ReLU): the FPN laterals.
 template <typename T>
 struct DwPwParams {
     const T *in; T *out;
-    const T *dw_w;        // [9][cin]
+    const typename DwWeightT<T>::type *dw_w;        // [9][cin] (fp32 when T = int8)
     const float *dw_b;    // [cin]
     const T *pw_w;        // MFMA-fragment packed (pack.h), k = cin
     const float *pw_b;    // [cout]
     const T *lat_w = nullptr; const float *lat_b = nullptr; T *lat_out = nullptr;   // optional fused FPN lateral (cout -> 64)
+    const float *pw_m = nullptr, *lat_m = nullptr;   // int8: requantisation multipliers per output channel
     int n, hin, win, hout, wout;
     int cin, cout, stride;
     bool has_dw;
@@ -71,6 +78,8 @@ struct Conv3Params {
     const T *in; int in_ld, in_off;       // input pixel stride / channel offset (elements)
     const T *up;                          // nullptr, or coarser level [n][h/2][w/2][64]
     const T *w; const float *b;           // packed (k = 9*cin), bias[cout]
+    const float *m = nullptr;             // int8: per-output-channel requantisation multiplier
+    float a_lat = 1.f, a_up = 1.f;        // fused upsample+add: staged = lat * a_lat + up * a_up (int8 scale ratios)
     T *out0; int ld0, off0, n0;           // output channels [0, n0)    -> out0[pixel*ld0 + off0 + c]
     T *out1; int ld1, off1;               // output channels [n0, cout) -> out1[pixel*ld1 + off1 + c - n0]
     int n, h, w_, cin, cout;
@@ -84,6 +93,7 @@ template <typename T>
 struct HeadParams {
     const T *in;                          // [n][h][w][64] = rf_cX_det_concat_relu
     const T *w; const float *b;           // packed 32x64, bias[32]: cls 0..3, bbox 4..11, landmark 12..31
+    const float *m = nullptr;             // int8: per-channel dequantisation multiplier (w_scale * in_scale)
     int n, h, w_, stride, anchor_offset;  // anchor_offset = global index of (a=0, iy=0, ix=0) of this stride
     float base[2][4];                     // the 2 base anchors of this stride (RetinaFace.cpp:34-103)
     int net_h, net_w;

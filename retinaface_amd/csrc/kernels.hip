@@ -16,14 +16,31 @@ namespace rf {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
+typedef signed char i8x16 __attribute__((ext_vector_type(16)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
 template <typename T> struct Vec;
 template <> struct Vec<half_t> { static constexpr int N = 8; typedef f16x8 type; };
 template <> struct Vec<float> { static constexpr int N = 4; typedef f32x4 type; };
+template <> struct Vec<int8_t> { static constexpr int N = 16; typedef i8x16 type; };
+
+// storage type -> value: fp16 / fp32 are plain conversions; int8 is round-to-nearest + saturate to [-127, 127]
+// (symmetric TensorRT-style quantisation; the scale is folded into the producer's multiplier / bias on the host)
+template <typename T> __device__ __forceinline__ T to_T(float v);
+template <> __device__ __forceinline__ half_t to_T<half_t>(float v) { return (half_t)v; }
+template <> __device__ __forceinline__ float to_T<float>(float v) { return v; }
+template <> __device__ __forceinline__ int8_t to_T<int8_t>(float v) { return (int8_t)(int)fminf(fmaxf(rintf(v), -127.f), 127.f); }
+
+// depthwise weights: same type as the activations, except int8 activations use fp32 weights (the stencil runs on the
+// VALU in fp32 anyway; only the GEMMs gain from int8)
+template <typename T> struct DwWeight { typedef T type; };
+template <> struct DwWeight<int8_t> { typedef float type; };
 
 template <typename T> struct Mma;
 template <> struct Mma<half_t> {
     static constexpr int K = 32, KPL = 8;
     typedef f16x8 Frag;
+    typedef f32x4 Acc;
     static __device__ __forceinline__ Frag zero() { Frag f; for (int e = 0; e < 8; e++) f[e] = (half_t)0; return f; }
     static __device__ __forceinline__ f32x4 mma(Frag a, Frag b, f32x4 c) {
         return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
@@ -32,9 +49,21 @@ template <> struct Mma<half_t> {
 template <> struct Mma<float> {
     static constexpr int K = 4, KPL = 1;
     typedef float Frag;
+    typedef f32x4 Acc;
     static __device__ __forceinline__ Frag zero() { return 0.f; }
     static __device__ __forceinline__ f32x4 mma(Frag a, Frag b, f32x4 c) {
         return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+    }
+};
+
+// int8: v_mfma_i32_16x16x64_i8, 16 consecutive k per lane (one 16-byte NHWC run), int32 accumulate
+template <> struct Mma<int8_t> {
+    static constexpr int K = 64, KPL = 16;
+    typedef i32x4 Frag;
+    typedef i32x4 Acc;
+    static __device__ __forceinline__ Frag zero() { Frag f = {0, 0, 0, 0}; return f; }
+    static __device__ __forceinline__ Acc mma(Frag a, Frag b, Acc c) {
+        return __builtin_amdgcn_mfma_i32_16x16x64_i8(a, b, c, 0, 0, 0);
     }
 };
 
@@ -199,7 +228,7 @@ struct GemmPipe {
         if constexpr (PIPE) load(0, 0);
     }
     // xf(j, kc) returns the activation (B) fragment of pixel tile j for K-chunk kc
-    template <typename XF> __device__ __forceinline__ void run(f32x4 (&acc)[NI][NJ], XF &&xf) {
+    template <typename XF> __device__ __forceinline__ void run(typename M::Acc (&acc)[NI][NJ], XF &&xf) {
         if constexpr (PIPE) {
 #pragma unroll
             for (int g = 0; g < NG; g++) {
@@ -235,15 +264,17 @@ struct GemmPipe {
     }
 };
 
-// epilogue: bias (+ReLU), convert, 4 consecutive output channels of one pixel -> LDS tile s_out[pixel][LDO]
-template <typename T, int LDO>
-__device__ __forceinline__ void store_acc(T *s_out, f32x4 bv, f32x4 acc, int ct, int pt, int lane, bool relu) {
+// epilogue: y = acc * mult + bias (+ReLU), convert, 4 consecutive output channels of one pixel -> LDS tile
+// s_out[pixel][LDO].  fp16 / fp32: mult = 1 (fma(a, 1, b) = a + b exactly).  int8: acc is int32, mult[c] =
+// w_scale[c] * in_scale / out_scale and bias = b / out_scale, so y is already in units of the output quantum.
+template <typename T, int LDO, typename ACC>
+__device__ __forceinline__ void store_acc(T *s_out, f32x4 mult, f32x4 bv, ACC acc, int ct, int pt, int lane, bool relu) {
     const int c0 = acc_cout(ct, lane, 0);
     const int p = acc_pixel(pt, lane);
     float v[4];
 #pragma unroll
     for (int r = 0; r < 4; r++) {
-        v[r] = acc[r] + bv[r];
+        v[r] = fmaf((float)acc[r], mult[r], bv[r]);
         if (relu) v[r] = fmaxf(v[r], 0.f);
     }
     if constexpr (sizeof(T) == 2) {
@@ -252,12 +283,22 @@ __device__ __forceinline__ void store_acc(T *s_out, f32x4 bv, f32x4 acc, int ct,
 #pragma unroll
         for (int r = 0; r < 4; r++) h[r] = (half_t)v[r];
         *(f16x4 *)(s_out + p * LDO + c0) = h;
-    } else {
+    } else if constexpr (sizeof(T) == 4) {
         f32x4 f;
 #pragma unroll
         for (int r = 0; r < 4; r++) f[r] = v[r];
         *(f32x4 *)(s_out + p * LDO + c0) = f;
+    } else {
+        uint32_t packed = 0;
+#pragma unroll
+        for (int r = 0; r < 4; r++) packed |= ((uint32_t)(uint8_t)to_T<int8_t>(v[r])) << (8 * r);
+        *(uint32_t *)(s_out + p * LDO + c0) = packed;
     }
+}
+
+__device__ __forceinline__ f32x4 load_mult(const float *m, int c0) {
+    const f32x4 ones = {1.f, 1.f, 1.f, 1.f};
+    return m ? *(const f32x4 *)(m + c0) : ones;
 }
 
 // =============================================================================================
@@ -282,11 +323,13 @@ constexpr int ST_IPX = 2 * ST_HC + 1;                          // 69 input pixel
 constexpr int ST_GRP = (ST_IPX + 3) / 4;                       // 18 staging groups of 4 pixels (12 B in, 16 B out)
 constexpr int ST_ROWD = ST_GRP * 4;                            // 72 dwords (BGRX pixels) per staged row
 
+template <typename TO>
 struct StemArgs {
-    const FrameDesc *frames; half_t *out;
+    const FrameDesc *frames; TO *out;
     const half_t *w0;                 // conv0 weights: 4 A fragments [hi k<32 | lo k<32 | hi k>=32 | lo k>=32][64 lanes][8]
     const float *b0;                  // [8]
     const half_t *dw_w; const float *dw_b; const half_t *pw_w; const float *pw_b;
+    const float *pw_m;                // nullptr, or (int8 output) per-channel multiplier 1 / out_scale; pw_b pre-divided
     int ho, wo, tiles_x, tiles_y, nblk;
 };
 
@@ -303,19 +346,21 @@ __device__ __forceinline__ void u8x4_to_f16(uint32_t v, f16x8 &dst, int at) {
     dst[at] = lo.h[0]; dst[at + 1] = lo.h[1]; dst[at + 2] = hi.h[0]; dst[at + 3] = hi.h[1];
 }
 
-__global__ __launch_bounds__(kThreads, 7) void stem_kernel(StemArgs a) {
-    typedef half_t T;
+template <typename TO>
+__global__ __launch_bounds__(kThreads, 7) void stem_kernel(StemArgs<TO> a) {
+    typedef half_t T;                                 // compute type of the stem; TO = storage type of its output
     typedef Mma<T> M;
-    constexpr int LDA = 16, LDO = 24;
+    constexpr int LDA = 16;
+    constexpr int LDO = 16 + Vec<TO>::N;              // output tile row stride in TO elements (16 B of padding)
     // LDS (20.6 KB -> 7 workgroups per CU): s_out reuses the staged patch + conv0 tile, both dead after phase 3
-    constexpr int IN_BYTES = ST_IR * ST_ROWD * 4, C0_BYTES = ST_PTILES * 16 * 8 * 2, OUT_BYTES = ST_P * LDO * 2;
+    constexpr int IN_BYTES = ST_IR * ST_ROWD * 4, C0_BYTES = ST_PTILES * 16 * 8 * 2, OUT_BYTES = ST_P * LDO * (int)sizeof(TO);
     constexpr int REGION_B = IN_BYTES + C0_BYTES > OUT_BYTES ? IN_BYTES + C0_BYTES : OUT_BYTES;
     __shared__ __attribute__((aligned(16))) unsigned char s_raw[ST_P * LDA * 2 + 9 * 8 * 2 + REGION_B];
     T *s_a = (T *)s_raw;
     T *s_dw = s_a + ST_P * LDA;
     uint32_t *s_in = (uint32_t *)(s_raw + ST_P * LDA * 2 + 9 * 8 * 2);              // BGRX pixels
     T *s_c0 = (T *)((unsigned char *)s_in + IN_BYTES);
-    T *s_out = (T *)s_in;
+    TO *s_out = (TO *)s_in;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int bid = xcd_remap(blockIdx.x, a.nblk);
@@ -332,6 +377,7 @@ __global__ __launch_bounds__(kThreads, 7) void stem_kernel(StemArgs a) {
     GemmPipe<T, 1, 4, 1, 1> pipe;
     pipe.init(a.pw_w, 0, lane);
     const f32x4 pw_bias = *(const f32x4 *)(a.pw_b + acc_cout(0, lane, 0));
+    const f32x4 pw_mult = load_mult(a.pw_m, acc_cout(0, lane, 0));
     float dw_bias[8];
 #pragma unroll
     for (int e = 0; e < 8; e++) dw_bias[e] = a.dw_b[e];
@@ -444,27 +490,31 @@ __global__ __launch_bounds__(kThreads, 7) void stem_kernel(StemArgs a) {
         return kb == 0 ? *(const M::Frag *)(s_a + acc_pixel(wave + j * 4, lane) * LDA) : M::zero();
     });
 #pragma unroll
-    for (int j = 0; j < 4; j++) store_acc<T, LDO>(s_out, pw_bias, acc[0][j], 0, wave + j * 4, lane, true);
+    for (int j = 0; j < 4; j++) store_acc<TO, LDO>(s_out, pw_mult, pw_bias, acc[0][j], 0, wave + j * 4, lane, true);
     __syncthreads();
-    T *outb = a.out + (size_t)img * a.ho * a.wo * 16;
-    for (int i = tid; i < ST_P * 2; i += kThreads) {
-        const int p = i >> 1, cv = i & 1;
+    typedef typename Vec<TO>::type VO;
+    constexpr int OPV = 16 / Vec<TO>::N;                                  // 16-byte chunks per output pixel
+    TO *outb = a.out + (size_t)img * a.ho * a.wo * 16;
+    for (int i = tid; i < ST_P * OPV; i += kThreads) {
+        const int p = i / OPV, cv = i % OPV;
         const int oy = oy0 + p / ST_TW, ox = ox0 + p % ST_TW;
         if (oy < a.ho && ox < a.wo)
-            *(f16x8 *)(outb + ((size_t)oy * a.wo + ox) * 16 + cv * 8) = *(const f16x8 *)(s_out + p * LDO + cv * 8);
+            *(VO *)(outb + ((size_t)oy * a.wo + ox) * 16 + cv * Vec<TO>::N) = *(const VO *)(s_out + p * LDO + cv * Vec<TO>::N);
     }
 }
 
-void launch_stem(hipStream_t s, const StemParams &p) {
+template <typename TO> void launch_stem(hipStream_t s, const StemParams<TO> &p) {
     const int ho = p.net_h / 2, wo = p.net_w / 2;      // conv2 output = conv0 output size (stride-1 block)
-    StemArgs a;
+    StemArgs<TO> a;
     a.frames = p.frames; a.out = p.out; a.w0 = p.w0; a.b0 = p.b0;
-    a.dw_w = p.dw_w; a.dw_b = p.dw_b; a.pw_w = p.pw_w; a.pw_b = p.pw_b;
+    a.dw_w = p.dw_w; a.dw_b = p.dw_b; a.pw_w = p.pw_w; a.pw_b = p.pw_b; a.pw_m = p.pw_m;
     a.ho = ho; a.wo = wo;
     a.tiles_x = (wo + ST_TW - 1) / ST_TW; a.tiles_y = (ho + ST_TH - 1) / ST_TH;
     a.nblk = p.n * a.tiles_x * a.tiles_y;
-    hipLaunchKernelGGL(stem_kernel, dim3(a.nblk), dim3(kThreads), 0, s, a);
+    hipLaunchKernelGGL(stem_kernel<TO>, dim3(a.nblk), dim3(kThreads), 0, s, a);
 }
+template void launch_stem<half_t>(hipStream_t, const StemParams<half_t> &);
+template void launch_stem<int8_t>(hipStream_t, const StemParams<int8_t> &);
 
 // =============================================================================================
 // K_b  depthwise 3x3 + BN + ReLU  ->  pointwise 1x1 + BN + ReLU   (13 backbone pairs, prototxt :55-1193)
@@ -480,33 +530,37 @@ void launch_stem(hipStream_t s, const StemParams &p) {
 //   phase 5  (LAT) second GEMM 64 x COUT on the LDS-resident output tile, same epilogue
 // =============================================================================================
 template <typename T, int CIN, int COUT, int STRIDE, bool HAS_DW, int TH, int TW> struct DwPwCfg {
+    typedef typename DwWeight<T>::type DW;
     static constexpr int VEC = Vec<T>::N;
     static constexpr int P = TH * TW;
     static constexpr int HR = HAS_DW ? (TH - 1) * STRIDE + 3 : 0;
     static constexpr int HC = HAS_DW ? (TW - 1) * STRIDE + 3 : 0;
     static constexpr int LDA = CIN + VEC;
     static constexpr int LDO = COUT + VEC;
-    static constexpr int IN_ELEMS = HR * HC * CIN + (HAS_DW ? 9 * CIN : 0);
-    static constexpr int A_ELEMS = P * LDA;
-    static constexpr int O_ELEMS = P * LDO;
-    static constexpr bool ALIAS_OUT = HAS_DW && IN_ELEMS >= O_ELEMS;   // s_out reuses the dead halo region
-    static constexpr size_t LDS_BYTES = sizeof(T) * (size_t)(IN_ELEMS + A_ELEMS + (ALIAS_OUT ? 0 : O_ELEMS));
+    static constexpr size_t IN_BYTES = sizeof(T) * (size_t)(HR * HC * CIN);
+    static constexpr size_t DW_BYTES = HAS_DW ? sizeof(DW) * (size_t)(9 * CIN) : 0;
+    static constexpr size_t A_BYTES = sizeof(T) * (size_t)(P * LDA);
+    static constexpr size_t O_BYTES = sizeof(T) * (size_t)(P * LDO);
+    static constexpr bool ALIAS_OUT = HAS_DW && IN_BYTES + DW_BYTES >= O_BYTES;   // s_out reuses the dead halo region
+    static constexpr size_t LDS_BYTES = IN_BYTES + DW_BYTES + A_BYTES + (ALIAS_OUT ? 0 : O_BYTES);
     static_assert(P % 16 == 0 && CIN % VEC == 0 && COUT % 16 == 0, "bad tile");
     static_assert(kThreads % (CIN / VEC) == 0, "a thread must keep one channel group across its depthwise items");
+    static_assert(IN_BYTES % 16 == 0 && DW_BYTES % 16 == 0 && A_BYTES % 16 == 0, "LDS carve must stay 16-byte aligned");
     // These kernels are latency chains (load -> stencil -> GEMM -> store) hidden only by other resident workgroups, and
     // their time is (grid / resident workgroups) rounds x chain latency.  The big-map layers (CIN <= 64: thousands of
     // workgroups per launch) are therefore compiled for as many workgroups per CU as LDS allows (1 wave per SIMD each)
     // with a shallow weight prefetch; the small-map layers (<= 1 round) keep the deep prefetch instead.
     static constexpr int LDS_OCC = (int)(160 * 1024 / LDS_BYTES) > 8 ? 8 : (int)(160 * 1024 / LDS_BYTES);
-    static constexpr bool BIG_MAP = CIN <= 64 && HAS_DW && sizeof(T) == 2;
+    static constexpr bool BIG_MAP = CIN <= 64 && HAS_DW && sizeof(T) <= 2;
     static constexpr int OCC = BIG_MAP ? (LDS_OCC < 1 ? 1 : LDS_OCC) : 1;
     static constexpr int GFRAGS = BIG_MAP ? 4 : 12;
 };
 
 template <typename T>
 struct DwPwArgs {
-    const T *in; T *out; const T *dw_w; const float *dw_b; const T *pw_w; const float *pw_b;
+    const T *in; T *out; const typename DwWeight<T>::type *dw_w; const float *dw_b; const T *pw_w; const float *pw_b;
     const T *lat_w; const float *lat_b; T *lat_out;
+    const float *pw_m, *lat_m;        // int8: per-output-channel requantisation multipliers (nullptr otherwise)
     int hin, win, hout, wout, tiles_x, tiles_y, nblk;
 };
 
@@ -517,11 +571,12 @@ __global__ __launch_bounds__(kThreads, (DwPwCfg<T, CIN, COUT, STRIDE, HAS_DW, TH
     typedef Mma<T> M;
     constexpr int VEC = C::VEC, P = C::P, HC = C::HC, HR = C::HR, LDA = C::LDA, LDO = C::LDO;
     constexpr int CPV = CIN / VEC;
+    typedef typename C::DW DW;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     T *s_in = (T *)smem;
-    T *s_dw = s_in + HR * HC * CIN;
-    T *s_a = s_in + C::IN_ELEMS;
-    T *s_out = C::ALIAS_OUT ? s_in : s_a + C::A_ELEMS;
+    DW *s_dw = (DW *)(smem + C::IN_BYTES);
+    T *s_a = (T *)(smem + C::IN_BYTES + C::DW_BYTES);
+    T *s_out = C::ALIAS_OUT ? s_in : (T *)(smem + C::IN_BYTES + C::DW_BYTES + C::A_BYTES);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -539,16 +594,20 @@ __global__ __launch_bounds__(kThreads, (DwPwCfg<T, CIN, COUT, STRIDE, HAS_DW, TH
     const int wn = wave % WS::WN, wp = wave / WS::WN;
     GemmPipe<T, WS::NI, WS::NJ, KCH, WS::WN, C::GFRAGS> pipe;
     pipe.init(a.pw_w, wn, lane);
-    f32x4 pw_bias[WS::NI];
+    f32x4 pw_bias[WS::NI], pw_mult[WS::NI];
 #pragma unroll
-    for (int i = 0; i < WS::NI; i++) pw_bias[i] = *(const f32x4 *)(a.pw_b + acc_cout(wn + i * WS::WN, lane, 0));
+    for (int i = 0; i < WS::NI; i++) {
+        pw_bias[i] = *(const f32x4 *)(a.pw_b + acc_cout(wn + i * WS::WN, lane, 0));
+        pw_mult[i] = load_mult(a.pw_m, acc_cout(wn + i * WS::WN, lane, 0));
+    }
     // lateral: 64 output channels = 4 tiles, one per wave, all pixel tiles
     constexpr int LKCH = (COUT + M::K - 1) / M::K;
     GemmPipe<T, 1, PT, LAT ? LKCH : 1, 4, C::GFRAGS> lpipe;
-    f32x4 lat_bias = vzero<f32x4, 4>();
+    f32x4 lat_bias = vzero<f32x4, 4>(), lat_mult = vzero<f32x4, 4>();
     if constexpr (LAT) {
         lpipe.init(a.lat_w, wave, lane);
         lat_bias = *(const f32x4 *)(a.lat_b + acc_cout(wave, lane, 0));
+        lat_mult = load_mult(a.lat_m, acc_cout(wave, lane, 0));
     }
     float dw_bias[VEC];
     if constexpr (HAS_DW) {
@@ -566,7 +625,8 @@ __global__ __launch_bounds__(kThreads, (DwPwCfg<T, CIN, COUT, STRIDE, HAS_DW, TH
                 v = *(const V *)(inb + ((size_t)iy * a.win + ix) * CIN + cv * VEC);
             *(V *)(s_in + pix * CIN + cv * VEC) = v;
         }
-        for (int i = tid; i < 9 * CPV; i += kThreads) *(V *)(s_dw + i * VEC) = *(const V *)(a.dw_w + i * VEC);
+        for (int i = tid; i < 9 * CIN * (int)sizeof(DW) / 16; i += kThreads)
+            ((f32x4 *)s_dw)[i] = ((const f32x4 *)a.dw_w)[i];
         __syncthreads();
         const int cv = tid % CPV;                 // kThreads % CPV == 0: the channel group is fixed per thread
         for (int i = tid; i < P * CPV; i += kThreads) {
@@ -580,13 +640,13 @@ __global__ __launch_bounds__(kThreads, (DwPwCfg<T, CIN, COUT, STRIDE, HAS_DW, TH
 #pragma unroll
                 for (int kx = 0; kx < 3; kx++) {
                     V x = *(const V *)(s_in + ((py * STRIDE + ky) * HC + px * STRIDE + kx) * CIN + cv * VEC);
-                    V wv = *(const V *)(s_dw + (ky * 3 + kx) * CIN + cv * VEC);
+                    const DW *wv = s_dw + (ky * 3 + kx) * CIN + cv * VEC;
 #pragma unroll
                     for (int e = 0; e < VEC; e++) acc[e] = fmaf((float)x[e], (float)wv[e], acc[e]);
                 }
             V r;
 #pragma unroll
-            for (int e = 0; e < VEC; e++) r[e] = (T)fmaxf(acc[e], 0.f);
+            for (int e = 0; e < VEC; e++) r[e] = to_T<T>(fmaxf(acc[e], 0.f));
             *(V *)(s_a + p * LDA + cv * VEC) = r;
         }
     } else {
@@ -601,11 +661,11 @@ __global__ __launch_bounds__(kThreads, (DwPwCfg<T, CIN, COUT, STRIDE, HAS_DW, TH
     __syncthreads();
 
     // ---- pointwise GEMM: D[cout][pixel], K = CIN
-    f32x4 acc[WS::NI][WS::NJ];
+    typename M::Acc acc[WS::NI][WS::NJ];
 #pragma unroll
     for (int i = 0; i < WS::NI; i++)
 #pragma unroll
-        for (int j = 0; j < WS::NJ; j++) acc[i][j] = vzero<f32x4, 4>();
+        for (int j = 0; j < WS::NJ; j++) acc[i][j] = vzero<typename M::Acc, 4>();
     pipe.run(acc, [&](int j, int kc) -> typename M::Frag {
         const int kb = kc * M::K + (lane >> 4) * M::KPL;
         const int p = acc_pixel(wp + j * WS::WP, lane);
@@ -615,7 +675,7 @@ __global__ __launch_bounds__(kThreads, (DwPwCfg<T, CIN, COUT, STRIDE, HAS_DW, TH
     for (int i = 0; i < WS::NI; i++)
 #pragma unroll
         for (int j = 0; j < WS::NJ; j++)
-            store_acc<T, LDO>(s_out, pw_bias[i], acc[i][j], wn + i * WS::WN, wp + j * WS::WP, lane, true);
+            store_acc<T, LDO>(s_out, pw_mult[i], pw_bias[i], acc[i][j], wn + i * WS::WN, wp + j * WS::WP, lane, true);
     __syncthreads();
 
     constexpr int OPV = COUT / VEC;
@@ -632,15 +692,15 @@ __global__ __launch_bounds__(kThreads, (DwPwCfg<T, CIN, COUT, STRIDE, HAS_DW, TH
         static_assert(LDA >= 64 + VEC, "lateral result tile must fit the depthwise tile");
         constexpr int LDL = 64 + VEC;
         T *s_lat = s_a;
-        f32x4 acc2[1][PT];
+        typename M::Acc acc2[1][PT];
 #pragma unroll
-        for (int j = 0; j < PT; j++) acc2[0][j] = vzero<f32x4, 4>();
+        for (int j = 0; j < PT; j++) acc2[0][j] = vzero<typename M::Acc, 4>();
         lpipe.run(acc2, [&](int j, int kc) -> typename M::Frag {
             const int kb = kc * M::K + (lane >> 4) * M::KPL;
             return *(const typename M::Frag *)(s_out + acc_pixel(j, lane) * LDO + kb);
         });
 #pragma unroll
-        for (int j = 0; j < PT; j++) store_acc<T, LDL>(s_lat, lat_bias, acc2[0][j], wave, j, lane, true);
+        for (int j = 0; j < PT; j++) store_acc<T, LDL>(s_lat, lat_mult, lat_bias, acc2[0][j], wave, j, lane, true);
         __syncthreads();
         constexpr int LPV = 64 / VEC;
         T *latb = a.lat_out + (size_t)img * a.hout * a.wout * 64;
@@ -659,7 +719,7 @@ static void dwpw_launch(hipStream_t s, const DwPwParams<T> *p, int tiles_x, int 
     auto kern = dwpw_kernel<T, CIN, COUT, STRIDE, HAS_DW, TH, TW, LAT>;
     static bool attr_set = false;
     if (!attr_set) { set_max_lds(kern, C::LDS_BYTES); attr_set = true; }
-    DwPwArgs<T> a{p->in, p->out, p->dw_w, p->dw_b, p->pw_w, p->pw_b, p->lat_w, p->lat_b, p->lat_out,
+    DwPwArgs<T> a{p->in, p->out, p->dw_w, p->dw_b, p->pw_w, p->pw_b, p->lat_w, p->lat_b, p->lat_out, p->pw_m, p->lat_m,
                   p->hin, p->win, p->hout, p->wout, tiles_x, tiles_y, p->n * tiles_x * tiles_y};
     hipLaunchKernelGGL(kern, dim3(a.nblk), dim3(kThreads), C::LDS_BYTES, s, a);
 }
@@ -686,7 +746,7 @@ static TileInfo dwpw_select(hipStream_t s, const DwPwParams<T> *p, int cin, int 
                             int wout) {
 #define RF_DWPW(CI, CO, ST, DW, TH_, TW_) \
     if (cin == CI && cout == CO && stride == ST && has_dw == DW) return dwpw_dispatch<T, CI, CO, ST, DW, TH_, TW_>(s, p, hout, wout);
-    RF_DWPW(8, 16, 1, true, 8, 32)
+    if constexpr (sizeof(T) > 1) { RF_DWPW(8, 16, 1, true, 8, 32) }      // int8: this block lives in the stem
     RF_DWPW(16, 32, 2, true, 8, 16)
     RF_DWPW(32, 32, 1, true, 8, 16)
     RF_DWPW(32, 64, 2, true, 8, 8)
@@ -711,8 +771,10 @@ template <typename T> TileInfo dwpw_tile_info(int cin, int cout, int stride, boo
 }
 template void launch_dwpw<half_t>(hipStream_t, const DwPwParams<half_t> &);
 template void launch_dwpw<float>(hipStream_t, const DwPwParams<float> &);
+template void launch_dwpw<int8_t>(hipStream_t, const DwPwParams<int8_t> &);
 template TileInfo dwpw_tile_info<half_t>(int, int, int, bool, int, int);
 template TileInfo dwpw_tile_info<float>(int, int, int, bool, int, int);
+template TileInfo dwpw_tile_info<int8_t>(int, int, int, bool, int, int);
 
 // =============================================================================================
 // K_c  dense 3x3 p1 s1 convolution + BN + ReLU as implicit GEMM (K = 9*CIN) on MFMA
@@ -733,14 +795,15 @@ template <typename T, int CIN, int COUT, int TH, int TW> struct Conv3Cfg {
     static constexpr int IN_ELEMS = HR * HC * LDI;
     static constexpr int O_ELEMS = P * LDO;
     static constexpr size_t LDS_BYTES = sizeof(T) * (size_t)(IN_ELEMS > O_ELEMS ? IN_ELEMS : O_ELEMS);
-    static constexpr int OCC = sizeof(T) == 2 ? 6 : 1;          // see DwPwCfg: rounds x chain latency
-    static constexpr int GFRAGS = sizeof(T) == 2 ? 4 : 12;
+    static constexpr int OCC = sizeof(T) <= 2 ? 6 : 1;          // see DwPwCfg: rounds x chain latency
+    static constexpr int GFRAGS = sizeof(T) <= 2 ? 4 : 12;
 };
 
 template <typename T>
 struct Conv3Level {
-    const T *in; const T *up; const T *w; const float *b; T *out0; T *out1;
+    const T *in; const T *up; const T *w; const float *b; const float *m; T *out0; T *out1;
     int in_ld, in_off, ld0, off0, n0, ld1, off1, h, w_, tiles_x, tiles_y, blk_begin;
+    float a_lat, a_up;      // UPADD: staged value = to_T(lat * a_lat + upsample * a_up); 1, 1 unless int8 (scale ratios)
 };
 template <typename T>
 struct Conv3Args {
@@ -779,9 +842,13 @@ __global__ __launch_bounds__(kThreads, (Conv3Cfg<T, CIN, COUT, TH, TW>::OCC)) vo
     const int wn = wave % WS::WN, wp = wave / WS::WN;
     GemmPipe<T, WS::NI, WS::NJ, KCH, WS::WN, C::GFRAGS> pipe;
     pipe.init(L.w, wn, lane);
-    f32x4 bias[WS::NI];
+    f32x4 bias[WS::NI], mult[WS::NI];
 #pragma unroll
-    for (int i = 0; i < WS::NI; i++) bias[i] = *(const f32x4 *)(L.b + acc_cout(wn + i * WS::WN, lane, 0));
+    for (int i = 0; i < WS::NI; i++) {
+        bias[i] = *(const f32x4 *)(L.b + acc_cout(wn + i * WS::WN, lane, 0));
+        mult[i] = load_mult(L.m, acc_cout(wn + i * WS::WN, lane, 0));
+    }
+    const float a_lat = L.a_lat, a_up = L.a_up;
 
     const T *in = L.in;
     const int in_ld = L.in_ld, in_off = L.in_off;
@@ -812,7 +879,7 @@ __global__ __launch_bounds__(kThreads, (Conv3Cfg<T, CIN, COUT, TH, TW>::OCC)) vo
                 tap(my2, mx, 0.1875f);
                 tap(my2, mx2, 0.0625f);
 #pragma unroll
-                for (int e = 0; e < VEC; e++) v[e] = (T)((float)v[e] + s[e]);
+                for (int e = 0; e < VEC; e++) v[e] = to_T<T>(fmaf((float)v[e], a_lat, s[e] * a_up));
             }
         }
         *(V *)(s_in + pix * LDI + cv * VEC) = v;
@@ -825,11 +892,11 @@ __global__ __launch_bounds__(kThreads, (Conv3Cfg<T, CIN, COUT, TH, TW>::OCC)) vo
         const int p = acc_pixel(wp + j * WS::WP, lane);
         pbase[j] = ((p / TW) * HC + p % TW) * LDI;
     }
-    f32x4 acc[WS::NI][WS::NJ];
+    typename M::Acc acc[WS::NI][WS::NJ];
 #pragma unroll
     for (int i = 0; i < WS::NI; i++)
 #pragma unroll
-        for (int j = 0; j < WS::NJ; j++) acc[i][j] = vzero<f32x4, 4>();
+        for (int j = 0; j < WS::NJ; j++) acc[i][j] = vzero<typename M::Acc, 4>();
     pipe.run(acc, [&](int j, int kc) -> typename M::Frag {
         const int kb = kc * M::K + (lane >> 4) * M::KPL;      // k = tap*CIN + c, KPL consecutive c of one tap
         const int tap = kb / CIN, c = kb % CIN;
@@ -841,7 +908,7 @@ __global__ __launch_bounds__(kThreads, (Conv3Cfg<T, CIN, COUT, TH, TW>::OCC)) vo
     for (int i = 0; i < WS::NI; i++)
 #pragma unroll
         for (int j = 0; j < WS::NJ; j++)
-            store_acc<T, LDO>(s_out, bias[i], acc[i][j], wn + i * WS::WN, wp + j * WS::WP, lane, true);
+            store_acc<T, LDO>(s_out, mult[i], bias[i], acc[i][j], wn + i * WS::WN, wp + j * WS::WP, lane, true);
     __syncthreads();
 
     constexpr int OPV = COUT / VEC;
@@ -869,8 +936,8 @@ static TileInfo conv3_dispatch(hipStream_t s, const Conv3Params<T> *p, int nlv, 
     for (int l = 0; l < 3; l++) {
         const Conv3Params<T> &q = p[l < nlv ? l : nlv - 1];
         int tiles_x = (q.w_ + TW - 1) / TW, tiles_y = (q.h + TH - 1) / TH;
-        a.lv[l] = Conv3Level<T>{q.in, q.up, q.w, q.b, q.out0, q.out1, q.in_ld, q.in_off, q.ld0, q.off0, q.n0, q.ld1, q.off1,
-                                q.h, q.w_, tiles_x, tiles_y, blk};
+        a.lv[l] = Conv3Level<T>{q.in, q.up, q.w, q.b, q.m, q.out0, q.out1, q.in_ld, q.in_off, q.ld0, q.off0, q.n0, q.ld1, q.off1,
+                                q.h, q.w_, tiles_x, tiles_y, blk, q.a_lat, q.a_up};
         if (l < nlv) blk += q.n * tiles_x * tiles_y;
         else a.lv[l].blk_begin = 0x7fffffff;
     }
@@ -919,8 +986,10 @@ template <typename T> TileInfo conv3x3_tile_info(int cin, int cout, int h, int w
 }
 template void launch_conv3x3<half_t>(hipStream_t, const Conv3Params<half_t> *, int);
 template void launch_conv3x3<float>(hipStream_t, const Conv3Params<float> *, int);
+template void launch_conv3x3<int8_t>(hipStream_t, const Conv3Params<int8_t> *, int);
 template TileInfo conv3x3_tile_info<half_t>(int, int, int, int);
 template TileInfo conv3x3_tile_info<float>(int, int, int, int);
+template TileInfo conv3x3_tile_info<int8_t>(int, int, int, int);
 
 // =============================================================================================
 // K_d  heads + softmax + decode + threshold compaction
@@ -970,7 +1039,7 @@ __device__ __forceinline__ void decode_anchor(const float *__restrict__ o /*32 h
 
 template <typename T>
 struct HeadLevel {
-    const T *in; const T *w; const float *b;
+    const T *in; const T *w; const float *b; const float *m;
     float *dump_prob, *dump_bbox, *dump_lmk;
     float base[2][4];
     int hw, w_, stride, anchor_offset, blocks_per_image, blk_begin;
@@ -1011,6 +1080,7 @@ __global__ __launch_bounds__(kThreads) void head_kernel(HeadArgs<T> a) {
     pipe.init(L.w, wn, lane);
     const float threshold = a.params->threshold;
     const f32x4 bias = *(const f32x4 *)(L.b + acc_cout(wn, lane, 0));
+    const f32x4 mult = load_mult(L.m, acc_cout(wn, lane, 0));          // int8: w_scale * in_scale -> real logits
 
     const T *inb = L.in + (size_t)img * hw * CIN;
     for (int i = tid; i < P * CPV; i += kThreads) {
@@ -1021,9 +1091,9 @@ __global__ __launch_bounds__(kThreads) void head_kernel(HeadArgs<T> a) {
     }
     __syncthreads();
 
-    f32x4 acc[1][WS::NJ];
+    typename M::Acc acc[1][WS::NJ];
 #pragma unroll
-    for (int j = 0; j < WS::NJ; j++) acc[0][j] = vzero<f32x4, 4>();
+    for (int j = 0; j < WS::NJ; j++) acc[0][j] = vzero<typename M::Acc, 4>();
     pipe.run(acc, [&](int j, int kc) -> typename M::Frag {
         const int kb = kc * M::K + (lane >> 4) * M::KPL;
         return *(const typename M::Frag *)(s_a + acc_pixel(wp + j * WS::WP, lane) * LDA + kb);
@@ -1033,7 +1103,7 @@ __global__ __launch_bounds__(kThreads) void head_kernel(HeadArgs<T> a) {
         const int p = acc_pixel(wp + j * WS::WP, lane);
         const int c0 = acc_cout(wn, lane, 0);
 #pragma unroll
-        for (int r = 0; r < 4; r++) s_o[p * HEAD_LDO + c0 + r] = acc[0][j][r] + bias[r];
+        for (int r = 0; r < 4; r++) s_o[p * HEAD_LDO + c0 + r] = fmaf((float)acc[0][j][r], mult[r], bias[r]);
     }
     __syncthreads();
 
@@ -1077,7 +1147,7 @@ template <typename T> void launch_head(hipStream_t s, const HeadParams<T> *level
     for (int l = 0; l < 3; l++) {
         const HeadParams<T> &p = levels[l < nlevels ? l : nlevels - 1];
         HeadLevel<T> &L = a.lv[l];
-        L.in = p.in; L.w = p.w; L.b = p.b;
+        L.in = p.in; L.w = p.w; L.b = p.b; L.m = p.m;
         L.dump_prob = p.dump_prob; L.dump_bbox = p.dump_bbox; L.dump_lmk = p.dump_lmk;
         for (int i = 0; i < 2; i++) for (int j = 0; j < 4; j++) L.base[i][j] = p.base[i][j];
         L.hw = p.h * p.w_; L.w_ = p.w_; L.stride = p.stride; L.anchor_offset = p.anchor_offset;
@@ -1093,6 +1163,7 @@ template <typename T> void launch_head(hipStream_t s, const HeadParams<T> *level
 }
 template void launch_head<half_t>(hipStream_t, const HeadParams<half_t> *, int);
 template void launch_head<float>(hipStream_t, const HeadParams<float> *, int);
+template void launch_head<int8_t>(hipStream_t, const HeadParams<int8_t> *, int);
 
 // =============================================================================================
 // K_e  per-image NMS: total order (score desc, anchor index asc), greedy suppression with the reference's

@@ -237,6 +237,7 @@ Plan compile_plan(const Model &m) {
         s.conv_b.out_blob = cat_out;
         s.conv_c.out_blob = cat_out;
     }
+    p.int8_scales = m.int8_scales;
     return p;
 }
 

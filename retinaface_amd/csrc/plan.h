@@ -40,6 +40,9 @@ struct Plan {
     FoldedConv lateral[3];                // [0] rf_c3_lateral (256->64), [1] rf_c2_lateral (128->64), [2] rf_c1_red_conv (64->64)
     FoldedConv aggr[2];                   // [0] rf_c2_aggr, [1] rf_c1_aggr  (input = lateral + bilinear x2 upsample of the coarser level)
     SshModule ssh[3];                     // strides 32, 16, 8
+    // TensorRT calibration cache: tensor (blob) name -> per-tensor activation scale, real ~= q * scale (SURVEY App. B.7;
+    // consumed by the int8 engine).  Empty when the model carries no table.
+    std::vector<std::pair<std::string, float>> int8_scales;
 };
 
 Plan compile_plan(const Model &m);        // throws ModelError when the graph is not the expected topology
