@@ -177,7 +177,7 @@ def main() -> None:
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt_max / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": {"fp16": "f16", "fp32": "f32", "int8": "i8"}[args.precision], "data": "synthetic",
-            "config": {"workload": f"{args.model} {args.precision} HIP, {W}x{H}, batch {B} per GPU (BASELINE.json configs[1] at 448x448 b=8)",
+            "config": {"workload": f"{args.model} {args.precision} HIP, {W}x{H}, batch {B} per GPU ({baseline_config(args)})",
                        "global_batch": B * world, "frame": [H, W], "threshold": args.threshold, "nms": 0.4,
                        "parallelism": f"dp{world} (image sharding, no data-path collective)",
                        "tickets_in_flight": slots, "lanes": lanes_opt, "steps_coalesced_per_launch": slots // max(lanes_opt, 1)},
@@ -198,6 +198,15 @@ def main() -> None:
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def baseline_config(args) -> str:
+    """Which BASELINE.json config this invocation corresponds to."""
+    key = (args.model, args.precision, args.height, args.width, args.batch)
+    return {("mnet25", "fp16", 448, 448, 8): "BASELINE.json configs[1], the metric point",
+            ("mnet-deconv-0517", "int8", 448, 448, 32): "BASELINE.json configs[2]",
+            ("mnet25", "fp16", 896, 1280, 1): "BASELINE.json configs[3]",
+            ("mnet25", "int8", 448, 448, 32): "BASELINE.json configs[4]: 256 images = 32 per GPU x 8 GPUs"}.get(key, "not a BASELINE.json config")
 
 
 def cpu_baseline(frames_np, args, det):
