@@ -210,3 +210,42 @@ def test_synthetic_frames_golden(stem, oracles):
         assert np.array_equal(r.anchor_indices(), g[f"idx05_{i}"])
         assert len(r.candidates) == int(g[f"ncand05_{i}"])
         assert np.allclose(r.rows(), g[f"det05_{i}"], rtol=1e-5, atol=2e-3)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# property tests: the two independent restatements of decode + NMS on random head tensors (ties, clipping, empties)
+from hypothesis import given, settings, strategies as st  # noqa: E402
+
+
+@settings(max_examples=25, deadline=None)
+@given(seed=st.integers(0, 2**31 - 1), thr=st.sampled_from([0.3, 0.5, 0.9]), nms_thr=st.sampled_from([0.2, 0.4, 0.7]),
+       quantise=st.booleans())
+def test_property_numpy_and_c_agree_on_random_heads(seed, thr, nms_thr, quantise):
+    """Random probabilities / deltas on a 64x96 net (6 + 24 + 96 cells x 2 anchors).  `quantise` snaps scores to a coarse
+    grid so equal scores (NMS tie order = anchor index) and exact-threshold scores (`conf <= thr` is dropped) occur."""
+    rng = np.random.default_rng(seed)
+    H, W = 64, 96
+    heads = {}
+    for s in HEAD_STRIDES:
+        h, w = H // s, W // s
+        p = rng.random((1, 4, h, w)).astype(np.float32)
+        if quantise:
+            p = (np.round(p * 10) / 10).astype(np.float32)
+        heads[f"face_rpn_cls_prob_reshape_stride{s}"] = p
+        heads[f"face_rpn_bbox_pred_stride{s}"] = rng.normal(0, 0.5, (1, 8, h, w)).astype(np.float32)
+        heads[f"face_rpn_landmark_pred_stride{s}"] = rng.normal(0, 0.5, (1, 20, h, w)).astype(np.float32)
+    cands = decode(heads, H, W, thr)
+    kept = nms(list(cands), nms_thr)
+    cand_c, cidx, kept_c, kidx = obuild.decode_nms(_heads9(heads), H, W, thr, nms_thr)
+    assert cidx.tolist() == [d.anchor_index for d in cands]
+    assert kidx.tolist() == [d.anchor_index for d in kept]
+    if cands:
+        a = np.stack([d.as_row() for d in cands])
+        assert np.array_equal(a[:, 0], cand_c[:, 0])                       # scores are copied, never recomputed
+        assert np.allclose(a, cand_c, rtol=3e-6, atol=2e-4)                # coordinates: numpy exp vs glibc expf
+        assert (a[:, 1] >= 0).all() and (a[:, 2] >= 0).all() and (a[:, 3] <= W - 1).all() and (a[:, 4] <= H - 1).all()
+    scores = [float(d.score) for d in kept]
+    assert scores == sorted(scores, reverse=True)
+    for i, a_ in enumerate(kept):                                          # survivors do not suppress each other
+        for b_ in kept[i + 1:]:
+            assert iou_plus1(a_.rect, b_.rect) <= nms_thr + 1e-6
