@@ -616,7 +616,7 @@ private:
             const float *wp = arena_.ptr<float>(c0_w_), *bp = arena_.ptr<float>(c0_b_);
             const FrameDesc *fr = L.d_frames + mb;
             T *o = cur;
-            op.launch = [=](hipStream_t s, int n) { launch_conv0<T>(s, fr, o, wp, bp, nullptr, nullptr, n, H, W); };
+            op.launch = [=](hipStream_t s, int n) { launch_conv0<T>(s, fr, o, wp, bp, n, H, W); };
             L.ops.push_back(op);
         }
         // FPN tap -> lateral index: block 4 (stride 8) -> lateral[2], block 10 (stride 16) -> [1], block 12 (stride 32) -> [0]

@@ -28,7 +28,7 @@ struct Candidate {
     int32_t anchor;
 };
 
-// Per-call scalars that live in device memory so a captured hipGraph stays valid across calls.
+// Per-launch scalars; they live in device memory (copied with the frame table) so a captured hipGraph stays valid.
 struct RunParams {
     float threshold;       // keep iff conf > threshold   (RetinaFace.cpp:693)
     float nms_threshold;   // suppress iff IoU > nms      (RetinaFace.cpp:486)
@@ -39,8 +39,8 @@ struct RunParams {
 // ---- K_a: preprocess (BGR u8 HWC -> RGB, top-left placement on a zero canvas; resizeconvertion.cu:46-63,
 //      165-185, 279-316 with factor 1) fused with mobilenet0_conv0 (3x3 s2 p1 3->8) + BN + ReLU.
 template <typename T>
-void launch_conv0(hipStream_t s, const FrameDesc *frames, T *out, const float *w, const float *b,
-                  const RunParams *params_in, RunParams *params_out, int n, int net_h, int net_w);
+void launch_conv0(hipStream_t s, const FrameDesc *frames, T *out, const float *w, const float *b, int n, int net_h,
+                  int net_w);
 
 // ---- K_a' (fp16 engine): K_a fused with the first depthwise/pointwise block; conv0 on MFMA (hi+lo split weights).
 template <typename TO>
@@ -117,8 +117,6 @@ void launch_nms(hipStream_t s, const NmsParams &p);
 // Area-average downscale of an over-size frame onto the net-size u8 canvas (NPPI_INTER_SUPER stand-in,
 // resizeconvertion.cu:298-311; closed-source NPP semantics -> "parity unpinned").
 void launch_resize_area(hipStream_t s, const FrameDesc *src, uint8_t *dst, int n, int net_h, int net_w);
-
-void launch_fill_u32(hipStream_t s, uint32_t *dst, uint32_t value, size_t count);
 
 // LDS bytes / tile geometry chosen for a layer (exposed for tests and DESIGN.md tables)
 struct TileInfo { int th, tw; size_t lds_bytes; int blocks_per_image; };

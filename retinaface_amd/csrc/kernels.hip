@@ -97,14 +97,10 @@ constexpr int C0_ROWD = 27;                    // LDS row stride in dwords (+1: 
 template <typename T>
 __global__ __launch_bounds__(kThreads) void conv0_kernel(const FrameDesc *__restrict__ frames, T *__restrict__ out,
                                                          const float *__restrict__ w, const float *__restrict__ b,
-                                                         const RunParams *__restrict__ params_in, RunParams *params_out,
                                                          int ho, int wo, int tiles_x, int tiles_y, int nblk) {
     __shared__ uint32_t s_in32[C0_IN * C0_ROWD];
     const uint8_t *s_in = (const uint8_t *)s_in32;
     const int tid = threadIdx.x;
-    // `frames` / `params_in` sit in pinned host memory (written by the CPU just before the launch, read here over
-    // PCIe: no H2D copy kernel per call).  One thread re-publishes the scalars in HBM for the head / NMS kernels.
-    if (blockIdx.x == 0 && tid == 0 && params_out) *params_out = *params_in;
     const int bid = xcd_remap(blockIdx.x, nblk);
     const int tx = bid % tiles_x;
     const int ty = (bid / tiles_x) % tiles_y;
@@ -172,18 +168,15 @@ __global__ __launch_bounds__(kThreads) void conv0_kernel(const FrameDesc *__rest
 }
 
 template <typename T>
-void launch_conv0(hipStream_t s, const FrameDesc *frames, T *out, const float *w, const float *b,
-                  const RunParams *params_in, RunParams *params_out, int n, int net_h, int net_w) {
+void launch_conv0(hipStream_t s, const FrameDesc *frames, T *out, const float *w, const float *b, int n, int net_h,
+                  int net_w) {
     int ho = net_h / 2, wo = net_w / 2;
     int tiles_x = (wo + C0_T - 1) / C0_T, tiles_y = (ho + C0_T - 1) / C0_T;
     int nblk = n * tiles_x * tiles_y;
-    hipLaunchKernelGGL(conv0_kernel<T>, dim3(nblk), dim3(kThreads), 0, s, frames, out, w, b, params_in, params_out, ho, wo, tiles_x,
-                       tiles_y, nblk);
+    hipLaunchKernelGGL(conv0_kernel<T>, dim3(nblk), dim3(kThreads), 0, s, frames, out, w, b, ho, wo, tiles_x, tiles_y, nblk);
 }
-template void launch_conv0<half_t>(hipStream_t, const FrameDesc *, half_t *, const float *, const float *, const RunParams *,
-                                   RunParams *, int, int, int);
-template void launch_conv0<float>(hipStream_t, const FrameDesc *, float *, const float *, const float *, const RunParams *,
-                                  RunParams *, int, int, int);
+template void launch_conv0<half_t>(hipStream_t, const FrameDesc *, half_t *, const float *, const float *, int, int, int);
+template void launch_conv0<float>(hipStream_t, const FrameDesc *, float *, const float *, const float *, int, int, int);
 
 // =============================================================================================
 // GEMM core shared by K_b / K_c / K_d:  acc[i][j] += W-fragment(ct_i, kc) x X-fragment(pt_j, kc)
@@ -535,7 +528,7 @@ template <typename T, int CIN, int COUT, int STRIDE, bool HAS_DW, int TH, int TW
     static constexpr int P = TH * TW;
     static constexpr int HR = HAS_DW ? (TH - 1) * STRIDE + 3 : 0;
     static constexpr int HC = HAS_DW ? (TW - 1) * STRIDE + 3 : 0;
-    static constexpr int LDA = CIN + VEC;
+    static constexpr int LDA = CIN + (CIN * sizeof(T) >= 64 ? VEC : 0);   // narrow rows: padding costs a resident workgroup
     static constexpr int LDO = COUT + VEC;
     static constexpr size_t IN_BYTES = sizeof(T) * (size_t)(HR * HC * CIN);
     static constexpr size_t DW_BYTES = HAS_DW ? sizeof(DW) * (size_t)(9 * CIN) : 0;
@@ -747,10 +740,10 @@ static TileInfo dwpw_select(hipStream_t s, const DwPwParams<T> *p, int cin, int 
 #define RF_DWPW(CI, CO, ST, DW, TH_, TW_) \
     if (cin == CI && cout == CO && stride == ST && has_dw == DW) return dwpw_dispatch<T, CI, CO, ST, DW, TH_, TW_>(s, p, hout, wout);
     if constexpr (sizeof(T) > 1) { RF_DWPW(8, 16, 1, true, 8, 32) }      // int8: this block lives in the stem
-    RF_DWPW(16, 32, 2, true, 8, 16)
-    RF_DWPW(32, 32, 1, true, 8, 16)
-    RF_DWPW(32, 64, 2, true, 8, 8)
-    RF_DWPW(64, 64, 1, true, 8, 8)
+    RF_DWPW(16, 32, 2, true, 8, 8)
+    RF_DWPW(32, 32, 1, true, 8, 8)
+    RF_DWPW(32, 64, 2, true, 4, 8)
+    RF_DWPW(64, 64, 1, true, 4, 8)
     RF_DWPW(64, 128, 2, true, 4, 8)
     RF_DWPW(128, 128, 1, true, 4, 8)
     RF_DWPW(128, 256, 2, true, 4, 8)
@@ -966,7 +959,7 @@ static TileInfo conv3_select(hipStream_t s, const Conv3Params<T> *p, int nlv, in
     // channel tiles still split over 4 waves (COUT % 32 == 0); everything else 8x8
     const bool small = nlv == 1 && (size_t)h * w <= 32 * 32;
     if (cin == 64 && cout == 64)
-        return small ? conv3_dispatch<T, 64, 64, 4, 8>(s, p, nlv, h, w) : conv3_dispatch<T, 64, 64, 8, 8>(s, p, nlv, h, w);
+        return conv3_dispatch<T, 64, 64, 4, 8>(s, p, nlv, h, w);
     if (cin == 16 && cout == 32)
         return small ? conv3_dispatch<T, 16, 32, 4, 8>(s, p, nlv, h, w) : conv3_dispatch<T, 16, 32, 8, 8>(s, p, nlv, h, w);
     if (cin == 64 && cout == 48) return conv3_dispatch<T, 64, 48, 8, 8>(s, p, nlv, h, w);
@@ -1343,15 +1336,6 @@ __global__ __launch_bounds__(kThreads) void resize_area_kernel(const FrameDesc *
 void launch_resize_area(hipStream_t s, const FrameDesc *src, uint8_t *dst, int n, int net_h, int net_w) {
     dim3 grid((net_w + 31) / 32, (net_h + 7) / 8, n);
     hipLaunchKernelGGL(resize_area_kernel, grid, dim3(kThreads), 0, s, src, dst, net_h, net_w);
-}
-
-__global__ void fill_u32_kernel(uint32_t *dst, uint32_t v, size_t n) {
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) dst[i] = v;
-}
-void launch_fill_u32(hipStream_t s, uint32_t *dst, uint32_t value, size_t count) {
-    if (!count) return;
-    hipLaunchKernelGGL(fill_u32_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, s, dst, value, count);
 }
 
 }  // namespace rf
