@@ -132,10 +132,11 @@ def test_synthetic_batch8_against_golden(rfa, stem, prec):
             assert abs(ncand[i] - int(g[f"ncand{tag}_{i}"])) <= TOL[prec]["ncand"]
 
 
-@pytest.mark.parametrize("thr", [0.5, 0.1, 0.02])
+@pytest.mark.parametrize("thr", [0.5, 0.1, 0.02, 0.004, 0.0015])
 def test_postprocessing_is_exact_given_the_gpu_head_blobs(rfa, crop448, thr):
     """Decode + regression + clip + NMS on the device vs the plain-C restatement fed the device's own head blobs:
-    anchor indices and scores bit-exact, coordinates to expf-ulp -- also with hundreds of candidates (thr 0.02)."""
+    anchor indices and scores bit-exact, coordinates to expf-ulp.  The thresholds walk through all three sort paths of the
+    NMS kernel: single-wave rank sort (<= 64 candidates), 256-thread rank sort (<= 256), bitonic network (more)."""
     det = engine(rfa, "mnet25", FP32, (448, 448), keep_outputs=True, use_graph=False)
     got = det.detect(crop448, thr)
     heads9 = [det.get_output(n) for s in HEAD_STRIDES for n in head_names(s)]
@@ -147,6 +148,10 @@ def test_postprocessing_is_exact_given_the_gpu_head_blobs(rfa, crop448, thr):
     assert np.abs(rows - kept).max(initial=0.0) <= 1e-4
     if thr == 0.02:
         assert len(cidx) > 60
+    if thr == 0.004:
+        assert 64 < len(cidx) <= 4096
+    if thr == 0.0015:
+        assert 256 < len(cidx) <= 4096, len(cidx)
 
 
 INT8 = 2
