@@ -10,14 +10,16 @@ reference computes on the path BASELINE.json names:
   decode       reference retinaface/RetinaFace.cpp:999-1072 (+ helpers :9-199, :378-432)
   NMS          reference retinaface/RetinaFace.cpp:434-492
 
-PARITY STATUS: *parity unpinned by the reference*.  The reference ships no tests, no golden
-vectors and no runnable build of its own path in this environment (Caffe / TensorRT / OpenCV /
-NPP are all absent).  The oracle is therefore pinned by
-  (1) two independent forward implementations (PyTorch-CPU conv kernels vs. a plain numpy
-      im2col/einsum implementation) that must agree to fp32 round-off,
-  (2) a literal numpy restatement of decode/NMS cross-checked against a plain-C restatement,
-  (3) the semantic check that data/img.jpg yields the 6 faces at the scores SURVEY.md records.
-Golden vectors frozen from it live in tests/golden/ (generator: tools/make_golden.py).
+PARITY STATUS: *pinned by the reference's own code* for preprocess / anchors / decode / NMS; *restated* for the forward.
+  * The reference's retinaface/RetinaFace.cpp compiles here, unmodified and from where it lies, against stand-in
+    third-party headers (oracle/build_ref.py, oracle/ref_shim/, oracle/ref_harness.cpp -> oracle/_ref/).
+    tests/test_reference_pin.py holds retinaface_post.py and csrc/rf_post_ref.c bit-exact to that build, live and through
+    tests/golden/ref_pin.npz (minted from it by tools/make_ref_golden.py).
+  * The forward's arithmetic lives in BVLC Caffe / TensorRT 5.1 -- un-vendored, un-pinned, absent.  caffe_forward.py
+    restates Caffe's published layer semantics and is pinned by two independent conv back-ends agreeing to fp32
+    round-off plus the semantic check that data/img.jpg yields the 6 faces at the scores SURVEY.md records.
+  * NPP's closed-source SUPER resize (oversize frames) stays "parity unpinned".
+Golden vectors live in tests/golden/ (generators: tools/make_ref_golden.py, tools/make_golden.py).
 
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this package.
 The product (retinaface_amd/) never does and fails loudly if its HIP library is missing.

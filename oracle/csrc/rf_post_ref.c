@@ -14,8 +14,9 @@
  *
  * Built WITHOUT -mfma / -ffast-math so every float op rounds where the reference's
  * x86-64 build rounds.  "0.5 * (w - 1.0)" is double arithmetic in the reference; kept.
- * PARITY STATUS: parity unpinned by the reference (it has no tests); this file is
- * cross-checked against the independent numpy restatement in oracle/retinaface_post.py.
+ * PARITY STATUS: pinned.  The reference has no tests, but its own RetinaFace.cpp compiles here against stand-in
+ * third-party headers (oracle/build_ref.py); tests/test_reference_pin.py holds this file bit-exact to that build
+ * (live, and through the frozen vectors of tests/golden/ref_pin.npz) and to the numpy restatement.
  */
 #include <math.h>
 #include <stdint.h>

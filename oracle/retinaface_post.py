@@ -15,6 +15,20 @@ import numpy as np
 f32 = np.float32
 f64 = np.float64
 
+# exp() at RetinaFace.cpp:389-390 resolves to std::exp(float) (<cmath> + `using namespace std`), i.e. glibc's expf.
+# numpy's float32 exp is a different (SIMD) implementation that is 1 ulp off on some inputs -- found when this file was
+# pinned against the reference build (oracle/build_ref.py) -- so call the same libm the reference links.
+import ctypes as _C
+import ctypes.util as _Cu
+
+_libm = _C.CDLL(_Cu.find_library("m") or "libm.so.6")
+_libm.expf.restype = _C.c_float
+_libm.expf.argtypes = [_C.c_float]
+
+
+def expf(x) -> np.float32:
+    return f32(_libm.expf(float(f32(x))))
+
 FEAT_STRIDES = (32, 16, 8)                       # RetinaFace.cpp:246 (_feat_stride_fpn)
 ANCHOR_SCALES = {32: (32, 16), 16: (8, 4), 8: (2, 1)}   # RetinaFace.cpp:247-268
 ANCHOR_BASE_SIZE = 16
@@ -132,8 +146,8 @@ def bbox_pred(anchor, regress):
     ctr_y = f32(f64(y1) + 0.5 * (f64(height) - 1.0))
     pred_ctr_x = f32(f32(dx * width) + ctr_x)
     pred_ctr_y = f32(f32(dy * height) + ctr_y)
-    pred_w = f32(np.exp(dw, dtype=np.float32) * width)
-    pred_h = f32(np.exp(dh, dtype=np.float32) * height)
+    pred_w = f32(expf(dw) * width)
+    pred_h = f32(expf(dh) * height)
     return (f32(f64(pred_ctr_x) - 0.5 * (f64(pred_w) - 1.0)),
             f32(f64(pred_ctr_y) - 0.5 * (f64(pred_h) - 1.0)),
             f32(f64(pred_ctr_x) + 0.5 * (f64(pred_w) - 1.0)),

@@ -76,6 +76,23 @@ template <typename V, int N> __device__ __forceinline__ V vzero() {
 
 constexpr int kThreads = 256;   // 4 wavefronts
 
+// Phase timeline of a workgroup (probe builds only: make TRACE=1 -> libretinaface_amd_trace.so, tools/probes/phase_trace.py).
+// Wave 0 of every workgroup stamps s_memtime at each phase boundary of the kernel selected by g_trace_kernel.
+#ifdef RF_KERNEL_TRACE
+constexpr int kTraceSlots = 12, kTraceBlocks = 8192;
+__device__ unsigned long long g_trace[kTraceBlocks * kTraceSlots];
+__device__ int g_trace_kernel = 0;        // 1 = stem, 2 = dwpw, 3 = conv3x3, 4 = head
+__device__ unsigned g_trace_grid = 0;     // only launches with this many workgroups stamp (0 = any): one launch per trace
+#define RF_TRACE(kid, slot)                                                                                  \
+    do {                                                                                                     \
+        if (g_trace_kernel == (kid) && threadIdx.x == 0 && blockIdx.x < kTraceBlocks &&                       \
+            (g_trace_grid == 0 || gridDim.x == g_trace_grid))                                                 \
+            g_trace[blockIdx.x * kTraceSlots + (slot)] = __builtin_amdgcn_s_memtime();                         \
+    } while (0)
+#else
+#define RF_TRACE(kid, slot) do { } while (0)
+#endif
+
 template <typename F>
 static void set_max_lds(F func, size_t bytes) {
     if (bytes > 48 * 1024) (void)hipFuncSetAttribute((const void *)func, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
@@ -579,6 +596,7 @@ __global__ __launch_bounds__(kThreads, (DwPwCfg<T, CIN, COUT, STRIDE, HAS_DW, TH
     const int img = bid / (a.tiles_x * a.tiles_y);
     const int oy0 = ty * TH, ox0 = tx * TW;
     const T *inb = a.in + (size_t)img * a.hin * a.win * CIN;
+    RF_TRACE(2, 0);
 
     // ---- phase 0: everything that only depends on kernel arguments is requested first
     constexpr int NT = COUT / 16, PT = P / 16;
@@ -620,7 +638,9 @@ __global__ __launch_bounds__(kThreads, (DwPwCfg<T, CIN, COUT, STRIDE, HAS_DW, TH
         }
         for (int i = tid; i < 9 * CIN * (int)sizeof(DW) / 16; i += kThreads)
             ((f32x4 *)s_dw)[i] = ((const f32x4 *)a.dw_w)[i];
+        RF_TRACE(2, 1);
         __syncthreads();
+        RF_TRACE(2, 2);
         const int cv = tid % CPV;                 // kThreads % CPV == 0: the channel group is fixed per thread
         for (int i = tid; i < P * CPV; i += kThreads) {
             int p = i / CPV;
@@ -651,7 +671,9 @@ __global__ __launch_bounds__(kThreads, (DwPwCfg<T, CIN, COUT, STRIDE, HAS_DW, TH
             *(V *)(s_a + p * LDA + cv * VEC) = v;
         }
     }
+    RF_TRACE(2, 3);
     __syncthreads();
+    RF_TRACE(2, 4);
 
     // ---- pointwise GEMM: D[cout][pixel], K = CIN
     typename M::Acc acc[WS::NI][WS::NJ];
@@ -669,7 +691,9 @@ __global__ __launch_bounds__(kThreads, (DwPwCfg<T, CIN, COUT, STRIDE, HAS_DW, TH
 #pragma unroll
         for (int j = 0; j < WS::NJ; j++)
             store_acc<T, LDO>(s_out, pw_mult[i], pw_bias[i], acc[i][j], wn + i * WS::WN, wp + j * WS::WP, lane, true);
+    RF_TRACE(2, 5);
     __syncthreads();
+    RF_TRACE(2, 6);
 
     constexpr int OPV = COUT / VEC;
     T *outb = a.out + (size_t)img * a.hout * a.wout * COUT;
@@ -679,6 +703,7 @@ __global__ __launch_bounds__(kThreads, (DwPwCfg<T, CIN, COUT, STRIDE, HAS_DW, TH
         if (oy < a.hout && ox < a.wout)
             *(V *)(outb + ((size_t)oy * a.wout + ox) * COUT + cv * VEC) = *(const V *)(s_out + p * LDO + cv * VEC);
     }
+    RF_TRACE(2, 7);
 
     if constexpr (LAT) {
         // ---- fused lateral: D2[64][pixel] = Wlat[64][COUT] x out_tile; s_a (dead since the barrier above) takes the result
@@ -827,6 +852,7 @@ __global__ __launch_bounds__(kThreads, (Conv3Cfg<T, CIN, COUT, TH, TW>::OCC)) vo
     const int oy0 = ty * TH, ox0 = tx * TW;
     const int lh = L.h, lw = L.w_;
     const size_t img_pix = (size_t)img * lh * lw;
+    RF_TRACE(3, 0);
 
     constexpr int NT = COUT / 16, PT = P / 16;
     typedef WaveSplit<NT, PT> WS;
@@ -877,7 +903,9 @@ __global__ __launch_bounds__(kThreads, (Conv3Cfg<T, CIN, COUT, TH, TW>::OCC)) vo
         }
         *(V *)(s_in + pix * LDI + cv * VEC) = v;
     }
+    RF_TRACE(3, 1);
     __syncthreads();
+    RF_TRACE(3, 2);
 
     int pbase[WS::NJ];
 #pragma unroll
@@ -896,13 +924,17 @@ __global__ __launch_bounds__(kThreads, (Conv3Cfg<T, CIN, COUT, TH, TW>::OCC)) vo
         const int koff = ((tap / 3) * HC + tap % 3) * LDI + c;
         return kb < KTOT ? *(const typename M::Frag *)(s_in + pbase[j] + koff) : M::zero();
     });
+    RF_TRACE(3, 3);
     __syncthreads();      // every wave is done reading s_in before it is overwritten as s_out
+    RF_TRACE(3, 4);
 #pragma unroll
     for (int i = 0; i < WS::NI; i++)
 #pragma unroll
         for (int j = 0; j < WS::NJ; j++)
             store_acc<T, LDO>(s_out, mult[i], bias[i], acc[i][j], wn + i * WS::WN, wp + j * WS::WP, lane, true);
+    RF_TRACE(3, 5);
     __syncthreads();
+    RF_TRACE(3, 6);
 
     constexpr int OPV = COUT / VEC;
     T *out0 = L.out0, *out1 = L.out1;
@@ -917,6 +949,7 @@ __global__ __launch_bounds__(kThreads, (Conv3Cfg<T, CIN, COUT, TH, TW>::OCC)) vo
             *(V *)dst = *(const V *)(s_out + p * LDO + c);
         }
     }
+    RF_TRACE(3, 7);
 }
 
 template <typename T, int CIN, int COUT, int TH, int TW>
@@ -1337,5 +1370,17 @@ void launch_resize_area(hipStream_t s, const FrameDesc *src, uint8_t *dst, int n
     dim3 grid((net_w + 31) / 32, (net_h + 7) / 8, n);
     hipLaunchKernelGGL(resize_area_kernel, grid, dim3(kThreads), 0, s, src, dst, net_h, net_w);
 }
+
+#ifdef RF_KERNEL_TRACE
+extern "C" int rf_trace_select(int kernel_id, unsigned grid) {
+    static unsigned long long zeros[kTraceBlocks * kTraceSlots];
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_trace), zeros, sizeof(zeros));
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_trace_grid), &grid, sizeof(unsigned));
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_trace_kernel), &kernel_id, sizeof(int));
+}
+extern "C" int rf_trace_read(unsigned long long *dst, int nblocks) {
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_trace), (size_t)nblocks * kTraceSlots * sizeof(unsigned long long));
+}
+#endif
 
 }  // namespace rf

@@ -154,6 +154,29 @@ def test_postprocessing_is_exact_given_the_gpu_head_blobs(rfa, crop448, thr):
         assert 256 < len(cidx) <= 4096, len(cidx)
 
 
+@pytest.mark.parametrize("prec", [FP32, FP16])
+def test_postprocessing_against_the_reference_build_itself(rfa, crop448, prec):
+    """Same property, but the checker is the reference's OWN RetinaFace::postProcess (RetinaFace.cpp:495-574, compiled
+    unmodified into oracle/_ref by oracle/build_ref.py in the dev container; the prebuilt .so travels here): the device's
+    head blobs go into the reference's engine slots, its decode + NMS must keep the same faces in the same order."""
+    from oracle import build_ref
+    if not build_ref.available():
+        pytest.skip("oracle/_ref/libretinaface_ref.so not shipped with this snapshot")
+    det = engine(rfa, "mnet-deconv-0517", prec, (448, 448), keep_outputs=True, use_graph=False)
+    ref = build_ref.ReferenceRetinaFace(448, 448)
+    try:
+        for thr in (0.5, 0.1, 0.02, 0.004):
+            got = det.detect(crop448, thr)
+            ref.set_heads(0, [det.get_output(n) for n in build_ref.HEAD_BLOBS])
+            want = ref.postprocess(0, thr)
+            rows = np.stack([d.as_row() for d in got]) if got else np.zeros((0, 15), np.float32)
+            assert len(rows) == len(want) and len(want) > 0, (thr, len(rows), len(want))
+            assert np.array_equal(rows[:, 0], want[:, 0])
+            assert np.abs(rows - want).max() <= 1e-4
+    finally:
+        ref.close()
+
+
 INT8 = 2
 
 

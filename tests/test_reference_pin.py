@@ -1,0 +1,189 @@
+"""Pins the oracle against the REFERENCE ITSELF.
+
+Two layers, both CPU-only (they run in `-m "not gpu"`):
+  * frozen vectors  tests/golden/ref_pin.npz, minted by tools/make_ref_golden.py from the reference's own
+                    retinaface/RetinaFace.cpp compiled unmodified (oracle/build_ref.py) -- available everywhere;
+  * live            the same comparisons against oracle/_ref/libretinaface_ref.so when it is present (built in the dev
+                    container from /root/reference, travels prebuilt to the GPU box), on fresh seeds, plus the real
+                    detect() / detectBatchImages() driven end to end with the oracle's forward as the "engine".
+Everything here is bit-exact: same visiting order, same float rounding points, same libm expf.
+"""
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+from oracle import build as cbuild
+from oracle import build_ref
+from oracle import retinaface_post as post
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PIN = np.load(os.path.join(ROOT, "tests", "golden", "ref_pin.npz"))
+POST_THRESHOLDS = (0.5, 0.9, 0.1, 0.02)
+NMS_THRESHOLDS = (0.3, 0.4, 0.6)
+
+live = pytest.mark.skipif(not build_ref.available(), reason="oracle/_ref not built and /root/reference absent")
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def heads_dict(heads9):
+    return {n: np.asarray(a)[None] for n, a in zip(build_ref.HEAD_BLOBS, heads9)}
+
+
+def oracle_post(heads9, net_h, net_w, thr, nms_thr=0.4):
+    """python restatement and C restatement, which must agree with each other first"""
+    c = post.decode(heads_dict(heads9), net_h, net_w, thr)
+    py = post.nms(list(c), nms_thr)
+    rows = np.stack([d.as_row() for d in py]) if py else np.zeros((0, 15), np.float32)
+    _, _, kept, _ = cbuild.decode_nms(heads9, net_h, net_w, thr, nms_thr)
+    assert np.array_equal(rows, kept.reshape(-1, 15))
+    return rows
+
+
+def rows_to_dets(rows):
+    return [post.Detection(np.float32(r[0]), tuple(np.float32(v) for v in r[1:5]), list(r[5:10]), list(r[10:15]), i)
+            for i, r in enumerate(rows)]
+
+
+def oracle_nms(rows, thr):
+    keep = post.nms(rows_to_dets(rows), thr)
+    return np.stack([d.as_row() for d in keep]) if keep else np.zeros((0, 15), np.float32)
+
+
+# ------------------------------------------------------------------------------------------------ frozen vectors
+
+def test_pin_anchors():
+    base = post.base_anchors()
+    for lvl, s in enumerate((32, 16, 8)):
+        a = post.anchors_plane(448 // s, 448 // s, s, base[s]).reshape(-1, 4).astype(np.float32)
+        assert sha(a) == str(PIN[f"anchors448_s{s}_sha"])
+        assert np.array_equal(a.astype(np.float64).sum(axis=0), PIN[f"anchors448_s{s}_sum"])
+        assert np.array_equal(post.anchors_plane(5, 7, s, base[s]).reshape(-1, 4), PIN[f"anchors_plane_5x7_s{s}"])
+        assert sha(cbuild.anchors_plane(lvl, 448 // s, 448 // s)) == str(PIN[f"anchors448_s{s}_sha"])
+
+
+def test_pin_regression():
+    for a, r, p, box, lm in zip(PIN["reg_anchors"], PIN["reg_deltas"], PIN["reg_pts"], PIN["reg_boxes"], PIN["reg_landmarks"]):
+        assert np.array_equal(np.array(post.bbox_pred(a, r), np.float32), box)
+        # reference FacePts order x[5],y[5]; the oracle helper takes interleaved x0,y0,.. like the blob
+        inter = np.stack([p[:5], p[5:]], axis=1).reshape(-1)
+        xs, ys = post.landmark_pred(a, inter)
+        assert np.array_equal(np.array(xs + ys, np.float32), lm)
+
+
+@pytest.mark.parametrize("case", ["nms40", "nms300", "nms12ties"])
+def test_pin_nms(case):
+    rows = PIN[f"{case}_in"]
+    for t in NMS_THRESHOLDS:
+        assert np.array_equal(oracle_nms(rows, t), PIN[f"{case}_out_{t}"]), (case, t)
+
+
+@pytest.mark.parametrize("stem", ["mnet-deconv-0517", "mnet25"])
+def test_pin_postprocess_crop448(stem):
+    g = np.load(os.path.join(ROOT, "tests", "golden", f"crop448_{stem}.npz"))
+    heads = [g[n] for n in build_ref.HEAD_BLOBS]
+    for t in POST_THRESHOLDS:
+        want = PIN[f"crop448_{stem}_post_{t}"]
+        assert np.array_equal(oracle_post(heads, 448, 448, t), want), t
+    assert np.array_equal(PIN[f"crop448_{stem}_post_0.5"], g["det"])      # the oracle golden IS the reference's answer
+
+
+@pytest.mark.parametrize("case", ["dense", "sparse"])
+def test_pin_postprocess_random_heads(case):
+    heads = [PIN[f"rand_{case}_{n}"] for n in build_ref.HEAD_BLOBS]
+    sizes = []
+    for t in POST_THRESHOLDS:
+        want = PIN[f"rand_{case}_post_{t}"]
+        sizes.append(len(want))
+        assert np.array_equal(oracle_post(heads, 96, 128, t), want), t
+    assert max(sizes) > (20 if case == "dense" else 2)               # the case is not vacuous
+
+
+def test_pin_preprocess():
+    small = PIN["pre_small_frame"]
+    x = post.preprocess_trt_identity(small, 64, 96)
+    assert np.array_equal(x[0], PIN["pre_small_input"])
+    full = post.preprocess_trt_identity(PIN["pre_full_frame"], 64, 96)
+    assert sha(np.concatenate([full, x])) == str(PIN["pre_batch_input_sha"])
+
+
+# ------------------------------------------------------------------------------------------------ live reference
+
+@live
+def test_live_anchor_planes():
+    ref = build_ref.ReferenceRetinaFace(896, 1280)
+    base = post.base_anchors()
+    try:
+        for lvl, s in enumerate((32, 16, 8)):
+            assert np.array_equal(ref.anchors(s), post.anchors_plane(896 // s, 1280 // s, s, base[s]).reshape(-1, 4))
+            for h, w in ((1, 1), (3, 11), (17, 2)):
+                assert np.array_equal(ref.anchors_plane(h, w, lvl), post.anchors_plane(h, w, s, base[s]).reshape(-1, 4))
+    finally:
+        ref.close()
+
+
+@live
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_live_postprocess_random(seed):
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from make_ref_golden import random_faces, random_heads
+    rng = np.random.default_rng(seed)
+    net_h, net_w = 32 * int(rng.integers(2, 6)), 32 * int(rng.integers(2, 6))
+    ref = build_ref.ReferenceRetinaFace(net_h, net_w)
+    try:
+        heads = random_heads(rng, net_h, net_w, float(rng.choice([0.5, 0.1, 0.01])))
+        slot = int(rng.integers(0, 8))
+        ref.set_heads(slot, heads)
+        for t in (0.5, 0.2, 0.8):
+            assert np.array_equal(ref.postprocess(slot, t), oracle_post(heads, net_h, net_w, t)), t
+        faces = random_faces(rng, int(rng.integers(1, 400)), 448)
+        for t in (0.2, 0.4, 0.7):
+            assert np.array_equal(ref.nms(faces, t), oracle_nms(faces, t)), t
+        assert len(ref.nms(np.zeros((0, 15), np.float32), 0.4)) == 0
+    finally:
+        ref.close()
+
+
+@live
+def test_live_detect_end_to_end():
+    """The reference's real detect() and detectBatchImages(): its preprocess feeds the oracle's forward (standing in for
+    the absent TensorRT engine), its decode + NMS read the result; oracle.pipeline must give the same rows, bit for bit."""
+    from oracle.caffe_forward import HEAD_STRIDES, head_names
+    from oracle.caffe_io import read_rfw
+    from oracle.pipeline import OracleDetector
+    from retinaface_amd.frames import synth_frames
+
+    od = OracleDetector(read_rfw(os.path.join(ROOT, "assets", "mnet-deconv-0517.rfw")))
+    names = [n for s in HEAD_STRIDES for n in head_names(s)]
+    assert names == build_ref.HEAD_BLOBS
+
+    def forward(x):
+        outs = []
+        for i in range(x.shape[0]):
+            b = od.forward(x[i:i + 1])
+            outs.append([b[n][0] for n in names])
+        return outs
+
+    H = W = 448
+    frames = synth_frames(H, W, 3, 1)
+    frames[2] = np.ascontiguousarray(frames[2][:400, :380])          # smaller than the net: zero padded bottom/right
+    ref = build_ref.ReferenceRetinaFace(H, W, forward)
+    try:
+        for f in frames[:2]:
+            got = ref.detect(f, 0.5)
+            assert np.array_equal(ref.last_input(), post.preprocess_trt_identity(f, H, W))
+            want = od.detect(f, 0.5, 0.4, net_hw=(H, W))
+            assert len(got) > 0 and np.array_equal(got, want.rows())
+        per_image = ref.detect_batch(frames, 0.3)
+        assert ref.forward_calls == 3                                 # one engine call for the whole batch
+        x = ref.last_input()
+        for i, f in enumerate(frames):
+            assert np.array_equal(x[i:i + 1], post.preprocess_trt_identity(f, H, W))
+            assert np.array_equal(per_image[i], od.detect(f, 0.3, 0.4, net_hw=(H, W)).rows())
+    finally:
+        ref.close()
