@@ -42,7 +42,7 @@ def main() -> None:
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--profile-iters", type=int, default=50)
     ap.add_argument("--lanes", type=int, default=0, help="launches in flight (0 = engine default: 3)")
-    ap.add_argument("--coalesce", type=int, default=0, help="enqueued batches merged per launch (0 = engine default: 4)")
+    ap.add_argument("--coalesce", type=int, default=0, help="enqueued batches merged per launch (0 = engine default: 16)")
     args = ap.parse_args()
 
     import numpy as np

@@ -69,7 +69,7 @@ typedef struct rf_options {
     int32_t lanes;              /* launches that may be in flight at once (default 3): each lane owns a stream, its
                                    activation buffers and its hipGraphs */
     int32_t coalesce;           /* rf_enqueue_batch_device() batches merged into ONE launch of up to max_batch*coalesce
-                                   images (default 4; 1 = off).  A merged launch starts when it is full or when one of
+                                   images (default 16, max 32; 1 = off).  A merged launch starts when it is full or when one of
                                    its tickets is waited for.  rf_num_slots() = lanes * coalesce. */
 } rf_options;
 

@@ -101,7 +101,7 @@ public:
         if (mc < 64 || mc > 4096 || (mc & (mc - 1))) throw ArgError("max_candidates must be a power of two in [64, 4096]");
         if (opt_.max_detections < 1 || opt_.max_detections > 4096) throw ArgError("max_detections must be in [1, 4096]");
         if (opt_.lanes < 1 || opt_.lanes > 16) throw ArgError("lanes must be in [1, 16]");
-        if (opt_.coalesce < 1 || opt_.coalesce > 16) throw ArgError("coalesce must be in [1, 16]");
+        if (opt_.coalesce < 1 || opt_.coalesce > 32) throw ArgError("coalesce must be in [1, 32]");
         cap_images_ = opt_.max_batch * opt_.coalesce;
         tickets_.resize(4 * opt_.lanes * opt_.coalesce + 8);
         if (opt_.device >= 0) RF_HIP(hipSetDevice(opt_.device));

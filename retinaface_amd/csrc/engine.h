@@ -31,7 +31,9 @@ struct EngineOptions {
     int max_detections = 256;
     bool use_graph = true;
     int lanes = 3;                   // launches in flight (each lane has its own stream + buffers + graphs)
-    int coalesce = 4;                // enqueued batches merged into one launch (max_batch * coalesce images)
+    int coalesce = 16;               // enqueued batches merged into one launch (max_batch * coalesce images): the kernels are
+                                     // persistent and pipeline tile t+1's loads under tile t's compute, which pays off once
+                                     // a launch holds several tiles per resident workgroup (measured: 4 -> 16 = +8 %)
     bool keep_outputs = false;
     std::string model_stem = "mnet-deconv-0517";
 };

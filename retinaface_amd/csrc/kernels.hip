@@ -79,17 +79,21 @@ constexpr int kThreads = 256;   // 4 wavefronts
 // Phase timeline of a workgroup (probe builds only: make TRACE=1 -> libretinaface_amd_trace.so, tools/probes/phase_trace.py).
 // Wave 0 of every workgroup stamps s_memtime at each phase boundary of the kernel selected by g_trace_kernel.
 #ifdef RF_KERNEL_TRACE
+// probe build only (make trace; tools/probes/phase_trace.py): thread 0 of every workgroup stamps s_memtime at phase
+// boundaries of the launch whose tile count equals g_trace_key (tile counts identify a launch; grids are derived)
 constexpr int kTraceSlots = 12, kTraceBlocks = 8192;
 __device__ unsigned long long g_trace[kTraceBlocks * kTraceSlots];
-__device__ int g_trace_kernel = 0;        // 1 = stem, 2 = dwpw, 3 = conv3x3, 4 = head
-__device__ unsigned g_trace_grid = 0;     // only launches with this many workgroups stamp (0 = any): one launch per trace
+__device__ int g_trace_kernel = 0;        // 2 = dwpw, 3 = conv3x3
+__device__ unsigned g_trace_key = 0;      // 0 = any launch of that kernel family
+#define RF_TRACE_KEY(expr) const unsigned rf_trace_key = (unsigned)(expr)
 #define RF_TRACE(kid, slot)                                                                                  \
     do {                                                                                                     \
         if (g_trace_kernel == (kid) && threadIdx.x == 0 && blockIdx.x < kTraceBlocks &&                       \
-            (g_trace_grid == 0 || gridDim.x == g_trace_grid))                                                 \
+            (g_trace_key == 0 || rf_trace_key == g_trace_key))                                                \
             g_trace[blockIdx.x * kTraceSlots + (slot)] = __builtin_amdgcn_s_memtime();                         \
     } while (0)
 #else
+#define RF_TRACE_KEY(expr) do { } while (0)
 #define RF_TRACE(kid, slot) do { } while (0)
 #endif
 
@@ -240,6 +244,9 @@ struct GemmPipe {
     // xf(j, kc) returns the activation (B) fragment of pixel tile j for K-chunk kc
     template <typename XF> __device__ __forceinline__ void run(typename M::Acc (&acc)[NI][NJ], XF &&xf) {
         if constexpr (PIPE) {
+            Frag x[2][NJ];                 // activation fragments one K-chunk ahead of their MFMAs (see gemm_stationary)
+#pragma unroll
+            for (int j = 0; j < NJ; j++) x[0][j] = xf(j, 0);
 #pragma unroll
             for (int g = 0; g < NG; g++) {
                 if (g + 1 < NG) load(g + 1, (g + 1) & 1);
@@ -247,13 +254,14 @@ struct GemmPipe {
                 for (int c = 0; c < G; c++) {
                     const int kc = g * G + c;
                     if (kc < KCH) {
-                        Frag x[NJ];
+                        if (kc + 1 < KCH) {
 #pragma unroll
-                        for (int j = 0; j < NJ; j++) x[j] = xf(j, kc);
+                            for (int j = 0; j < NJ; j++) x[(kc + 1) & 1][j] = xf(j, kc + 1);
+                        }
 #pragma unroll
                         for (int i = 0; i < NI; i++)
 #pragma unroll
-                            for (int j = 0; j < NJ; j++) acc[i][j] = M::mma(buf[g & 1][c][i], x[j], acc[i][j]);
+                            for (int j = 0; j < NJ; j++) acc[i][j] = M::mma(buf[g & 1][c][i], x[kc & 1][j], acc[i][j]);
                     }
                 }
             }
@@ -273,6 +281,32 @@ struct GemmPipe {
         }
     }
 };
+
+// GEMM with the weight fragments resident in registers: acc[i][j] += w[i][kc] x xf(j, kc).  The activation (B) fragments are
+// read from LDS DEPTH-1 K-chunks ahead of the MFMAs that use them -- written out explicitly, because the compiler keeps
+// source order here and would otherwise expose one LDS round trip (~100+ cycles) per K-chunk against 16 cycles per MFMA.
+template <typename T, int NI, int NJ, int KCH, int DEPTH = (NJ >= 4 ? 2 : 3), typename XF>
+__device__ __forceinline__ void gemm_stationary(typename Mma<T>::Acc (&acc)[NI][NJ], const typename Mma<T>::Frag (&w)[NI][KCH], XF &&xf) {
+    typedef Mma<T> M;
+    typename M::Frag x[DEPTH][NJ];
+#pragma unroll
+    for (int d = 0; d < DEPTH - 1; d++)
+        if (d < KCH) {
+#pragma unroll
+            for (int j = 0; j < NJ; j++) x[d][j] = xf(j, d);
+        }
+#pragma unroll
+    for (int kc = 0; kc < KCH; kc++) {
+        if (kc + DEPTH - 1 < KCH) {
+#pragma unroll
+            for (int j = 0; j < NJ; j++) x[(kc + DEPTH - 1) % DEPTH][j] = xf(j, kc + DEPTH - 1);
+        }
+#pragma unroll
+        for (int i = 0; i < NI; i++)
+#pragma unroll
+            for (int j = 0; j < NJ; j++) acc[i][j] = M::mma(w[i][kc], x[kc % DEPTH][j], acc[i][j]);
+    }
+}
 
 // epilogue: y = acc * mult + bias (+ReLU), convert, 4 consecutive output channels of one pixel -> LDS tile
 // s_out[pixel][LDO].  fp16 / fp32: mult = 1 (fma(a, 1, b) = a + b exactly).  int8: acc is int32, mult[c] =
@@ -541,6 +575,7 @@ template void launch_stem<int8_t>(hipStream_t, const StemParams<int8_t> &);
 // =============================================================================================
 template <typename T, int CIN, int COUT, int STRIDE, bool HAS_DW, int TH, int TW> struct DwPwCfg {
     typedef typename DwWeight<T>::type DW;
+    typedef Mma<T> M;
     static constexpr int VEC = Vec<T>::N;
     static constexpr int P = TH * TW;
     static constexpr int HR = HAS_DW ? (TH - 1) * STRIDE + 3 : 0;
@@ -551,19 +586,32 @@ template <typename T, int CIN, int COUT, int STRIDE, bool HAS_DW, int TH, int TW
     static constexpr size_t DW_BYTES = HAS_DW ? sizeof(DW) * (size_t)(9 * CIN) : 0;
     static constexpr size_t A_BYTES = sizeof(T) * (size_t)(P * LDA);
     static constexpr size_t O_BYTES = sizeof(T) * (size_t)(P * LDO);
-    static constexpr bool ALIAS_OUT = HAS_DW && IN_BYTES + DW_BYTES >= O_BYTES;   // s_out reuses the dead halo region
-    static constexpr size_t LDS_BYTES = IN_BYTES + DW_BYTES + A_BYTES + (ALIAS_OUT ? 0 : O_BYTES);
+    // The kernel is persistent: a workgroup walks tiles t, t+G, t+2G, ... and stages tile t+G while it computes tile t,
+    // so the halo region is live during the whole tile and s_out cannot reuse it.
+    static constexpr size_t LDS_BYTES = IN_BYTES + DW_BYTES + A_BYTES + O_BYTES;
     static_assert(P % 16 == 0 && CIN % VEC == 0 && COUT % 16 == 0, "bad tile");
     static_assert(kThreads % (CIN / VEC) == 0, "a thread must keep one channel group across its depthwise items");
     static_assert(IN_BYTES % 16 == 0 && DW_BYTES % 16 == 0 && A_BYTES % 16 == 0, "LDS carve must stay 16-byte aligned");
-    // These kernels are latency chains (load -> stencil -> GEMM -> store) hidden only by other resident workgroups, and
-    // their time is (grid / resident workgroups) rounds x chain latency.  The big-map layers (CIN <= 64: thousands of
-    // workgroups per launch) are therefore compiled for as many workgroups per CU as LDS allows (1 wave per SIMD each)
-    // with a shallow weight prefetch; the small-map layers (<= 1 round) keep the deep prefetch instead.
+    // GEMM split and weight residency.  fp16 / int8: the wave's whole share of the pointwise matrix (NI x KCH MFMA
+    // A-fragments, 4 VGPRs each) is loaded ONCE per workgroup and stays in registers for every tile it walks
+    // ("weights stationary"), so the tile loop has no global load except the prefetch of the next tile -- nothing the
+    // in-order vmcnt would make that prefetch wait behind.  Only when the share is too big for the register file
+    // (256x256) do the fragments stream from L2 per tile through GemmPipe.  fp32 (parity engine): always streamed.
+    static constexpr int NT = COUT / 16, PT = P / 16;
+    typedef WaveSplit<NT, PT> WS;
+    static constexpr int KCH = (CIN + M::K - 1) / M::K;
+    static constexpr bool STAT = sizeof(T) <= 2 && WS::NI * KCH <= 16;
+    // in flight per thread while a tile is computed: the next tile's halo, 16 B per register group
+    static constexpr int STAGE_ITEMS = HAS_DW ? HR * HC * (CIN / VEC) : P * (CIN / VEC);
+    static constexpr int NPF = (STAGE_ITEMS + kThreads - 1) / kThreads;
+    // Time = (tiles / resident workgroups) x per-tile chain, so the big-map layers (CIN <= 64: thousands of tiles per
+    // launch) are compiled for as many workgroups per CU as LDS allows; the small-map layers let the compiler take the
+    // registers it wants (weights stationary + deep accumulators).
     static constexpr int LDS_OCC = (int)(160 * 1024 / LDS_BYTES) > 8 ? 8 : (int)(160 * 1024 / LDS_BYTES);
     static constexpr bool BIG_MAP = CIN <= 64 && HAS_DW && sizeof(T) <= 2;
-    static constexpr int OCC = BIG_MAP ? (LDS_OCC < 1 ? 1 : LDS_OCC) : 1;
-    static constexpr int GFRAGS = BIG_MAP ? 4 : 12;
+    static constexpr int OCC_CAP = sizeof(T) == 1 ? (CIN >= 64 ? 3 : 4) : (CIN >= 64 ? 4 : 5);   // 170 / 128 / 102 VGPRs: the largest budgets that compile without spills
+    static constexpr int OCC = BIG_MAP ? (LDS_OCC < 1 ? 1 : (LDS_OCC > OCC_CAP ? OCC_CAP : LDS_OCC)) : 1;
+    static constexpr int GFRAGS = 12;                      // streamed case only
 };
 
 template <typename T>
@@ -571,7 +619,7 @@ struct DwPwArgs {
     const T *in; T *out; const typename DwWeight<T>::type *dw_w; const float *dw_b; const T *pw_w; const float *pw_b;
     const T *lat_w; const float *lat_b; T *lat_out;
     const float *pw_m, *lat_m;        // int8: per-output-channel requantisation multipliers (nullptr otherwise)
-    int hin, win, hout, wout, tiles_x, tiles_y, nblk;
+    int hin, win, hout, wout, tiles_x, tiles_y, nblk;     // nblk = tiles in the launch (the grid may be smaller)
 };
 
 template <typename T, int CIN, int COUT, int STRIDE, bool HAS_DW, int TH, int TW, bool LAT>
@@ -579,32 +627,36 @@ __global__ __launch_bounds__(kThreads, (DwPwCfg<T, CIN, COUT, STRIDE, HAS_DW, TH
     typedef DwPwCfg<T, CIN, COUT, STRIDE, HAS_DW, TH, TW> C;
     typedef typename Vec<T>::type V;
     typedef Mma<T> M;
-    constexpr int VEC = C::VEC, P = C::P, HC = C::HC, HR = C::HR, LDA = C::LDA, LDO = C::LDO;
-    constexpr int CPV = CIN / VEC;
+    typedef typename M::Frag Frag;
+    typedef typename C::WS WS;
+    constexpr int VEC = C::VEC, P = C::P, HC = C::HC, LDA = C::LDA, LDO = C::LDO;
+    constexpr int CPV = CIN / VEC, PT = C::PT, KCH = C::KCH, NPF = C::NPF;
+    constexpr bool STAT = C::STAT;
     typedef typename C::DW DW;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     T *s_in = (T *)smem;
     DW *s_dw = (DW *)(smem + C::IN_BYTES);
     T *s_a = (T *)(smem + C::IN_BYTES + C::DW_BYTES);
-    T *s_out = C::ALIAS_OUT ? s_in : (T *)(smem + C::IN_BYTES + C::DW_BYTES + C::A_BYTES);
+    T *s_out = (T *)(smem + C::IN_BYTES + C::DW_BYTES + C::A_BYTES);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
-    const int bid = xcd_remap(blockIdx.x, a.nblk);
-    const int tx = bid % a.tiles_x;
-    const int ty = (bid / a.tiles_x) % a.tiles_y;
-    const int img = bid / (a.tiles_x * a.tiles_y);
-    const int oy0 = ty * TH, ox0 = tx * TW;
-    const T *inb = a.in + (size_t)img * a.hin * a.win * CIN;
+    const int G = gridDim.x;
+    const int first = xcd_remap(blockIdx.x, G);
+    const int tiles_per_img = a.tiles_x * a.tiles_y;
+    RF_TRACE_KEY(a.nblk);
     RF_TRACE(2, 0);
 
-    // ---- phase 0: everything that only depends on kernel arguments is requested first
-    constexpr int NT = COUT / 16, PT = P / 16;
-    typedef WaveSplit<NT, PT> WS;
-    constexpr int KCH = (CIN + M::K - 1) / M::K;
+    // ---- once per workgroup: weights, biases, depthwise taps
     const int wn = wave % WS::WN, wp = wave / WS::WN;
-    GemmPipe<T, WS::NI, WS::NJ, KCH, WS::WN, C::GFRAGS> pipe;
-    pipe.init(a.pw_w, wn, lane);
+    Frag wst[STAT ? WS::NI : 1][STAT ? KCH : 1];
+    if constexpr (STAT) {
+        const Frag *wsrc = (const Frag *)a.pw_w + (size_t)wn * KCH * 64 + lane;
+#pragma unroll
+        for (int i = 0; i < WS::NI; i++)
+#pragma unroll
+            for (int kc = 0; kc < KCH; kc++) wst[i][kc] = wsrc[((i * WS::WN) * KCH + kc) * 64];
+    }
     f32x4 pw_bias[WS::NI], pw_mult[WS::NI];
 #pragma unroll
     for (int i = 0; i < WS::NI; i++) {
@@ -613,10 +665,15 @@ __global__ __launch_bounds__(kThreads, (DwPwCfg<T, CIN, COUT, STRIDE, HAS_DW, TH
     }
     // lateral: 64 output channels = 4 tiles, one per wave, all pixel tiles
     constexpr int LKCH = (COUT + M::K - 1) / M::K;
-    GemmPipe<T, 1, PT, LAT ? LKCH : 1, 4, C::GFRAGS> lpipe;
+    constexpr bool LSTAT = LAT && sizeof(T) <= 2 && LKCH <= 8;
+    Frag lst[1][LSTAT ? LKCH : 1];
     f32x4 lat_bias = vzero<f32x4, 4>(), lat_mult = vzero<f32x4, 4>();
     if constexpr (LAT) {
-        lpipe.init(a.lat_w, wave, lane);
+        if constexpr (LSTAT) {
+            const Frag *lsrc = (const Frag *)a.lat_w + (size_t)wave * LKCH * 64 + lane;
+#pragma unroll
+            for (int kc = 0; kc < LKCH; kc++) lst[0][kc] = lsrc[kc * 64];
+        }
         lat_bias = *(const f32x4 *)(a.lat_b + acc_cout(wave, lane, 0));
         lat_mult = load_mult(a.lat_m, acc_cout(wave, lane, 0));
     }
@@ -624,122 +681,215 @@ __global__ __launch_bounds__(kThreads, (DwPwCfg<T, CIN, COUT, STRIDE, HAS_DW, TH
     if constexpr (HAS_DW) {
 #pragma unroll
         for (int e = 0; e < VEC; e++) dw_bias[e] = a.dw_b[(tid % CPV) * VEC + e];
+        for (int i = tid; i < 9 * CIN * (int)sizeof(DW) / 16; i += kThreads)
+            ((f32x4 *)s_dw)[i] = ((const f32x4 *)a.dw_w)[i];          // visible after the first barrier below
     }
 
-    if constexpr (HAS_DW) {
-        const int iy0 = oy0 * STRIDE - 1, ix0 = ox0 * STRIDE - 1;
-        for (int i = tid; i < HR * HC * CPV; i += kThreads) {
-            int pix = i / CPV, cv = i % CPV;
-            int iy = iy0 + pix / HC, ix = ix0 + pix % HC;
-            V v = vzero<V, VEC>();
-            if (iy >= 0 && iy < a.hin && ix >= 0 && ix < a.win)
-                v = *(const V *)(inb + ((size_t)iy * a.win + ix) * CIN + cv * VEC);
-            *(V *)(s_in + pix * CIN + cv * VEC) = v;
+    // ---- the halo (or, without a depthwise stage, the tile itself) of tile t -> registers.  The loads are unconditional
+    // (clamped addresses) and the zero padding is applied when the registers are written to LDS: no branch around a
+    // load, so the compiler's vmcnt bookkeeping inside the tile loop stays exact.
+    V pre[NPF];
+    unsigned pre_ok = 0;
+    auto fetch = [&](int t) {
+        const int tx = t % a.tiles_x, ty = (t / a.tiles_x) % a.tiles_y, img = t / tiles_per_img;
+        const T *inb = a.in + (size_t)img * a.hin * a.win * CIN;
+        const int iy0 = HAS_DW ? ty * TH * STRIDE - 1 : ty * TH, ix0 = HAS_DW ? tx * TW * STRIDE - 1 : tx * TW;
+        pre_ok = 0;
+#pragma unroll
+        for (int k = 0; k < NPF; k++) {
+            int i = tid + k * kThreads;
+            i = i < C::STAGE_ITEMS ? i : C::STAGE_ITEMS - 1;
+            const int pix = i / CPV, cv = i % CPV;
+            const int iy = iy0 + (HAS_DW ? pix / HC : pix / TW), ix = ix0 + (HAS_DW ? pix % HC : pix % TW);
+            const bool ok = iy >= 0 && iy < a.hin && ix >= 0 && ix < a.win;
+            const int cy = iy < 0 ? 0 : (iy >= a.hin ? a.hin - 1 : iy), cx = ix < 0 ? 0 : (ix >= a.win ? a.win - 1 : ix);
+            pre[k] = *(const V *)(inb + ((size_t)cy * a.win + cx) * CIN + cv * VEC);
+            pre_ok |= (ok ? 1u : 0u) << k;
         }
-        for (int i = tid; i < 9 * CIN * (int)sizeof(DW) / 16; i += kThreads)
-            ((f32x4 *)s_dw)[i] = ((const f32x4 *)a.dw_w)[i];
+    };
+    // ---- tile (img, oy0, ox0), finished in LDS, -> HBM: 16 B per lane, fully coalesced NHWC rows
+    auto store_tile = [&](int img, int oy0, int ox0) {
+        constexpr int OPV = COUT / VEC;
+        T *outb = a.out + (size_t)img * a.hout * a.wout * COUT;
+        for (int i = tid; i < P * OPV; i += kThreads) {
+            int p = i / OPV, cv = i % OPV;
+            int oy = oy0 + p / TW, ox = ox0 + p % TW;
+            if (oy < a.hout && ox < a.wout)
+                *(V *)(outb + ((size_t)oy * a.wout + ox) * COUT + cv * VEC) = *(const V *)(s_out + p * LDO + cv * VEC);
+        }
+        if constexpr (LAT) {
+            constexpr int LDL = 64 + VEC, LPV = 64 / VEC;
+            T *latb = a.lat_out + (size_t)img * a.hout * a.wout * 64;
+            for (int i = tid; i < P * LPV; i += kThreads) {
+                int p = i / LPV, cv = i % LPV;
+                int oy = oy0 + p / TW, ox = ox0 + p % TW;
+                if (oy < a.hout && ox < a.wout)
+                    *(V *)(latb + ((size_t)oy * a.wout + ox) * 64 + cv * VEC) = *(const V *)(s_a + p * LDL + cv * VEC);
+            }
+        }
+    };
+    if (first < a.nblk) fetch(first);
+    // every once-per-workgroup load has landed before the loop: inside it the only loads in flight are the prefetch
+    __builtin_amdgcn_s_waitcnt(0x0F70);       // vmcnt(0), expcnt / lgkmcnt untouched
+
+    // The tile loop is software pipelined around the memory round trips:
+    //   stage(t): registers -> LDS | fetch(t+G) issued | store(t-1): LDS -> HBM | barrier | stencil | GEMM | epilogue
+    // so tile t's compute covers both the flight of tile t+G's loads and the acknowledgement of tile t-1's stores.
+    int p_img = -1, p_oy0 = 0, p_ox0 = 0;
+    for (int t = first; t < a.nblk; t += G) {
+        const int tx = t % a.tiles_x, ty = (t / a.tiles_x) % a.tiles_y, img = t / tiles_per_img;
+        RF_TRACE(2, 8);
+
+        // ---- phase 1: staged registers -> LDS (zero padding here), previous tile -> HBM
+#pragma unroll
+        for (int k = 0; k < NPF; k++) {
+            const int i = tid + k * kThreads;
+            if (i < C::STAGE_ITEMS) {
+                const V v = (pre_ok >> k) & 1u ? pre[k] : vzero<V, VEC>();
+                if constexpr (HAS_DW) *(V *)(s_in + (i / CPV) * CIN + (i % CPV) * VEC) = v;
+                else *(V *)(s_a + (i / CPV) * LDA + (i % CPV) * VEC) = v;
+            }
+        }
+        RF_TRACE(2, 9);
+        // the next tile's loads are issued before the previous tile's stores: on the in-order vmcnt the stores are then
+        // younger than the loads, and by the time the loads are waited for (one tile of compute later) both have landed
+        if (t + G < a.nblk) fetch(t + G);
+        RF_TRACE(2, 10);
+        if (p_img >= 0) store_tile(p_img, p_oy0, p_ox0);
+        p_img = img; p_oy0 = ty * TH; p_ox0 = tx * TW;
         RF_TRACE(2, 1);
         __syncthreads();
         RF_TRACE(2, 2);
-        const int cv = tid % CPV;                 // kThreads % CPV == 0: the channel group is fixed per thread
-        for (int i = tid; i < P * CPV; i += kThreads) {
-            int p = i / CPV;
-            int py = p / TW, px = p % TW;
-            float acc[VEC];
+
+        if constexpr (HAS_DW) {
+            // ---- phase 2: depthwise stencil
+            const int cv = tid % CPV;                 // kThreads % CPV == 0: the channel group is fixed per thread
+            for (int i = tid; i < P * CPV; i += kThreads) {
+                int p = i / CPV;
+                int py = p / TW, px = p % TW;
+                float acc[VEC];
 #pragma unroll
-            for (int e = 0; e < VEC; e++) acc[e] = dw_bias[e];
+                for (int e = 0; e < VEC; e++) acc[e] = dw_bias[e];
+                V xs[9];               // all nine taps requested before the first is used: one LDS round trip, not nine
 #pragma unroll
-            for (int ky = 0; ky < 3; ky++)
+                for (int k9 = 0; k9 < 9; k9++)
+                    xs[k9] = *(const V *)(s_in + ((py * STRIDE + k9 / 3) * HC + px * STRIDE + k9 % 3) * CIN + cv * VEC);
 #pragma unroll
-                for (int kx = 0; kx < 3; kx++) {
-                    V x = *(const V *)(s_in + ((py * STRIDE + ky) * HC + px * STRIDE + kx) * CIN + cv * VEC);
-                    const DW *wv = s_dw + (ky * 3 + kx) * CIN + cv * VEC;
+                for (int k9 = 0; k9 < 9; k9++) {
+                    const DW *wv = s_dw + k9 * CIN + cv * VEC;
 #pragma unroll
-                    for (int e = 0; e < VEC; e++) acc[e] = fmaf((float)x[e], (float)wv[e], acc[e]);
+                    for (int e = 0; e < VEC; e++) acc[e] = fmaf((float)xs[k9][e], (float)wv[e], acc[e]);
                 }
-            V r;
+                V r;
 #pragma unroll
-            for (int e = 0; e < VEC; e++) r[e] = to_T<T>(fmaxf(acc[e], 0.f));
-            *(V *)(s_a + p * LDA + cv * VEC) = r;
+                for (int e = 0; e < VEC; e++) r[e] = to_T<T>(fmaxf(acc[e], 0.f));
+                *(V *)(s_a + p * LDA + cv * VEC) = r;
+            }
+            RF_TRACE(2, 3);
+            __syncthreads();
+            RF_TRACE(2, 4);
         }
-    } else {
-        for (int i = tid; i < P * CPV; i += kThreads) {
-            int p = i / CPV, cv = i % CPV;
-            int oy = oy0 + p / TW, ox = ox0 + p % TW;
-            V v = vzero<V, VEC>();
-            if (oy < a.hin && ox < a.win) v = *(const V *)(inb + ((size_t)oy * a.win + ox) * CIN + cv * VEC);
-            *(V *)(s_a + p * LDA + cv * VEC) = v;
-        }
-    }
-    RF_TRACE(2, 3);
-    __syncthreads();
-    RF_TRACE(2, 4);
 
-    // ---- pointwise GEMM: D[cout][pixel], K = CIN
-    typename M::Acc acc[WS::NI][WS::NJ];
+        // ---- phase 3: pointwise GEMM  D[cout][pixel], K = CIN
+        typename M::Acc acc[WS::NI][WS::NJ];
 #pragma unroll
-    for (int i = 0; i < WS::NI; i++)
+        for (int i = 0; i < WS::NI; i++)
 #pragma unroll
-        for (int j = 0; j < WS::NJ; j++) acc[i][j] = vzero<typename M::Acc, 4>();
-    pipe.run(acc, [&](int j, int kc) -> typename M::Frag {
-        const int kb = kc * M::K + (lane >> 4) * M::KPL;
-        const int p = acc_pixel(wp + j * WS::WP, lane);
-        return kb < CIN ? *(const typename M::Frag *)(s_a + p * LDA + kb) : M::zero();
-    });
-#pragma unroll
-    for (int i = 0; i < WS::NI; i++)
-#pragma unroll
-        for (int j = 0; j < WS::NJ; j++)
-            store_acc<T, LDO>(s_out, pw_mult[i], pw_bias[i], acc[i][j], wn + i * WS::WN, wp + j * WS::WP, lane, true);
-    RF_TRACE(2, 5);
-    __syncthreads();
-    RF_TRACE(2, 6);
-
-    constexpr int OPV = COUT / VEC;
-    T *outb = a.out + (size_t)img * a.hout * a.wout * COUT;
-    for (int i = tid; i < P * OPV; i += kThreads) {
-        int p = i / OPV, cv = i % OPV;
-        int oy = oy0 + p / TW, ox = ox0 + p % TW;
-        if (oy < a.hout && ox < a.wout)
-            *(V *)(outb + ((size_t)oy * a.wout + ox) * COUT + cv * VEC) = *(const V *)(s_out + p * LDO + cv * VEC);
-    }
-    RF_TRACE(2, 7);
-
-    if constexpr (LAT) {
-        // ---- fused lateral: D2[64][pixel] = Wlat[64][COUT] x out_tile; s_a (dead since the barrier above) takes the result
-        static_assert(LDA >= 64 + VEC, "lateral result tile must fit the depthwise tile");
-        constexpr int LDL = 64 + VEC;
-        T *s_lat = s_a;
-        typename M::Acc acc2[1][PT];
-#pragma unroll
-        for (int j = 0; j < PT; j++) acc2[0][j] = vzero<typename M::Acc, 4>();
-        lpipe.run(acc2, [&](int j, int kc) -> typename M::Frag {
+            for (int j = 0; j < WS::NJ; j++) acc[i][j] = vzero<typename M::Acc, 4>();
+        auto xf = [&](int j, int kc) -> Frag {
             const int kb = kc * M::K + (lane >> 4) * M::KPL;
-            return *(const typename M::Frag *)(s_out + acc_pixel(j, lane) * LDO + kb);
-        });
-#pragma unroll
-        for (int j = 0; j < PT; j++) store_acc<T, LDL>(s_lat, lat_mult, lat_bias, acc2[0][j], wave, j, lane, true);
-        __syncthreads();
-        constexpr int LPV = 64 / VEC;
-        T *latb = a.lat_out + (size_t)img * a.hout * a.wout * 64;
-        for (int i = tid; i < P * LPV; i += kThreads) {
-            int p = i / LPV, cv = i % LPV;
-            int oy = oy0 + p / TW, ox = ox0 + p % TW;
-            if (oy < a.hout && ox < a.wout)
-                *(V *)(latb + ((size_t)oy * a.wout + ox) * 64 + cv * VEC) = *(const V *)(s_lat + p * LDL + cv * VEC);
+            const int p = acc_pixel(wp + j * WS::WP, lane);
+            return kb < CIN ? *(const Frag *)(s_a + p * LDA + kb) : M::zero();
+        };
+        if constexpr (STAT) {
+            gemm_stationary<T, WS::NI, WS::NJ, KCH>(acc, wst, xf);
+        } else {
+            GemmPipe<T, WS::NI, WS::NJ, KCH, WS::WN, C::GFRAGS> pipe;
+            pipe.init(a.pw_w, wn, lane);
+            pipe.run(acc, xf);
         }
+        // ---- phase 4: bias + ReLU -> LDS (stored to HBM while the next tile is staged)
+#pragma unroll
+        for (int i = 0; i < WS::NI; i++)
+#pragma unroll
+            for (int j = 0; j < WS::NJ; j++)
+                store_acc<T, LDO>(s_out, pw_mult[i], pw_bias[i], acc[i][j], wn + i * WS::WN, wp + j * WS::WP, lane, true);
+        RF_TRACE(2, 5);
+        __syncthreads();
+        RF_TRACE(2, 6);
+
+        if constexpr (LAT) {
+            // ---- phase 5: fused lateral  D2[64][pixel] = Wlat[64][COUT] x out_tile; s_a (dead since the barrier above)
+            // takes the result and is read by store_tile before the next tile's first barrier, written again after it
+            static_assert(LDA >= 64 + VEC, "lateral result tile must fit the depthwise tile");
+            constexpr int LDL = 64 + VEC;
+            typename M::Acc acc2[1][PT];
+#pragma unroll
+            for (int j = 0; j < PT; j++) acc2[0][j] = vzero<typename M::Acc, 4>();
+            auto lf = [&](int j, int kc) -> Frag {
+                const int kb = kc * M::K + (lane >> 4) * M::KPL;
+                return *(const Frag *)(s_out + acc_pixel(j, lane) * LDO + kb);
+            };
+            if constexpr (LSTAT) {
+                gemm_stationary<T, 1, PT, LKCH>(acc2, lst, lf);
+            } else {
+                GemmPipe<T, 1, PT, LKCH, 4, C::GFRAGS> lpipe;
+                lpipe.init(a.lat_w, wave, lane);
+                lpipe.run(acc2, lf);
+            }
+#pragma unroll
+            for (int j = 0; j < PT; j++) store_acc<T, LDL>(s_a, lat_mult, lat_bias, acc2[0][j], wave, j, lane, true);
+            __syncthreads();
+        }
+        RF_TRACE(2, 7);
     }
+    if (p_img >= 0) store_tile(p_img, p_oy0, p_ox0);
+}
+
+// Persistent grid: as many workgroups as the chip keeps resident (CUs x RESIDENT), trimmed so every workgroup walks the
+// same number of tiles (no nearly-empty last round).  Launches with fewer tiles than that get one tile per workgroup.
+static int g_num_cus = 0;
+static int num_cus() {
+    if (!g_num_cus) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 256;
+        g_num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    return g_num_cus;
+}
+// Below `min_rounds` x resident tiles the hardware dispatcher's dynamic one-tile-per-workgroup schedule is at least as
+// good as walking two tiles in sequence, so the grid stays one workgroup per tile.
+static float persist_min_rounds() {
+    static float v = -1.f;
+    if (v < 0.f) {
+        const char *e = getenv("RF_PERSIST_MIN_ROUNDS");      // probe knob (tools/probes), default measured on MI355X
+        v = e ? (float)atof(e) : 1.0f;
+    }
+    return v;
+}
+static int persistent_grid(int tiles, int resident_per_cu) {
+    const int resident = num_cus() * (resident_per_cu > 0 ? resident_per_cu : 1);
+    if ((float)tiles <= persist_min_rounds() * (float)resident) return tiles;
+    const int rounds = (tiles + resident - 1) / resident;
+    return (tiles + rounds - 1) / rounds;
+}
+template <typename F> static int resident_per_cu(F kern, size_t lds_bytes) {
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)kern, kThreads, lds_bytes) != hipSuccess || nb < 1) nb = 1;
+    return nb;
 }
 
 template <typename T, int CIN, int COUT, int STRIDE, bool HAS_DW, int TH, int TW, bool LAT>
 static void dwpw_launch(hipStream_t s, const DwPwParams<T> *p, int tiles_x, int tiles_y) {
     typedef DwPwCfg<T, CIN, COUT, STRIDE, HAS_DW, TH, TW> C;
     auto kern = dwpw_kernel<T, CIN, COUT, STRIDE, HAS_DW, TH, TW, LAT>;
-    static bool attr_set = false;
-    if (!attr_set) { set_max_lds(kern, C::LDS_BYTES); attr_set = true; }
+    static int resident = 0;
+    if (!resident) { set_max_lds(kern, C::LDS_BYTES); resident = resident_per_cu(kern, C::LDS_BYTES); }
     DwPwArgs<T> a{p->in, p->out, p->dw_w, p->dw_b, p->pw_w, p->pw_b, p->lat_w, p->lat_b, p->lat_out, p->pw_m, p->lat_m,
                   p->hin, p->win, p->hout, p->wout, tiles_x, tiles_y, p->n * tiles_x * tiles_y};
-    hipLaunchKernelGGL(kern, dim3(a.nblk), dim3(kThreads), C::LDS_BYTES, s, a);
+    const int grid = sizeof(T) <= 2 ? persistent_grid(a.nblk, resident) : a.nblk;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), C::LDS_BYTES, s, a);
 }
 
 template <typename T, int CIN, int COUT, int STRIDE, bool HAS_DW, int TH, int TW>
@@ -805,28 +955,44 @@ template TileInfo dwpw_tile_info<int8_t>(int, int, int, bool, int, int);
 //   strides 32, 16 and 8 is 3 launches, not 9.
 // =============================================================================================
 template <typename T, int CIN, int COUT, int TH, int TW> struct Conv3Cfg {
+    typedef Mma<T> M;
     static constexpr int VEC = Vec<T>::N;
     static constexpr int P = TH * TW;
     static constexpr int HR = TH + 2, HC = TW + 2;
     static constexpr int LDI = CIN + VEC;
     static constexpr int LDO = COUT + VEC;
-    static constexpr int IN_ELEMS = HR * HC * LDI;
-    static constexpr int O_ELEMS = P * LDO;
-    static constexpr size_t LDS_BYTES = sizeof(T) * (size_t)(IN_ELEMS > O_ELEMS ? IN_ELEMS : O_ELEMS);
-    static constexpr int OCC = sizeof(T) <= 2 ? 6 : 1;          // see DwPwCfg: rounds x chain latency
-    static constexpr int GFRAGS = sizeof(T) <= 2 ? 4 : 12;
+    static constexpr size_t IN_BYTES = sizeof(T) * (size_t)(HR * HC * LDI);
+    static constexpr size_t O_BYTES = sizeof(T) * (size_t)(P * LDO);
+    // persistent + software pipelined like K_b: tile t+G is staged while tile t's result is still being stored, so the
+    // halo tile and the result tile are separate LDS regions (and the GEMM -> epilogue barrier disappears)
+    static constexpr size_t LDS_BYTES = IN_BYTES + O_BYTES;
+    static_assert(IN_BYTES % 16 == 0, "LDS carve must stay 16-byte aligned");
+    // wave split: output-channel tiles first.  3 channel tiles (the merged 64->48 SSH conv) run on 3 of the 4 waves: each
+    // keeps one tile's whole weight share in registers; the 4th wave only stages and stores.
+    static constexpr int NT = COUT / 16, PT = P / 16;
+    static constexpr bool ODD = NT == 3;
+    typedef WaveSplit<ODD ? 4 : NT, PT> WS;
+    static constexpr int WN = ODD ? 3 : WS::WN, WP = ODD ? 1 : WS::WP, NI = ODD ? 1 : WS::NI, NJ = ODD ? PT : WS::NJ;
+    static constexpr int KTOT = 9 * CIN;
+    static constexpr int KCH = (KTOT + M::K - 1) / M::K;
+    static constexpr bool STAT = sizeof(T) <= 2 && NI * KCH <= 18;          // weights stationary in registers (see DwPwCfg)
+    static constexpr int STAGE_ITEMS = HR * HC * (CIN / VEC);
+    static constexpr int NPF = (STAGE_ITEMS + kThreads - 1) / kThreads;
+    static constexpr int OCC = sizeof(T) <= 2 ? (CIN >= 64 ? 3 : 5) : 1;    // 64-channel input: 72 weight VGPRs -> 170-VGPR budget; else 102
+    static constexpr int GFRAGS = 12;                                      // streamed case only
 };
 
 template <typename T>
 struct Conv3Level {
     const T *in; const T *up; const T *w; const float *b; const float *m; T *out0; T *out1;
-    int in_ld, in_off, ld0, off0, n0, ld1, off1, h, w_, tiles_x, tiles_y, blk_begin;
+    int in_ld, in_off, ld0, off0, n0, ld1, off1, h, w_, tiles_x, tiles_y;
+    int ntiles;             // tiles of this level in the launch
+    int gb_begin, gsz;      // the level's share of the grid: workgroups [gb_begin, gb_begin + gsz) walk its tiles
     float a_lat, a_up;      // UPADD: staged value = to_T(lat * a_lat + upsample * a_up); 1, 1 unless int8 (scale ratios)
 };
 template <typename T>
 struct Conv3Args {
     Conv3Level<T> lv[3];
-    int nblk;
 };
 
 template <typename T, int CIN, int COUT, int TH, int TW, bool UPADD>
@@ -834,122 +1000,204 @@ __global__ __launch_bounds__(kThreads, (Conv3Cfg<T, CIN, COUT, TH, TW>::OCC)) vo
     typedef Conv3Cfg<T, CIN, COUT, TH, TW> C;
     typedef typename Vec<T>::type V;
     typedef Mma<T> M;
-    constexpr int VEC = C::VEC, P = C::P, HC = C::HC, HR = C::HR, LDI = C::LDI, LDO = C::LDO;
-    constexpr int CPV = CIN / VEC;
+    typedef typename M::Frag Frag;
+    constexpr int VEC = C::VEC, P = C::P, HC = C::HC, LDI = C::LDI, LDO = C::LDO;
+    constexpr int CPV = CIN / VEC, KTOT = C::KTOT, KCH = C::KCH, NPF = C::NPF;
+    constexpr int WN = C::WN, WP = C::WP, NI = C::NI, NJ = C::NJ;
+    constexpr bool STAT = C::STAT;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     T *s_in = (T *)smem;
-    T *s_out = (T *)smem;     // reused after the GEMM (barrier in between)
+    T *s_out = (T *)(smem + C::IN_BYTES);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
-    const int gbid = xcd_remap(blockIdx.x, a.nblk);
-    const int lvl = (gbid >= a.lv[1].blk_begin ? 1 : 0) + (gbid >= a.lv[2].blk_begin ? 1 : 0);
+    const int gbid = xcd_remap(blockIdx.x, gridDim.x);
+    const int lvl = (gbid >= a.lv[1].gb_begin ? 1 : 0) + (gbid >= a.lv[2].gb_begin ? 1 : 0);
     const Conv3Level<T> &L = a.lv[lvl];
-    const int bid = gbid - L.blk_begin;
-    const int tx = bid % L.tiles_x;
-    const int ty = (bid / L.tiles_x) % L.tiles_y;
-    const int img = bid / (L.tiles_x * L.tiles_y);
-    const int oy0 = ty * TH, ox0 = tx * TW;
+    const int first = gbid - L.gb_begin, G = L.gsz, ntiles = L.ntiles;
+    const int tiles_x = L.tiles_x, tiles_per_img = L.tiles_x * L.tiles_y;
     const int lh = L.h, lw = L.w_;
-    const size_t img_pix = (size_t)img * lh * lw;
+    RF_TRACE_KEY(a.lv[0].ntiles);
     RF_TRACE(3, 0);
 
-    constexpr int NT = COUT / 16, PT = P / 16;
-    typedef WaveSplit<NT, PT> WS;
-    constexpr int KTOT = 9 * CIN;
-    constexpr int KCH = (KTOT + M::K - 1) / M::K;
-    const int wn = wave % WS::WN, wp = wave / WS::WN;
-    GemmPipe<T, WS::NI, WS::NJ, KCH, WS::WN, C::GFRAGS> pipe;
-    pipe.init(L.w, wn, lane);
-    f32x4 bias[WS::NI], mult[WS::NI];
+    // ---- once per workgroup: this wave's weight share and biases
+    const int wn = C::ODD ? wave : wave % WN, wp = C::ODD ? 0 : wave / WN;
+    const bool gemm_wave = !C::ODD || wave < 3;
+    const int wnc = gemm_wave ? wn : 0;            // the idle wave reads tile 0's constants and never uses them
+    Frag wst[STAT ? NI : 1][STAT ? KCH : 1];
+    if constexpr (STAT) {
+        const Frag *wsrc = (const Frag *)L.w + (size_t)wnc * KCH * 64 + lane;
 #pragma unroll
-    for (int i = 0; i < WS::NI; i++) {
-        bias[i] = *(const f32x4 *)(L.b + acc_cout(wn + i * WS::WN, lane, 0));
-        mult[i] = load_mult(L.m, acc_cout(wn + i * WS::WN, lane, 0));
+        for (int i = 0; i < NI; i++)
+#pragma unroll
+            for (int kc = 0; kc < KCH; kc++) wst[i][kc] = wsrc[((i * WN) * KCH + kc) * 64];
+    }
+    f32x4 bias[NI], mult[NI];
+#pragma unroll
+    for (int i = 0; i < NI; i++) {
+        bias[i] = *(const f32x4 *)(L.b + acc_cout(wnc + i * WN, lane, 0));
+        mult[i] = load_mult(L.m, acc_cout(wnc + i * WN, lane, 0));
     }
     const float a_lat = L.a_lat, a_up = L.a_up;
-
     const T *in = L.in;
     const int in_ld = L.in_ld, in_off = L.in_off;
-    for (int i = tid; i < HR * HC * CPV; i += kThreads) {
-        int pix = i / CPV, cv = i % CPV;
-        int iy = oy0 - 1 + pix / HC, ix = ox0 - 1 + pix % HC;
-        V v = vzero<V, VEC>();
-        if (iy >= 0 && iy < lh && ix >= 0 && ix < lw) {
-            v = *(const V *)(in + (img_pix + (size_t)iy * lw + ix) * in_ld + in_off + cv * VEC);
+
+    // ---- halo tile of tile t -> registers: unconditional loads from clamped addresses, padding applied when staged
+    V pre[NPF];
+    V upv[UPADD ? NPF : 1][4];
+    unsigned pre_ok = 0;          // bit 5k: pixel inside the map; bits 5k+1..5k+4: upsample taps inside the coarse map
+    auto fetch = [&](int t) {
+        const int tx = t % tiles_x, ty = (t / tiles_x) % L.tiles_y, img = t / tiles_per_img;
+        const size_t img_pix = (size_t)img * lh * lw;
+        const int iy0 = ty * TH - 1, ix0 = tx * TW - 1;
+        pre_ok = 0;
+#pragma unroll
+        for (int k = 0; k < NPF; k++) {
+            int i = tid + k * kThreads;
+            i = i < C::STAGE_ITEMS ? i : C::STAGE_ITEMS - 1;
+            const int pix = i / CPV, cv = i % CPV;
+            const int iy = iy0 + pix / HC, ix = ix0 + pix % HC;
+            const bool ok = iy >= 0 && iy < lh && ix >= 0 && ix < lw;
+            const int cy = iy < 0 ? 0 : (iy >= lh ? lh - 1 : iy), cx = ix < 0 ? 0 : (ix >= lw ? lw - 1 : ix);
+            pre[k] = *(const V *)(in + (img_pix + (size_t)cy * lw + cx) * in_ld + in_off + cv * VEC);
+            pre_ok |= (ok ? 1u : 0u) << (5 * k);
             if constexpr (UPADD) {
                 // out[2m] = .75 in[m] + .25 in[m-1];  out[2m+1] = .75 in[m] + .25 in[m+1];  taps outside = 0
                 const int hh = lh >> 1, wh = lw >> 1;
-                const int my = iy >> 1, mx = ix >> 1;
-                const int my2 = (iy & 1) ? my + 1 : my - 1, mx2 = (ix & 1) ? mx + 1 : mx - 1;
+                const int my = cy >> 1, mx = cx >> 1;
+                const int my2 = (cy & 1) ? my + 1 : my - 1, mx2 = (cx & 1) ? mx + 1 : mx - 1;
                 const T *ub = L.up + (size_t)img * hh * wh * CIN + cv * VEC;
-                float s[VEC];
+                const int ys[4] = {my, my, my2, my2}, xs[4] = {mx, mx2, mx, mx2};
 #pragma unroll
-                for (int e = 0; e < VEC; e++) s[e] = 0.f;
-                auto tap = [&](int yy, int xx, float wgt) {
-                    if (yy >= 0 && yy < hh && xx >= 0 && xx < wh) {
-                        V u = *(const V *)(ub + ((size_t)yy * wh + xx) * CIN);
-#pragma unroll
-                        for (int e = 0; e < VEC; e++) s[e] = fmaf(wgt, (float)u[e], s[e]);
-                    }
-                };
-                tap(my, mx, 0.5625f);
-                tap(my, mx2, 0.1875f);
-                tap(my2, mx, 0.1875f);
-                tap(my2, mx2, 0.0625f);
-#pragma unroll
-                for (int e = 0; e < VEC; e++) v[e] = to_T<T>(fmaf((float)v[e], a_lat, s[e] * a_up));
+                for (int q = 0; q < 4; q++) {
+                    const bool tok = ys[q] >= 0 && ys[q] < hh && xs[q] >= 0 && xs[q] < wh;
+                    const int yy = ys[q] < 0 ? 0 : (ys[q] >= hh ? hh - 1 : ys[q]), xx = xs[q] < 0 ? 0 : (xs[q] >= wh ? wh - 1 : xs[q]);
+                    upv[k][q] = *(const V *)(ub + ((size_t)yy * wh + xx) * CIN);
+                    pre_ok |= (tok ? 1u : 0u) << (5 * k + 1 + q);
+                }
             }
         }
-        *(V *)(s_in + pix * LDI + cv * VEC) = v;
-    }
-    RF_TRACE(3, 1);
-    __syncthreads();
-    RF_TRACE(3, 2);
-
-    int pbase[WS::NJ];
-#pragma unroll
-    for (int j = 0; j < WS::NJ; j++) {
-        const int p = acc_pixel(wp + j * WS::WP, lane);
-        pbase[j] = ((p / TW) * HC + p % TW) * LDI;
-    }
-    typename M::Acc acc[WS::NI][WS::NJ];
-#pragma unroll
-    for (int i = 0; i < WS::NI; i++)
-#pragma unroll
-        for (int j = 0; j < WS::NJ; j++) acc[i][j] = vzero<typename M::Acc, 4>();
-    pipe.run(acc, [&](int j, int kc) -> typename M::Frag {
-        const int kb = kc * M::K + (lane >> 4) * M::KPL;      // k = tap*CIN + c, KPL consecutive c of one tap
-        const int tap = kb / CIN, c = kb % CIN;
-        const int koff = ((tap / 3) * HC + tap % 3) * LDI + c;
-        return kb < KTOT ? *(const typename M::Frag *)(s_in + pbase[j] + koff) : M::zero();
-    });
-    RF_TRACE(3, 3);
-    __syncthreads();      // every wave is done reading s_in before it is overwritten as s_out
-    RF_TRACE(3, 4);
-#pragma unroll
-    for (int i = 0; i < WS::NI; i++)
-#pragma unroll
-        for (int j = 0; j < WS::NJ; j++)
-            store_acc<T, LDO>(s_out, mult[i], bias[i], acc[i][j], wn + i * WS::WN, wp + j * WS::WP, lane, true);
-    RF_TRACE(3, 5);
-    __syncthreads();
-    RF_TRACE(3, 6);
-
-    constexpr int OPV = COUT / VEC;
+    };
+    // ---- tile (img, oy0, ox0), finished in LDS, -> HBM (two destinations: the concat slice and the next conv's input)
     T *out0 = L.out0, *out1 = L.out1;
     const int n0 = L.n0, ld0 = L.ld0, off0 = L.off0, ld1 = L.ld1, off1 = L.off1;
-    for (int i = tid; i < P * OPV; i += kThreads) {
-        int p = i / OPV, cv = i % OPV;
-        int oy = oy0 + p / TW, ox = ox0 + p % TW;
-        if (oy < lh && ox < lw) {
-            const size_t pix = img_pix + (size_t)oy * lw + ox;
-            const int c = cv * VEC;
-            T *dst = c < n0 ? out0 + pix * ld0 + off0 + c : out1 + pix * ld1 + off1 + (c - n0);
-            *(V *)dst = *(const V *)(s_out + p * LDO + c);
+    auto store_tile = [&](int img, int oy0, int ox0) {
+        constexpr int OPV = COUT / VEC;
+        const size_t img_pix = (size_t)img * lh * lw;
+        for (int i = tid; i < P * OPV; i += kThreads) {
+            int p = i / OPV, cv = i % OPV;
+            int oy = oy0 + p / TW, ox = ox0 + p % TW;
+            if (oy < lh && ox < lw) {
+                const size_t pix = img_pix + (size_t)oy * lw + ox;
+                const int c = cv * VEC;
+                T *dst = c < n0 ? out0 + pix * ld0 + off0 + c : out1 + pix * ld1 + off1 + (c - n0);
+                *(V *)dst = *(const V *)(s_out + p * LDO + c);
+            }
         }
+    };
+    if (first < ntiles) fetch(first);
+    __builtin_amdgcn_s_waitcnt(0x0F70);       // vmcnt(0): once-per-workgroup loads have landed before the tile loop
+
+    int pbase[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; j++) {
+        const int p = acc_pixel(wp + j * WP, lane);
+        pbase[j] = ((p / TW) * HC + p % TW) * LDI;
     }
+
+    // tile loop:  stage(t) | fetch(t+G) issued | store(t-1) | barrier | GEMM(t) | epilogue(t) -> s_out | barrier
+    int p_img = -1, p_oy0 = 0, p_ox0 = 0;
+    for (int t = first; t < ntiles; t += G) {
+        const int tx = t % tiles_x, ty = (t / tiles_x) % L.tiles_y, img = t / tiles_per_img;
+        RF_TRACE(3, 8);
+#pragma unroll
+        for (int k = 0; k < NPF; k++) {
+            const int i = tid + k * kThreads;
+            if (i < C::STAGE_ITEMS) {
+                V v = vzero<V, VEC>();
+                if ((pre_ok >> (5 * k)) & 1u) {
+                    v = pre[k];
+                    if constexpr (UPADD) {
+                        const float wq[4] = {0.5625f, 0.1875f, 0.1875f, 0.0625f};
+                        float sacc[VEC];
+#pragma unroll
+                        for (int e = 0; e < VEC; e++) sacc[e] = 0.f;
+#pragma unroll
+                        for (int q = 0; q < 4; q++) {
+                            const bool tok = (pre_ok >> (5 * k + 1 + q)) & 1u;
+#pragma unroll
+                            for (int e = 0; e < VEC; e++) sacc[e] = fmaf(wq[q], tok ? (float)upv[k][q][e] : 0.f, sacc[e]);
+                        }
+#pragma unroll
+                        for (int e = 0; e < VEC; e++) v[e] = to_T<T>(fmaf((float)v[e], a_lat, sacc[e] * a_up));
+                    }
+                }
+                *(V *)(s_in + (i / CPV) * LDI + (i % CPV) * VEC) = v;
+            }
+        }
+        RF_TRACE(3, 9);
+        if (t + G < ntiles) fetch(t + G);
+        RF_TRACE(3, 10);
+        if (p_img >= 0) store_tile(p_img, p_oy0, p_ox0);
+        p_img = img; p_oy0 = ty * TH; p_ox0 = tx * TW;
+        RF_TRACE(3, 1);
+        __syncthreads();
+        RF_TRACE(3, 2);
+
+        if (gemm_wave) {
+            typename M::Acc acc[NI][NJ];
+#pragma unroll
+            for (int i = 0; i < NI; i++)
+#pragma unroll
+                for (int j = 0; j < NJ; j++) acc[i][j] = vzero<typename M::Acc, 4>();
+            auto xf = [&](int j, int kc) -> Frag {
+                const int kb = kc * M::K + (lane >> 4) * M::KPL;      // k = tap*CIN + c, KPL consecutive c of one tap
+                const int tap = kb / CIN, c = kb % CIN;
+                const int koff = ((tap / 3) * HC + tap % 3) * LDI + c;
+                return kb < KTOT ? *(const Frag *)(s_in + pbase[j] + koff) : M::zero();
+            };
+            if constexpr (STAT) {
+                gemm_stationary<T, NI, NJ, KCH>(acc, wst, xf);
+            } else {
+                GemmPipe<T, NI, NJ, KCH, WN, C::GFRAGS> pipe;
+                pipe.init(L.w, wn, lane);
+                pipe.run(acc, xf);
+            }
+            RF_TRACE(3, 3);
+#pragma unroll
+            for (int i = 0; i < NI; i++)
+#pragma unroll
+                for (int j = 0; j < NJ; j++)
+                    store_acc<T, LDO>(s_out, mult[i], bias[i], acc[i][j], wn + i * WN, wp + j * WP, lane, true);
+        }
+        RF_TRACE(3, 5);
+        __syncthreads();
+        RF_TRACE(3, 6);
+    }
+    if (p_img >= 0) store_tile(p_img, p_oy0, p_ox0);
     RF_TRACE(3, 7);
+}
+
+template <typename T, int CIN, int COUT, int TH, int TW, bool UPADD>
+static void conv3_launch(hipStream_t s, Conv3Args<T> &a, int nlv, int total_tiles) {
+    typedef Conv3Cfg<T, CIN, COUT, TH, TW> C;
+    auto kern = conv3x3_kernel<T, CIN, COUT, TH, TW, UPADD>;
+    static int resident = 0;
+    if (!resident) { set_max_lds(kern, C::LDS_BYTES); resident = resident_per_cu(kern, C::LDS_BYTES); }
+    // grid: persistent size for the whole launch, shared out to the levels in proportion to their tiles
+    const int want = sizeof(T) <= 2 ? persistent_grid(total_tiles, resident) : total_tiles;
+    int grid = 0;
+    for (int l = 0; l < 3; l++) {
+        Conv3Level<T> &L = a.lv[l];
+        if (l >= nlv) { L.gb_begin = 0x7fffffff; L.gsz = 1; L.ntiles = 0; continue; }
+        long g = want == total_tiles ? L.ntiles : ((long)L.ntiles * want + total_tiles - 1) / total_tiles;
+        if (g < 1) g = 1;
+        if (g > L.ntiles) g = L.ntiles;
+        L.gb_begin = grid;
+        L.gsz = (int)g;
+        grid += (int)g;
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), C::LDS_BYTES, s, a);
 }
 
 template <typename T, int CIN, int COUT, int TH, int TW>
@@ -958,30 +1206,19 @@ static TileInfo conv3_dispatch(hipStream_t s, const Conv3Params<T> *p, int nlv, 
     TileInfo ti{TH, TW, C::LDS_BYTES, ((w + TW - 1) / TW) * ((h + TH - 1) / TH)};
     if (!p) return ti;
     Conv3Args<T> a;
-    int blk = 0;
+    int total = 0;
     for (int l = 0; l < 3; l++) {
         const Conv3Params<T> &q = p[l < nlv ? l : nlv - 1];
         int tiles_x = (q.w_ + TW - 1) / TW, tiles_y = (q.h + TH - 1) / TH;
         a.lv[l] = Conv3Level<T>{q.in, q.up, q.w, q.b, q.m, q.out0, q.out1, q.in_ld, q.in_off, q.ld0, q.off0, q.n0, q.ld1, q.off1,
-                                q.h, q.w_, tiles_x, tiles_y, blk, q.a_lat, q.a_up};
-        if (l < nlv) blk += q.n * tiles_x * tiles_y;
-        else a.lv[l].blk_begin = 0x7fffffff;
+                                q.h, q.w_, tiles_x, tiles_y, q.n * tiles_x * tiles_y, 0, 1, q.a_lat, q.a_up};
+        if (l < nlv) total += q.n * tiles_x * tiles_y;
     }
-    a.nblk = blk;
     if (p[0].up) {
-        if constexpr (CIN == 64 && COUT == 64) {
-            auto kern = conv3x3_kernel<T, CIN, COUT, TH, TW, true>;
-            static bool attr_set = false;
-            if (!attr_set) { set_max_lds(kern, C::LDS_BYTES); attr_set = true; }
-            hipLaunchKernelGGL(kern, dim3(a.nblk), dim3(kThreads), C::LDS_BYTES, s, a);
-        } else {
-            abort();
-        }
+        if constexpr (CIN == 64 && COUT == 64) conv3_launch<T, CIN, COUT, TH, TW, true>(s, a, nlv, total);
+        else abort();
     } else {
-        auto kern = conv3x3_kernel<T, CIN, COUT, TH, TW, false>;
-        static bool attr_set = false;
-        if (!attr_set) { set_max_lds(kern, C::LDS_BYTES); attr_set = true; }
-        hipLaunchKernelGGL(kern, dim3(a.nblk), dim3(kThreads), C::LDS_BYTES, s, a);
+        conv3_launch<T, CIN, COUT, TH, TW, false>(s, a, nlv, total);
     }
     return ti;
 }
@@ -1375,7 +1612,7 @@ void launch_resize_area(hipStream_t s, const FrameDesc *src, uint8_t *dst, int n
 extern "C" int rf_trace_select(int kernel_id, unsigned grid) {
     static unsigned long long zeros[kTraceBlocks * kTraceSlots];
     (void)hipMemcpyToSymbol(HIP_SYMBOL(g_trace), zeros, sizeof(zeros));
-    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_trace_grid), &grid, sizeof(unsigned));
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_trace_key), &grid, sizeof(unsigned));
     return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_trace_kernel), &kernel_id, sizeof(int));
 }
 extern "C" int rf_trace_read(unsigned long long *dst, int nblocks) {

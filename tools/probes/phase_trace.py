@@ -1,5 +1,5 @@
 """Probe: phase timeline inside the dwpw / conv3x3 workgroups (needs `make -C retinaface_amd/csrc trace`).
-usage: phase_trace.py {dwpw|conv3} IMAGES GRID [GRID...]
+usage: phase_trace.py {dwpw|conv3} IMAGES TILES [TILES...]   (TILES = tile count of the launch to trace; conv3: of its first level)
 Runs eager passes at IMAGES per launch; for each GRID (workgroups of the launch to trace: picks one launch of the kernel
 family) prints, per phase boundary, the mean time since the workgroup's first stamp (s_memtime = shader cycles, shown at
 a nominal 2.4 GHz), the launch span and when workgroups started (rounds show up as steps)."""
@@ -10,7 +10,7 @@ os.environ["RETINAFACE_AMD_LIB"] = os.path.join(ROOT, "retinaface_amd", "lib", "
 import numpy as np, torch, retinaface_amd
 from retinaface_amd.frames import synth_frames
 lib = retinaface_amd.load_library()
-family = sys.argv[1]; n = int(sys.argv[2]); grids = [int(g) for g in sys.argv[3:]]
+family = sys.argv[1]; n = int(sys.argv[2]); grids = [int(g) for g in sys.argv[3:]]   # GRID = workgroups of the launch (persistent grid size)
 frames = torch.from_numpy(np.stack(synth_frames(448, 448, 8, config=1))).cuda(); torch.cuda.synchronize()
 ptrs = [frames[i % 8].data_ptr() for i in range(8)]
 det = retinaface_amd.RetinaFace(os.path.join(ROOT, "assets"), "net3", 0.4, net_hw=(448, 448), model_stem="mnet25", lanes=1,
@@ -22,7 +22,10 @@ def run():
     for t in tickets: det.wait(t, 8)
 for _ in range(3): run()
 NB, NS, GHZ = 8192, 12, 2.4
-names = ["start", "loads issued+LDS written", "barrier 1", "stencil/GEMM done", "barrier 2", "epilogue->LDS", "barrier 3", "stored"]
+# stamp slots, in program order inside the LAST tile a workgroup walked (slot 0 = workgroup start, 7 = after the loop / lateral)
+ORDER = {"dwpw": [8, 9, 10, 1, 2, 3, 4, 5, 6, 7], "conv3": [8, 9, 10, 1, 2, 3, 5, 6]}
+LABEL = {8: "tile loop top", 9: "prefetch landed + staged to LDS", 10: "next tile's loads issued", 1: "previous tile's stores issued",
+         2: "barrier", 3: "stencil (dwpw) / GEMM (conv3) done", 4: "barrier", 5: "GEMM + epilogue -> LDS", 6: "barrier", 7: "lateral / end"}
 for grid in grids:
     lib.rf_trace_select(kid, grid); torch.cuda.synchronize()
     run()
@@ -32,11 +35,13 @@ for grid in grids:
     tr = tr[tr[:, 0] > 0]
     if not len(tr):
         print(f"{family} grid {grid}: no stamps"); continue
-    tr = tr[(np.diff(tr[:, :8], axis=1) >= 0).all(axis=1)]
-    rel = (tr[:, :8] - tr[:, :1]) / GHZ
-    span = (tr[:, 7].max() - tr[:, 0].min()) / GHZ
-    print(f"{family} grid {grid}: {len(tr)} workgroups traced (first {NB} of the launch); span {span / 1e3:.2f} us")
-    for i, nme in enumerate(names):
-        print(f"  {nme:28s} mean {rel[:, i].mean():7.0f} ns   p10 {np.percentile(rel[:, i], 10):7.0f}   p90 {np.percentile(rel[:, i], 90):7.0f}")
-    starts = (tr[:, 0] - tr[:, 0].min()) / GHZ
-    print("  workgroup start deciles (ns):", " ".join(f"{np.percentile(starts, p):.0f}" for p in range(0, 101, 10)))
+    order = ORDER[family]
+    seq = tr[:, order]
+    okm = (np.diff(seq, axis=1) >= 0).all(axis=1)
+    seq = seq[okm]
+    life = (tr[okm][:, order[-1]] - tr[okm][:, 0]) / GHZ
+    print(f"{family} grid {grid}: {len(seq)} workgroups; workgroup lifetime mean {life.mean() / 1e3:.2f} us (p90 {np.percentile(life, 90) / 1e3:.2f})")
+    d = np.diff(seq, axis=1) / GHZ
+    for i in range(d.shape[1]):
+        print(f"  -> {LABEL[order[i + 1]]:36s} mean {d[:, i].mean():7.0f} ns   p10 {np.percentile(d[:, i], 10):7.0f}   p90 {np.percentile(d[:, i], 90):7.0f}")
+    print(f"  last tile total {d.sum(axis=1).mean():7.0f} ns")
