@@ -330,7 +330,7 @@ public:
 private:
     static constexpr size_t kNone = (size_t)-1;
     struct GemmW { size_t w, b, m = kNone; };          // m: int8 requantisation multipliers (absent otherwise)
-    struct DwW { size_t w, b; };
+    struct DwW { size_t w, b, mma = 0; };
 
     struct Lane {
         hipStream_t stream = nullptr;
@@ -443,7 +443,24 @@ private:
                 else w[(size_t)t * c + ch] = Cast<DWT>::from(v);
             }
         if constexpr (kInt8) for (auto &v : b) v /= mid_scale;
-        return DwW{arena_.put(w), arena_.put(b)};
+        DwW r{arena_.put(w), arena_.put(b), 0};
+        if constexpr (std::is_same<T, half_t>::value) {
+            // the same taps as diagonal MFMA A fragments (pack.h dw_mma_dword): [c/16][5][64] dwords
+            if (c % 16 == 0) {
+                std::vector<uint32_t> mm((size_t)(c / 16) * kDwMmaChunks * 64);
+                for (int g = 0; g < c / 16; g++)
+                    for (int lane = 0; lane < 64; lane++) {
+                        uint16_t w9[9];
+                        for (int t = 0; t < 9; t++) {
+                            half_t h = w[(size_t)t * c + g * 16 + (lane & 15)];
+                            std::memcpy(&w9[t], &h, 2);
+                        }
+                        for (int kc = 0; kc < kDwMmaChunks; kc++) mm[((size_t)g * kDwMmaChunks + kc) * 64 + lane] = dw_mma_dword(kc, lane, w9);
+                    }
+                r.mma = arena_.put(mm);
+            }
+        }
+        return r;
     }
 
     void upload_weights(const Plan &plan) {
@@ -630,6 +647,7 @@ private:
             DwPwParams<T> p;
             p.in = cur; p.out = out;
             p.dw_w = arena_.ptr<DWT>(dw_w_[i].w); p.dw_b = arena_.ptr<float>(dw_w_[i].b);
+            if (dw_w_[i].mma) p.dw_mma = arena_.ptr<uint32_t>(dw_w_[i].mma);
             p.pw_w = arena_.ptr<T>(pw_w_[i].w); p.pw_b = arena_.ptr<float>(pw_w_[i].b); p.pw_m = mult_ptr(pw_w_[i]);
             p.n = 0; p.hin = h; p.win = w; p.hout = ho; p.wout = wo;
             p.cin = c; p.cout = blk.pw.cout; p.stride = blk.dw.stride; p.has_dw = true;

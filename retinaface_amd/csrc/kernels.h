@@ -60,6 +60,8 @@ struct DwPwParams {
     const T *in; T *out;
     const typename DwWeightT<T>::type *dw_w;        // [9][cin] (fp32 when T = int8)
     const float *dw_b;    // [cin]
+    const uint32_t *dw_mma = nullptr;   // fp16 engine: the depthwise taps as per-lane dwords of DIAGONAL MFMA A fragments,
+                                        // [cin/16][5][64] (dw_mma_dword in pack.h): the stencil runs on the matrix cores
     const T *pw_w;        // MFMA-fragment packed (pack.h), k = cin
     const float *pw_b;    // [cout]
     const T *lat_w = nullptr; const float *lat_b = nullptr; T *lat_out = nullptr;   // optional fused FPN lateral (cout -> 64)

@@ -199,6 +199,43 @@ void launch_conv0(hipStream_t s, const FrameDesc *frames, T *out, const float *w
 template void launch_conv0<half_t>(hipStream_t, const FrameDesc *, half_t *, const float *, const float *, int, int, int);
 template void launch_conv0<float>(hipStream_t, const FrameDesc *, float *, const float *, const float *, int, int, int);
 
+// Global traffic of the persistent kernels goes through buffer descriptors (one per image, rebuilt from scalars per tile):
+// 32-bit per-lane byte offsets that are constants of the thread (tile origin added with one v_add), and the hardware range
+// check instead of clamps and masks -- a row above / below the image is a negative / too-large offset and reads as zero
+// (stores are dropped); only the column test needs an instruction.  This took ~20 VALU + ~10 SALU per 16-byte item out of
+// loops that are a few hundred instructions per tile.  (The scalar soffset is NOT range-checked, hence everything in voffset.)
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+constexpr unsigned kOobOffset = 0x80000000u;
+template <typename P> __device__ __forceinline__ auto image_rsrc(P *base, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc((void *)base, 0, (int)bytes, 0x00020000);
+}
+template <typename V, typename R> __device__ __forceinline__ V buf_load16(R rsrc, unsigned off) {
+    return __builtin_bit_cast(V, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)off, 0, 0));
+}
+template <typename V, typename R> __device__ __forceinline__ void buf_store16(R rsrc, unsigned off, V v) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsrc, (int)off, 0, 0);
+}
+
+// Tile walk of the persistent kernels: tile id t -> (tx, ty, img), advanced by a fixed step G without dividing.
+struct TileCoord {
+    int tx, ty, img;
+    __device__ TileCoord(int t, int tiles_x, int tiles_y) : tx(t % tiles_x), ty((t / tiles_x) % tiles_y), img(t / (tiles_x * tiles_y)) {}
+};
+struct TileStep {
+    int sx, sy, si, nx, ny;
+    __device__ TileStep(int g, int tiles_x, int tiles_y)
+        : sx(g % tiles_x), sy((g / tiles_x) % tiles_y), si(g / (tiles_x * tiles_y)), nx(tiles_x), ny(tiles_y) {}
+    __device__ __forceinline__ void advance(TileCoord &c) const {
+        c.tx += sx;
+        const int cx = c.tx >= nx ? 1 : 0;
+        c.tx -= cx ? nx : 0;
+        c.ty += sy + cx;
+        const int cy = c.ty >= ny ? 1 : 0;
+        c.ty -= cy ? ny : 0;
+        c.img += si + cy;
+    }
+};
+
 // =============================================================================================
 // GEMM core shared by K_b / K_c / K_d:  acc[i][j] += W-fragment(ct_i, kc) x X-fragment(pt_j, kc)
 // 4 waves split the output-channel tiles first (WN), the pixel tiles second (WP).
@@ -582,8 +619,14 @@ template <typename T, int CIN, int COUT, int STRIDE, bool HAS_DW, int TH, int TW
     static constexpr int HC = HAS_DW ? (TW - 1) * STRIDE + 3 : 0;
     static constexpr int LDA = CIN + (CIN * sizeof(T) >= 64 ? VEC : 0);   // narrow rows: padding costs a resident workgroup
     static constexpr int LDO = COUT + VEC;
-    static constexpr size_t IN_BYTES = sizeof(T) * (size_t)(HR * HC * CIN);
-    static constexpr size_t DW_BYTES = HAS_DW ? sizeof(DW) * (size_t)(9 * CIN) : 0;
+    // fp16 engine: the depthwise stencil runs on the matrix cores as a diagonal-weight 3x3 conv per 16-channel group (see
+    // pack.h dw_mma_dword): these kernels are VALU-issue bound (SQ counters: VALU busy 70-100 % of issue cycles, MFMA < 10 %)
+    // and the stencil was ~45 % of their VALU instructions.  Needs the (group, pixel-tile) pairs to split over 4 waves.
+    static constexpr bool DWMMA = HAS_DW && sizeof(T) == 2 && CIN % 16 == 0 && ((CIN / 16) * (P / 16)) % 4 == 0 &&
+                                  (CIN >= 64 || (P / 16) % (4 / (CIN / 16 > 0 ? CIN / 16 : 1)) == 0);
+    static constexpr int LDIN = DWMMA ? CIN + VEC : CIN;                  // halo rows padded: the B-fragment reads stride by pixel
+    static constexpr size_t IN_BYTES = sizeof(T) * (size_t)(HR * HC * LDIN);
+    static constexpr size_t DW_BYTES = HAS_DW && !DWMMA ? sizeof(DW) * (size_t)(9 * CIN) : 0;
     static constexpr size_t A_BYTES = sizeof(T) * (size_t)(P * LDA);
     static constexpr size_t O_BYTES = sizeof(T) * (size_t)(P * LDO);
     // The kernel is persistent: a workgroup walks tiles t, t+G, t+2G, ... and stages tile t+G while it computes tile t,
@@ -616,7 +659,7 @@ template <typename T, int CIN, int COUT, int STRIDE, bool HAS_DW, int TH, int TW
 
 template <typename T>
 struct DwPwArgs {
-    const T *in; T *out; const typename DwWeight<T>::type *dw_w; const float *dw_b; const T *pw_w; const float *pw_b;
+    const T *in; T *out; const typename DwWeight<T>::type *dw_w; const float *dw_b; const uint32_t *dw_mma; const T *pw_w; const float *pw_b;
     const T *lat_w; const float *lat_b; T *lat_out;
     const float *pw_m, *lat_m;        // int8: per-output-channel requantisation multipliers (nullptr otherwise)
     int hin, win, hout, wout, tiles_x, tiles_y, nblk;     // nblk = tiles in the launch (the grid may be smaller)
@@ -629,9 +672,9 @@ __global__ __launch_bounds__(kThreads, (DwPwCfg<T, CIN, COUT, STRIDE, HAS_DW, TH
     typedef Mma<T> M;
     typedef typename M::Frag Frag;
     typedef typename C::WS WS;
-    constexpr int VEC = C::VEC, P = C::P, HC = C::HC, LDA = C::LDA, LDO = C::LDO;
+    constexpr int VEC = C::VEC, P = C::P, HC = C::HC, LDA = C::LDA, LDO = C::LDO, LDIN = C::LDIN;
     constexpr int CPV = CIN / VEC, PT = C::PT, KCH = C::KCH, NPF = C::NPF;
-    constexpr bool STAT = C::STAT;
+    constexpr bool STAT = C::STAT, DWMMA = C::DWMMA;
     typedef typename C::DW DW;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     T *s_in = (T *)smem;
@@ -643,7 +686,6 @@ __global__ __launch_bounds__(kThreads, (DwPwCfg<T, CIN, COUT, STRIDE, HAS_DW, TH
     const int lane = tid & 63, wave = tid >> 6;
     const int G = gridDim.x;
     const int first = xcd_remap(blockIdx.x, G);
-    const int tiles_per_img = a.tiles_x * a.tiles_y;
     RF_TRACE_KEY(a.nblk);
     RF_TRACE(2, 0);
 
@@ -678,57 +720,96 @@ __global__ __launch_bounds__(kThreads, (DwPwCfg<T, CIN, COUT, STRIDE, HAS_DW, TH
         lat_mult = load_mult(a.lat_m, acc_cout(wave, lane, 0));
     }
     float dw_bias[VEC];
-    if constexpr (HAS_DW) {
+    if constexpr (HAS_DW && !DWMMA) {
 #pragma unroll
         for (int e = 0; e < VEC; e++) dw_bias[e] = a.dw_b[(tid % CPV) * VEC + e];
         for (int i = tid; i < 9 * CIN * (int)sizeof(DW) / 16; i += kThreads)
             ((f32x4 *)s_dw)[i] = ((const f32x4 *)a.dw_w)[i];          // visible after the first barrier below
     }
+    // depthwise on MFMA: wave -> (channel group, pixel tile) pairs; per group 5 diagonal A fragments, each kept as ONE dword
+    // per lane and expanded to 4 when used
+    constexpr int NG = CIN / 16 > 0 ? CIN / 16 : 1, DKCH = kDwMmaChunks;
+    constexpr int GW = DWMMA ? (NG >= 4 ? NG / 4 : 1) : 1;          // groups per wave
+    constexpr int PW = DWMMA ? (NG * PT / 4) / GW : 1;              // pixel tiles per wave and group
+    uint32_t dwv[GW][DKCH];
+    f32x4 dwb4[GW];
+    int dpix[PW], dtap[DKCH];
+    const int dsel = dw_mma_dword_index(lane);
+    if constexpr (DWMMA) {
+#pragma unroll
+        for (int gi = 0; gi < GW; gi++) {
+            const int g = NG >= 4 ? wave + 4 * gi : wave % NG;
+#pragma unroll
+            for (int kc = 0; kc < DKCH; kc++) dwv[gi][kc] = a.dw_mma[(g * DKCH + kc) * 64 + lane];
+            dwb4[gi] = *(const f32x4 *)(a.dw_b + acc_cout(g, lane, 0));
+        }
+#pragma unroll
+        for (int pi = 0; pi < PW; pi++) {
+            const int pt = NG >= 4 ? pi : wave / NG + pi * (4 / NG);
+            const int p = acc_pixel(pt, lane);
+            dpix[pi] = ((p / TW) * STRIDE * HC + (p % TW) * STRIDE) * LDIN + ((lane >> 4) & 1) * 8;
+        }
+#pragma unroll
+        for (int kc = 0; kc < DKCH; kc++) {
+            const int tap = kc * 2 + (lane >> 5);                   // k = tap*16 + c; lanes 32..63 hold the chunk's second tap
+            dtap[kc] = tap < 9 ? ((tap / 3) * HC + tap % 3) * LDIN : -1;
+        }
+    }
 
-    // ---- the halo (or, without a depthwise stage, the tile itself) of tile t -> registers.  The loads are unconditional
-    // (clamped addresses) and the zero padding is applied when the registers are written to LDS: no branch around a
-    // load, so the compiler's vmcnt bookkeeping inside the tile loop stays exact.
+    // ---- the halo (or, without a depthwise stage, the tile itself) of a tile -> registers: unconditional buffer loads,
+    // zero padding by the hardware range check (rows) and a poisoned offset (columns)
     V pre[NPF];
-    unsigned pre_ok = 0;
-    auto fetch = [&](int t) {
-        const int tx = t % a.tiles_x, ty = (t / a.tiles_x) % a.tiles_y, img = t / tiles_per_img;
-        const T *inb = a.in + (size_t)img * a.hin * a.win * CIN;
+    int koff[NPF], kdx[NPF];
+#pragma unroll
+    for (int k = 0; k < NPF; k++) {
+        int i = tid + k * kThreads;
+        i = i < C::STAGE_ITEMS ? i : C::STAGE_ITEMS - 1;
+        const int pix = i / CPV, cv = i % CPV;
+        const int dy = HAS_DW ? pix / HC : pix / TW, dx = HAS_DW ? pix % HC : pix % TW;
+        koff[k] = ((dy * a.win + dx) * CIN + cv * VEC) * (int)sizeof(T);
+        kdx[k] = dx;
+    }
+    const unsigned in_img_bytes = (unsigned)(a.hin * a.win * CIN) * (unsigned)sizeof(T);
+    const unsigned out_img_bytes = (unsigned)(a.hout * a.wout * COUT) * (unsigned)sizeof(T);
+    auto fetch = [&](int tx, int ty, int img) {
+        const auto rs = image_rsrc(a.in + (size_t)img * a.hin * a.win * CIN, in_img_bytes);
         const int iy0 = HAS_DW ? ty * TH * STRIDE - 1 : ty * TH, ix0 = HAS_DW ? tx * TW * STRIDE - 1 : tx * TW;
-        pre_ok = 0;
+        const int sbase = (iy0 * a.win + ix0) * CIN * (int)sizeof(T);
 #pragma unroll
         for (int k = 0; k < NPF; k++) {
-            int i = tid + k * kThreads;
-            i = i < C::STAGE_ITEMS ? i : C::STAGE_ITEMS - 1;
-            const int pix = i / CPV, cv = i % CPV;
-            const int iy = iy0 + (HAS_DW ? pix / HC : pix / TW), ix = ix0 + (HAS_DW ? pix % HC : pix % TW);
-            const bool ok = iy >= 0 && iy < a.hin && ix >= 0 && ix < a.win;
-            const int cy = iy < 0 ? 0 : (iy >= a.hin ? a.hin - 1 : iy), cx = ix < 0 ? 0 : (ix >= a.win ? a.win - 1 : ix);
-            pre[k] = *(const V *)(inb + ((size_t)cy * a.win + cx) * CIN + cv * VEC);
-            pre_ok |= (ok ? 1u : 0u) << k;
+            const unsigned off = (unsigned)(ix0 + kdx[k]) < (unsigned)a.win ? (unsigned)(koff[k] + sbase) : kOobOffset;
+            pre[k] = buf_load16<V>(rs, off);
         }
     };
     // ---- tile (img, oy0, ox0), finished in LDS, -> HBM: 16 B per lane, fully coalesced NHWC rows
     auto store_tile = [&](int img, int oy0, int ox0) {
         constexpr int OPV = COUT / VEC;
-        T *outb = a.out + (size_t)img * a.hout * a.wout * COUT;
+        const auto ro = image_rsrc(a.out + (size_t)img * a.hout * a.wout * COUT, out_img_bytes);
+        const int obase = (oy0 * a.wout + ox0) * COUT * (int)sizeof(T);
         for (int i = tid; i < P * OPV; i += kThreads) {
-            int p = i / OPV, cv = i % OPV;
-            int oy = oy0 + p / TW, ox = ox0 + p % TW;
-            if (oy < a.hout && ox < a.wout)
-                *(V *)(outb + ((size_t)oy * a.wout + ox) * COUT + cv * VEC) = *(const V *)(s_out + p * LDO + cv * VEC);
+            const int p = i / OPV, cv = i % OPV;
+            const int py = p / TW, px = p % TW;
+            const unsigned off = ox0 + px < a.wout ? (unsigned)(((py * a.wout + px) * COUT + cv * VEC) * (int)sizeof(T) + obase) : kOobOffset;
+            buf_store16(ro, off, *(const V *)(s_out + p * LDO + cv * VEC));
         }
         if constexpr (LAT) {
             constexpr int LDL = 64 + VEC, LPV = 64 / VEC;
-            T *latb = a.lat_out + (size_t)img * a.hout * a.wout * 64;
+            const auto rl = image_rsrc(a.lat_out + (size_t)img * a.hout * a.wout * 64, (unsigned)(a.hout * a.wout * 64) * (unsigned)sizeof(T));
+            const int lbase = (oy0 * a.wout + ox0) * 64 * (int)sizeof(T);
             for (int i = tid; i < P * LPV; i += kThreads) {
-                int p = i / LPV, cv = i % LPV;
-                int oy = oy0 + p / TW, ox = ox0 + p % TW;
-                if (oy < a.hout && ox < a.wout)
-                    *(V *)(latb + ((size_t)oy * a.wout + ox) * 64 + cv * VEC) = *(const V *)(s_a + p * LDL + cv * VEC);
+                const int p = i / LPV, cv = i % LPV;
+                const int py = p / TW, px = p % TW;
+                const unsigned off = ox0 + px < a.wout ? (unsigned)(((py * a.wout + px) * 64 + cv * VEC) * (int)sizeof(T) + lbase) : kOobOffset;
+                buf_store16(rl, off, *(const V *)(s_a + p * LDL + cv * VEC));
             }
         }
     };
-    if (first < a.nblk) fetch(first);
+    // tile walk t = first, first + G, ...: (tx, ty, img) advance by the decomposed step with carries -- no division per tile
+    // (a uniform integer division is ~16 scalar instructions, and these loops are a few hundred instructions per tile)
+    const TileStep step(G, a.tiles_x, a.tiles_y);
+    TileCoord cur(first, a.tiles_x, a.tiles_y), nxt = cur;
+    step.advance(nxt);
+    if (first < a.nblk) fetch(cur.tx, cur.ty, cur.img);
     // every once-per-workgroup load has landed before the loop: inside it the only loads in flight are the prefetch
     __builtin_amdgcn_s_waitcnt(0x0F70);       // vmcnt(0), expcnt / lgkmcnt untouched
 
@@ -737,23 +818,24 @@ __global__ __launch_bounds__(kThreads, (DwPwCfg<T, CIN, COUT, STRIDE, HAS_DW, TH
     // so tile t's compute covers both the flight of tile t+G's loads and the acknowledgement of tile t-1's stores.
     int p_img = -1, p_oy0 = 0, p_ox0 = 0;
     for (int t = first; t < a.nblk; t += G) {
-        const int tx = t % a.tiles_x, ty = (t / a.tiles_x) % a.tiles_y, img = t / tiles_per_img;
+        const int tx = cur.tx, ty = cur.ty, img = cur.img;
         RF_TRACE(2, 8);
 
-        // ---- phase 1: staged registers -> LDS (zero padding here), previous tile -> HBM
+        // ---- phase 1: staged registers -> LDS, next tile's loads issued, previous tile -> HBM
 #pragma unroll
         for (int k = 0; k < NPF; k++) {
             const int i = tid + k * kThreads;
             if (i < C::STAGE_ITEMS) {
-                const V v = (pre_ok >> k) & 1u ? pre[k] : vzero<V, VEC>();
-                if constexpr (HAS_DW) *(V *)(s_in + (i / CPV) * CIN + (i % CPV) * VEC) = v;
-                else *(V *)(s_a + (i / CPV) * LDA + (i % CPV) * VEC) = v;
+                if constexpr (HAS_DW) *(V *)(s_in + (i / CPV) * LDIN + (i % CPV) * VEC) = pre[k];
+                else *(V *)(s_a + (i / CPV) * LDA + (i % CPV) * VEC) = pre[k];
             }
         }
         RF_TRACE(2, 9);
         // the next tile's loads are issued before the previous tile's stores: on the in-order vmcnt the stores are then
         // younger than the loads, and by the time the loads are waited for (one tile of compute later) both have landed
-        if (t + G < a.nblk) fetch(t + G);
+        if (t + G < a.nblk) fetch(nxt.tx, nxt.ty, nxt.img);
+        cur = nxt;
+        step.advance(nxt);
         RF_TRACE(2, 10);
         if (p_img >= 0) store_tile(p_img, p_oy0, p_ox0);
         p_img = img; p_oy0 = ty * TH; p_ox0 = tx * TW;
@@ -761,8 +843,41 @@ __global__ __launch_bounds__(kThreads, (DwPwCfg<T, CIN, COUT, STRIDE, HAS_DW, TH
         __syncthreads();
         RF_TRACE(2, 2);
 
-        if constexpr (HAS_DW) {
-            // ---- phase 2: depthwise stencil
+        if constexpr (DWMMA) {
+            // ---- phase 2 (fp16): depthwise 3x3 as diagonal-weight implicit GEMM, D[c][pixel] per 16-channel group
+            const f32x4 ones = {1.f, 1.f, 1.f, 1.f};
+#pragma unroll
+            for (int gi = 0; gi < GW; gi++) {
+                const int g = NG >= 4 ? wave + 4 * gi : wave % NG;
+                typename M::Acc dacc[PW];
+#pragma unroll
+                for (int pi = 0; pi < PW; pi++) dacc[pi] = vzero<typename M::Acc, 4>();
+#pragma unroll
+                for (int kc = 0; kc < DKCH; kc++) {
+                    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+                    u32x4 wa;
+                    uint32_t wd = dwv[gi][kc];
+                    asm volatile("" : "+v"(wd));        // opaque: keeps the 4-dword expansion inside the tile loop (1 VGPR, not 4, per fragment)
+#pragma unroll
+                    for (int d = 0; d < 4; d++) wa[d] = dsel == d ? wd : 0u;
+                    const Frag af = __builtin_bit_cast(Frag, wa);
+#pragma unroll
+                    for (int pi = 0; pi < PW; pi++) {
+                        const Frag bf = dtap[kc] >= 0 ? *(const Frag *)(s_in + dpix[pi] + dtap[kc] + g * 16) : M::zero();
+                        dacc[pi] = M::mma(af, bf, dacc[pi]);
+                    }
+                }
+#pragma unroll
+                for (int pi = 0; pi < PW; pi++) {
+                    const int pt = NG >= 4 ? pi : wave / NG + pi * (4 / NG);
+                    store_acc<T, LDA>(s_a, ones, dwb4[gi], dacc[pi], g, pt, lane, true);
+                }
+            }
+            RF_TRACE(2, 3);
+            __syncthreads();
+            RF_TRACE(2, 4);
+        } else if constexpr (HAS_DW) {
+            // ---- phase 2: depthwise stencil on the VALU (fp32 parity engine, int8, and shapes the MFMA split does not fit)
             const int cv = tid % CPV;                 // kThreads % CPV == 0: the channel group is fixed per thread
             for (int i = tid; i < P * CPV; i += kThreads) {
                 int p = i / CPV;
@@ -773,7 +888,7 @@ __global__ __launch_bounds__(kThreads, (DwPwCfg<T, CIN, COUT, STRIDE, HAS_DW, TH
                 V xs[9];               // all nine taps requested before the first is used: one LDS round trip, not nine
 #pragma unroll
                 for (int k9 = 0; k9 < 9; k9++)
-                    xs[k9] = *(const V *)(s_in + ((py * STRIDE + k9 / 3) * HC + px * STRIDE + k9 % 3) * CIN + cv * VEC);
+                    xs[k9] = *(const V *)(s_in + ((py * STRIDE + k9 / 3) * HC + px * STRIDE + k9 % 3) * LDIN + cv * VEC);
 #pragma unroll
                 for (int k9 = 0; k9 < 9; k9++) {
                     const DW *wv = s_dw + k9 * CIN + cv * VEC;
@@ -886,7 +1001,7 @@ static void dwpw_launch(hipStream_t s, const DwPwParams<T> *p, int tiles_x, int 
     auto kern = dwpw_kernel<T, CIN, COUT, STRIDE, HAS_DW, TH, TW, LAT>;
     static int resident = 0;
     if (!resident) { set_max_lds(kern, C::LDS_BYTES); resident = resident_per_cu(kern, C::LDS_BYTES); }
-    DwPwArgs<T> a{p->in, p->out, p->dw_w, p->dw_b, p->pw_w, p->pw_b, p->lat_w, p->lat_b, p->lat_out, p->pw_m, p->lat_m,
+    DwPwArgs<T> a{p->in, p->out, p->dw_w, p->dw_b, p->dw_mma, p->pw_w, p->pw_b, p->lat_w, p->lat_b, p->lat_out, p->pw_m, p->lat_m,
                   p->hin, p->win, p->hout, p->wout, tiles_x, tiles_y, p->n * tiles_x * tiles_y};
     const int grid = sizeof(T) <= 2 ? persistent_grid(a.nblk, resident) : a.nblk;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), C::LDS_BYTES, s, a);
@@ -1015,7 +1130,7 @@ __global__ __launch_bounds__(kThreads, (Conv3Cfg<T, CIN, COUT, TH, TW>::OCC)) vo
     const int lvl = (gbid >= a.lv[1].gb_begin ? 1 : 0) + (gbid >= a.lv[2].gb_begin ? 1 : 0);
     const Conv3Level<T> &L = a.lv[lvl];
     const int first = gbid - L.gb_begin, G = L.gsz, ntiles = L.ntiles;
-    const int tiles_x = L.tiles_x, tiles_per_img = L.tiles_x * L.tiles_y;
+    const int tiles_x = L.tiles_x;
     const int lh = L.h, lw = L.w_;
     RF_TRACE_KEY(a.lv[0].ntiles);
     RF_TRACE(3, 0);
@@ -1042,38 +1157,47 @@ __global__ __launch_bounds__(kThreads, (Conv3Cfg<T, CIN, COUT, TH, TW>::OCC)) vo
     const T *in = L.in;
     const int in_ld = L.in_ld, in_off = L.in_off;
 
-    // ---- halo tile of tile t -> registers: unconditional loads from clamped addresses, padding applied when staged
+    // ---- halo tile of a tile -> registers: unconditional buffer loads, padding by range check + poisoned offsets (K_b)
     V pre[NPF];
     V upv[UPADD ? NPF : 1][4];
-    unsigned pre_ok = 0;          // bit 5k: pixel inside the map; bits 5k+1..5k+4: upsample taps inside the coarse map
-    auto fetch = [&](int t) {
-        const int tx = t % tiles_x, ty = (t / tiles_x) % L.tiles_y, img = t / tiles_per_img;
-        const size_t img_pix = (size_t)img * lh * lw;
+    int koff[NPF], kdyx[NPF];
+#pragma unroll
+    for (int k = 0; k < NPF; k++) {
+        int i = tid + k * kThreads;
+        i = i < C::STAGE_ITEMS ? i : C::STAGE_ITEMS - 1;
+        const int pix = i / CPV, cv = i % CPV;
+        const int dy = pix / HC, dx = pix % HC;
+        koff[k] = ((dy * lw + dx) * in_ld + cv * VEC) * (int)sizeof(T);
+        kdyx[k] = dy << 16 | dx;
+    }
+    const unsigned in_img_bytes = (unsigned)(lh * lw * in_ld - in_off) * (unsigned)sizeof(T);
+    const int hh = lh >> 1, wh = lw >> 1;
+    const unsigned up_img_bytes = (unsigned)(hh * wh * CIN) * (unsigned)sizeof(T);
+    unsigned pre_ok = 0;          // UPADD only: bit k = staged pixel k lies inside the map (outside, the blend must give 0)
+    auto fetch = [&](int tx, int ty, int img) {
+        const auto rs = image_rsrc(in + (size_t)img * lh * lw * in_ld + in_off, in_img_bytes);
         const int iy0 = ty * TH - 1, ix0 = tx * TW - 1;
+        const int sbase = (iy0 * lw + ix0) * in_ld * (int)sizeof(T);
         pre_ok = 0;
 #pragma unroll
         for (int k = 0; k < NPF; k++) {
-            int i = tid + k * kThreads;
-            i = i < C::STAGE_ITEMS ? i : C::STAGE_ITEMS - 1;
-            const int pix = i / CPV, cv = i % CPV;
-            const int iy = iy0 + pix / HC, ix = ix0 + pix % HC;
-            const bool ok = iy >= 0 && iy < lh && ix >= 0 && ix < lw;
-            const int cy = iy < 0 ? 0 : (iy >= lh ? lh - 1 : iy), cx = ix < 0 ? 0 : (ix >= lw ? lw - 1 : ix);
-            pre[k] = *(const V *)(in + (img_pix + (size_t)cy * lw + cx) * in_ld + in_off + cv * VEC);
-            pre_ok |= (ok ? 1u : 0u) << (5 * k);
+            const int ix = ix0 + (kdyx[k] & 0xffff);
+            const unsigned off = (unsigned)ix < (unsigned)lw ? (unsigned)(koff[k] + sbase) : kOobOffset;
+            pre[k] = buf_load16<V>(rs, off);
             if constexpr (UPADD) {
-                // out[2m] = .75 in[m] + .25 in[m-1];  out[2m+1] = .75 in[m] + .25 in[m+1];  taps outside = 0
-                const int hh = lh >> 1, wh = lw >> 1;
-                const int my = cy >> 1, mx = cx >> 1;
-                const int my2 = (cy & 1) ? my + 1 : my - 1, mx2 = (cx & 1) ? mx + 1 : mx - 1;
-                const T *ub = L.up + (size_t)img * hh * wh * CIN + cv * VEC;
+                // out[2m] = .75 in[m] + .25 in[m-1];  out[2m+1] = .75 in[m] + .25 in[m+1];  taps outside the coarse map = 0
+                const int iy = iy0 + (kdyx[k] >> 16);
+                pre_ok |= ((unsigned)iy < (unsigned)lh && (unsigned)ix < (unsigned)lw ? 1u : 0u) << k;
+                const auto ru = image_rsrc(L.up + (size_t)img * hh * wh * CIN, up_img_bytes);
+                const int cvo = (int)((tid + k * kThreads) % CPV) * VEC * (int)sizeof(T);
+                const int my = iy >> 1, mx = ix >> 1;
+                const int my2 = (iy & 1) ? my + 1 : my - 1, mx2 = (ix & 1) ? mx + 1 : mx - 1;
                 const int ys[4] = {my, my, my2, my2}, xs[4] = {mx, mx2, mx, mx2};
 #pragma unroll
                 for (int q = 0; q < 4; q++) {
-                    const bool tok = ys[q] >= 0 && ys[q] < hh && xs[q] >= 0 && xs[q] < wh;
-                    const int yy = ys[q] < 0 ? 0 : (ys[q] >= hh ? hh - 1 : ys[q]), xx = xs[q] < 0 ? 0 : (xs[q] >= wh ? wh - 1 : xs[q]);
-                    upv[k][q] = *(const V *)(ub + ((size_t)yy * wh + xx) * CIN);
-                    pre_ok |= (tok ? 1u : 0u) << (5 * k + 1 + q);
+                    // rows outside [0, hh) land outside the descriptor's range; columns need the explicit test
+                    const unsigned uo = (unsigned)xs[q] < (unsigned)wh ? (unsigned)((ys[q] * wh + xs[q]) * CIN * (int)sizeof(T) + cvo) : kOobOffset;
+                    upv[k][q] = buf_load16<V>(ru, uo);
                 }
             }
         }
@@ -1083,19 +1207,24 @@ __global__ __launch_bounds__(kThreads, (Conv3Cfg<T, CIN, COUT, TH, TW>::OCC)) vo
     const int n0 = L.n0, ld0 = L.ld0, off0 = L.off0, ld1 = L.ld1, off1 = L.off1;
     auto store_tile = [&](int img, int oy0, int ox0) {
         constexpr int OPV = COUT / VEC;
-        const size_t img_pix = (size_t)img * lh * lw;
+        const auto r0 = image_rsrc(out0 + (size_t)img * lh * lw * ld0 + off0, (unsigned)(lh * lw * ld0 - off0) * (unsigned)sizeof(T));
+        const auto r1 = image_rsrc(out1 + (size_t)img * lh * lw * ld1 + off1, (unsigned)(lh * lw * ld1 - off1) * (unsigned)sizeof(T));
+        const int pbase = oy0 * lw + ox0;
         for (int i = tid; i < P * OPV; i += kThreads) {
-            int p = i / OPV, cv = i % OPV;
-            int oy = oy0 + p / TW, ox = ox0 + p % TW;
-            if (oy < lh && ox < lw) {
-                const size_t pix = img_pix + (size_t)oy * lw + ox;
-                const int c = cv * VEC;
-                T *dst = c < n0 ? out0 + pix * ld0 + off0 + c : out1 + pix * ld1 + off1 + (c - n0);
-                *(V *)dst = *(const V *)(s_out + p * LDO + c);
-            }
+            const int p = i / OPV, cv = i % OPV;
+            const int py = p / TW, px = p % TW;
+            const int c = cv * VEC;
+            const int pix = pbase + py * lw + px;
+            const bool okx = ox0 + px < lw;
+            const V v = *(const V *)(s_out + p * LDO + c);
+            if (c < n0) buf_store16(r0, okx ? (unsigned)((pix * ld0 + c) * (int)sizeof(T)) : kOobOffset, v);
+            else buf_store16(r1, okx ? (unsigned)((pix * ld1 + (c - n0)) * (int)sizeof(T)) : kOobOffset, v);
         }
     };
-    if (first < ntiles) fetch(first);
+    const TileStep step(G, tiles_x, L.tiles_y);
+    TileCoord cur(first, tiles_x, L.tiles_y), nxt = cur;
+    step.advance(nxt);
+    if (first < ntiles) fetch(cur.tx, cur.ty, cur.img);
     __builtin_amdgcn_s_waitcnt(0x0F70);       // vmcnt(0): once-per-workgroup loads have landed before the tile loop
 
     int pbase[NJ];
@@ -1108,35 +1237,33 @@ __global__ __launch_bounds__(kThreads, (Conv3Cfg<T, CIN, COUT, TH, TW>::OCC)) vo
     // tile loop:  stage(t) | fetch(t+G) issued | store(t-1) | barrier | GEMM(t) | epilogue(t) -> s_out | barrier
     int p_img = -1, p_oy0 = 0, p_ox0 = 0;
     for (int t = first; t < ntiles; t += G) {
-        const int tx = t % tiles_x, ty = (t / tiles_x) % L.tiles_y, img = t / tiles_per_img;
+        const int tx = cur.tx, ty = cur.ty, img = cur.img;
         RF_TRACE(3, 8);
 #pragma unroll
         for (int k = 0; k < NPF; k++) {
             const int i = tid + k * kThreads;
             if (i < C::STAGE_ITEMS) {
-                V v = vzero<V, VEC>();
-                if ((pre_ok >> (5 * k)) & 1u) {
-                    v = pre[k];
-                    if constexpr (UPADD) {
-                        const float wq[4] = {0.5625f, 0.1875f, 0.1875f, 0.0625f};
-                        float sacc[VEC];
+                V v = pre[k];
+                if constexpr (UPADD) {
+                    const float wq[4] = {0.5625f, 0.1875f, 0.1875f, 0.0625f};
+                    float sacc[VEC];
 #pragma unroll
-                        for (int e = 0; e < VEC; e++) sacc[e] = 0.f;
+                    for (int e = 0; e < VEC; e++) sacc[e] = 0.f;
 #pragma unroll
-                        for (int q = 0; q < 4; q++) {
-                            const bool tok = (pre_ok >> (5 * k + 1 + q)) & 1u;
+                    for (int q = 0; q < 4; q++)
 #pragma unroll
-                            for (int e = 0; e < VEC; e++) sacc[e] = fmaf(wq[q], tok ? (float)upv[k][q][e] : 0.f, sacc[e]);
-                        }
+                        for (int e = 0; e < VEC; e++) sacc[e] = fmaf(wq[q], (float)upv[k][q][e], sacc[e]);
+                    const bool ok = (pre_ok >> k) & 1u;
 #pragma unroll
-                        for (int e = 0; e < VEC; e++) v[e] = to_T<T>(fmaf((float)v[e], a_lat, sacc[e] * a_up));
-                    }
+                    for (int e = 0; e < VEC; e++) v[e] = ok ? to_T<T>(fmaf((float)v[e], a_lat, sacc[e] * a_up)) : to_T<T>(0.f);
                 }
                 *(V *)(s_in + (i / CPV) * LDI + (i % CPV) * VEC) = v;
             }
         }
         RF_TRACE(3, 9);
-        if (t + G < ntiles) fetch(t + G);
+        if (t + G < ntiles) fetch(nxt.tx, nxt.ty, nxt.img);
+        cur = nxt;
+        step.advance(nxt);
         RF_TRACE(3, 10);
         if (p_img >= 0) store_tile(p_img, p_oy0, p_ox0);
         p_img = img; p_oy0 = ty * TH; p_ox0 = tx * TW;

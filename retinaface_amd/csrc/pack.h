@@ -49,4 +49,19 @@ RF_HD inline int xcd_remap(int bid, int nblk) {
     return base + i;
 }
 
+// Depthwise 3x3 on the matrix cores (fp16 engine): for a group of 16 channels the stencil is a dense 3x3 conv 16 -> 16 whose
+// weight matrix is diagonal, K = 9 taps x 16 channels = 144 -> 5 MFMA K-chunks of 32 (k = tap*16 + c, like K_c).  Lane l of
+// A fragment (group g, chunk kc) holds row c' = l & 15, columns k = kc*32 + (l >> 4)*8 + e, e < 8: at most ONE of its 8
+// halves is non-zero (c == c'), so the fragment is rebuilt in registers from one dword per lane: the fp16 weight bits,
+// already shifted into the half it occupies; the dword index inside the 4-dword fragment is ((c' & 7) >> 1) for every kc.
+// Returns that dword for lane `lane` given w9[tap] = the 9 fp16 weight bit patterns of channel g*16 + (lane & 15).
+RF_HD inline uint32_t dw_mma_dword(int kc, int lane, const uint16_t *w9) {
+    const int c = lane & 15, kgrp = lane >> 4;
+    const int tap = kc * 2 + (kgrp >> 1);
+    if (tap >= 9 || (c >> 3) != (kgrp & 1)) return 0u;       // this lane's 8 columns do not contain channel c
+    return (c & 1) ? ((uint32_t)w9[tap] << 16) : (uint32_t)w9[tap];
+}
+RF_HD inline int dw_mma_dword_index(int lane) { return ((lane & 15) & 7) >> 1; }
+constexpr int kDwMmaChunks = 5;
+
 }  // namespace rf
