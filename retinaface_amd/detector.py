@@ -121,6 +121,18 @@ class RetinaFace:
         _lib.check(self._lib.rf_enqueue_batch_device(self._h, p, r, c, s, n, float(threshold), C.byref(t)), self._h)
         return t.value
 
+    def prepare_device_batch(self, ptrs, rows, cols, steps=None):
+        """Build the C argument arrays of rf_enqueue_batch_device once for a batch of device frames that is submitted
+        repeatedly (a ring of camera buffers): what a C/C++ caller keeps on its side anyway.  Returns an opaque batch."""
+        n = len(ptrs)
+        steps = [3 * x for x in cols] if steps is None else steps
+        return ((C.c_void_p * n)(*ptrs), (C.c_int * n)(*rows), (C.c_int * n)(*cols), (C.c_int * n)(*steps), n, C.c_int())
+
+    def enqueue_prepared(self, batch, threshold: float = 0.5) -> int:
+        p, r, c, s, n, t = batch
+        _lib.check(self._lib.rf_enqueue_batch_device(self._h, p, r, c, s, n, threshold, C.byref(t)), self._h)
+        return t.value
+
     def wait(self, ticket: int, n: int) -> List[List[Detection]]:
         cap = self.max_detections
         out = (rf_face * (n * cap))()

@@ -6,6 +6,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <cstdint>
 #include <vector>
 
 #include "../../retinaface_amd/csrc/pack.h"
@@ -88,6 +89,26 @@ int main() {
             int m = xcd_remap(b, nblk);
             if (m < 0 || m >= nblk || seen[m]++) { printf("FAIL xcd_remap nblk=%d\n", nblk); bad++; break; }
         }
+    }
+    // depthwise-on-MFMA: expanding the per-lane dword (dw_mma_dword / dw_mma_dword_index) must reproduce the A fragment of the
+    // diagonal 16 x 144 matrix  A[c'][tap*16 + c] = (c == c') ? w[tap][c'] : 0  under the 16x16x32 A-operand layout
+    {
+        uint16_t w[16][9];
+        for (int c = 0; c < 16; c++)
+            for (int t = 0; t < 9; t++) w[c][t] = (uint16_t)(0x3c00 + 37 * c + t);        // distinct non-zero bit patterns
+        for (int kc = 0; kc < kDwMmaChunks; kc++)
+            for (int lane = 0; lane < 64; lane++) {
+                uint32_t dword = dw_mma_dword(kc, lane, w[lane & 15]);
+                uint16_t frag[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                int d = dw_mma_dword_index(lane);
+                frag[2 * d] = (uint16_t)(dword & 0xffff);
+                frag[2 * d + 1] = (uint16_t)(dword >> 16);
+                for (int e = 0; e < 8; e++) {
+                    int row = lane & 15, k = kc * 32 + (lane >> 4) * 8 + e, tap = k / 16, c = k % 16;
+                    uint16_t want = (tap < 9 && c == row) ? w[row][tap] : 0;
+                    if (frag[e] != want) { if (!bad) printf("FAIL dw_mma kc=%d lane=%d e=%d\n", kc, lane, e); bad++; }
+                }
+            }
     }
     printf(bad ? "test_pack: FAILED\n" : "test_pack: ok\n");
     return bad ? 1 : 0;

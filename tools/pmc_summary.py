@@ -2,7 +2,7 @@
 """Combine the two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE -- they do not fit one pass, MI355X_MICROARCH.md
 "rocprofv3 PMC slots") into per-kernel HBM bytes per launch.  gfx950 correction from the same guide: FETCH_SIZE
 reports exactly half the bytes of a wide coalesced read stream, so it is doubled; WRITE_SIZE is used as reported
-(uncalibrated per the guide).  Usage: pmc_summary.py fetch.db write.db out.json"""
+(uncalibrated per the guide).  Usage: pmc_summary.py fetch.db write.db out.json [images_per_launch]"""
 import json
 import re
 import sqlite3
@@ -32,7 +32,7 @@ def per_kernel(db_path, counter):
     return {(r[0], r[1]): (r[2], r[3]) for r in rows}
 
 
-def main(fetch_db, write_db, out):
+def main(fetch_db, write_db, out, images_per_launch=8):
     f = per_kernel(fetch_db, "FETCH_SIZE")
     w = per_kernel(write_db, "WRITE_SIZE")
     res = []
@@ -45,12 +45,13 @@ def main(fetch_db, write_db, out):
         res.append({"kernel": descriptor(name), "symbol": name, "grid_threads": grid, "launches_sampled": f.get(key, (0, 0))[0],
                     "fetch_size_bytes_raw": fk, "fetch_bytes_corrected_x2": 2 * fk, "write_size_bytes": wk,
                     "hbm_bytes_per_launch": 2 * fk + wk})
-    json.dump({"note": "per launch at batch 8, 448x448, fp16, eager launches (PMC collection faults under hipGraph replay); "
-                       "FETCH_SIZE doubled per MI355X_MICROARCH.md section HBM", "kernels": res}, open(out, "w"), indent=1)
+    json.dump({"note": f"per launch of {images_per_launch} images, 448x448, fp16, eager launches (tools/probes/pmc_probe.py; PMC collection "
+                       "faults under hipGraph replay); FETCH_SIZE doubled per MI355X_MICROARCH.md section HBM",
+               "images_per_launch": int(images_per_launch), "kernels": res}, open(out, "w"), indent=1)
     for r in res:
         print(f"{r['kernel'][:90]:90s} grid {r['grid_threads']:8d}  fetch*2 {r['fetch_bytes_corrected_x2'] / 1e6:8.3f} MB  "
               f"write {r['write_size_bytes'] / 1e6:8.3f} MB")
 
 
 if __name__ == "__main__":
-    main(*sys.argv[1:4])
+    main(*sys.argv[1:5])
