@@ -102,6 +102,40 @@ static void set_max_lds(F func, size_t bytes) {
     if (bytes > 48 * 1024) (void)hipFuncSetAttribute((const void *)func, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
 
+// Persistent grid: as many workgroups as the chip keeps resident (CUs x RESIDENT), trimmed so every workgroup walks the
+// same number of tiles (no nearly-empty last round).  Launches with fewer tiles than that get one tile per workgroup.
+static int g_num_cus = 0;
+static int num_cus() {
+    if (!g_num_cus) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 256;
+        g_num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    return g_num_cus;
+}
+// Below `min_rounds` x resident tiles the hardware dispatcher's dynamic one-tile-per-workgroup schedule is at least as
+// good as walking two tiles in sequence, so the grid stays one workgroup per tile.
+static float persist_min_rounds() {
+    static float v = -1.f;
+    if (v < 0.f) {
+        const char *e = getenv("RF_PERSIST_MIN_ROUNDS");      // probe knob (tools/probes), default measured on MI355X
+        v = e ? (float)atof(e) : 1.0f;
+    }
+    return v;
+}
+static int persistent_grid(int tiles, int resident_per_cu) {
+    const int resident = num_cus() * (resident_per_cu > 0 ? resident_per_cu : 1);
+    if ((float)tiles <= persist_min_rounds() * (float)resident) return tiles;
+    const int rounds = (tiles + resident - 1) / resident;
+    return (tiles + rounds - 1) / rounds;
+}
+template <typename F> static int resident_per_cu(F kern, size_t lds_bytes) {
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)kern, kThreads, lds_bytes) != hipSuccess || nb < 1) nb = 1;
+    return nb;
+}
+
 // =============================================================================================
 // K_a  preprocess + conv0
 //   reference: cudaMemset + imageROIResize8U3C (factor 1 = top-left copy) + convertBGR2RGBfloatKernel +
@@ -464,45 +498,48 @@ __global__ __launch_bounds__(kThreads, 7) void stem_kernel(StemArgs<TO> a) {
     for (int e = 0; e < 8; e++) dw_bias[e] = a.dw_b[e];
 
     // ---- phase 1: stage the u8 patch as BGRX dwords.  One item = 4 pixels = 12 consecutive frame bytes at an arbitrary
-    //      alignment: 4 aligned dword loads, realigned with v_alignbyte, expanded 3 -> 4 bytes, one 16-byte LDS store.
-    //      Bytes outside the frame are the zero canvas / conv padding.
-    const int iy0 = 2 * oy0 - 3;                                  // input row of patch row 0
-    const int bx0 = (2 * ox0 - 3) * 3;                            // input byte column of patch pixel 0
-    const uintptr_t base = (uintptr_t)fd.ptr;
-    const long long row_bytes = (long long)fd.cols * 3;
-    for (int i = tid; i < ST_IR * ST_GRP; i += kThreads) {
-        const int r = i / ST_GRP, g = i % ST_GRP;
-        const int iy = iy0 + r;
-        uint32_t w0 = 0, w1 = 0, w2 = 0;                          // the 12 bytes
-        if (iy >= 0 && iy < fd.rows) {
-            const long long off = (long long)bx0 + 12 * g;         // byte offset in the row
-            const uintptr_t lo = base + (size_t)iy * fd.step;
-            if (off >= 0 && off + 16 <= row_bytes) {               // interior: may over-read up to 3 bytes, still inside the row
-                const uintptr_t A = lo + off, a0 = A & ~(uintptr_t)3;
-                const uint32_t sh = (uint32_t)(A & 3);
-                const uint32_t *p = (const uint32_t *)a0;
-                const uint32_t d0 = p[0], d1 = p[1], d2 = p[2], d3 = p[3];
-                w0 = __builtin_amdgcn_alignbyte(d1, d0, sh);
-                w1 = __builtin_amdgcn_alignbyte(d2, d1, sh);
-                w2 = __builtin_amdgcn_alignbyte(d3, d2, sh);
-            } else {
-                const uint8_t *q = (const uint8_t *)lo;
-#pragma unroll
-                for (int k = 0; k < 12; k++) {
-                    const long long o = off + k;
-                    const uint32_t byte = (o >= 0 && o < row_bytes) ? q[o] : 0u;
-                    if (k < 4) w0 |= byte << (8 * k);
-                    else if (k < 8) w1 |= byte << (8 * (k - 4));
-                    else w2 |= byte << (8 * (k - 8));
-                }
+    //      alignment, fetched as the 4 aligned dwords that contain them (ONE buffer_load_dwordx4), realigned with
+    //      v_alignbyte, expanded 3 -> 4 bytes per pixel, one 16-byte LDS store.  The frame is addressed through a descriptor
+    //      whose base is the frame pointer rounded DOWN to a dword and whose size is rounded UP to one: every fetched dword
+    //      is an aligned memory dword holding at least one frame byte (never straddles a page); rows above the frame are
+    //      negative offsets and read 0 (hardware range check), rows below are poisoned; bytes left / right of a row are
+    //      cleared here.  All 32-bit: no 64-bit address arithmetic or compares on the saturated VALU.
+    {
+        const int iy0 = 2 * oy0 - 3;                                  // input row of patch row 0
+        const int bx0 = (2 * ox0 - 3) * 3;                            // input byte column of patch pixel 0
+        const uintptr_t fp = (uintptr_t)fd.ptr;
+        const int delta = (int)(fp & 3);
+        const unsigned fbytes = ((unsigned)delta + (unsigned)fd.rows * (unsigned)fd.step + 3u) & ~3u;
+        const auto rs = image_rsrc((const uint8_t *)(fp & ~(uintptr_t)3), fbytes);
+        const int row_bytes = fd.cols * 3;
+        for (int i = tid; i < ST_IR * ST_GRP; i += kThreads) {
+            const int r = i / ST_GRP, g = i % ST_GRP;
+            const int iy = iy0 + r;
+            const int off = bx0 + 12 * g;                              // byte column of the item's first byte
+            // the leftmost item starts 9 bytes (3 pixels of conv padding) before the row: fetch from the row start and shift --
+            // in row 0 those bytes would be a negative offset whose 4th dword wraps to 0, which the hardware treats as out of range
+            const int A = delta + iy * fd.step + (off < 0 ? 0 : off);
+            const u32x4 d = __builtin_amdgcn_raw_buffer_load_b128(rs, (unsigned)iy < (unsigned)fd.rows ? (A & ~3) : (int)kOobOffset, 0, 0);
+            const uint32_t sh = (uint32_t)(A & 3);
+            uint32_t w0 = __builtin_amdgcn_alignbyte(d[1], d[0], sh);
+            uint32_t w1 = __builtin_amdgcn_alignbyte(d[2], d[1], sh);
+            uint32_t w2 = __builtin_amdgcn_alignbyte(d[3], d[2], sh);
+            static_assert((2 * 0 * ST_TW - 3) * 3 == -9, "the left border item starts exactly 9 bytes before the row");
+            if (off < 0) { w2 = w0 << 8; w1 = 0u; w0 = 0u; }           // fetched from column 0: move bytes 0..2 to 9..11
+            if (off < 0 || off + 12 > row_bytes) {                     // left / right border of the frame: clear outside bytes
+                const int lo = off < 0 ? -off : 0, hi = row_bytes - off < 12 ? row_bytes - off : 12;
+                auto bmask = [](int nb) -> uint32_t { return nb <= 0 ? 0u : (nb >= 4 ? 0xffffffffu : (1u << (8 * nb)) - 1u); };
+                w0 &= bmask(hi) & ~bmask(lo);
+                w1 &= bmask(hi - 4) & ~bmask(lo - 4);
+                w2 &= bmask(hi - 8) & ~bmask(lo - 8);
             }
+            uint4 o4;
+            o4.x = w0 & 0x00ffffffu;
+            o4.y = ((w0 >> 24) | (w1 << 8)) & 0x00ffffffu;
+            o4.z = ((w1 >> 16) | (w2 << 16)) & 0x00ffffffu;
+            o4.w = w2 >> 8;
+            *(uint4 *)(s_in + r * ST_ROWD + g * 4) = o4;
         }
-        uint4 o4;
-        o4.x = w0 & 0x00ffffffu;
-        o4.y = ((w0 >> 24) | (w1 << 8)) & 0x00ffffffu;
-        o4.z = ((w1 >> 16) | (w2 << 16)) & 0x00ffffffu;
-        o4.w = w2 >> 8;
-        *(uint4 *)(s_in + r * ST_ROWD + g * 4) = o4;
     }
     if (tid < 9) *(f16x8 *)(s_dw + tid * 8) = *(const f16x8 *)(a.dw_w + tid * 8);
     __syncthreads();
@@ -575,12 +612,14 @@ __global__ __launch_bounds__(kThreads, 7) void stem_kernel(StemArgs<TO> a) {
     __syncthreads();
     typedef typename Vec<TO>::type VO;
     constexpr int OPV = 16 / Vec<TO>::N;                                  // 16-byte chunks per output pixel
-    TO *outb = a.out + (size_t)img * a.ho * a.wo * 16;
+    const auto ro = image_rsrc(a.out + (size_t)img * a.ho * a.wo * 16, (unsigned)(a.ho * a.wo * 16) * (unsigned)sizeof(TO));
+    const int obase = (oy0 * a.wo + ox0) * 16 * (int)sizeof(TO);
     for (int i = tid; i < ST_P * OPV; i += kThreads) {
         const int p = i / OPV, cv = i % OPV;
-        const int oy = oy0 + p / ST_TW, ox = ox0 + p % ST_TW;
-        if (oy < a.ho && ox < a.wo)
-            *(VO *)(outb + ((size_t)oy * a.wo + ox) * 16 + cv * Vec<TO>::N) = *(const VO *)(s_out + p * LDO + cv * Vec<TO>::N);
+        const int py = p / ST_TW, px = p % ST_TW;
+        // rows below the map fall outside the descriptor and are dropped; columns need the explicit test
+        const unsigned off = ox0 + px < a.wo ? (unsigned)(((py * a.wo + px) * 16 + cv * Vec<TO>::N) * (int)sizeof(TO) + obase) : kOobOffset;
+        buf_store16(ro, off, *(const VO *)(s_out + p * LDO + cv * Vec<TO>::N));
     }
 }
 
@@ -959,40 +998,6 @@ __global__ __launch_bounds__(kThreads, (DwPwCfg<T, CIN, COUT, STRIDE, HAS_DW, TH
         RF_TRACE(2, 7);
     }
     if (p_img >= 0) store_tile(p_img, p_oy0, p_ox0);
-}
-
-// Persistent grid: as many workgroups as the chip keeps resident (CUs x RESIDENT), trimmed so every workgroup walks the
-// same number of tiles (no nearly-empty last round).  Launches with fewer tiles than that get one tile per workgroup.
-static int g_num_cus = 0;
-static int num_cus() {
-    if (!g_num_cus) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 256;
-        g_num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    }
-    return g_num_cus;
-}
-// Below `min_rounds` x resident tiles the hardware dispatcher's dynamic one-tile-per-workgroup schedule is at least as
-// good as walking two tiles in sequence, so the grid stays one workgroup per tile.
-static float persist_min_rounds() {
-    static float v = -1.f;
-    if (v < 0.f) {
-        const char *e = getenv("RF_PERSIST_MIN_ROUNDS");      // probe knob (tools/probes), default measured on MI355X
-        v = e ? (float)atof(e) : 1.0f;
-    }
-    return v;
-}
-static int persistent_grid(int tiles, int resident_per_cu) {
-    const int resident = num_cus() * (resident_per_cu > 0 ? resident_per_cu : 1);
-    if ((float)tiles <= persist_min_rounds() * (float)resident) return tiles;
-    const int rounds = (tiles + resident - 1) / resident;
-    return (tiles + rounds - 1) / rounds;
-}
-template <typename F> static int resident_per_cu(F kern, size_t lds_bytes) {
-    int nb = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)kern, kThreads, lds_bytes) != hipSuccess || nb < 1) nb = 1;
-    return nb;
 }
 
 template <typename T, int CIN, int COUT, int STRIDE, bool HAS_DW, int TH, int TW, bool LAT>
