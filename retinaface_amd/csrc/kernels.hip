@@ -237,7 +237,9 @@ template void launch_conv0<float>(hipStream_t, const FrameDesc *, float *, const
 // 32-bit per-lane byte offsets that are constants of the thread (tile origin added with one v_add), and the hardware range
 // check instead of clamps and masks -- a row above / below the image is a negative / too-large offset and reads as zero
 // (stores are dropped); only the column test needs an instruction.  This took ~20 VALU + ~10 SALU per 16-byte item out of
-// loops that are a few hundred instructions per tile.  (The scalar soffset is NOT range-checked, hence everything in voffset.)
+// loops that are a few hundred instructions per tile.  Measured semantics on gfx950 (tools/probes/buffer_oob.cpp): the check is
+// per dword of a multi-dword access, an offset that wraps past 2^32 is out of range, soffset is included in the check (but is
+// unsigned, so the possibly negative tile origin is added into voffset), unaligned offsets work, out-of-range stores are dropped.
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 constexpr unsigned kOobOffset = 0x80000000u;
 template <typename P> __device__ __forceinline__ auto image_rsrc(P *base, unsigned bytes) {
@@ -694,6 +696,8 @@ template <typename T, int CIN, int COUT, int STRIDE, bool HAS_DW, int TH, int TW
     static constexpr int OCC_CAP = sizeof(T) == 1 ? (CIN >= 64 ? 3 : 4) : (CIN >= 64 ? 4 : 5);   // 170 / 128 / 102 VGPRs: the largest budgets that compile without spills
     static constexpr int OCC = BIG_MAP ? (LDS_OCC < 1 ? 1 : (LDS_OCC > OCC_CAP ? OCC_CAP : LDS_OCC)) : 1;
     static constexpr int GFRAGS = 12;                      // streamed case only
+    // (capping the 128-channel blocks at 128 VGPRs for a 4th workgroup per CU spills 33 registers: 18 -> 37 us, measured)
+    template <bool LAT> static constexpr int occ() { return OCC; }
 };
 
 template <typename T>
@@ -705,7 +709,7 @@ struct DwPwArgs {
 };
 
 template <typename T, int CIN, int COUT, int STRIDE, bool HAS_DW, int TH, int TW, bool LAT>
-__global__ __launch_bounds__(kThreads, (DwPwCfg<T, CIN, COUT, STRIDE, HAS_DW, TH, TW>::OCC)) void dwpw_kernel(DwPwArgs<T> a) {
+__global__ __launch_bounds__(kThreads, (DwPwCfg<T, CIN, COUT, STRIDE, HAS_DW, TH, TW>::template occ<LAT>())) void dwpw_kernel(DwPwArgs<T> a) {
     typedef DwPwCfg<T, CIN, COUT, STRIDE, HAS_DW, TH, TW> C;
     typedef typename Vec<T>::type V;
     typedef Mma<T> M;
@@ -1250,12 +1254,16 @@ __global__ __launch_bounds__(kThreads, (Conv3Cfg<T, CIN, COUT, TH, TW>::OCC)) vo
             if (i < C::STAGE_ITEMS) {
                 V v = pre[k];
                 if constexpr (UPADD) {
-                    const float wq[4] = {0.5625f, 0.1875f, 0.1875f, 0.0625f};
+                    // the tap weights live in registers (not literals) so that each MAC is one v_fma_mix_f32 on the fp16 tap
+                    // instead of a convert + fmac pair: this staging blend is ~half of the kernel's VALU instructions
+                    float wq[4] = {0.5625f, 0.1875f, 0.1875f, 0.0625f};
+#pragma unroll
+                    for (int q = 0; q < 4; q++) asm volatile("" : "+s"(wq[q]));
                     float sacc[VEC];
 #pragma unroll
-                    for (int e = 0; e < VEC; e++) sacc[e] = 0.f;
+                    for (int e = 0; e < VEC; e++) sacc[e] = wq[0] * (float)upv[k][0][e];
 #pragma unroll
-                    for (int q = 0; q < 4; q++)
+                    for (int q = 1; q < 4; q++)
 #pragma unroll
                         for (int e = 0; e < VEC; e++) sacc[e] = fmaf(wq[q], (float)upv[k][q][e], sacc[e]);
                     const bool ok = (pre_ok >> k) & 1u;

@@ -269,6 +269,49 @@ def test_edge_cases_empty_small_strided_and_chunked(rfa, oracles, crop448, prec)
     assert [d.anchor_index for d in a] == [d.anchor_index for d in b] and all(x.rect == y.rect for x, y in zip(a, b))
 
 
+@pytest.mark.parametrize("prec", [FP32, FP16])
+def test_odd_net_size_partial_tiles_and_unaligned_frames(rfa, oracles, base_frame, prec):
+    """A net size whose feature maps are not multiples of any tile (352 x 608 -> 176x304 ... 11x19): every kernel has partial
+    tiles on the right / bottom, the persistent tile walk wraps rows and images at odd counts, and the hardware-range-check
+    padding of the buffer descriptors is exercised on all four borders.  Frames: net-sized, smaller than the net, and a view at
+    an odd byte offset (frame pointer not dword aligned, row step not a multiple of 4)."""
+    hw = (352, 608)
+    det = engine(rfa, "mnet-deconv-0517", prec, hw)
+    od = oracles["mnet-deconv-0517"]
+    full = np.ascontiguousarray(base_frame[100:100 + hw[0], 400:400 + hw[1]])
+    small = np.ascontiguousarray(base_frame[100:100 + 301, 400:400 + 517])
+    backing = np.zeros((hw[0], hw[1] * 3 + 7), np.uint8)                   # odd row step
+    flat = backing.reshape(-1)[1:1 + (hw[0] - 1) * backing.shape[1] + hw[1] * 3]
+    odd = np.lib.stride_tricks.as_strided(flat, shape=(hw[0], hw[1], 3), strides=(backing.shape[1], 3, 1))
+    odd[:] = full
+    assert odd.ctypes.data % 4 == 1 and odd.strides[0] % 4 != 0
+    for name, frame in (("full", full), ("small", small), ("odd", odd)):
+        ref = od.detect(np.ascontiguousarray(frame), 0.5, 0.4, net_hw=hw)
+        assert len(ref.detections) >= 2, name
+        compare(det.detect(frame, 0.5), ref.rows(), ref.anchor_indices(), prec)
+    # 19 frames in one call: chunks of 8 + 8 + 3 coalesced into launches whose tile counts are odd multiples
+    many = [full, small, np.ascontiguousarray(odd)] * 6 + [full]
+    want = [od.detect(f, 0.5, 0.4, net_hw=hw).anchor_indices().tolist() for f in (full, small, np.ascontiguousarray(odd))]
+    got = det.detectBatchImages(many, 0.5)
+    assert [[d.anchor_index for d in r] for r in got] == (want * 6 + [want[0]])
+
+
+def test_prepared_device_batches_pipeline(rfa):
+    """prepare_device_batch / enqueue_prepared (descriptor arrays built once): results equal the plain enqueue path, for
+    more tickets in flight than one launch holds."""
+    import torch
+    from retinaface_amd.frames import synth_frames
+    det = engine(rfa, "mnet25", FP16, (448, 448))
+    frames = synth_frames(448, 448, 8, config=3)
+    d = torch.from_numpy(np.stack(frames)).cuda()
+    ptrs = [d[i].data_ptr() for i in range(8)]
+    want = [[x.anchor_index for x in r] for r in det.detect_device(ptrs, [448] * 8, [448] * 8, 0.5)]
+    batch = det.prepare_device_batch(ptrs, [448] * 8, [448] * 8)
+    tickets = [det.enqueue_prepared(batch, 0.5) for _ in range(det.num_slots())]
+    for t in tickets:
+        assert [[x.anchor_index for x in r] for r in det.wait(t, 8)] == want
+
+
 def test_device_resident_and_async_entry_points(rfa):
     import torch
     from retinaface_amd.frames import synth_frames
