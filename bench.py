@@ -30,8 +30,8 @@ MFMA_F16_PEAK_TFLOPS = 2500.0  # dense fp16/bf16 MFMA
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=400)
-    ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--steps", type=int, default=8000)
+    ap.add_argument("--warmup", type=int, default=400)
     ap.add_argument("--batch", type=int, default=8, help="images per GPU per step")
     ap.add_argument("--height", type=int, default=448)
     ap.add_argument("--width", type=int, default=448)
