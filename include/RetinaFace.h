@@ -57,6 +57,10 @@ public:
     void detectBatchImages(vector<cv::Mat> imgs, float threshold = 0.5);
     void detect(const Mat &img, float threshold = 0.5, float scales = 1.0);
 
+    /* the reference's Caffe-build detect (`void detect(Mat img, ...)`, RetinaFace.cpp:943-1075; it cannot share the name with
+       the TensorRT-build signature above, RetinaFace.h:70): no resize, pad to x32, run at that size; result in lastResult() */
+    void detectPad32(const Mat &img, float threshold = 0.5);
+
     /* additive accessors */
     const vector<FaceDetectInfo> &lastResult() const { return last_; }
     const vector<vector<FaceDetectInfo>> &lastBatchResult() const { return lastBatch_; }

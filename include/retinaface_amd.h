@@ -105,6 +105,16 @@ int rf_detect_batch(rf_handle h, const uint8_t *const *bgr, const int *rows, con
                     const int *steps, int n, float threshold,
                     rf_face *out, int cap_per_image, int *counts);
 
+/* The reference's Caffe-build detect (`void RetinaFace::detect(Mat img, ...)`, RetinaFace.cpp:943-1075): NO resize and no
+ * fixed network size -- every frame is zero-padded right/bottom to the next multiple of 32 (:950-953), the net is reshaped
+ * to that size (:965-966), anchors are regenerated for it (:1035) and boxes are clipped to the padded size (:1055).
+ * Coordinates are therefore source-frame pixels.  The handle keeps one engine per distinct padded size it has seen (created
+ * on first use, least-recently-used evicted beyond 8); frames of one call are grouped by size and results returned in call
+ * order.  `on_device` != 0: the frame pointers are device pointers.  Size limit as in the reference: 4096 x 3072. */
+int rf_detect_batch_pad32(rf_handle h, const uint8_t *const *bgr, const int *rows, const int *cols,
+                          const int *steps, int n, int on_device, float threshold,
+                          rf_face *out, int cap_per_image, int *counts);
+
 /* Same, frames already resident in device memory (HBM) on the engine's device. */
 int rf_detect_batch_device(rf_handle h, const void *const *d_bgr, const int *rows, const int *cols,
                            const int *steps, int n, float threshold,

@@ -44,6 +44,8 @@ SYMBOLS = {
                                   C.c_float, _PP(rf_face), C.c_int, _PP(C.c_int)]),
     "rf_detect_batch_device": (C.c_int, [C.c_void_p, _PP(C.c_void_p), _PP(C.c_int), _PP(C.c_int), _PP(C.c_int),
                                          C.c_int, C.c_float, _PP(rf_face), C.c_int, _PP(C.c_int)]),
+    "rf_detect_batch_pad32": (C.c_int, [C.c_void_p, _PP(C.c_void_p), _PP(C.c_int), _PP(C.c_int), _PP(C.c_int), C.c_int,
+                                        C.c_int, C.c_float, _PP(rf_face), C.c_int, _PP(C.c_int)]),
     "rf_num_slots": (C.c_int, [C.c_void_p]),
     "rf_enqueue_batch_device": (C.c_int, [C.c_void_p, _PP(C.c_void_p), _PP(C.c_int), _PP(C.c_int), _PP(C.c_int),
                                           C.c_int, C.c_float, _PP(C.c_int)]),

@@ -47,6 +47,18 @@ void RetinaFace::detectBatchImages(vector<cv::Mat> imgs, float threshold) {
     }
 }
 
+void RetinaFace::detectPad32(const Mat &img, float threshold) {
+    last_.clear();
+    if (img.empty()) return;                       // RetinaFace.cpp:945-947
+    const uint8_t *ptr = img.data;
+    int rows = img.rows, cols = img.cols, step = (int)(size_t)img.step, count = 0;
+    vector<rf_face> faces(maxDet_);
+    check(rf_detect_batch_pad32(h_, &ptr, &rows, &cols, &step, 1, 0, threshold, faces.data(), maxDet_, &count), h_, "RetinaFace::detectPad32");
+    int k = count < maxDet_ ? count : maxDet_;
+    last_.resize(k);
+    if (k) memcpy(last_.data(), faces.data(), (size_t)k * sizeof(rf_face));
+}
+
 void RetinaFace::detect(const Mat &img, float threshold, float /*scales: unused in the reference too*/) {
     last_.clear();
     if (img.empty()) return;                       // RetinaFace.cpp:578-580

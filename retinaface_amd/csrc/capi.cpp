@@ -1,7 +1,11 @@
 // capi.cpp -- extern "C" boundary (include/retinaface_amd.h) over rf::Engine.  Exceptions never cross it.
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <list>
 #include <string>
+#include <utility>
+#include <vector>
 
 #include "engine.h"
 
@@ -12,6 +16,11 @@ thread_local std::string g_create_error;
 struct rf_engine {
     std::unique_ptr<rf::Engine> eng;
     std::string error;
+    // rf_detect_batch_pad32: one engine per padded frame size, most recently used first
+    std::string model_dir, network;
+    float nms = 0.4f;
+    rf::EngineOptions opt;
+    std::list<std::pair<std::pair<int, int>, std::unique_ptr<rf::Engine>>> pool;
 };
 
 namespace {
@@ -58,6 +67,7 @@ int rf_create(const char *model_dir, const char *network, float nms_threshold, c
         auto eng = rf::Engine::create(model_dir, network ? network : "net3", nms_threshold, eo);
         rf_engine *h = new rf_engine;
         h->eng = std::move(eng);
+        h->model_dir = model_dir; h->network = network ? network : "net3"; h->nms = nms_threshold; h->opt = eo;
         *out = h;
         return RF_OK;
     });
@@ -94,6 +104,67 @@ int rf_detect_batch(rf_handle h, const uint8_t *const *bgr, const int *rows, con
 int rf_detect_batch_device(rf_handle h, const void *const *d_bgr, const int *rows, const int *cols, const int *steps,
                            int n, float threshold, rf_face *out, int cap_per_image, int *counts) {
     return detect_common(h, (const uint8_t *const *)d_bgr, rows, cols, steps, n, true, threshold, out, cap_per_image, counts);
+}
+
+namespace {
+constexpr size_t kPoolEngines = 8;
+
+rf::Engine *pool_engine(rf_engine *h, int hs, int ws) {
+    const std::pair<int, int> key(hs, ws);
+    for (auto it = h->pool.begin(); it != h->pool.end(); ++it)
+        if (it->first == key) {
+            h->pool.splice(h->pool.begin(), h->pool, it);
+            return h->pool.front().second.get();
+        }
+    rf::EngineOptions eo = h->opt;
+    eo.net_h = hs; eo.net_w = ws;
+    eo.lanes = 1; eo.coalesce = 1; eo.keep_outputs = false;
+    // activations scale with the frame: keep a pooled engine's footprint near max_batch x 448^2 worth of pixels
+    const long px = (long)hs * ws, budget = (long)std::max(eo.max_batch, 1) * 448 * 448;
+    eo.max_batch = (int)std::max(1L, std::min((long)eo.max_batch, budget / px));
+    if (h->pool.size() >= kPoolEngines) h->pool.pop_back();
+    h->pool.emplace_front(key, rf::Engine::create(h->model_dir, h->network, h->nms, eo));
+    return h->pool.front().second.get();
+}
+}  // namespace
+
+int rf_detect_batch_pad32(rf_handle h, const uint8_t *const *bgr, const int *rows, const int *cols, const int *steps, int n,
+                          int on_device, float threshold, rf_face *out, int cap_per_image, int *counts) {
+    if (!h) return RF_ERR_INVALID_ARG;
+    return guarded(h, [&]() -> int {
+        if (n < 0 || (n > 0 && (!bgr || !rows || !cols || !counts))) throw rf::ArgError("null argument");
+        std::vector<char> done(n, 0);
+        bool truncated = false;
+        for (int i = 0; i < n; i++) {
+            if (done[i]) continue;
+            if (!bgr[i] || rows[i] <= 0 || cols[i] <= 0) { counts[i] = 0; done[i] = 1; continue; }    // img.empty(), :945-947
+            if (rows[i] > 4096 * 3072 / std::max(cols[i], 1)) throw rf::ArgError("frame larger than 4096x3072 (RetinaFace.cpp:325)");
+            const int hs = (rows[i] + 31) / 32 * 32, ws = (cols[i] + 31) / 32 * 32;                   // :950-951
+            std::vector<int> idx;
+            for (int j = i; j < n; j++)
+                if (!done[j] && bgr[j] && rows[j] > 0 && cols[j] > 0 && (rows[j] + 31) / 32 * 32 == hs && (cols[j] + 31) / 32 * 32 == ws)
+                    idx.push_back(j);
+            rf::Engine &eng = *pool_engine(h, hs, ws);
+            const int m = (int)idx.size();
+            std::vector<const uint8_t *> f(m);
+            std::vector<int> r(m), c(m), st(m), cnt(m);
+            for (int k = 0; k < m; k++) { f[k] = bgr[idx[k]]; r[k] = rows[idx[k]]; c[k] = cols[idx[k]]; st[k] = steps ? steps[idx[k]] : cols[idx[k]] * 3; }
+            std::vector<rf_face> tmp((size_t)m * std::max(cap_per_image, 0));
+            bool tr = false;
+            eng.detect(f.data(), r.data(), c.data(), st.data(), m, on_device != 0, threshold, out ? tmp.data() : nullptr, cap_per_image,
+                       cnt.data(), &tr);
+            truncated = truncated || tr;
+            for (int k = 0; k < m; k++) {
+                counts[idx[k]] = cnt[k];
+                if (out)
+                    memcpy(out + (size_t)idx[k] * cap_per_image, tmp.data() + (size_t)k * cap_per_image,
+                           sizeof(rf_face) * (size_t)std::min(cnt[k], cap_per_image));
+                done[idx[k]] = 1;
+            }
+        }
+        if (truncated) { h->error = "more candidates / detections than the configured caps"; return RF_ERR_TRUNCATED; }
+        return RF_OK;
+    });
 }
 
 int rf_num_slots(rf_handle h) { return h ? h->eng->num_slots() : RF_ERR_INVALID_ARG; }

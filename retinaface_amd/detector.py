@@ -103,6 +103,33 @@ class RetinaFace:
             ptrs[i], rows[i], cols[i], steps[i] = im.ctypes.data, im.shape[0], im.shape[1], im.strides[0]
         return self._run(self._lib.rf_detect_batch, ptrs, rows, cols, steps, n, threshold)
 
+    def detect_pad32(self, imgs: Sequence[np.ndarray], threshold: float = 0.5) -> List[List[Detection]]:
+        """The reference's Caffe-build detect (RetinaFace.cpp:943-1075): no resize, each frame zero-padded to the next
+        multiple of 32 and run at that size, boxes clipped to the padded size, coordinates in source-frame pixels.
+        anchor_index of the returned detections is -1 (anchor tables differ per size)."""
+        n = len(imgs)
+        if n == 0:
+            return []
+        ptrs = (C.c_void_p * n)()
+        rows, cols, steps = (C.c_int * n)(), (C.c_int * n)(), (C.c_int * n)()
+        keep = []
+        for i, im in enumerate(imgs):
+            if im is None or im.size == 0:
+                ptrs[i], rows[i], cols[i], steps[i] = None, 0, 0, 0
+                continue
+            if im.dtype != np.uint8 or im.ndim != 3 or im.shape[2] != 3:
+                raise ValueError("frames must be uint8 H x W x 3 (CV_8UC3, BGR)")
+            if im.strides[2] != 1 or im.strides[1] != 3:
+                im = np.ascontiguousarray(im)
+            keep.append(im)
+            ptrs[i], rows[i], cols[i], steps[i] = im.ctypes.data, im.shape[0], im.shape[1], im.strides[0]
+        cap = self.max_detections
+        out = (rf_face * (n * cap))()
+        counts = (C.c_int * n)()
+        st = _lib.check(self._lib.rf_detect_batch_pad32(self._h, ptrs, rows, cols, steps, n, 0, float(threshold), out, cap, counts), self._h)
+        self.truncated = st == _lib.RF_ERR_TRUNCATED
+        return self._collect(out, counts, n, cap, anchors=False)
+
     # ------------------------------------------------------------------ device-resident frames
     def detect_device(self, ptrs: Sequence[int], rows: Sequence[int], cols: Sequence[int], threshold: float = 0.5,
                       steps: Optional[Sequence[int]] = None) -> List[List[Detection]]:

@@ -296,6 +296,29 @@ def test_odd_net_size_partial_tiles_and_unaligned_frames(rfa, oracles, base_fram
     assert [[d.anchor_index for d in r] for r in got] == (want * 6 + [want[0]])
 
 
+@pytest.mark.parametrize("prec", [FP32, FP16])
+def test_pad32_variant_is_the_reference_caffe_build_detect(rfa, oracles, base_frame, prec):
+    """rf_detect_batch_pad32 = `RetinaFace::detect(Mat img, ...)` of the Caffe build (RetinaFace.cpp:943-1075): no fixed net
+    size, pad to x32, per-size anchors, clip to the padded size.  Checked against oracle.pipeline's Caffe variant on the
+    reference's own image at its native 1280x886 and on odd crops, mixed in one call (engines are pooled per size)."""
+    from retinaface_amd.frames import load_base_frame
+    det = engine(rfa, "mnet-deconv-0517", prec, (448, 448))
+    od = oracles["mnet-deconv-0517"]
+    native = load_base_frame()                                   # data/img.jpg as shipped: 886 x 1280
+    assert native.shape[0] % 32 != 0
+    frames = [native, np.ascontiguousarray(native[100:433, 380:901]), np.ascontiguousarray(native[60:380, 300:811]),
+              np.ascontiguousarray(native[100:433, 380:901][:, ::-1])]
+    got = det.detect_pad32(frames + [None], 0.5)
+    assert got[4] == []
+    t = TOL[prec]
+    for f, g in zip(frames, got):
+        ref = od.detect(f, 0.5, 0.4)                             # net_hw=None: the Caffe variant
+        assert len(ref.detections) >= 1 and len(g) == len(ref.detections), (f.shape, len(g), len(ref.detections))
+        for a, r in zip(g, ref.rows()):
+            assert iou_plus1(a.rect, r[1:5]) >= 1 - t["iou"] and abs(a.score - r[0]) <= t["score"]
+            assert a.rect[2] <= (f.shape[1] + 31) // 32 * 32 - 1 and a.rect[3] <= (f.shape[0] + 31) // 32 * 32 - 1
+
+
 def test_prepared_device_batches_pipeline(rfa):
     """prepare_device_batch / enqueue_prepared (descriptor arrays built once): results equal the plain enqueue path, for
     more tickets in flight than one launch holds."""
