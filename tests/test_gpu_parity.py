@@ -187,17 +187,17 @@ def _match(got, ref_rows):
 
 @pytest.mark.parametrize("stem", STEMS)
 def test_int8_engine_against_the_fp32_oracle(rfa, oracles, base_frame, crop448, stem):
-    """int8 engine (TensorRT-style: per-tensor activation scales from the shipped calibration table, per-channel weight
-    scales, i8 MFMA).  Quantisation noise moves boxes by ~1 px and can hand the NMS win to a neighbouring anchor, so
-    the bar is stated per face, not per anchor: same number of faces, every oracle face matched with IoU >= 0.93, scores
-    within 0.03.  mnet25 weights reuse the 0517 table (the only one the reference ships; BASELINE config 5): a table
-    calibrated for other weights, flagged as an approximation in SURVEY.md App. B.7 -- it must still find the same faces,
-    with a looser IoU >= 0.88 (measured worst 0.929)."""
+    """int8 engine (TensorRT-style: per-tensor activation scales from a calibration table, per-channel weight scales, i8 MFMA).
+    Quantisation noise moves boxes by ~1 px and can hand the NMS win to a neighbouring anchor, so the bar is stated per face,
+    not per anchor: same number of faces, every oracle face matched with IoU >= 0.93, scores within 0.03.  0517 uses the
+    TensorRT table the reference ships.  mnet25 has none in the reference: assets/mnet25.table.int8 is generated by
+    tools/calibrate_int8.py (99.999th-percentile rule on 48 calibration frames; measured worst IoU 0.916 on synthetic frames,
+    0.977 on the reference image -- with the borrowed 0517 table it was 0.912 / 0.903), bar IoU >= 0.90."""
     from retinaface_amd.frames import synth_frames
     det = engine(rfa, stem, INT8, (448, 448))
     g = golden(f"synth448_{stem}.npz")
     res = det.detectBatchImages(synth_frames(448, 448, 8, config=1), 0.5)
-    min_iou = 0.93 if stem == "mnet-deconv-0517" else 0.88
+    min_iou = 0.93 if stem == "mnet-deconv-0517" else 0.90
     for i in range(8):
         ref = g[f"det05_{i}"]
         assert len(res[i]) == len(ref), (i, len(res[i]), len(ref))

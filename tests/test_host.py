@@ -103,8 +103,10 @@ def test_cxx_loader_reads_the_reference_files(stem, built_lib, tmp_path):
     the plan compiled from the .rfw."""
     m = os.path.join(REFERENCE, "model")
     out = str(tmp_path / (stem + ".rfw"))
+    # 0517: the TensorRT table the reference ships; mnet25: the table tools/calibrate_int8.py generated (assets/)
+    table = os.path.join(m, "mnet-deconv-0517.table.int8") if stem == "mnet-deconv-0517" else os.path.join(ASSETS, "mnet25.table.int8")
     st = built_lib.rf_convert_model(os.path.join(m, stem + ".prototxt").encode(), os.path.join(m, stem + ".caffemodel").encode(),
-                                    os.path.join(m, "mnet-deconv-0517.table.int8").encode(), out.encode())
+                                    table.encode(), out.encode())
     assert st == 0, built_lib.rf_last_error(None)
     assert open(out, "rb").read() == open(os.path.join(ASSETS, stem + ".rfw"), "rb").read()
     a = _folded(built_lib, m, stem, "ssh0.b")
@@ -239,3 +241,42 @@ def test_result_gather_over_gloo_world2():
     for p in procs:
         p.join(60)
     assert res == [(0, True), (1, True)]
+
+
+def test_int8_calibration_math():
+    """tools/calibrate_int8.py: the entropy threshold clips far outliers but keeps a clean Gaussian's tail, the host-side
+    depthwise / bilinear x2 helpers equal the torch ops of the layers they stand in for, and the shipped mnet25 table parses
+    and covers every tensor name the shipped TensorRT 0517 table has a counterpart for in the int8 engine."""
+    import importlib.util
+    import torch
+    import torch.nn.functional as F
+    spec = importlib.util.spec_from_file_location("calibrate_int8", os.path.join(ROOT, "tools", "calibrate_int8.py"))
+    cal = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(cal)
+    rng = np.random.default_rng(0)
+    x = np.abs(rng.standard_normal(500_000)).astype(np.float32)
+    amax = float(x.max())
+    h, _ = np.histogram(x, bins=cal.NBINS, range=(0, amax))
+    assert cal.entropy_threshold(h, amax / cal.NBINS) > 0.8 * amax          # nothing to clip
+    x[:50] *= 12                                                             # 0.01 % outliers at 12x
+    amax = float(x.max())
+    h, _ = np.histogram(x, bins=cal.NBINS, range=(0, amax))
+    t = cal.entropy_threshold(h, amax / cal.NBINS)
+    assert 3.0 < t < 8.0 and t < 0.3 * amax, (t, amax)
+    a = rng.standard_normal((9, 11, 8)).astype(np.float32)
+    w = rng.standard_normal((8, 3, 3, 1)).astype(np.float32)
+    b = rng.standard_normal(8).astype(np.float32)
+    for st in (1, 2):
+        ref = F.relu(F.conv2d(torch.from_numpy(a.transpose(2, 0, 1))[None], torch.from_numpy(w.transpose(0, 3, 1, 2)),
+                              torch.from_numpy(b), stride=st, padding=1, groups=8))[0].numpy().transpose(1, 2, 0)
+        assert np.abs(cal.depthwise(a, w, b, st) - ref).max() < 1e-5
+    k = np.outer([.25, .75, .75, .25], [.25, .75, .75, .25]).astype(np.float32)
+    ref = F.conv_transpose2d(torch.from_numpy(a.transpose(2, 0, 1))[None], torch.from_numpy(np.tile(k, (8, 1, 1, 1))), stride=2,
+                             padding=1, groups=8)[0].numpy().transpose(1, 2, 0)
+    assert np.abs(cal.upsample2(a) - ref).max() < 1e-5
+    from oracle.caffe_io import read_int8_table
+    own = read_int8_table(os.path.join(ROOT, "assets", "mnet25.table.int8"))
+    trt = read_int8_table(os.path.join(ROOT, "assets", "mnet-deconv-0517.table.int8"))
+    assert set(own) <= set(trt) and len(own) >= 43
+    ratio = np.array([own[n] / trt[n] for n in own])                         # different weights, same architecture: same ballpark
+    assert 0.3 < np.median(ratio) < 3.0

@@ -1,0 +1,214 @@
+#!/usr/bin/env python3
+"""INT8 calibration-table generator: writes the per-tensor activation scales the int8 engine needs
+in the reference's own text format (`model/mnet-deconv-0517.table.int8`: header line, then `tensor-name: <big-endian hex of
+the f32 scale>`, real ~= q * scale; reader: trtnetbase.cpp:31-44, retinaface_amd/csrc/model.cpp).
+
+The reference's INT8-Calibration-Tool only feeds batches to TensorRT's IInt8EntropyCalibrator2; the calibration itself is
+inside TensorRT (closed source).  This tool implements the published entropy calibration (NVIDIA, "8-bit inference with
+TensorRT", GTC 2017): per tensor a 2048-bin histogram of |x| over the calibration set, and the clipping threshold T among
+bins 128..2048 that minimises KL(P || Q) between the clipped distribution and its 128-level quantisation; scale = T / 127.
+PARITY STATUS: unpinned (no reference implementation to compare with); sanity-checked against the shipped 0517 table
+(`--compare`), and by the parity of the int8 engine that consumes the result (tests/test_gpu_parity.py).
+
+Activations come from THIS repo's fp32 HIP engine (debug_activation of every fused op's output); the tensors the fused
+kernels never materialise are rebuilt on the host from those: the depthwise outputs (3x3 stencil with the BN-folded
+weights from rf_plan_folded) and the upsample+add tensors `_plus0/_plus1` (closed-form bilinear x2).  Needs a GPU.
+
+usage: python tools/calibrate_int8.py --model mnet25 --out gpurun_out/mnet25.table.int8 [--frames 48] [--compare table]
+"""
+import argparse
+import ctypes as C
+import os
+import struct
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+NBINS, NQ = 2048, 128
+
+
+def entropy_threshold(hist: np.ndarray, bin_width: float, step: int = 8) -> float:
+    """Clipping threshold minimising KL(P || Q): P = the histogram clipped at bin i with the outliers folded into the last
+    bin, Q = the bins below i (without the outliers) merged into NQ levels of i // NQ bins each (remainder into the last
+    level) and spread back uniformly over the non-empty bins of each level."""
+    hist = hist.astype(np.float64)
+    if hist.sum() == 0:
+        return bin_width * NBINS
+    best_i, best_kl = NBINS, np.inf
+    for i in range(NQ, NBINS + 1, step):
+        p = hist[:i].copy()
+        p[i - 1] += hist[i:].sum()                       # P: clipped values saturate into the last bin
+        nz = p > 0
+        m = i // NQ
+        src = hist[:i]                                   # Q is built from the bins below the clip WITHOUT the saturated mass
+        level = src[:NQ * m].reshape(NQ, m).sum(axis=1)
+        level[-1] += src[NQ * m:].sum()
+        cnt = nz[:NQ * m].reshape(NQ, m).sum(axis=1).astype(np.float64)
+        cnt[-1] += nz[NQ * m:].sum()
+        per = np.divide(level, cnt, out=np.zeros(NQ), where=cnt > 0)
+        q = np.concatenate([np.repeat(per, m), np.full(i - NQ * m, per[-1])])
+        q = np.where(nz, q, 0.0)
+        if q.sum() <= 0 or np.any(q[nz] <= 0):
+            continue
+        ps, qs = p / p.sum(), q / q.sum()
+        kl = float(np.sum(ps[nz] * np.log(ps[nz] / qs[nz])))
+        if kl < best_kl:
+            best_kl, best_i = kl, i
+    return (best_i + 0.5) * bin_width
+
+
+def depthwise(x: np.ndarray, w: np.ndarray, b: np.ndarray, stride: int) -> np.ndarray:
+    """x (H, W, C) fp32, w (C, 3, 3, 1) BN-folded, pad 1 -> ReLU(dw(x)) (Ho, Wo, C)."""
+    h, wd, c = x.shape
+    xp = np.zeros((h + 2, wd + 2, c), np.float32)
+    xp[1:-1, 1:-1] = x
+    ho, wo = (h + 2 - 3) // stride + 1, (wd + 2 - 3) // stride + 1
+    acc = np.broadcast_to(b.astype(np.float32), (ho, wo, c)).copy()
+    for ky in range(3):
+        for kx in range(3):
+            acc += xp[ky:ky + stride * (ho - 1) + 1:stride, kx:kx + stride * (wo - 1) + 1:stride] * w[:, ky, kx, 0]
+    return np.maximum(acc, 0)
+
+
+def upsample2(x: np.ndarray) -> np.ndarray:
+    """Deconvolution k4 s2 p1 with the fixed bilinear kernel, zero boundary: (h, w, c) -> (2h, 2w, c)."""
+    h, w, c = x.shape
+    xp = np.zeros((h + 2, w + 2, c), np.float32)
+    xp[1:-1, 1:-1] = x
+    rows = np.empty((2 * h, w + 2, c), np.float32)
+    rows[0::2] = 0.75 * xp[1:-1] + 0.25 * xp[:-2]
+    rows[1::2] = 0.75 * xp[1:-1] + 0.25 * xp[2:]
+    out = np.empty((2 * h, 2 * w, c), np.float32)
+    out[:, 0::2] = 0.75 * rows[:, 1:-1] + 0.25 * rows[:, :-2]
+    out[:, 1::2] = 0.75 * rows[:, 1:-1] + 0.25 * rows[:, 2:]
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--model", default="mnet25")
+    ap.add_argument("--out", default=None)
+    ap.add_argument("--frames", type=int, default=48)
+    ap.add_argument("--height", type=int, default=448)
+    ap.add_argument("--width", type=int, default=448)
+    ap.add_argument("--compare", default=None, help="an existing table to print side by side")
+    ap.add_argument("--rule", default="kl", help="threshold rule: kl (entropy), kl_keep0, p0.999 / p0.9999 / p0.99999 (percentiles), kl_or_p0.9999, amax")
+    args = ap.parse_args()
+
+    import retinaface_amd
+    from retinaface_amd import _lib
+    from retinaface_amd.frames import padded_base_frame, synth_frames
+    assets = os.path.join(ROOT, "assets")
+    lib = _lib.load_library()
+
+    def folded(op):
+        dims = (C.c_int * 4)()
+        assert lib.rf_plan_folded(assets.encode(), args.model.encode(), op.encode(), None, 0, None, 0, dims) == 0
+        n = dims[0] * dims[1] * dims[2] * dims[3]
+        w, b = np.empty(n, np.float32), np.empty(dims[0], np.float32)
+        assert lib.rf_plan_folded(assets.encode(), args.model.encode(), op.encode(), w.ctypes.data_as(C.POINTER(C.c_float)), n,
+                                  b.ctypes.data_as(C.POINTER(C.c_float)), dims[0], dims) == 0
+        return w.reshape(dims[0], dims[1], dims[2], dims[3]), b
+
+    H, W = args.height, args.width
+    base = padded_base_frame()
+    rng = np.random.default_rng(2026)
+    # calibration set: a quarter synthetic face-bearing frames (what bench.py feeds), the rest augmented crops of the one real
+    # photo the reference ships (random position, flip, 0.5x..1.5x nearest-neighbour rescale): natural backgrounds and a
+    # spread of face sizes -- with synthetic grey backgrounds only, the entropy thresholds come out ~2x tighter than TensorRT's
+    frames = synth_frames(H, W, args.frames // 4, config=77)
+    real = base[:886]                                          # without the zero padding rows
+    while len(frames) < args.frames:
+        sc = float(rng.choice([0.5, 0.75, 1.0, 1.0, 1.5]))
+        ys = (np.arange(int(real.shape[0] * sc)) / sc).astype(int)
+        xs = (np.arange(int(real.shape[1] * sc)) / sc).astype(int)
+        img = real[ys][:, xs]
+        if rng.random() < 0.5:
+            img = img[:, ::-1]
+        canvas = np.zeros((max(H, img.shape[0]), max(W, img.shape[1]), 3), np.uint8)
+        canvas[:img.shape[0], :img.shape[1]] = img
+        y, x = int(rng.integers(0, canvas.shape[0] - H + 1)), int(rng.integers(0, canvas.shape[1] - W + 1))
+        frames.append(np.ascontiguousarray(canvas[y:y + H, x:x + W]))
+
+    det = retinaface_amd.RetinaFace(assets, "net3", 0.4, precision=retinaface_amd.PRECISION_FP32, net_hw=(H, W),
+                                    model_stem=args.model, keep_outputs=True, use_graph=False, lanes=1, coalesce=1)
+    dws = [folded(f"dw{i}") for i in range(13)]
+    strides = [1, 2, 1, 2, 1, 2, 1, 1, 1, 1, 1, 2, 1]
+    pw_names = [f"mobilenet0_relu{2 * i + 2}_fwd" for i in range(13)]
+    dw_names = [f"mobilenet0_relu{2 * i + 1}_fwd" for i in range(13)]
+
+    def tensors(frame):
+        """name -> activation for every tensor the int8 engine has a scale lookup for (engine.cpp upload_weights)."""
+        det.detect(frame, 0.5)
+        t = {}
+        conv0 = det.debug_activation("mobilenet0_relu0_fwd")
+        prev = conv0
+        for i in range(13):
+            w, b = dws[i]
+            t[dw_names[i]] = depthwise(prev, w, b, strides[i])
+            prev = det.debug_activation(pw_names[i])
+            t[pw_names[i]] = prev
+        lat = {c: det.debug_activation(f"rf_c{c}_{'red_conv' if c == 1 else 'lateral'}_relu") for c in (3, 2, 1)}
+        for c in (3, 2, 1):
+            t[f"rf_c{c}_{'red_conv' if c == 1 else 'lateral'}_relu"] = lat[c]
+        aggr2 = det.debug_activation("rf_c2_aggr_relu")
+        aggr1 = det.debug_activation("rf_c1_aggr_relu")
+        t["rf_c2_aggr_relu"], t["rf_c1_aggr_relu"] = aggr2, aggr1
+        t["_plus0"] = lat[2] + upsample2(lat[3])
+        t["_plus1"] = lat[1] + upsample2(aggr2)
+        for c in (3, 2, 1):
+            for n in ("context_conv1_relu", "context_conv3_1_relu", "concat_relu"):
+                t[f"rf_c{c}_det_{n}"] = det.debug_activation(f"rf_c{c}_det_{n}")
+        return t
+
+    # pass 1: ranges; pass 2: histograms
+    amax = {}
+    for f in frames:
+        for n, a in tensors(f).items():
+            amax[n] = max(amax.get(n, 0.0), float(np.abs(a).max()))
+    hist = {n: np.zeros(NBINS, np.int64) for n in amax}
+    for f in frames:
+        for n, a in tensors(f).items():
+            h, _ = np.histogram(np.abs(a), bins=NBINS, range=(0.0, max(amax[n], 1e-12)))
+            hist[n] += h
+    scales = {"data": 255.0 / 127.0}                            # raw u8 pixels; the stem reads them exactly anyway
+    variants = {}
+    for n in hist:
+        bw = amax[n] / NBINS
+        h0 = hist[n].copy()
+        hist[n][0] = 0                                          # ReLU zeros carry no information about the range
+        t_kl = entropy_threshold(hist[n], bw)
+        cdf = np.cumsum(hist[n]) / max(hist[n].sum(), 1)
+        pct = {q: (int(np.searchsorted(cdf, q)) + 1) * bw for q in (0.999, 0.9999, 0.99999)}
+        variants[n] = {"kl": t_kl, "kl_keep0": entropy_threshold(h0, bw), **{f"p{q}": v for q, v in pct.items()},
+                       "kl_or_p0.9999": max(t_kl, pct[0.9999]), "amax": amax[n]}
+        scales[n] = variants[n][args.rule] / 127.0
+
+    other = {}
+    if args.compare:
+        for line in open(args.compare).read().splitlines()[1:]:
+            if ": " in line:
+                k, v = line.rsplit(": ", 1)
+                other[k] = struct.unpack(">f", bytes.fromhex(v))[0]
+    if other:
+        print("rule vs shipped table: median / min / max of (threshold / shipped threshold) over", len(variants), "tensors")
+        for rule in next(iter(variants.values())):
+            r = np.array([variants[n][rule] / 127.0 / other[n] for n in variants if n in other])
+            print(f"  {rule:16s} median {np.median(r):.2f}  min {r.min():.2f}  max {r.max():.2f}  mean |log2| {np.abs(np.log2(r)).mean():.3f}")
+    for n in sorted(scales):
+        extra = f"   shipped {other[n]:.5f}  ratio {scales[n] / other[n]:.2f}" if n in other else ""
+        print(f"{n:44s} amax {amax.get(n, 255.0):9.3f}  scale {scales[n]:.5f}  (T = {scales[n] * 127:8.3f}){extra}")
+    if args.out:
+        os.makedirs(os.path.dirname(os.path.abspath(args.out)), exist_ok=True)
+        with open(args.out, "w") as fo:
+            fo.write("TRT-5102-EntropyCalibration2\n")        # the header both readers (and TensorRT) expect; provenance: this tool
+            for n, s in scales.items():
+                fo.write(f"{n}: {struct.pack('>f', np.float32(s)).hex()}\n")
+        print("wrote", args.out)
+
+
+if __name__ == "__main__":
+    main()

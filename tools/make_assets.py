@@ -3,7 +3,8 @@
 /root/reference is mounted).
 
   assets/mnet-deconv-0517.rfw   graph + blobs + TensorRT int8 scales of model/mnet-deconv-0517.*
-  assets/mnet25.rfw             same for model/mnet25.* (the 0517 table is attached; it is the only one shipped)
+  assets/mnet25.rfw             same for model/mnet25.* with assets/mnet25.table.int8 (tools/calibrate_int8.py; the reference
+                                ships a table for 0517 only)
   assets/faces_1280x886.png     lossless copy of the decoded pixels of data/img.jpg (the reference's only image fixture)
 
 The .rfw container is this repo's own format (oracle/caffe_io.py, retinaface_amd/csrc/model.cpp):
@@ -26,10 +27,15 @@ REF = os.environ.get("RF_REFERENCE", "/root/reference")
 def main():
     out = os.path.join(ROOT, "assets")
     os.makedirs(out, exist_ok=True)
-    table = os.path.join(REF, "model", "mnet-deconv-0517.table.int8")
+    shipped = os.path.join(REF, "model", "mnet-deconv-0517.table.int8")
     for stem in ("mnet-deconv-0517", "mnet25"):
+        # 0517: the TensorRT table the reference ships.  mnet25: the reference ships none; assets/mnet25.table.int8 is produced
+        # by tools/calibrate_int8.py (same text format) -- without it the 0517 table is attached as an approximation.
+        own = os.path.join(out, stem + ".table.int8")
+        table = own if stem != "mnet-deconv-0517" and os.path.exists(own) else shipped
         net = load_caffe_model(os.path.join(REF, "model", stem + ".prototxt"),
                                os.path.join(REF, "model", stem + ".caffemodel"), table)
+        print(stem, "int8 table:", table)
         dst = os.path.join(out, stem + ".rfw")
         write_rfw(net, dst)
         back = read_rfw(dst)
