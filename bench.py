@@ -166,6 +166,10 @@ def main() -> None:
             "bound": "hbm", "kernel": dom["name"], "kernel_instance": dom["kernel"],
             "achieved": dom["alg_bytes"] / (dom["ms"] * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": dom["alg_bytes"] / (dom["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": traffic,
+            # SURVEY.md 8d also asks for the fraction of the MEASURED copy peak (6.29 TB/s, MI355X_MICROARCH.md) and, from the PMC
+            # traffic, the kernel's real HBM rate
+            "frac_of_measured_copy_peak_6290": dom["alg_bytes"] / (dom["ms"] * 1e-3) / 1e9 / 6290.0,
+            "traffic_GBs": (traffic / (dom["ms"] * 1e-3) / 1e9) if traffic else None,
             "kernel_ms": dom["ms"], "kernel_alg_bytes": dom["alg_bytes"],
             "kernel_share_of_gpu_time": dom["ms"] / kernel_ms,
             "images_per_launch": B * per_launch,
