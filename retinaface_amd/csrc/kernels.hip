@@ -97,6 +97,15 @@ __device__ unsigned g_trace_key = 0;      // 0 = any launch of that kernel famil
 #define RF_TRACE(kid, slot) do { } while (0)
 #endif
 
+// Row stride (in elements) of an LDS tile whose rows are read as MFMA B fragments (16 lanes = 16 consecutive pixels, 16 B each,
+// 4 such groups one 16-byte column apart): measured on gfx950 (tools/probes/lds_b128.cpp) a ds_read_b128 of that pattern costs
+// one replay less when the row stride in bytes is 32 mod 64 (32, 96, 160, 288 ...) than at 16 / 48 mod 64 (48, 80, 144 ...),
+// and 128 / 256-byte strides are the worst.  Rows are padded up to the next such stride.
+template <typename T> constexpr int lds_row(int c) {
+    const int bytes = c * (int)sizeof(T);
+    return (bytes + ((32 - bytes % 64) + 64) % 64) / (int)sizeof(T);
+}
+
 template <typename F>
 static void set_max_lds(F func, size_t bytes) {
     if (bytes > 48 * 1024) (void)hipFuncSetAttribute((const void *)func, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
@@ -658,14 +667,16 @@ template <typename T, int CIN, int COUT, int STRIDE, bool HAS_DW, int TH, int TW
     static constexpr int P = TH * TW;
     static constexpr int HR = HAS_DW ? (TH - 1) * STRIDE + 3 : 0;
     static constexpr int HC = HAS_DW ? (TW - 1) * STRIDE + 3 : 0;
-    static constexpr int LDA = CIN + (CIN * sizeof(T) >= 64 ? VEC : 0);   // narrow rows: padding costs a resident workgroup
-    static constexpr int LDO = COUT + VEC;
+    // B-fragment rows of the pointwise GEMM / result tile (read as B fragments by the fused lateral).  Rows of 256 B and more keep
+    // the 16-byte pad: lds_row's 32-byte pad measured slower there (18.1 -> 19.1 us on the 128-channel blocks).
+    static constexpr int LDA = CIN * sizeof(T) >= 256 ? CIN + VEC : lds_row<T>(CIN);
+    static constexpr int LDO = COUT * sizeof(T) >= 256 ? COUT + VEC : lds_row<T>(COUT);
     // fp16 engine: the depthwise stencil runs on the matrix cores as a diagonal-weight 3x3 conv per 16-channel group (see
     // pack.h dw_mma_dword): these kernels are VALU-issue bound (SQ counters: VALU busy 70-100 % of issue cycles, MFMA < 10 %)
     // and the stencil was ~45 % of their VALU instructions.  Needs the (group, pixel-tile) pairs to split over 4 waves.
     static constexpr bool DWMMA = HAS_DW && sizeof(T) == 2 && CIN % 16 == 0 && ((CIN / 16) * (P / 16)) % 4 == 0 &&
                                   (CIN >= 64 || (P / 16) % (4 / (CIN / 16 > 0 ? CIN / 16 : 1)) == 0);
-    static constexpr int LDIN = DWMMA ? CIN + VEC : CIN;                  // halo rows padded: the B-fragment reads stride by pixel
+    static constexpr int LDIN = DWMMA ? (CIN * sizeof(T) >= 256 ? CIN + VEC : lds_row<T>(CIN)) : CIN;   // halo rows padded: the B-fragment reads stride by pixel
     static constexpr size_t IN_BYTES = sizeof(T) * (size_t)(HR * HC * LDIN);
     static constexpr size_t DW_BYTES = HAS_DW && !DWMMA ? sizeof(DW) * (size_t)(9 * CIN) : 0;
     static constexpr size_t A_BYTES = sizeof(T) * (size_t)(P * LDA);
@@ -1083,8 +1094,8 @@ template <typename T, int CIN, int COUT, int TH, int TW> struct Conv3Cfg {
     static constexpr int VEC = Vec<T>::N;
     static constexpr int P = TH * TW;
     static constexpr int HR = TH + 2, HC = TW + 2;
-    static constexpr int LDI = CIN + VEC;
-    static constexpr int LDO = COUT + VEC;
+    static constexpr int LDI = lds_row<T>(CIN);
+    static constexpr int LDO = lds_row<T>(COUT) > COUT ? lds_row<T>(COUT) : COUT + VEC;
     static constexpr size_t IN_BYTES = sizeof(T) * (size_t)(HR * HC * LDI);
     static constexpr size_t O_BYTES = sizeof(T) * (size_t)(P * LDO);
     // persistent + software pipelined like K_b: tile t+G is staged while tile t's result is still being stored, so the
