@@ -1471,7 +1471,7 @@ template <typename T>
 __global__ __launch_bounds__(kThreads) void head_kernel(HeadArgs<T> a) {
     typedef typename Vec<T>::type V;
     typedef Mma<T> M;
-    constexpr int VEC = Vec<T>::N, CIN = 64, COUT = 32, P = HEAD_P, LDA = CIN + VEC;
+    constexpr int VEC = Vec<T>::N, CIN = 64, COUT = 32, P = HEAD_P, LDA = lds_row<T>(CIN);
     constexpr int CPV = CIN / VEC;
     __shared__ __attribute__((aligned(16))) T s_a[P * LDA];
     __shared__ float s_o[P * HEAD_LDO];
