@@ -61,6 +61,9 @@ public:
        the TensorRT-build signature above, RetinaFace.h:70): no resize, pad to x32, run at that size; result in lastResult() */
     void detectPad32(const Mat &img, float threshold = 0.5);
 
+    /* `scale` of RetinaFace.cpp:585-589: multiply lastResult() coordinates by it for source-frame pixels (:732-739, commented) */
+    float frameScale(const Mat &img) const { return rf_frame_scale(h_, img.rows, img.cols); }
+
     /* additive accessors */
     const vector<FaceDetectInfo> &lastResult() const { return last_; }
     const vector<vector<FaceDetectInfo>> &lastBatchResult() const { return lastBatch_; }

@@ -115,6 +115,11 @@ int rf_detect_batch_pad32(rf_handle h, const uint8_t *const *bgr, const int *row
                           const int *steps, int n, int on_device, float threshold,
                           rf_face *out, int cap_per_image, int *counts);
 
+/* Factor by which the coordinates returned for a rows x cols frame must be multiplied to land in source-frame pixels:
+ * max(cols / net_w, rows / net_h, 1) -- `scale` in RetinaFace.cpp:585-589; the reference's own mapping back is commented
+ * out (:732-739), so results stay in network-input pixels and this is what a caller applies.  1.0 for frames that fit. */
+float rf_frame_scale(rf_handle h, int rows, int cols);
+
 /* Same, frames already resident in device memory (HBM) on the engine's device. */
 int rf_detect_batch_device(rf_handle h, const void *const *d_bgr, const int *rows, const int *cols,
                            const int *steps, int n, float threshold,

@@ -46,6 +46,7 @@ SYMBOLS = {
                                          C.c_int, C.c_float, _PP(rf_face), C.c_int, _PP(C.c_int)]),
     "rf_detect_batch_pad32": (C.c_int, [C.c_void_p, _PP(C.c_void_p), _PP(C.c_int), _PP(C.c_int), _PP(C.c_int), C.c_int,
                                         C.c_int, C.c_float, _PP(rf_face), C.c_int, _PP(C.c_int)]),
+    "rf_frame_scale": (C.c_float, [C.c_void_p, C.c_int, C.c_int]),
     "rf_num_slots": (C.c_int, [C.c_void_p]),
     "rf_enqueue_batch_device": (C.c_int, [C.c_void_p, _PP(C.c_void_p), _PP(C.c_int), _PP(C.c_int), _PP(C.c_int),
                                           C.c_int, C.c_float, _PP(C.c_int)]),

@@ -167,6 +167,13 @@ int rf_detect_batch_pad32(rf_handle h, const uint8_t *const *bgr, const int *row
     });
 }
 
+float rf_frame_scale(rf_handle h, int rows, int cols) {
+    if (!h || rows <= 0 || cols <= 0) return 1.f;
+    const float sw = (float)cols / (float)h->eng->net_w(), sh = (float)rows / (float)h->eng->net_h();     // RetinaFace.cpp:585-589
+    const float sc = sw > sh ? sw : sh;
+    return sc > 1.f ? sc : 1.f;
+}
+
 int rf_num_slots(rf_handle h) { return h ? h->eng->num_slots() : RF_ERR_INVALID_ARG; }
 
 int rf_enqueue_batch_device(rf_handle h, const void *const *d_bgr, const int *rows, const int *cols, const int *steps,

@@ -103,6 +103,10 @@ class RetinaFace:
             ptrs[i], rows[i], cols[i], steps[i] = im.ctypes.data, im.shape[0], im.shape[1], im.strides[0]
         return self._run(self._lib.rf_detect_batch, ptrs, rows, cols, steps, n, threshold)
 
+    def frame_scale(self, rows: int, cols: int) -> float:
+        """Multiply returned coordinates by this to get source-frame pixels (1.0 unless the frame is larger than the net)."""
+        return float(self._lib.rf_frame_scale(self._h, int(rows), int(cols)))
+
     def detect_pad32(self, imgs: Sequence[np.ndarray], threshold: float = 0.5) -> List[List[Detection]]:
         """The reference's Caffe-build detect (RetinaFace.cpp:943-1075): no resize, each frame zero-padded to the next
         multiple of 32 and run at that size, boxes clipped to the padded size, coordinates in source-frame pixels.

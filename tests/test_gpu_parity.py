@@ -411,6 +411,9 @@ def test_oversize_frame_is_area_averaged_down(rfa, base_frame):
     wide = np.concatenate([up, up], axis=1)                     # 896 x 1792 -> factor 0.25 -> 224 x 448
     c = det.detect(wide, 0.3)
     assert all(d.rect[3] <= 224 + 16 for d in c)
+    # the factor that maps results back to source pixels (`scale`, RetinaFace.cpp:585-589 / :732-739)
+    assert det.frame_scale(896, 896) == 2.0 and det.frame_scale(896, 1792) == 4.0 and det.frame_scale(300, 448) == 1.0
+    assert all(abs(x.rect[0] * 2.0 - 2 * y.rect[0]) < 1e-6 for x, y in zip(a, b))
 
 
 def test_cxx_class_drop_in(rfa, tmp_path):
