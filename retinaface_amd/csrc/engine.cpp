@@ -175,7 +175,14 @@ public:
             throw ArgError("wait: invalid ticket");
         Ticket &t = tickets_[ticket];
         if (t.state == Ticket::PENDING) launch_pending();          // its super-batch has not been launched yet
-        if (t.state == Ticket::LAUNCHED) harvest(lanes_[t.lane]);  // first waiter of a super-batch collects all of it
+        if (t.state == Ticket::LAUNCHED) {
+            // About to block on a running super-batch: a partial one queued behind it starts now and runs on its own lane
+            // meanwhile (the tail of a burst overlaps instead of serialising).  When the waited batch has already finished
+            // nothing is flushed -- in a steady pipeline the pending batch keeps filling up to max_batch x coalesce images.
+            Lane &L = lanes_[t.lane];
+            if (L.busy && hipEventQuery(L.done) == hipErrorNotReady) launch_pending();
+            harvest(L);                                             // first waiter of a super-batch collects all of it
+        }
         bool tr = false;
         last_lane_ = t.lane;
         last_first_image_ = t.first_image;
