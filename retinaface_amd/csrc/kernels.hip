@@ -97,15 +97,6 @@ __device__ unsigned g_trace_key = 0;      // 0 = any launch of that kernel famil
 #define RF_TRACE(kid, slot) do { } while (0)
 #endif
 
-// Row stride (in elements) of an LDS tile whose rows are read as MFMA B fragments (16 lanes = 16 consecutive pixels, 16 B each,
-// 4 such groups one 16-byte column apart): measured on gfx950 (tools/probes/lds_b128.cpp) a ds_read_b128 of that pattern costs
-// one replay less when the row stride in bytes is 32 mod 64 (32, 96, 160, 288 ...) than at 16 / 48 mod 64 (48, 80, 144 ...),
-// and 128 / 256-byte strides are the worst.  Rows are padded up to the next such stride.
-template <typename T> constexpr int lds_row(int c) {
-    const int bytes = c * (int)sizeof(T);
-    return (bytes + ((32 - bytes % 64) + 64) % 64) / (int)sizeof(T);
-}
-
 template <typename F>
 static void set_max_lds(F func, size_t bytes) {
     if (bytes > 48 * 1024) (void)hipFuncSetAttribute((const void *)func, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
@@ -134,10 +125,7 @@ static float persist_min_rounds() {
     return v;
 }
 static int persistent_grid(int tiles, int resident_per_cu) {
-    const int resident = num_cus() * (resident_per_cu > 0 ? resident_per_cu : 1);
-    if ((float)tiles <= persist_min_rounds() * (float)resident) return tiles;
-    const int rounds = (tiles + resident - 1) / resident;
-    return (tiles + rounds - 1) / rounds;
+    return persistent_grid_size(tiles, num_cus() * (resident_per_cu > 0 ? resident_per_cu : 1), persist_min_rounds());
 }
 template <typename F> static int resident_per_cu(F kern, size_t lds_bytes) {
     int nb = 0;
@@ -260,26 +248,6 @@ template <typename V, typename R> __device__ __forceinline__ V buf_load16(R rsrc
 template <typename V, typename R> __device__ __forceinline__ void buf_store16(R rsrc, unsigned off, V v) {
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsrc, (int)off, 0, 0);
 }
-
-// Tile walk of the persistent kernels: tile id t -> (tx, ty, img), advanced by a fixed step G without dividing.
-struct TileCoord {
-    int tx, ty, img;
-    __device__ TileCoord(int t, int tiles_x, int tiles_y) : tx(t % tiles_x), ty((t / tiles_x) % tiles_y), img(t / (tiles_x * tiles_y)) {}
-};
-struct TileStep {
-    int sx, sy, si, nx, ny;
-    __device__ TileStep(int g, int tiles_x, int tiles_y)
-        : sx(g % tiles_x), sy((g / tiles_x) % tiles_y), si(g / (tiles_x * tiles_y)), nx(tiles_x), ny(tiles_y) {}
-    __device__ __forceinline__ void advance(TileCoord &c) const {
-        c.tx += sx;
-        const int cx = c.tx >= nx ? 1 : 0;
-        c.tx -= cx ? nx : 0;
-        c.ty += sy + cx;
-        const int cy = c.ty >= ny ? 1 : 0;
-        c.ty -= cy ? ny : 0;
-        c.img += si + cy;
-    }
-};
 
 // =============================================================================================
 // GEMM core shared by K_b / K_c / K_d:  acc[i][j] += W-fragment(ct_i, kc) x X-fragment(pt_j, kc)

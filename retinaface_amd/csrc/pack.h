@@ -65,4 +65,48 @@ RF_HD inline uint32_t dw_mma_dword(int kc, int lane, const uint16_t *w9) {
 RF_HD inline int dw_mma_dword_index(int lane) { return ((lane & 15) & 7) >> 1; }
 constexpr int kDwMmaChunks = 5;
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Persistent-kernel bookkeeping shared by the kernels and the host unit test (tests/csrc/test_pack.cpp)
+// ---------------------------------------------------------------------------------------------------------------------
+
+// Tile walk of the persistent kernels: tile id t -> (tx, ty, img), advanced by a fixed step G without dividing (a uniform
+// integer division is ~16 scalar instructions, and the tile loops are a few hundred instructions per tile).
+struct TileCoord {
+    int tx, ty, img;
+    RF_HD TileCoord(int t, int tiles_x, int tiles_y) : tx(t % tiles_x), ty((t / tiles_x) % tiles_y), img(t / (tiles_x * tiles_y)) {}
+};
+struct TileStep {
+    int sx, sy, si, nx, ny;
+    RF_HD TileStep(int g, int tiles_x, int tiles_y)
+        : sx(g % tiles_x), sy((g / tiles_x) % tiles_y), si(g / (tiles_x * tiles_y)), nx(tiles_x), ny(tiles_y) {}
+    RF_HD inline void advance(TileCoord &c) const {
+        c.tx += sx;
+        const int cx = c.tx >= nx ? 1 : 0;
+        c.tx -= cx ? nx : 0;
+        c.ty += sy + cx;
+        const int cy = c.ty >= ny ? 1 : 0;
+        c.ty -= cy ? ny : 0;
+        c.img += si + cy;
+    }
+};
+
+// Grid of a persistent launch: as many workgroups as the chip keeps resident, trimmed so that every workgroup walks the same
+// number of tiles (no nearly-empty last round).  At or below `min_rounds` x resident tiles the hardware dispatcher's dynamic
+// one-tile-per-workgroup schedule is at least as good as walking two tiles in sequence: one workgroup per tile.
+RF_HD inline int persistent_grid_size(int tiles, int resident, float min_rounds) {
+    if (resident < 1) resident = 1;
+    if ((float)tiles <= min_rounds * (float)resident) return tiles;
+    const int rounds = (tiles + resident - 1) / resident;
+    return (tiles + rounds - 1) / rounds;
+}
+
+// Row stride (in elements) of an LDS tile whose rows are read as MFMA B fragments (16 lanes = 16 consecutive pixels, 16 B each,
+// 4 such groups one 16-byte column apart): measured on gfx950 (tools/probes/lds_b128.cpp) a ds_read_b128 of that pattern costs
+// one replay less when the row stride in bytes is 32 mod 64 (32, 96, 160, 288 ...) than at 16 / 48 mod 64 (48, 80, 144 ...),
+// and 128 / 256-byte strides are the worst.  Rows are padded up to the next such stride.
+template <typename T> constexpr int lds_row(int c) {
+    const int bytes = c * (int)sizeof(T);
+    return (bytes + ((32 - bytes % 64) + 64) % 64) / (int)sizeof(T);
+}
+
 }  // namespace rf

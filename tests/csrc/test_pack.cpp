@@ -110,6 +110,34 @@ int main() {
                 }
             }
     }
+    // persistent tile walk: advancing by the decomposed step must equal decoding t + G from scratch, for awkward shapes
+    for (int tiles_x : {1, 2, 7, 11, 38}) for (int tiles_y : {1, 3, 7, 28}) for (int n : {1, 3, 128}) {
+        const int tiles = tiles_x * tiles_y * n;
+        for (int g : {1, 2, 5, 7, tiles_x, tiles_x * tiles_y, tiles_x * tiles_y + 1, 717, 1792, tiles}) {
+            if (g < 1 || g > tiles) continue;
+            TileStep step(g, tiles_x, tiles_y);
+            for (int first : {0, g / 2, g - 1}) {
+                TileCoord c(first, tiles_x, tiles_y);
+                for (int t = first; t < tiles; t += g) {
+                    TileCoord want(t, tiles_x, tiles_y);
+                    if (c.tx != want.tx || c.ty != want.ty || c.img != want.img) { if (!bad) printf("FAIL tile walk %dx%dx%d g=%d t=%d\n", tiles_x, tiles_y, n, g, t); bad++; break; }
+                    step.advance(c);
+                }
+            }
+        }
+    }
+    // persistent grid: never more workgroups than tiles or than resident, and every workgroup walks the same number of tiles +-1
+    for (int tiles : {1, 8, 767, 768, 769, 896, 1536, 3584, 12544, 25088}) for (int resident : {256, 768, 1792}) {
+        for (float mr : {1.0f, 1.5f}) {
+            const int g = persistent_grid_size(tiles, resident, mr);
+            const int lo = tiles / g, hi = (tiles + g - 1) / g;
+            const bool one_each = (float)tiles <= mr * (float)resident;
+            if (g < 1 || g > tiles || (!one_each && g > resident) || (one_each && g != tiles) || hi - lo > 1) { printf("FAIL persistent_grid_size(%d, %d, %.1f) = %d\n", tiles, resident, mr, g); bad++; }
+        }
+    }
+    // LDS rows: 16-byte aligned, at least as wide as asked, 32 mod 64 bytes
+    if (lds_row<unsigned short>(64) != 80 || lds_row<unsigned short>(16) != 16 || lds_row<unsigned short>(32) != 48 || lds_row<float>(64) != 72 ||
+        lds_row<signed char>(64) != 96 || lds_row<unsigned short>(48) != 48) { printf("FAIL lds_row\n"); bad++; }
     printf(bad ? "test_pack: FAILED\n" : "test_pack: ok\n");
     return bad ? 1 : 0;
 }
