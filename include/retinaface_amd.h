@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define RF_ABI_VERSION 1
+#define RF_ABI_VERSION 2
 
 typedef enum rf_status {
     RF_OK = 0,
@@ -60,7 +60,8 @@ typedef struct rf_options {
     int32_t precision;          /* rf_precision; default RF_PRECISION_FP16 */
     int32_t net_h, net_w;       /* 0 = the prototxt / .rfw input dims; must be multiples of 32 */
     int32_t max_batch;          /* images per launch (default 8); larger batches are chunked */
-    int32_t device;             /* HIP device ordinal + 1; 0 = the calling thread's current HIP device */
+    int32_t device;             /* HIP device ordinal + 1; 0 = the calling thread's current HIP device.  Calls may come from any
+                                   thread: every entry point binds the engine's device for its duration and restores the caller's */
     int32_t max_candidates;     /* pre-NMS candidates kept per image (default 4096, power of two) */
     int32_t max_detections;     /* post-NMS faces returned per image (default 256) */
     int32_t use_graph;          /* 1 (default) = replay a captured hipGraph per batch size; 2 = off */
@@ -71,6 +72,10 @@ typedef struct rf_options {
     int32_t coalesce;           /* rf_enqueue_batch_device() batches merged into ONE launch of up to max_batch*coalesce
                                    images (default 16, max 32; 1 = off).  A merged launch starts when it is full or when one of
                                    its tickets is waited for.  rf_num_slots() = lanes * coalesce. */
+    /* ---- fields added in ABI 2 (a caller compiled against ABI 1 passes the shorter struct_size and gets the defaults) ---- */
+    int32_t copy_threads;       /* host threads (the caller's included) that stage host frames into pinned memory; 0 = min(8, cores/4) */
+    int32_t n_devices;          /* > 1: one engine per entry of devices[], every rf_detect_batch* call is sharded by image over them */
+    const int32_t *devices;     /* HIP device ordinals (0-based; an ordinal may repeat); NULL / n_devices <= 1: `device` above */
 } rf_options;
 
 typedef struct rf_engine *rf_handle;
@@ -134,6 +139,23 @@ int rf_num_slots(rf_handle h);
 int rf_enqueue_batch_device(rf_handle h, const void *const *d_bgr, const int *rows, const int *cols,
                             const int *steps, int n, float threshold, int *ticket);
 int rf_wait(rf_handle h, int ticket, rf_face *out, int cap_per_image, int *counts);
+
+/* Asynchronous form of rf_detect_batch: frames in HOST memory, exactly what the reference's callers hold (cv::Mat data / step,
+ * RetinaFace.cpp:594, :760-782 upload them inside the call).  The frames are copied into the engine's pinned staging ring before
+ * the call returns (the caller may reuse its buffers at once) by options.copy_threads host threads, cross PCIe as ONE DMA per
+ * enqueue on the lane's stream, and that upload overlaps the compute of the super-batches already in flight on the other lanes.
+ * Collect with rf_wait.  Frames inside a range registered with rf_host_register skip the staging copy: the DMA engine reads
+ * them in place, so they must stay unchanged until the ticket has been waited for. */
+int rf_enqueue_batch(rf_handle h, const uint8_t *const *bgr, const int *rows, const int *cols,
+                     const int *steps, int n, float threshold, int *ticket);
+
+/* Pin a caller-owned host range (a ring of camera / decoder buffers reused across calls) for in-place DMA, and release it.
+ * rf_host_unregister first waits for every launch that may still read the range; rf_destroy releases what is left. */
+int rf_host_register(rf_handle h, const void *ptr, size_t bytes);
+int rf_host_unregister(rf_handle h, const void *ptr);
+
+/* Engines behind the handle: 1, or options.n_devices for an image-sharding multi-device handle. */
+int rf_num_devices(rf_handle h);
 
 /* Global anchor index (offset(stride) + a*h*w + iy*w + ix, strides 32,16,8) of each
  * detection of image `image` of the most recent completed batch, in the same order as out[]. */

@@ -29,7 +29,8 @@ class rf_options(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("precision", C.c_int32), ("net_h", C.c_int32), ("net_w", C.c_int32),
                 ("max_batch", C.c_int32), ("device", C.c_int32), ("max_candidates", C.c_int32),
                 ("max_detections", C.c_int32), ("use_graph", C.c_int32), ("keep_outputs", C.c_int32),
-                ("model_stem", C.c_char_p), ("lanes", C.c_int32), ("coalesce", C.c_int32)]
+                ("model_stem", C.c_char_p), ("lanes", C.c_int32), ("coalesce", C.c_int32),
+                ("copy_threads", C.c_int32), ("n_devices", C.c_int32), ("devices", C.POINTER(C.c_int32))]
 
 
 # every symbol include/retinaface_amd.h declares: name -> (restype, argtypes)
@@ -51,6 +52,11 @@ SYMBOLS = {
     "rf_enqueue_batch_device": (C.c_int, [C.c_void_p, _PP(C.c_void_p), _PP(C.c_int), _PP(C.c_int), _PP(C.c_int),
                                           C.c_int, C.c_float, _PP(C.c_int)]),
     "rf_wait": (C.c_int, [C.c_void_p, C.c_int, _PP(rf_face), C.c_int, _PP(C.c_int)]),
+    "rf_enqueue_batch": (C.c_int, [C.c_void_p, _PP(C.c_void_p), _PP(C.c_int), _PP(C.c_int), _PP(C.c_int),
+                                   C.c_int, C.c_float, _PP(C.c_int)]),
+    "rf_host_register": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    "rf_host_unregister": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "rf_num_devices": (C.c_int, [C.c_void_p]),
     "rf_last_anchor_indices": (C.c_int, [C.c_void_p, C.c_int, _PP(C.c_int32), C.c_int]),
     "rf_last_candidate_counts": (C.c_int, [C.c_void_p, _PP(C.c_int), C.c_int]),
     "rf_last_timings": (C.c_int, [C.c_void_p, _PP(C.c_float), _PP(C.c_float), _PP(C.c_float), _PP(C.c_float)]),
@@ -63,6 +69,7 @@ SYMBOLS = {
                                  C.c_size_t, _PP(C.c_int)]),
 }
 
+ABI_VERSION = 2      # include/retinaface_amd.h RF_ABI_VERSION
 _lib = None
 
 
@@ -87,7 +94,7 @@ def load_library() -> C.CDLL:
         fn = getattr(lib, name)          # AttributeError here = header/library mismatch
         fn.restype = res
         fn.argtypes = args
-    if lib.rf_abi_version() != 1:
+    if lib.rf_abi_version() != ABI_VERSION:
         raise RuntimeError("libretinaface_amd.so ABI version mismatch")
     _lib = lib
     return lib

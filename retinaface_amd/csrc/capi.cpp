@@ -1,5 +1,6 @@
 // capi.cpp -- extern "C" boundary (include/retinaface_amd.h) over rf::Engine.  Exceptions never cross it.
 #include <algorithm>
+#include <cstddef>
 #include <cstdlib>
 #include <cstring>
 #include <list>
@@ -48,8 +49,14 @@ int rf_create(const char *model_dir, const char *network, float nms_threshold, c
         if (!model_dir || !out) throw rf::ArgError("model_dir / out_handle is null");
         *out = nullptr;
         rf::EngineOptions eo;
+        rf_options ocopy;
         if (o) {
-            if (o->struct_size != sizeof(rf_options)) throw rf::ArgError("rf_options.struct_size mismatch");
+            // ABI 1 callers pass the struct up to `coalesce`; the fields added later default to 0
+            const size_t v1 = offsetof(rf_options, copy_threads);
+            if (o->struct_size != sizeof(rf_options) && o->struct_size != v1) throw rf::ArgError("rf_options.struct_size mismatch");
+            memset(&ocopy, 0, sizeof(ocopy));
+            memcpy(&ocopy, o, o->struct_size);
+            o = &ocopy;
             if (o->precision == RF_PRECISION_FP32 || o->precision == RF_PRECISION_FP16 || o->precision == RF_PRECISION_INT8)
                 eo.precision = o->precision;
             else throw rf::ArgError("unknown precision");
@@ -63,6 +70,9 @@ int rf_create(const char *model_dir, const char *network, float nms_threshold, c
             if (o->model_stem && *o->model_stem) eo.model_stem = o->model_stem;
             if (o->lanes) eo.lanes = o->lanes;
             if (o->coalesce) eo.coalesce = o->coalesce;
+            eo.copy_threads = o->copy_threads;
+            if (o->n_devices < 0 || (o->n_devices > 0 && !o->devices)) throw rf::ArgError("n_devices / devices mismatch");
+            for (int i = 0; i < o->n_devices; i++) eo.devices.push_back(o->devices[i]);
         }
         auto eng = rf::Engine::create(model_dir, network ? network : "net3", nms_threshold, eo);
         rf_engine *h = new rf_engine;
@@ -119,6 +129,7 @@ rf::Engine *pool_engine(rf_engine *h, int hs, int ws) {
     rf::EngineOptions eo = h->opt;
     eo.net_h = hs; eo.net_w = ws;
     eo.lanes = 1; eo.coalesce = 1; eo.keep_outputs = false;
+    if (!eo.devices.empty()) { eo.device = eo.devices[0]; eo.devices.clear(); }     // per-size engines live on the first device
     // activations scale with the frame: keep a pooled engine's footprint near max_batch x 448^2 worth of pixels
     const long px = (long)hs * ws, budget = (long)std::max(eo.max_batch, 1) * 448 * 448;
     eo.max_batch = (int)std::max(1L, std::min((long)eo.max_batch, budget / px));
@@ -179,8 +190,29 @@ int rf_num_slots(rf_handle h) { return h ? h->eng->num_slots() : RF_ERR_INVALID_
 int rf_enqueue_batch_device(rf_handle h, const void *const *d_bgr, const int *rows, const int *cols, const int *steps,
                             int n, float threshold, int *ticket) {
     if (!h || !ticket) return RF_ERR_INVALID_ARG;
-    return guarded(h, [&]() -> int { *ticket = h->eng->enqueue(d_bgr, rows, cols, steps, n, threshold); return RF_OK; });
+    return guarded(h, [&]() -> int { *ticket = h->eng->enqueue(d_bgr, rows, cols, steps, n, true, threshold); return RF_OK; });
 }
+
+int rf_enqueue_batch(rf_handle h, const uint8_t *const *bgr, const int *rows, const int *cols, const int *steps, int n,
+                     float threshold, int *ticket) {
+    if (!h || !ticket) return RF_ERR_INVALID_ARG;
+    return guarded(h, [&]() -> int {
+        *ticket = h->eng->enqueue((const void *const *)bgr, rows, cols, steps, n, false, threshold);
+        return RF_OK;
+    });
+}
+
+int rf_host_register(rf_handle h, const void *ptr, size_t bytes) {
+    if (!h) return RF_ERR_INVALID_ARG;
+    return guarded(h, [&]() -> int { h->eng->host_register(ptr, bytes); return RF_OK; });
+}
+
+int rf_host_unregister(rf_handle h, const void *ptr) {
+    if (!h) return RF_ERR_INVALID_ARG;
+    return guarded(h, [&]() -> int { h->eng->host_unregister(ptr); return RF_OK; });
+}
+
+int rf_num_devices(rf_handle h) { return h ? h->eng->num_devices() : RF_ERR_INVALID_ARG; }
 
 int rf_wait(rf_handle h, int ticket, rf_face *out, int cap_per_image, int *counts) {
     if (!h) return RF_ERR_INVALID_ARG;

@@ -2,9 +2,13 @@
 #include "engine.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
+#include <condition_variable>
 #include <cstring>
+#include <mutex>
 #include <set>
+#include <thread>
 
 #include "pack.h"
 
@@ -18,6 +22,108 @@ namespace rf {
     } while (0)
 
 namespace {
+
+// The HIP current device is per host thread and defaults to 0: every entry point binds the calling thread to the engine's
+// device for the duration of the call and puts the caller's device back (rf_options.device may differ from it, and the
+// caller may use another thread per call -- the header only promises one caller thread AT A TIME).
+class DeviceGuard {
+public:
+    explicit DeviceGuard(int dev) : dev_(dev) {
+        if (hipGetDevice(&prev_) != hipSuccess) prev_ = dev;
+        if (prev_ != dev_) (void)hipSetDevice(dev_);
+        bind_launch_device(dev_);
+    }
+    ~DeviceGuard() {
+        if (prev_ != dev_) { (void)hipSetDevice(prev_); bind_launch_device(prev_); }
+    }
+    DeviceGuard(const DeviceGuard &) = delete;
+    DeviceGuard &operator=(const DeviceGuard &) = delete;
+private:
+    int dev_, prev_ = 0;
+};
+
+// Host frames reach the GPU through pinned staging memory; the copy into it is the only per-byte CPU work of the hot path and a
+// single core moves ~10 GB/s, a fifth of what PCIe Gen5 takes.  A few helper threads split every enqueue's rows between them
+// (the caller's thread works too), so staging runs at memory speed and the DMA engine sees ONE large copy per enqueue.
+class ParallelCopier {
+public:
+    struct Job { uint8_t *dst; const uint8_t *src; size_t row_bytes, rows, src_step; };
+    explicit ParallelCopier(int helpers) {
+        for (int i = 0; i < helpers; i++) threads_.emplace_back([this] { worker(); });
+    }
+    ~ParallelCopier() {
+        { std::lock_guard<std::mutex> lk(mu_); stop_ = true; }
+        cv_.notify_all();
+        for (auto &t : threads_) t.join();
+    }
+    void run(const std::vector<Job> &jobs) {
+        // pieces of ~256 KB: whole rows of one frame
+        std::vector<Job> pcs;
+        for (const Job &j : jobs) {
+            if (!j.rows || !j.row_bytes) continue;
+            const size_t per = std::max<size_t>(1, (256 << 10) / j.row_bytes);
+            for (size_t r = 0; r < j.rows; r += per)
+                pcs.push_back(Job{j.dst + r * j.row_bytes, j.src + r * j.src_step, j.row_bytes, std::min(per, j.rows - r), j.src_step});
+        }
+        if (pcs.empty()) return;
+        if (threads_.empty() || pcs.size() == 1) { for (const Job &p : pcs) copy(p); return; }
+        {
+            std::unique_lock<std::mutex> lk(mu_);
+            idle_cv_.wait(lk, [this] { return busy_ == 0; });      // a helper that woke late for the previous round has left drain()
+            pieces_.swap(pcs);
+            next_.store(0);
+            left_ = pieces_.size();
+            gen_++;
+        }
+        cv_.notify_all();
+        drain();
+        std::unique_lock<std::mutex> lk(mu_);
+        done_cv_.wait(lk, [this] { return left_ == 0; });
+    }
+private:
+    static void copy(const Job &p) {
+        if (p.src_step == p.row_bytes) { memcpy(p.dst, p.src, p.row_bytes * p.rows); return; }
+        for (size_t r = 0; r < p.rows; r++) memcpy(p.dst + r * p.row_bytes, p.src + r * p.src_step, p.row_bytes);
+    }
+    void drain() {                       // pieces_ only changes while no helper is in here (busy_ == 0, under mu_)
+        size_t done = 0;
+        for (;;) {
+            const size_t i = next_.fetch_add(1);
+            if (i >= pieces_.size()) break;
+            copy(pieces_[i]);
+            done++;
+        }
+        if (done) {
+            std::lock_guard<std::mutex> lk(mu_);
+            left_ -= done;
+            if (left_ == 0) done_cv_.notify_all();
+        }
+    }
+    void worker() {
+        unsigned long seen = 0;
+        for (;;) {
+            {
+                std::unique_lock<std::mutex> lk(mu_);
+                cv_.wait(lk, [&] { return stop_ || gen_ != seen; });
+                if (stop_) return;
+                seen = gen_;
+                busy_++;
+            }
+            drain();
+            std::lock_guard<std::mutex> lk(mu_);
+            if (--busy_ == 0) idle_cv_.notify_all();
+        }
+    }
+    std::vector<std::thread> threads_;
+    std::vector<Job> pieces_;
+    std::atomic<size_t> next_{0};
+    size_t left_ = 0;
+    int busy_ = 0;
+    unsigned long gen_ = 0;
+    bool stop_ = false;
+    std::mutex mu_;
+    std::condition_variable cv_, done_cv_, idle_cv_;
+};
 
 template <typename T> struct Cast;
 template <> struct Cast<float> { static float from(float v) { return v; } static float to(float v) { return v; } };
@@ -102,22 +208,33 @@ public:
         if (opt_.max_detections < 1 || opt_.max_detections > 4096) throw ArgError("max_detections must be in [1, 4096]");
         if (opt_.lanes < 1 || opt_.lanes > 16) throw ArgError("lanes must be in [1, 16]");
         if (opt_.coalesce < 1 || opt_.coalesce > 32) throw ArgError("coalesce must be in [1, 32]");
+        if (opt_.copy_threads < 0 || opt_.copy_threads > 64) throw ArgError("copy_threads must be in [0, 64]");
         cap_images_ = opt_.max_batch * opt_.coalesce;
         tickets_.resize(4 * opt_.lanes * opt_.coalesce + 8);
-        if (opt_.device >= 0) RF_HIP(hipSetDevice(opt_.device));
-        RF_HIP(hipGetDevice(&device_));
+        if (opt_.device >= 0) device_ = opt_.device;
+        else RF_HIP(hipGetDevice(&device_));
+        int ndev = 0;
+        RF_HIP(hipGetDeviceCount(&ndev));
+        if (device_ < 0 || device_ >= ndev) throw ArgError("device ordinal " + std::to_string(device_) + " out of range (" + std::to_string(ndev) + " devices)");
+        DeviceGuard guard(device_);                  // the caller's current device is put back when construction ends
         upload_weights(plan);
         lanes_.resize(opt_.lanes);
         for (auto &l : lanes_) build_lane(l, plan);
+        const int hw = (int)std::thread::hardware_concurrency();
+        const int helpers = opt_.copy_threads > 0 ? opt_.copy_threads - 1 : std::max(0, std::min(8, hw / 4) - 1);
+        copier_.reset(new ParallelCopier(helpers));
     }
 
     ~EngineImpl() override {
+        DeviceGuard guard(device_);
+        for (auto &r : registered_) if (r.owned) (void)hipHostUnregister((void *)r.base);
         for (auto &l : lanes_) {
             if (l.stream) (void)hipStreamSynchronize(l.stream);
             for (auto &kv : l.graphs) (void)hipGraphExecDestroy(kv.second);
             for (hipEvent_t e : l.time_ev) (void)hipEventDestroy(e);
             if (l.done) (void)hipEventDestroy(l.done);
-            if (l.d_raw) (void)hipFree(l.d_raw);
+            if (l.d_stage) (void)hipFree(l.d_stage);
+            if (l.h_stage) (void)hipHostFree(l.h_stage);
             if (l.stream) (void)hipStreamDestroy(l.stream);
         }
         for (void *p : dev_allocs_) (void)hipFree(p);
@@ -131,7 +248,11 @@ public:
                 float threshold, rf_face *out, int cap_per_image, int *counts, bool *truncated) override {
         if (n < 0 || (n > 0 && (!frames || !rows || !cols || !counts))) throw ArgError("null argument");
         if (cap_per_image < 0 || (cap_per_image > 0 && !out)) throw ArgError("out is null");
+        DeviceGuard guard(device_);
         *truncated = false;
+        // every frame is checked before the first chunk is launched: a bad frame in a later chunk must not leave earlier
+        // chunks in flight with nobody waiting for them
+        for (int i = 0; i < n; i++) check_frame(frames[i], rows[i], cols[i], steps ? steps[i] : cols[i] * 3);
         std::vector<int> all_cand;
         std::vector<std::vector<int32_t>> all_anchor;
         // a synchronous call keeps up to `lanes` chunks of max_batch images in flight and collects them in order
@@ -140,81 +261,66 @@ public:
             int ticket = inflight.front().first, base = inflight.front().second;
             inflight.erase(inflight.begin());
             bool tr = false;
-            wait(ticket, out ? out + (size_t)base * cap_per_image : nullptr, cap_per_image, counts + base, &tr);
+            wait_impl(ticket, out ? out + (size_t)base * cap_per_image : nullptr, cap_per_image, counts + base, &tr);
             *truncated = *truncated || tr;
             all_cand.insert(all_cand.end(), last_cand_counts_.begin(), last_cand_counts_.end());
             for (int i = 0; i < last_n_; i++) all_anchor.push_back(std::move(last_anchor_[i]));
         };
         const bool timed = !opt_.use_graph;             // the eager engine measures the pre / infer / post split
-        for (int base = 0; base < n; base += opt_.max_batch) {
-            int m = std::min(opt_.max_batch, n - base);
-            std::vector<int> st(m);
-            for (int i = 0; i < m; i++) st[i] = steps ? steps[base + i] : cols[base + i] * 3;
-            if ((int)inflight.size() == (int)lanes_.size() || (timed && !inflight.empty())) collect();
-            int ticket = submit(frames + base, rows + base, cols + base, st.data(), m, on_device, threshold, true);
-            inflight.emplace_back(ticket, base);
+        try {
+            for (int base = 0; base < n; base += opt_.max_batch) {
+                int m = std::min(opt_.max_batch, n - base);
+                std::vector<int> st(m);
+                for (int i = 0; i < m; i++) st[i] = steps ? steps[base + i] : cols[base + i] * 3;
+                if ((int)inflight.size() == (int)lanes_.size() || (timed && !inflight.empty())) collect();
+                int ticket = submit(frames + base, rows + base, cols + base, st.data(), m, on_device, threshold, true);
+                inflight.emplace_back(ticket, base);
+            }
+            while (!inflight.empty()) collect();
+        } catch (...) {
+            // hand every ticket of this call back to the pool (results dropped) before the error leaves
+            for (auto &tb : inflight) {
+                try { bool tr = false; wait_impl(tb.first, nullptr, 0, nullptr, &tr); } catch (...) { tickets_[tb.first].state = Ticket::FREE; }
+            }
+            throw;
         }
-        while (!inflight.empty()) collect();
         if (n > opt_.max_batch) last_first_image_ = -1000000;   // blob accessors are per-launch: not valid for chunked calls
         last_n_ = n;                         // the "most recent completed batch" of a chunked call is the whole call
         last_cand_counts_.swap(all_cand);
         last_anchor_.swap(all_anchor);
     }
 
-    int enqueue(const void *const *d_frames, const int *rows, const int *cols, const int *steps, int n,
+    int enqueue(const void *const *frames, const int *rows, const int *cols, const int *steps, int n, bool on_device,
                 float threshold) override {
         if (n < 1 || n > opt_.max_batch) throw ArgError("enqueue: n must be in [1, max_batch]");
-        if (!d_frames || !rows || !cols) throw ArgError("null argument");
+        if (!frames || !rows || !cols) throw ArgError("null argument");
+        DeviceGuard guard(device_);
         std::vector<int> st(n);
-        for (int i = 0; i < n; i++) st[i] = steps ? steps[i] : cols[i] * 3;
-        return submit((const uint8_t *const *)d_frames, rows, cols, st.data(), n, true, threshold, false);
+        for (int i = 0; i < n; i++) {
+            st[i] = steps ? steps[i] : cols[i] * 3;
+            check_frame((const uint8_t *)frames[i], rows[i], cols[i], st[i]);
+        }
+        return submit((const uint8_t *const *)frames, rows, cols, st.data(), n, on_device, threshold, false);
     }
 
     void wait(int ticket, rf_face *out, int cap_per_image, int *counts, bool *truncated) override {
-        if (ticket < 0 || ticket >= (int)tickets_.size() || tickets_[ticket].state == Ticket::FREE)
-            throw ArgError("wait: invalid ticket");
-        Ticket &t = tickets_[ticket];
-        if (t.state == Ticket::PENDING) launch_pending();          // its super-batch has not been launched yet
-        if (t.state == Ticket::LAUNCHED) {
-            // About to block on a running super-batch: a partial one queued behind it starts now and runs on its own lane
-            // meanwhile (the tail of a burst overlaps instead of serialising).  When the waited batch has already finished
-            // nothing is flushed -- in a steady pipeline the pending batch keeps filling up to max_batch x coalesce images.
-            Lane &L = lanes_[t.lane];
-            if (L.busy && hipEventQuery(L.done) == hipErrorNotReady) launch_pending();
-            harvest(L);                                             // first waiter of a super-batch collects all of it
-        }
-        bool tr = false;
-        last_lane_ = t.lane;
-        last_first_image_ = t.first_image;
-        last_n_ = t.n;
-        last_cand_counts_.assign(t.n, 0);
-        if ((int)last_anchor_.size() < t.n) last_anchor_.resize(t.n);      // per-image vectors keep their capacity across waits
-        for (int i = 0; i < t.n; i++) {
-            int kept = t.kept[i], ncand = t.ncand[i];
-            last_cand_counts_[i] = ncand;
-            if (ncand > opt_.max_candidates) tr = true;
-            int avail = std::min(kept, opt_.max_detections);
-            if (kept > opt_.max_detections) tr = true;
-            if (counts) counts[i] = kept;
-            int ncopy = std::min(avail, cap_per_image);
-            if (avail > cap_per_image) tr = true;
-            const Candidate *src = t.records.data() + t.first_record[i];
-            last_anchor_[i].resize(avail);
-            for (int k = 0; k < avail; k++) last_anchor_[i][k] = src[k].anchor;
-            for (int k = 0; k < ncopy; k++) memcpy(&out[(size_t)i * cap_per_image + k], &src[k], sizeof(rf_face));
-        }
-        if (t.timed) {
-            Lane &s = lanes_[t.lane];
-            float a = 0, b = 0, c = 0;
-            (void)hipEventElapsedTime(&a, s.time_ev[0], s.time_ev[1]);
-            (void)hipEventElapsedTime(&b, s.time_ev[1], s.time_ev[2]);
-            (void)hipEventElapsedTime(&c, s.time_ev[2], s.time_ev[3]);
-            t_pre_ = a; t_infer_ = b; t_post_ = c; t_total_ = a + b + c;
-            have_split_ = true;
-        }
-        t.state = Ticket::FREE;
-        if (truncated) *truncated = tr;
+        if (cap_per_image < 0 || (cap_per_image > 0 && !out)) throw ArgError("wait: out is null");
+        DeviceGuard guard(device_);
+        wait_impl(ticket, out, cap_per_image, counts, truncated);
     }
+
+    void host_register(const void *ptr, size_t bytes) override {
+        if (!ptr || !bytes) throw ArgError("host_register: null / empty range");
+        DeviceGuard guard(device_);
+        RF_HIP(hipHostRegister((void *)ptr, bytes, hipHostRegisterPortable));
+        registered_.push_back(HostRange{(uintptr_t)ptr, bytes, true});
+    }
+    void host_adopt(const void *ptr, size_t bytes) override {
+        if (!ptr || !bytes) throw ArgError("host_register: null / empty range");
+        registered_.push_back(HostRange{(uintptr_t)ptr, bytes, false});
+    }
+    void host_unregister(const void *ptr) override { drop_range(ptr, true); }
+    void host_forget(const void *ptr) override { drop_range(ptr, false); }
 
     // tickets the caller may keep outstanding before it has to wait: every lane can hold a full super-batch
     int num_slots() const override { return (int)lanes_.size() * opt_.coalesce; }
@@ -238,6 +344,7 @@ public:
 
     long get_output(const std::string &blob, int image, float *dst, size_t cap) override {
         if (!opt_.keep_outputs) throw ArgError("rf_get_output needs options.keep_outputs = 1");
+        DeviceGuard guard(device_);
         static const char *kinds[3] = {"face_rpn_cls_prob_reshape_stride", "face_rpn_bbox_pred_stride",
                                        "face_rpn_landmark_pred_stride"};
         static const int chans[3] = {4, 8, 20};
@@ -259,6 +366,7 @@ public:
     }
 
     long debug_activation(const std::string &blob, int image, float *dst, size_t cap, int dims[3]) override {
+        DeviceGuard guard(device_);
         Lane &l = lanes_[last_lane_];
         auto it = l.acts.find(blob);
         if (it == l.acts.end()) throw ArgError("unknown activation '" + blob + "'");
@@ -279,6 +387,7 @@ public:
     int profile(const void *const *d_frames, int n, int iters, int cap, const char **names, const char **kernels,
                 float *avg_ms, double *alg_bytes, double *macs) override {
         if (n < 1 || n > cap_images_ || iters < 1) throw ArgError("profile: bad n / iters");
+        DeviceGuard guard(device_);
         launch_pending();
         Lane &l = lanes_[0];
         harvest(l);
@@ -361,8 +470,11 @@ private:
         RunParams *d_params = nullptr;
         int *d_cand_count = nullptr;
         Candidate *d_cand = nullptr;
-        uint8_t *d_canvas = nullptr, *d_raw = nullptr;
-        size_t raw_stride = 0;
+        uint8_t *d_canvas = nullptr;
+        // host frames: pinned staging block + its device twin (allocated on first use); a super-batch's frames are packed into
+        // it back to back and cross PCIe as one DMA per enqueue
+        uint8_t *h_stage = nullptr, *d_stage = nullptr;
+        size_t stage_cap = 0, stage_used = 0;
         float *d_dump[3][3] = {};
         bool busy = false;                    // a launched super-batch whose results have not been harvested yet
         int n_images = 0;                     // images of the super-batch being assembled / in flight on this lane
@@ -495,11 +607,22 @@ private:
             c0_hi_ = arena_.put(frag);
             // the stem computes its depthwise + pointwise block in fp16 whatever the storage type of its OUTPUT
             const auto &b0 = plan.blocks[0];
-            std::vector<half_t> dw((size_t)9 * 8);
+            std::vector<float> dw((size_t)9 * 8);                  // taps stay fp32 (see the stem kernel's header)
             for (int ch = 0; ch < 8; ch++)
-                for (int t = 0; t < 9; t++) dw[(size_t)t * 8 + ch] = (half_t)b0.dw.w[(size_t)ch * 9 + t];
+                for (int t = 0; t < 9; t++) dw[(size_t)t * 8 + ch] = b0.dw.w[(size_t)ch * 9 + t];
             stem_dw_ = DwW{arena_.put(dw), arena_.put(b0.dw.b)};
-            stem_pw_.w = arena_.put(pack_gemm<half_t>(b0.pw.w, b0.pw.cout, 8, 32, 8));
+            // pointwise 16 x 8: one A fragment whose K slots are [w_hi | w_hi | w_lo | 0] (pack.h stem_pw_slot)
+            std::vector<half_t> pwf((size_t)64 * 8, (half_t)0);
+            for (int lane = 0; lane < 64; lane++) {
+                int row = 0, use_lo = 0;
+                if (!stem_pw_slot(lane, &row, &use_lo)) continue;
+                for (int e = 0; e < 8; e++) {
+                    const float w = b0.pw.w[(size_t)row * 8 + e];
+                    const half_t hi = (half_t)w;
+                    pwf[(size_t)lane * 8 + e] = use_lo ? (half_t)(w - (float)hi) : hi;
+                }
+            }
+            stem_pw_.w = arena_.put(pwf);
             if constexpr (kInt8) {
                 const float os = scale_of(plan, b0.pw.out_blob);
                 std::vector<float> b(b0.pw.b), m(b0.pw.cout, 1.f / os);
@@ -615,7 +738,7 @@ private:
             StemParams<T> sp;
             sp.frames = L.d_frames + mb; sp.out = out;
             sp.w0 = arena_.ptr<half_t>(c0_hi_); sp.b0 = arena_.ptr<float>(c0_b_);
-            sp.dw_w = arena_.ptr<half_t>(stem_dw_.w); sp.dw_b = arena_.ptr<float>(stem_dw_.b);
+            sp.dw_w = arena_.ptr<float>(stem_dw_.w); sp.dw_b = arena_.ptr<float>(stem_dw_.b);
             sp.pw_w = arena_.ptr<half_t>(stem_pw_.w); sp.pw_b = arena_.ptr<float>(stem_pw_.b);
             sp.pw_m = mult_ptr(stem_pw_);
             sp.n = 0; sp.net_h = H; sp.net_w = W;
@@ -780,13 +903,90 @@ private:
     }
 
     // ------------------------------------------------------------------------------------------ run
-    void ensure_raw(Lane &L, size_t per_image) {
-        if (per_image <= L.raw_stride) return;
+    static size_t align256(size_t v) { return (v + 255) / 256 * 256; }
+
+    // img.empty() (RetinaFace.cpp:578-580) is legal and yields count 0; everything else must be a sane CV_8UC3 view
+    void check_frame(const uint8_t *ptr, int rows, int cols, int step) const {
+        if (!ptr || rows <= 0 || cols <= 0) return;
+        if (rows > 4096 * 3072 / std::max(cols, 1)) throw ArgError("frame larger than 4096x3072 (RetinaFace.cpp:325)");
+        if (step < cols * 3) throw ArgError("row step smaller than cols*3");
+    }
+
+    // Staging capacity of a lane: room for a full super-batch of net-sized frames, or for what one enqueue needs if that is more
+    // (sized by the frames actually staged, not by cap_images x the largest frame ever seen).
+    void ensure_stage(Lane &L, size_t need) {
+        if (need <= L.stage_cap) return;
+        const size_t want = std::max(need, (size_t)cap_images_ * align256((size_t)net_h_ * net_w_ * 3));
         RF_HIP(hipStreamSynchronize(L.stream));
-        if (L.d_raw) RF_HIP(hipFree(L.d_raw));
-        L.d_raw = nullptr;
-        L.raw_stride = ((per_image + 255) / 256) * 256;
-        RF_HIP(hipMalloc((void **)&L.d_raw, L.raw_stride * cap_images_));
+        if (L.d_stage) RF_HIP(hipFree(L.d_stage));
+        if (L.h_stage) RF_HIP(hipHostFree(L.h_stage));
+        L.d_stage = nullptr; L.h_stage = nullptr; L.stage_cap = 0;
+        RF_HIP(hipHostMalloc((void **)&L.h_stage, want, hipHostMallocDefault));
+        RF_HIP(hipMalloc((void **)&L.d_stage, want));
+        L.stage_cap = want;
+    }
+
+    bool is_registered(const uint8_t *p, size_t bytes) const {
+        for (const auto &r : registered_)
+            if ((uintptr_t)p >= r.base && (uintptr_t)p + bytes <= r.base + r.bytes) return true;
+        return false;
+    }
+    void drop_range(const void *ptr, bool unpin) {
+        DeviceGuard guard(device_);
+        for (size_t i = 0; i < registered_.size(); i++)
+            if (registered_[i].base == (uintptr_t)ptr) {
+                for (auto &l : lanes_) if (l.stream) RF_HIP(hipStreamSynchronize(l.stream));     // no DMA may still read it
+                if (unpin && registered_[i].owned) RF_HIP(hipHostUnregister((void *)ptr));
+                registered_.erase(registered_.begin() + i);
+                return;
+            }
+        throw ArgError("host_unregister: range was not registered on this handle");
+    }
+
+    void wait_impl(int ticket, rf_face *out, int cap_per_image, int *counts, bool *truncated) {
+        if (ticket < 0 || ticket >= (int)tickets_.size() || tickets_[ticket].state == Ticket::FREE)
+            throw ArgError("wait: invalid ticket");
+        Ticket &t = tickets_[ticket];
+        if (t.state == Ticket::PENDING) launch_pending();          // its super-batch has not been launched yet
+        if (t.state == Ticket::LAUNCHED) {
+            // About to block on a running super-batch: a partial one queued behind it starts now and runs on its own lane
+            // meanwhile (the tail of a burst overlaps instead of serialising).  When the waited batch has already finished
+            // nothing is flushed -- in a steady pipeline the pending batch keeps filling up to max_batch x coalesce images.
+            Lane &L = lanes_[t.lane];
+            if (L.busy && hipEventQuery(L.done) == hipErrorNotReady) launch_pending();
+            harvest(L);                                             // first waiter of a super-batch collects all of it
+        }
+        bool tr = false;
+        last_lane_ = t.lane;
+        last_first_image_ = t.first_image;
+        last_n_ = t.n;
+        last_cand_counts_.assign(t.n, 0);
+        if ((int)last_anchor_.size() < t.n) last_anchor_.resize(t.n);      // per-image vectors keep their capacity across waits
+        for (int i = 0; i < t.n; i++) {
+            int kept = t.kept[i], ncand = t.ncand[i];
+            last_cand_counts_[i] = ncand;
+            if (ncand > opt_.max_candidates) tr = true;
+            int avail = std::min(kept, opt_.max_detections);
+            if (kept > opt_.max_detections) tr = true;
+            if (counts) counts[i] = kept;
+            int ncopy = out ? std::min(avail, cap_per_image) : 0;
+            if (out && avail > cap_per_image) tr = true;
+            const Candidate *src = t.records.data() + t.first_record[i];
+            last_anchor_[i].resize(avail);
+            for (int k = 0; k < avail; k++) last_anchor_[i][k] = src[k].anchor;
+            for (int k = 0; k < ncopy; k++) memcpy(&out[(size_t)i * cap_per_image + k], &src[k], sizeof(rf_face));
+        }
+        if (t.timed) {
+            Lane &s = lanes_[t.lane];
+            float a = 0, b = 0, c = 0;
+            (void)hipEventElapsedTime(&a, s.time_ev[0], s.time_ev[1]);
+            (void)hipEventElapsedTime(&b, s.time_ev[1], s.time_ev[2]);
+            (void)hipEventElapsedTime(&c, s.time_ev[2], s.time_ev[3]);
+            t_pre_ = a; t_infer_ = b; t_post_ = c; t_total_ = a + b + c;
+            have_split_ = true;
+        }
+        t.state = Ticket::FREE;
+        if (truncated) *truncated = tr;
     }
 
     int alloc_ticket() {
@@ -828,6 +1028,7 @@ private:
         Lane &s = lanes_[pending_lane_];
         pending_lane_ = -1;
         const int n = s.n_images;
+        if (n == 0) return;
         *s.h_params = RunParams{s.threshold, nms_threshold_, n, 0};
         if (s.need_resize) {
             const int mb = cap_images_;
@@ -856,35 +1057,44 @@ private:
         for (int id : s.tickets) tickets_[id].state = Ticket::LAUNCHED;
     }
 
+    // One enqueue / one chunk of a synchronous call joins the super-batch being assembled (or opens the next lane).  Everything
+    // that can fail for a caller-side reason runs BEFORE any state changes: a thrown error leaves no half-open lane or ticket.
     int submit(const uint8_t *const *frames, const int *rows, const int *cols, const int *steps, int n, bool on_device,
                float threshold, bool sync_call) {
         const int mb = cap_images_;
-        bool need_resize = false;
-        size_t max_raw = 0;
+        bool need_resize = false, all_registered = true;
+        size_t stage_need = 0;
         std::vector<char> empty(n, 0);
+        std::vector<size_t> off(n, 0);
         for (int i = 0; i < n; i++) {
+            check_frame(frames[i], rows[i], cols[i], steps[i]);
             empty[i] = !frames[i] || rows[i] <= 0 || cols[i] <= 0;      // img.empty(), RetinaFace.cpp:578-580
             if (empty[i]) continue;
-            if (rows[i] > 4096 * 3072 / std::max(cols[i], 1)) throw ArgError("frame larger than 4096x3072 (RetinaFace.cpp:325)");
-            if (steps[i] < cols[i] * 3) throw ArgError("row step smaller than cols*3");
             if (rows[i] > net_h_ || cols[i] > net_w_) need_resize = true;
-            max_raw = std::max(max_raw, (size_t)rows[i] * cols[i] * 3);
+            if (!on_device) {
+                off[i] = stage_need;
+                stage_need += align256((size_t)rows[i] * cols[i] * 3);
+                all_registered = all_registered && is_registered(frames[i], (size_t)(rows[i] - 1) * steps[i] + (size_t)cols[i] * 3);
+            }
         }
         const bool eager_timed = sync_call && !opt_.use_graph;
-        // a pending super-batch is closed when this chunk does not fit, must not be mixed (different threshold, timed
-        // eager run), or needs a bigger host-frame staging buffer
+        // a pending super-batch is closed when this chunk does not fit (images or staging bytes) or must not be mixed with it
+        // (different threshold, timed eager run)
         if (pending_lane_ >= 0) {
             Lane &p = lanes_[pending_lane_];
             if (p.n_images + n > mb || p.threshold != threshold || eager_timed || p.timed ||
-                (!on_device && max_raw > p.raw_stride))
+                (stage_need && p.stage_used + stage_need > p.stage_cap))
                 launch_pending();
         }
+        const int id = alloc_ticket();
         if (pending_lane_ < 0) {
-            int lane = next_lane_;
-            next_lane_ = (next_lane_ + 1) % (int)lanes_.size();
+            const int lane = next_lane_;
             Lane &s = lanes_[lane];
             harvest(s);                       // waits for the previous super-batch on this lane, if any
+            if (stage_need) ensure_stage(s, stage_need);
+            next_lane_ = (next_lane_ + 1) % (int)lanes_.size();
             s.n_images = 0;
+            s.stage_used = 0;
             s.threshold = threshold;
             s.need_resize = false;
             s.timed = eager_timed;
@@ -894,27 +1104,42 @@ private:
             if (eager_timed) RF_HIP(hipEventRecord(s.time_ev[0], s.stream));
         }
         Lane &s = lanes_[pending_lane_];
-        if (!on_device) ensure_raw(s, max_raw);
-        const int id = alloc_ticket();
         Ticket &t = tickets_[id];
         t.state = Ticket::PENDING; t.lane = pending_lane_; t.first_image = s.n_images; t.n = n; t.timed = eager_timed;
+        try {
+            if (stage_need) {
+                uint8_t *hbase = s.h_stage + s.stage_used, *dbase = s.d_stage + s.stage_used;
+                if (all_registered) {
+                    // caller buffers pinned with rf_host_register: the DMA engine reads them in place
+                    for (int i = 0; i < n; i++)
+                        if (!empty[i])
+                            RF_HIP(hipMemcpy2DAsync(dbase + off[i], (size_t)cols[i] * 3, frames[i], (size_t)steps[i], (size_t)cols[i] * 3,
+                                                    (size_t)rows[i], hipMemcpyHostToDevice, s.stream));
+                } else {
+                    copy_jobs_.clear();
+                    for (int i = 0; i < n; i++)
+                        if (!empty[i])
+                            copy_jobs_.push_back(ParallelCopier::Job{hbase + off[i], frames[i], (size_t)cols[i] * 3, (size_t)rows[i], (size_t)steps[i]});
+                    copier_->run(copy_jobs_);          // the caller's buffers are free again when this returns
+                    RF_HIP(hipMemcpyAsync(dbase, hbase, stage_need, hipMemcpyHostToDevice, s.stream));
+                }
+            }
+        } catch (...) {
+            t.state = Ticket::FREE;
+            throw;
+        }
         for (int i = 0; i < n; i++) {
             const int img = s.n_images + i;
             FrameDesc src{nullptr, 0, 0, 0, 0};
             s.empty[img] = empty[i];
             if (!empty[i]) {
-                if (on_device) {
-                    src = FrameDesc{frames[i], rows[i], cols[i], steps[i], 0};
-                } else {
-                    uint8_t *dst = s.d_raw + (size_t)img * s.raw_stride;
-                    RF_HIP(hipMemcpy2DAsync(dst, (size_t)cols[i] * 3, frames[i], (size_t)steps[i], (size_t)cols[i] * 3,
-                                            (size_t)rows[i], hipMemcpyHostToDevice, s.stream));
-                    src = FrameDesc{dst, rows[i], cols[i], cols[i] * 3, 0};
-                }
+                if (on_device) src = FrameDesc{frames[i], rows[i], cols[i], steps[i], 0};
+                else src = FrameDesc{s.d_stage + s.stage_used + off[i], rows[i], cols[i], cols[i] * 3, 0};
             }
             s.h_frames[img] = src;
             s.h_frames[mb + img] = src;       // replaced by the canvas in launch_pending() when a resize is needed
         }
+        s.stage_used += stage_need;
         s.need_resize = s.need_resize || need_resize;
         s.n_images += n;
         s.tickets.push_back(id);
@@ -942,6 +1167,10 @@ private:
 
     // ------------------------------------------------------------------------------------------ state
     int device_ = 0;
+    std::unique_ptr<ParallelCopier> copier_;
+    std::vector<ParallelCopier::Job> copy_jobs_;
+    struct HostRange { uintptr_t base; size_t bytes; bool owned; };
+    std::vector<HostRange> registered_;       // rf_host_register ranges (pinned caller memory; owned = pinned by this engine)
     std::vector<hipEvent_t> prof_ev_;
     Arena arena_;
     size_t c0_w_ = 0, c0_b_ = 0, c0_hi_ = 0;
@@ -970,8 +1199,8 @@ private:
 
 }  // namespace
 
-std::unique_ptr<Engine> Engine::create(const std::string &model_dir, const std::string &network, float nms,
-                                       const EngineOptions &opt) {
+std::unique_ptr<Engine> Engine::create_single(const std::string &model_dir, const std::string &network, float nms,
+                                              const EngineOptions &opt) {
     // Only "net3" has an anchor configuration in the reference (RetinaFace.cpp:215-217, 245-271); the other
     // presets print "please reconfig anchor_cfg" and leave cfg empty.
     if (network != "net3") throw Unsupported("network preset '" + network + "' has no anchor configuration (only net3)");

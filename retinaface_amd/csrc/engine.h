@@ -20,7 +20,6 @@ namespace rf {
 
 struct HipError : std::runtime_error { using std::runtime_error::runtime_error; };
 struct ArgError : std::runtime_error { using std::runtime_error::runtime_error; };
-struct Unsupported : std::runtime_error { using std::runtime_error::runtime_error; };
 
 struct EngineOptions {
     int precision = RF_PRECISION_FP16;
@@ -35,6 +34,8 @@ struct EngineOptions {
                                      // persistent and pipeline tile t+1's loads under tile t's compute, which pays off once
                                      // a launch holds several tiles per resident workgroup (measured: 4 -> 16 = +8 %)
     bool keep_outputs = false;
+    int copy_threads = 0;            // threads (caller's included) that stage host frames into pinned memory; 0 = min(8, cores / 4)
+    std::vector<int> devices;        // more than one entry: one engine per device, batches sharded by image (multi.cpp)
     std::string model_stem = "mnet-deconv-0517";
 };
 
@@ -52,18 +53,29 @@ struct OpInfo {
 
 class Engine {
 public:
+    // opt.devices.size() > 1 gives the image-sharding multi-device engine (multi.cpp), otherwise one single-device engine
     static std::unique_ptr<Engine> create(const std::string &model_dir, const std::string &network, float nms,
                                           const EngineOptions &opt);
+    static std::unique_ptr<Engine> create_single(const std::string &model_dir, const std::string &network, float nms,
+                                                 const EngineOptions &opt);
     virtual ~Engine() {}
 
     // frames on host / device; synchronous
     virtual void detect(const uint8_t *const *frames, const int *rows, const int *cols, const int *steps, int n,
                         bool on_device, float threshold, rf_face *out, int cap_per_image, int *counts,
                         bool *truncated) = 0;
-    virtual int enqueue(const void *const *d_frames, const int *rows, const int *cols, const int *steps, int n,
+    // asynchronous: frames on host (staged through pinned memory before the call returns, unless the caller registered
+    // them with host_register) or on the device
+    virtual int enqueue(const void *const *frames, const int *rows, const int *cols, const int *steps, int n, bool on_device,
                         float threshold) = 0;
     virtual void wait(int ticket, rf_face *out, int cap_per_image, int *counts, bool *truncated) = 0;
     virtual int num_slots() const = 0;
+    // pinned caller memory: register pins the range (hipHostRegisterPortable) and records it; adopt / forget only record /
+    // drop a range another engine of the same handle pinned (multi-device handles pin once)
+    virtual void host_register(const void *ptr, size_t bytes) = 0;
+    virtual void host_unregister(const void *ptr) = 0;
+    virtual void host_adopt(const void *ptr, size_t bytes) = 0;
+    virtual void host_forget(const void *ptr) = 0;
 
     virtual int last_anchor_indices(int image, int32_t *out, int cap) const = 0;
     virtual int last_candidate_counts(int *counts, int n) const = 0;
@@ -76,6 +88,7 @@ public:
     int net_h() const { return net_h_; }
     int net_w() const { return net_w_; }
     int max_batch() const { return opt_.max_batch; }
+    virtual int num_devices() const { return 1; }
 
 protected:
     EngineOptions opt_;

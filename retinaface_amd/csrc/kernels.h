@@ -5,13 +5,22 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <stdexcept>
+
 namespace rf {
 
 typedef _Float16 half_t;
 
+// a request the engine has no kernel instance / configuration for (C ABI: RF_ERR_UNSUPPORTED)
+struct Unsupported : std::runtime_error { using std::runtime_error::runtime_error; };
+
 // depthwise weights are stored in the activation type, except fp32 for int8 activations
 template <typename T> struct DwWeightT { typedef T type; };
 template <> struct DwWeightT<int8_t> { typedef float type; };
+
+// The launch helpers keep per-device state (CU count, LDS attribute / occupancy of each kernel instance); the engine tells
+// them which device the calling thread is bound to (engine.cpp DeviceGuard).
+void bind_launch_device(int device);
 
 // One input frame: CV_8UC3 BGR, row y at ptr + y*step (cv::Mat data/step; RetinaFace.cpp:594).
 struct FrameDesc {
@@ -47,7 +56,8 @@ template <typename TO>
 struct StemParams {
     const FrameDesc *frames; TO *out;              // out: [n][net_h/2][net_w/2][16], fp16 or int8
     const half_t *w0; const float *b0;             // conv0: 4 A fragments (hi/lo x k<32/k>=32), K = (ky,kx,BGRX) 36 -> 64
-    const half_t *dw_w; const float *dw_b; const half_t *pw_w; const float *pw_b;
+    const float *dw_w; const float *dw_b;          // depthwise taps [9][8], fp32
+    const half_t *pw_w; const float *pw_b;         // pointwise 16 x 8 as one A fragment with K slots [hi | hi | lo | 0] (pack.h)
     const float *pw_m = nullptr;                   // int8 output: 1 / out_scale per channel (pw_b pre-divided)
     int n, net_h, net_w;
 };

@@ -102,17 +102,33 @@ static void set_max_lds(F func, size_t bytes) {
     if (bytes > 48 * 1024) (void)hipFuncSetAttribute((const void *)func, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
 
+// Per-device launch state.  Function attributes (dynamic-LDS limit) and occupancy are properties of (kernel, device): with more
+// than one engine in a process (rf_options.devices) each device sets them up on its first launch.  The engine binds the calling
+// thread's device with bind_launch_device() (engine.cpp DeviceGuard); unbound threads ask the runtime.
+constexpr int kMaxDevices = 32;
+static thread_local int t_launch_device = -1;
+void bind_launch_device(int device) { t_launch_device = device; }
+static int launch_device() {
+    int dev = t_launch_device;
+    if (dev < 0 && hipGetDevice(&dev) != hipSuccess) dev = 0;
+    return dev >= 0 && dev < kMaxDevices ? dev : 0;
+}
+
+// Launch helpers report a shape they have no kernel instance for as rf::Unsupported (the C ABI maps it to RF_ERR_UNSUPPORTED);
+// the engine validates the layer table up front, so this is a programming error -- but never an abort().
+typedef Unsupported LaunchUnsupported;
+
 // Persistent grid: as many workgroups as the chip keeps resident (CUs x RESIDENT), trimmed so every workgroup walks the
 // same number of tiles (no nearly-empty last round).  Launches with fewer tiles than that get one tile per workgroup.
-static int g_num_cus = 0;
+static int g_num_cus[kMaxDevices] = {};
 static int num_cus() {
-    if (!g_num_cus) {
-        int dev = 0;
+    const int dev = launch_device();
+    if (!g_num_cus[dev]) {
         hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 256;
-        g_num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return 256;
+        g_num_cus[dev] = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     }
-    return g_num_cus;
+    return g_num_cus[dev];
 }
 // Below `min_rounds` x resident tiles the hardware dispatcher's dynamic one-tile-per-workgroup schedule is at least as
 // good as walking two tiles in sequence, so the grid stays one workgroup per tile.
@@ -131,6 +147,12 @@ template <typename F> static int resident_per_cu(F kern, size_t lds_bytes) {
     int nb = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)kern, kThreads, lds_bytes) != hipSuccess || nb < 1) nb = 1;
     return nb;
+}
+// first launch of a kernel instance on the current device: raise its dynamic-LDS limit, query its residency
+template <typename F> static int kernel_residency(int (&cache)[kMaxDevices], F kern, size_t lds_bytes) {
+    const int dev = launch_device();
+    if (!cache[dev]) { set_max_lds(kern, lds_bytes); cache[dev] = resident_per_cu(kern, lds_bytes); }
+    return cache[dev];
 }
 
 // =============================================================================================
@@ -406,6 +428,11 @@ __device__ __forceinline__ f32x4 load_mult(const float *m, int c0) {
 //     pixels = two aligned ds_read_b32; u8 -> fp16 is exact and takes 1 instruction per byte
 //     (v_perm_b32 builds 0x6400|b = 1024 + b, v_pk_add_f16 subtracts 1024);
 //   * weights are split hi + lo in fp16 (two more MFMAs) so conv0 keeps fp32-grade weights on raw 0..255 inputs.
+//   * everything BETWEEN the frame and the 16-channel output stays fp32-grade although it never leaves LDS: the conv0 tile is
+//     fp32, the depthwise taps are fp32, and the depthwise result feeds the pointwise MFMA as an fp16 hi + lo pair against
+//     hi / lo weights in the otherwise empty K slots (8 real channels of K = 32) -- one MFMA, no extra LDS.  On raw 0..255
+//     pixels these three tensors carry values up to ~1.5e3 whose fp16 rounding was 73 % of the box-error variance of the
+//     whole fp16 engine (tools/fp16_error_budget.py); with them wide the engine is inside north_star's 1e-3 IoU.
 //   Tile: 8 x 32 outputs of conv2 <- 10 x 34 conv0 pixels (halo recompute 1.33x) <- 21 x 69 input pixels.
 // =============================================================================================
 constexpr int ST_TH = 8, ST_TW = 32, ST_P = ST_TH * ST_TW;
@@ -422,7 +449,8 @@ struct StemArgs {
     const FrameDesc *frames; TO *out;
     const half_t *w0;                 // conv0 weights: 4 A fragments [hi k<32 | lo k<32 | hi k>=32 | lo k>=32][64 lanes][8]
     const float *b0;                  // [8]
-    const half_t *dw_w; const float *dw_b; const half_t *pw_w; const float *pw_b;
+    const float *dw_w; const float *dw_b;     // depthwise taps [9][8] fp32
+    const half_t *pw_w; const float *pw_b;    // pointwise 16 x 8 as ONE A fragment, K slots [hi | hi | lo | 0] (stem_pw_fragment, pack.h)
     const float *pw_m;                // nullptr, or (int8 output) per-channel multiplier 1 / out_scale; pw_b pre-divided
     int ho, wo, tiles_x, tiles_y, nblk;
 };
@@ -440,21 +468,29 @@ __device__ __forceinline__ void u8x4_to_f16(uint32_t v, f16x8 &dst, int at) {
     dst[at] = lo.h[0]; dst[at + 1] = lo.h[1]; dst[at + 2] = hi.h[0]; dst[at + 3] = hi.h[1];
 }
 
+// fp32 conv0 tile: pixel q = 8 floats (32 B); its two 16-byte halves are swapped on odd (q >> 3), so 16 consecutive pixels
+// read as ds_read_b128 touch every bank once (at a plain 32-byte stride lanes i and i + 8 of a 16-lane group collide)
+__device__ __forceinline__ int c0_half(int q, int half) { return half ^ ((q >> 3) & 1); }
+
 template <typename TO>
 __global__ __launch_bounds__(kThreads, 7) void stem_kernel(StemArgs<TO> a) {
     typedef half_t T;                                 // compute type of the stem; TO = storage type of its output
     typedef Mma<T> M;
-    constexpr int LDA = 16;
+    constexpr int LDA = 16;                           // depthwise result per pixel: 8 x fp16 hi | 8 x fp16 lo (32 B)
     constexpr int LDO = 16 + Vec<TO>::N;              // output tile row stride in TO elements (16 B of padding)
-    // LDS (20.6 KB -> 7 workgroups per CU): s_out reuses the staged patch + conv0 tile, both dead after phase 3
-    constexpr int IN_BYTES = ST_IR * ST_ROWD * 4, C0_BYTES = ST_PTILES * 16 * 8 * 2, OUT_BYTES = ST_P * LDO * (int)sizeof(TO);
-    constexpr int REGION_B = IN_BYTES + C0_BYTES > OUT_BYTES ? IN_BYTES + C0_BYTES : OUT_BYTES;
-    __shared__ __attribute__((aligned(16))) unsigned char s_raw[ST_P * LDA * 2 + 9 * 8 * 2 + REGION_B];
+    // LDS (20.8 KB -> 7 workgroups per CU).  Two regions, each reused once the barrier after its last reader has passed:
+    //   region A: staged BGRX patch (phases 1-2)  ->  depthwise result hi/lo (phases 3-4)
+    //   region B: fp32 conv0 tile   (phases 2-3)  ->  output tile (phase 4 - store)
+    constexpr int IN_BYTES = ST_IR * ST_ROWD * 4, A_BYTES = ST_P * LDA * 2;
+    constexpr int C0_BYTES = ST_PTILES * 16 * 8 * 4, OUT_BYTES = ST_P * LDO * (int)sizeof(TO);
+    constexpr int REGION_A = IN_BYTES > A_BYTES ? IN_BYTES : A_BYTES;
+    constexpr int REGION_B = C0_BYTES > OUT_BYTES ? C0_BYTES : OUT_BYTES;
+    __shared__ __attribute__((aligned(16))) unsigned char s_raw[REGION_A + REGION_B + 9 * 8 * 4];
+    uint32_t *s_in = (uint32_t *)s_raw;                                             // BGRX pixels
     T *s_a = (T *)s_raw;
-    T *s_dw = s_a + ST_P * LDA;
-    uint32_t *s_in = (uint32_t *)(s_raw + ST_P * LDA * 2 + 9 * 8 * 2);              // BGRX pixels
-    T *s_c0 = (T *)((unsigned char *)s_in + IN_BYTES);
-    TO *s_out = (TO *)s_in;
+    float *s_c0 = (float *)(s_raw + REGION_A);
+    TO *s_out = (TO *)(s_raw + REGION_A);
+    float *s_dw = (float *)(s_raw + REGION_A + REGION_B);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int bid = xcd_remap(blockIdx.x, a.nblk);
@@ -488,7 +524,9 @@ __global__ __launch_bounds__(kThreads, 7) void stem_kernel(StemArgs<TO> a) {
         const int bx0 = (2 * ox0 - 3) * 3;                            // input byte column of patch pixel 0
         const uintptr_t fp = (uintptr_t)fd.ptr;
         const int delta = (int)(fp & 3);
-        const unsigned fbytes = ((unsigned)delta + (unsigned)fd.rows * (unsigned)fd.step + 3u) & ~3u;
+        // the descriptor ends with the last row's last pixel, not with a whole `step` (an ROI of a larger image has
+        // step > cols*3, and nothing past its last pixel may be touched)
+        const unsigned fbytes = ((unsigned)delta + (unsigned)(fd.rows - 1) * (unsigned)fd.step + (unsigned)fd.cols * 3u + 3u) & ~3u;
         const auto rs = image_rsrc((const uint8_t *)(fp & ~(uintptr_t)3), fbytes);
         const int row_bytes = fd.cols * 3;
         for (int i = tid; i < ST_IR * ST_GRP; i += kThreads) {
@@ -520,7 +558,7 @@ __global__ __launch_bounds__(kThreads, 7) void stem_kernel(StemArgs<TO> a) {
             *(uint4 *)(s_in + r * ST_ROWD + g * 4) = o4;
         }
     }
-    if (tid < 9) *(f16x8 *)(s_dw + tid * 8) = *(const f16x8 *)(a.dw_w + tid * 8);
+    if (tid < 18) *(f32x4 *)(s_dw + tid * 4) = *(const f32x4 *)(a.dw_w + tid * 4);
     __syncthreads();
 
     // ---- phase 2: conv0 on the 10 x 34 halo'd region: D[cout 16 (8 real)][pixel 16] += W[16][64] x patch[64][16]
@@ -548,16 +586,16 @@ __global__ __launch_bounds__(kThreads, 7) void stem_kernel(StemArgs<TO> a) {
             // conv0 pixels outside its own map are the ZERO PADDING of the depthwise conv, not conv0(zero input)
             const int cy = oy0 - 1 + hy, cx = ox0 - 1 + hx;
             const bool inside = cy >= 0 && cy < a.ho && cx >= 0 && cx < a.wo;
-            typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
-            f16x4 h;
+            f32x4 h;
 #pragma unroll
-            for (int r = 0; r < 4; r++) h[r] = inside ? (half_t)fmaxf(acc[r] + b0[r], 0.f) : (half_t)0;
-            *(f16x4 *)(s_c0 + q * 8 + kb * 4) = h;
+            for (int r = 0; r < 4; r++) h[r] = inside ? fmaxf(acc[r] + b0[r], 0.f) : 0.f;
+            *(f32x4 *)(s_c0 + q * 8 + c0_half(q, kb) * 4) = h;
         }
     }
     __syncthreads();
 
-    // ---- phase 3: depthwise 3x3 (conv1), one output pixel x 8 channels per thread
+    // ---- phase 3: depthwise 3x3 (conv1), one output pixel x 8 channels per thread, fp32 in / fp32 taps / fp32 accumulate;
+    //      the result is stored as an fp16 hi + lo pair (hi = RN(v), lo = RN(v - hi): 22 significant bits)
     {
         const int py = tid / ST_TW, px = tid % ST_TW;
         float acc[8];
@@ -567,15 +605,22 @@ __global__ __launch_bounds__(kThreads, 7) void stem_kernel(StemArgs<TO> a) {
         for (int ky = 0; ky < 3; ky++)
 #pragma unroll
             for (int kx = 0; kx < 3; kx++) {
-                const f16x8 x = *(const f16x8 *)(s_c0 + ((py + ky) * ST_HC + px + kx) * 8);
-                const f16x8 wv = *(const f16x8 *)(s_dw + (ky * 3 + kx) * 8);
+                const int q = (py + ky) * ST_HC + px + kx;
+                const f32x4 x0 = *(const f32x4 *)(s_c0 + q * 8 + c0_half(q, 0) * 4);
+                const f32x4 x1 = *(const f32x4 *)(s_c0 + q * 8 + c0_half(q, 1) * 4);
+                const f32x4 w0 = *(const f32x4 *)(s_dw + (ky * 3 + kx) * 8), w1 = *(const f32x4 *)(s_dw + (ky * 3 + kx) * 8 + 4);
 #pragma unroll
-                for (int e = 0; e < 8; e++) acc[e] = fmaf((float)x[e], (float)wv[e], acc[e]);
+                for (int e = 0; e < 4; e++) { acc[e] = fmaf(x0[e], w0[e], acc[e]); acc[e + 4] = fmaf(x1[e], w1[e], acc[e + 4]); }
             }
-        f16x8 r;
+        f16x8 hi, lo;
 #pragma unroll
-        for (int e = 0; e < 8; e++) r[e] = (half_t)fmaxf(acc[e], 0.f);
-        *(f16x8 *)(s_a + tid * LDA) = r;
+        for (int e = 0; e < 8; e++) {
+            const float v = fmaxf(acc[e], 0.f);
+            hi[e] = (half_t)v;
+            lo[e] = (half_t)(v - (float)hi[e]);
+        }
+        *(f16x8 *)(s_a + tid * LDA) = hi;        // region A: the staged patch is dead since the barrier after phase 2
+        *(f16x8 *)(s_a + tid * LDA + 8) = lo;
     }
     __syncthreads();
 
@@ -583,8 +628,9 @@ __global__ __launch_bounds__(kThreads, 7) void stem_kernel(StemArgs<TO> a) {
     f32x4 acc[1][4];
 #pragma unroll
     for (int j = 0; j < 4; j++) acc[0][j] = vzero<f32x4, 4>();
+    // K slots of the one MFMA: [W_hi x_hi | W_hi x_lo | W_lo x_hi | 0]
     pipe.run(acc, [&](int j, int) -> M::Frag {
-        return kb == 0 ? *(const M::Frag *)(s_a + acc_pixel(wave + j * 4, lane) * LDA) : M::zero();
+        return kb < 3 ? *(const M::Frag *)(s_a + acc_pixel(wave + j * 4, lane) * LDA + (kb & 1) * 8) : M::zero();
     });
 #pragma unroll
     for (int j = 0; j < 4; j++) store_acc<TO, LDO>(s_out, pw_mult, pw_bias, acc[0][j], 0, wave + j * 4, lane, true);
@@ -987,8 +1033,8 @@ template <typename T, int CIN, int COUT, int STRIDE, bool HAS_DW, int TH, int TW
 static void dwpw_launch(hipStream_t s, const DwPwParams<T> *p, int tiles_x, int tiles_y) {
     typedef DwPwCfg<T, CIN, COUT, STRIDE, HAS_DW, TH, TW> C;
     auto kern = dwpw_kernel<T, CIN, COUT, STRIDE, HAS_DW, TH, TW, LAT>;
-    static int resident = 0;
-    if (!resident) { set_max_lds(kern, C::LDS_BYTES); resident = resident_per_cu(kern, C::LDS_BYTES); }
+    static int resident_cache[kMaxDevices] = {};
+    const int resident = kernel_residency(resident_cache, kern, C::LDS_BYTES);
     DwPwArgs<T> a{p->in, p->out, p->dw_w, p->dw_b, p->dw_mma, p->pw_w, p->pw_b, p->lat_w, p->lat_b, p->lat_out, p->pw_m, p->lat_m,
                   p->hin, p->win, p->hout, p->wout, tiles_x, tiles_y, p->n * tiles_x * tiles_y};
     const int grid = sizeof(T) <= 2 ? persistent_grid(a.nblk, resident) : a.nblk;
@@ -1004,7 +1050,7 @@ static TileInfo dwpw_dispatch(hipStream_t s, const DwPwParams<T> *p, int hout, i
     if (p->lat_out) {
         // laterals tap the outputs of blocks 4 (64ch), 10 (128ch) and 12 (256ch)
         if constexpr (HAS_DW && STRIDE == 1 && CIN == COUT && COUT >= 64) dwpw_launch<T, CIN, COUT, STRIDE, HAS_DW, TH, TW, true>(s, p, tiles_x, tiles_y);
-        else abort();
+        else throw LaunchUnsupported("fused lateral: only stride-1 blocks with cin == cout >= 64 have a kernel instance");
     } else {
         dwpw_launch<T, CIN, COUT, STRIDE, HAS_DW, TH, TW, false>(s, p, tiles_x, tiles_y);
     }
@@ -1035,7 +1081,7 @@ static TileInfo dwpw_select(hipStream_t s, const DwPwParams<T> *p, int cin, int 
 
 template <typename T> void launch_dwpw(hipStream_t s, const DwPwParams<T> &p) {
     TileInfo ti = dwpw_select<T>(s, &p, p.cin, p.cout, p.stride, p.has_dw, p.hout, p.wout);
-    if (ti.th == 0) abort();   // engine validates the layer table up front (plan.cpp), unreachable
+    if (ti.th == 0) throw LaunchUnsupported("no depthwise/pointwise kernel instance for this layer shape");
 }
 template <typename T> TileInfo dwpw_tile_info(int cin, int cout, int stride, bool has_dw, int hout, int wout) {
     return dwpw_select<T>(nullptr, nullptr, cin, cout, stride, has_dw, hout, wout);
@@ -1301,8 +1347,8 @@ template <typename T, int CIN, int COUT, int TH, int TW, bool UPADD>
 static void conv3_launch(hipStream_t s, Conv3Args<T> &a, int nlv, int total_tiles) {
     typedef Conv3Cfg<T, CIN, COUT, TH, TW> C;
     auto kern = conv3x3_kernel<T, CIN, COUT, TH, TW, UPADD>;
-    static int resident = 0;
-    if (!resident) { set_max_lds(kern, C::LDS_BYTES); resident = resident_per_cu(kern, C::LDS_BYTES); }
+    static int resident_cache[kMaxDevices] = {};
+    const int resident = kernel_residency(resident_cache, kern, C::LDS_BYTES);
     // grid: persistent size for the whole launch, shared out to the levels in proportion to their tiles
     const int want = sizeof(T) <= 2 ? persistent_grid(total_tiles, resident) : total_tiles;
     int grid = 0;
@@ -1335,7 +1381,7 @@ static TileInfo conv3_dispatch(hipStream_t s, const Conv3Params<T> *p, int nlv, 
     }
     if (p[0].up) {
         if constexpr (CIN == 64 && COUT == 64) conv3_launch<T, CIN, COUT, TH, TW, true>(s, a, nlv, total);
-        else abort();
+        else throw LaunchUnsupported("fused upsample + add: only the 64 -> 64 aggregation conv has a kernel instance");
     } else {
         conv3_launch<T, CIN, COUT, TH, TW, false>(s, a, nlv, total);
     }
@@ -1357,11 +1403,12 @@ static TileInfo conv3_select(hipStream_t s, const Conv3Params<T> *p, int nlv, in
 }
 
 template <typename T> void launch_conv3x3(hipStream_t s, const Conv3Params<T> *levels, int nlevels) {
-    if (nlevels < 1 || nlevels > 3) abort();
+    if (nlevels < 1 || nlevels > 3) throw LaunchUnsupported("conv3x3: 1..3 levels per launch");
     for (int l = 1; l < nlevels; l++)
-        if (levels[l].cin != levels[0].cin || levels[l].cout != levels[0].cout || levels[l].up) abort();
+        if (levels[l].cin != levels[0].cin || levels[l].cout != levels[0].cout || levels[l].up)
+            throw LaunchUnsupported("conv3x3: the levels of one launch must share (cin, cout) and have no fused upsample");
     TileInfo ti = conv3_select<T>(s, levels, nlevels, levels[0].cin, levels[0].cout, levels[0].h, levels[0].w_);
-    if (ti.th == 0) abort();
+    if (ti.th == 0) throw LaunchUnsupported("no 3x3 kernel instance for this (cin, cout)");
 }
 template <typename T> TileInfo conv3x3_tile_info(int cin, int cout, int h, int w) {
     return conv3_select<T>(nullptr, nullptr, 1, cin, cout, h, w);
@@ -1523,7 +1570,7 @@ __global__ __launch_bounds__(kThreads) void head_kernel(HeadArgs<T> a) {
 }
 
 template <typename T> void launch_head(hipStream_t s, const HeadParams<T> *levels, int nlevels) {
-    if (nlevels < 1 || nlevels > 3) abort();
+    if (nlevels < 1 || nlevels > 3) throw LaunchUnsupported("heads: 1..3 strides per launch");
     HeadArgs<T> a;
     int blk = 0;
     for (int l = 0; l < 3; l++) {
@@ -1675,8 +1722,9 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(NmsParams a) {
 
 void launch_nms(hipStream_t s, const NmsParams &p) {
     size_t lds = (size_t)p.cap * (8 + 16 + 4 + 1) + (size_t)p.max_det * 4 + 16;
-    static size_t attr_bytes = 0;
-    if (lds > attr_bytes) { set_max_lds(nms_kernel, lds); attr_bytes = lds; }
+    static size_t attr_bytes[kMaxDevices] = {};
+    const int dev = launch_device();
+    if (lds > attr_bytes[dev]) { set_max_lds(nms_kernel, lds); attr_bytes[dev] = lds; }
     hipLaunchKernelGGL(nms_kernel, dim3(p.n), dim3(NMS_THREADS), lds, s, p);
 }
 

@@ -346,7 +346,10 @@ struct In {
     const std::string &b;
     size_t p = 0;
     explicit In(const std::string &buf) : b(buf) {}
-    void need(size_t n) { if (p + n > b.size()) throw ModelError("rfw: truncated file"); }
+    void need(size_t n) { if (n > b.size() - p) throw ModelError("rfw: truncated file"); }      // p <= b.size() always
+    // element counts read from the file are bounded by the bytes that are left (each element takes >= `each` bytes), so a
+    // corrupt count cannot drive a huge resize()
+    uint32_t count(size_t each) { uint32_t n = u32(); if ((size_t)n > (b.size() - p) / each) throw ModelError("rfw: count exceeds file size"); return n; }
     uint32_t u32() { need(4); uint32_t v; memcpy(&v, b.data() + p, 4); p += 4; return v; }
     int32_t i32() { return (int32_t)u32(); }
     float f32() { need(4); float v; memcpy(&v, b.data() + p, 4); p += 4; return v; }
@@ -423,30 +426,39 @@ Model load_rfw(const std::string &path) {
     m.name = in.str();
     m.input_name = in.str();
     for (int i = 0; i < 4; i++) m.input_shape[i] = (int)in.u32();
-    uint32_t nl = in.u32();
+    uint32_t nl = in.count(16);
     m.layers.resize(nl);
     for (auto &l : m.layers) {
         l.name = in.str();
         l.type = in.str();
-        l.bottoms.resize(in.u32());
+        l.bottoms.resize(in.count(4));
         for (auto &s : l.bottoms) s = in.str();
-        l.tops.resize(in.u32());
+        l.tops.resize(in.count(4));
         for (auto &s : l.tops) s = in.str();
         l.num_output = in.i32(); l.kernel = in.i32(); l.stride = in.i32(); l.pad = in.i32();
         l.group = in.i32(); l.bias_term = in.i32(); l.axis = in.i32(); l.scale_bias = in.i32();
         l.reshape_axis = in.i32(); l.reshape_num_axes = in.i32();
         l.eps = in.f32();
         l.eltwise_op = in.str();
-        l.crop_offsets.resize(in.u32());
+        l.crop_offsets.resize(in.count(4));
         for (auto &v : l.crop_offsets) v = in.i32();
-        l.reshape_dims.resize(in.u32());
+        l.reshape_dims.resize(in.count(4));
         for (auto &v : l.reshape_dims) v = in.i32();
-        l.blobs.resize(in.u32());
+        l.blobs.resize(in.count(8));
         for (auto &blob : l.blobs) {
             uint32_t layout = in.u32();
-            blob.dims.resize(in.u32());
-            for (auto &d : blob.dims) d = (int)in.u32();
-            size_t cnt = blob.dims.empty() ? 1 : blob.count();
+            uint32_t nd = in.count(4);
+            if (nd > 8) throw ModelError("rfw: blob with more than 8 dims");
+            blob.dims.resize(nd);
+            // every dim positive and the product checked against the bytes left BEFORE anything is sized by it
+            size_t cnt = 1;
+            const size_t max_cnt = (buf.size() - in.p) / 4;
+            for (auto &d : blob.dims) {
+                const uint32_t v = in.u32();
+                if (v == 0 || v > (1u << 24) || cnt > max_cnt / v) throw ModelError("rfw: bad blob dims");
+                d = (int)v;
+                cnt *= v;
+            }
             in.need(cnt * 4);
             blob.data.resize(cnt);
             memcpy(blob.data.data(), buf.data() + in.p, cnt * 4);
@@ -465,7 +477,7 @@ Model load_rfw(const std::string &path) {
             }
         }
     }
-    uint32_t ns = in.u32();
+    uint32_t ns = in.count(8);
     for (uint32_t i = 0; i < ns; i++) {
         std::string k = in.str();
         float v = in.f32();

@@ -65,6 +65,18 @@ RF_HD inline uint32_t dw_mma_dword(int kc, int lane, const uint16_t *w9) {
 RF_HD inline int dw_mma_dword_index(int lane) { return ((lane & 15) & 7) >> 1; }
 constexpr int kDwMmaChunks = 5;
 
+// Stem pointwise (8 -> 16 channels) as ONE v_mfma_f32_16x16x32_f16 with fp32-grade operands: the depthwise result reaches the
+// MFMA as an fp16 pair x = x_hi + x_lo (B operand: K group 0 = x_hi, 1 = x_lo, 2 = x_hi, 3 = 0) and the weight as w = w_hi + w_lo
+// (A operand: K group 0 = w_hi, 1 = w_hi, 2 = w_lo, 3 = 0), so D = w_hi x_hi + w_hi x_lo + w_lo x_hi (the dropped w_lo x_lo term is
+// 2^-22 relative).  Element (lane, e) of the A fragment for weight matrix w[cout 16][cin 8]; hi / lo are passed in as the two
+// roundings the caller computed (hi = fp16(w), lo = fp16(w - hi)).
+RF_HD inline bool stem_pw_slot(int lane, int *row, int *use_lo) {
+    const int kgrp = lane >> 4;
+    *row = lane & 15;
+    *use_lo = kgrp == 2;
+    return kgrp < 3;
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // Persistent-kernel bookkeeping shared by the kernels and the host unit test (tests/csrc/test_pack.cpp)
 // ---------------------------------------------------------------------------------------------------------------------

@@ -40,7 +40,8 @@ class RetinaFace:
     def __init__(self, model: str, network: str = "net3", nms: float = 0.4, *, precision: int = PRECISION_FP16,
                  net_hw: Optional[tuple] = None, max_batch: int = 8, model_stem: Optional[str] = None,
                  max_candidates: int = 0, max_detections: int = 0, use_graph: bool = True,
-                 keep_outputs: bool = False, device: Optional[int] = None, lanes: int = 0, coalesce: int = 0):
+                 keep_outputs: bool = False, device: Optional[int] = None, lanes: int = 0, coalesce: int = 0,
+                 devices: Optional[Sequence[int]] = None, copy_threads: int = 0):
         self._lib = _lib.load_library()
         o = rf_options()
         o.struct_size = C.sizeof(rf_options)
@@ -55,6 +56,10 @@ class RetinaFace:
         o.keep_outputs = 1 if keep_outputs else 0
         o.lanes = lanes
         o.coalesce = coalesce
+        o.copy_threads = copy_threads
+        if devices:       # more than one entry: one engine per entry, detectBatchImages sharded by image over them
+            self._devices = (C.c_int32 * len(devices))(*devices)
+            o.devices, o.n_devices = self._devices, len(devices)
         self._stem = model_stem.encode() if model_stem else None
         o.model_stem = self._stem
         h = C.c_void_p()
@@ -151,6 +156,32 @@ class RetinaFace:
         t = C.c_int()
         _lib.check(self._lib.rf_enqueue_batch_device(self._h, p, r, c, s, n, float(threshold), C.byref(t)), self._h)
         return t.value
+
+    def enqueue_host(self, imgs: Sequence[np.ndarray], threshold: float = 0.5) -> int:
+        """rf_enqueue_batch: frames in host memory (numpy, OpenCV layout); they are staged before this returns."""
+        return self.enqueue_prepared_host(self.prepare_host_batch(imgs), threshold)
+
+    def prepare_host_batch(self, imgs: Sequence[np.ndarray]):
+        """C argument arrays of rf_enqueue_batch for host frames that are submitted repeatedly (what a C caller keeps)."""
+        n = len(imgs)
+        keep = [np.ascontiguousarray(im) if (im.strides[2] != 1 or im.strides[1] != 3) else im for im in imgs]
+        return ((C.c_void_p * n)(*[im.ctypes.data for im in keep]), (C.c_int * n)(*[im.shape[0] for im in keep]),
+                (C.c_int * n)(*[im.shape[1] for im in keep]), (C.c_int * n)(*[im.strides[0] for im in keep]), n, C.c_int(), keep)
+
+    def enqueue_prepared_host(self, batch, threshold: float = 0.5) -> int:
+        p, r, c, s, n, t, _keep = batch
+        _lib.check(self._lib.rf_enqueue_batch(self._h, p, r, c, s, n, threshold, C.byref(t)), self._h)
+        return t.value
+
+    def host_register(self, arr: np.ndarray) -> None:
+        """Pin a caller-owned buffer (rf_host_register): frames inside it are DMA'd in place, without the staging copy."""
+        _lib.check(self._lib.rf_host_register(self._h, arr.ctypes.data, arr.nbytes), self._h)
+
+    def host_unregister(self, arr: np.ndarray) -> None:
+        _lib.check(self._lib.rf_host_unregister(self._h, arr.ctypes.data), self._h)
+
+    def num_devices(self) -> int:
+        return self._lib.rf_num_devices(self._h)
 
     def prepare_device_batch(self, ptrs, rows, cols, steps=None):
         """Build the C argument arrays of rf_enqueue_batch_device once for a batch of device frames that is submitted

@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol(built_lib):
     assert set(names) == set(_lib.SYMBOLS), set(names) ^ set(_lib.SYMBOLS)
     for n in names:
         assert getattr(built_lib, n) is not None
-    assert built_lib.rf_abi_version() == 1
+    assert built_lib.rf_abi_version() == 2
     assert C.sizeof(_lib.rf_face) == 60          # FaceDetectInfo, RetinaFace.h:37-42
 
 
