@@ -13,6 +13,7 @@
 #include <thread>
 
 #include "engine.h"
+#include "pack.h"
 
 namespace rf {
 
@@ -92,9 +93,8 @@ public:
 
     // contiguous slices of ceil(n / G) images; trailing devices may get fewer or none (shard_range in retinaface_amd/shard.py)
     static void shard(int n, int G, std::vector<int> &lo) {
-        const int per = (n + G - 1) / G;
         lo.resize(G + 1);
-        for (int g = 0; g <= G; g++) lo[g] = std::min(g * per, n);
+        for (int g = 0; g <= G; g++) lo[g] = shard_begin(n, G, g);
     }
 
     void detect(const uint8_t *const *frames, const int *rows, const int *cols, const int *steps, int n, bool on_device,

@@ -112,6 +112,14 @@ RF_HD inline int persistent_grid_size(int tiles, int resident, float min_rounds)
     return (tiles + rounds - 1) / rounds;
 }
 
+// Image sharding of one detectBatchImages() call over G devices (multi.cpp; the same rule as retinaface_amd/shard.py
+// shard_range): contiguous slices of ceil(n / G) images, trailing devices may get fewer or none.  lo[g] .. lo[g + 1].
+RF_HD inline int shard_begin(int n, int G, int g) {
+    const int per = (n + G - 1) / G;
+    const long b = (long)g * per;
+    return b < n ? (int)b : n;
+}
+
 // Row stride (in elements) of an LDS tile whose rows are read as MFMA B fragments (16 lanes = 16 consecutive pixels, 16 B each,
 // 4 such groups one 16-byte column apart): measured on gfx950 (tools/probes/lds_b128.cpp) a ds_read_b128 of that pattern costs
 // one replay less when the row stride in bytes is 32 mod 64 (32, 96, 160, 288 ...) than at 16 / 48 mod 64 (48, 80, 144 ...),

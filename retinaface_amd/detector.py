@@ -212,6 +212,11 @@ class RetinaFace:
         self.truncated = st == _lib.RF_ERR_TRUNCATED
         return list(counts[:n])
 
+    def last_wait_faces(self) -> np.ndarray:
+        """The result block the most recent wait_counts() filled, as a (max_batch, max_detections, 15) float view (no copy)."""
+        return np.ctypeslib.as_array(C.cast(self._wc_buf[0], C.POINTER(C.c_float)),
+                                     shape=(self.max_batch, self.max_detections, 15))
+
     def num_slots(self) -> int:
         return self._lib.rf_num_slots(self._h)
 

@@ -4,12 +4,12 @@ size-independent properties (batch-composition invariance, determinism, graph ==
 
 Tolerances (stated once, used everywhere):
   fp32 engine : anchor indices identical, candidate counts identical, box IoU >= 1 - 1e-5, |score| <= 1e-5
-  fp16 engine : anchor indices identical, box IoU >= 1 - 2e-3, |score| <= 2e-3, landmarks within 0.15 px,
-                candidate count within +-4 of the oracle (threshold margin band: an fp16 logit can move a
-                borderline candidate across `conf <= thr`).  north_star's 1e-3 IoU bound is met by the fp32
-                engine everywhere and by the fp16 engine on faces >= ~80 px (measured 2e-4..7e-4); on the
-                smallest synthetic faces (~50 px boxes) fp16 storage of ~30 chained layers costs up to 1.3e-3,
-                i.e. ~0.02 px per edge -- stated here rather than hidden behind a looser global tolerance.
+  fp16 engine : anchor indices identical, box IoU >= 1 - 1e-3 (north_star's bound), |score| <= 2e-3, landmarks within
+                0.15 px, candidate count within +-4 of the oracle (threshold margin band: an fp16 logit can move a
+                borderline candidate across `conf <= thr`).  Round 1 needed 2e-3 on ~50 px faces; the per-tensor error
+                budget (tools/fp16_error_budget.py) showed 73 % of the box-error variance came from three tensors that
+                never leave the stem kernel's LDS (conv0 output, first depthwise output and its taps, on raw 0..255
+                pixels); they are fp32-grade now and the whole engine sits at <= ~7e-4.
   post-processing alone (decode + NMS given the GPU's own head blobs, vs the plain-C restatement):
                 anchor indices and scores bit-exact, coordinates within 1e-4 px (expf ulp)
 """
@@ -27,7 +27,7 @@ from oracle.retinaface_post import iou_plus1, preprocess_trt_identity
 pytestmark = pytest.mark.gpu
 
 FP32, FP16 = 0, 1
-TOL = {FP32: dict(iou=1e-5, score=1e-5, lm=2e-3, ncand=0), FP16: dict(iou=2e-3, score=2e-3, lm=0.15, ncand=4)}
+TOL = {FP32: dict(iou=1e-5, score=1e-5, lm=2e-3, ncand=0), FP16: dict(iou=1e-3, score=2e-3, lm=0.15, ncand=4)}
 
 
 @pytest.fixture(scope="module")
@@ -104,8 +104,6 @@ def test_reference_fixture_image_1280x896(rfa, base_frame, stem, prec):
     got = det.detect(base_frame, 0.5)
     assert len(got) == 6
     compare(got, g["det"], g["det_idx"], prec)
-    if prec == FP16:      # faces of 100+ px: the fp16 engine is inside north_star's 1e-3 IoU bound here
-        assert all(iou_plus1(d.rect, r[1:5]) >= 1 - 1e-3 for d, r in zip(got, g["det"]))
     assert abs(det.last_candidate_counts(1)[0] - len(g["cand_idx"])) <= TOL[prec]["ncand"]
     got9 = det.detect(base_frame, 0.9)                   # main.cpp:43 uses 0.9
     compare(got9, g["det09"], g["det09_idx"], prec)
@@ -361,6 +359,160 @@ def test_device_resident_and_async_entry_points(rfa):
     for k, o in enumerate(outs):
         n = 1 + k % 8
         assert [[d.anchor_index for d in r] for r in o] == [[d.anchor_index for d in r] for r in host[:n]]
+
+
+def _key(res):
+    return [[(d.anchor_index, d.as_row().tobytes()) for d in r] for r in res]
+
+
+def test_host_frames_async_pipeline_and_registered_buffers(rfa):
+    """rf_enqueue_batch (frames in host memory, staged through pinned memory by the copy threads, one DMA per enqueue) and the
+    rf_host_register path (DMA straight from the caller's pinned range): bit-identical to the synchronous host call, with more
+    tickets in flight than the pipeline holds, ragged batch sizes, strided views and an empty frame."""
+    from retinaface_amd.frames import synth_frames
+    det = engine(rfa, "mnet25", FP16, (448, 448))
+    frames = synth_frames(448, 448, 8, config=11)
+    want = det.detectBatchImages(frames, 0.5)
+    wide = np.zeros((448, 500, 3), np.uint8)
+    wide[:, :448] = frames[1]
+    cases = [frames, frames[:3], [frames[0], wide[:, :448], None, frames[3]]]
+    exp = [_key(want), _key(want[:3]), [_key(want)[0], _key(want)[1], [], _key(want)[3]]]
+    tickets, outs = [], []
+    for k in range(3 * det.num_slots() + 2):
+        if len(tickets) == det.num_slots():
+            t, c = tickets.pop(0)
+            outs.append((c, det.wait(t, len(cases[c]))))
+        c = k % 3
+        imgs = [f if f is not None else np.zeros((0, 0, 3), np.uint8) for f in cases[c]]
+        tickets.append((det.enqueue_host(imgs, 0.5), c))
+    while tickets:
+        t, c = tickets.pop(0)
+        outs.append((c, det.wait(t, len(cases[c]))))
+    assert len(outs) == 3 * det.num_slots() + 2
+    for c, o in outs:
+        assert _key(o) == exp[c], c
+    # caller memory pinned once: frames inside the range are read in place
+    ring = np.stack(frames).copy()
+    det.host_register(ring)
+    try:
+        t = [det.enqueue_host([ring[i] for i in range(8)], 0.5) for _ in range(5)]
+        for x in t:
+            assert _key(det.wait(x, 8)) == _key(want)
+        assert _key(det.detectBatchImages([ring[i] for i in range(8)], 0.5)) == _key(want)
+    finally:
+        det.host_unregister(ring)
+    with pytest.raises(rfa._lib.RFError):
+        det.host_unregister(ring)                       # not registered any more
+    # a frame far larger than the staging block of this engine: staging grows to what ONE enqueue needs
+    small = engine(rfa, "mnet25", FP16, (448, 448), max_batch=1, lanes=1, coalesce=1)
+    big = np.zeros((1792, 1792, 3), np.uint8)
+    big[:448, :448] = frames[0]
+    assert len(small.detect(big, 0.5)) >= 0 and not small.truncated
+
+
+def test_multi_device_handle_shards_by_image(rfa):
+    """rf_options.devices: one engine + host thread per entry, detectBatchImages split into contiguous ceil(n / G) slices
+    (RetinaFace.cpp:749-940 is the call being sharded; per-image NMS :916-918 is why it shards).  The one-GPU box runs the
+    sharding logic as two and three engines on device 0: results, anchor indices and candidate counts must equal the
+    single-engine handle for every n, including n < G and slices that are chunked again inside an engine."""
+    import torch
+    from retinaface_amd.frames import synth_frames
+    one = engine(rfa, "mnet25", FP16, (448, 448))
+    frames = synth_frames(448, 448, 21, config=13)
+    for devs in ([0, 0], [0, 0, 0]):
+        multi = rfa.RetinaFace(ASSETS, "net3", 0.4, precision=FP16, net_hw=(448, 448), model_stem="mnet25", devices=devs)
+        assert multi.num_devices() == len(devs) and multi.num_slots() == len(devs) * one.num_slots()
+        for n in (1, 2, 5, 8, 21):
+            a = multi.detectBatchImages(frames[:n], 0.5)
+            ca = multi.last_candidate_counts(n)
+            b = one.detectBatchImages(frames[:n], 0.5)
+            assert _key(a) == _key(b), (devs, n)
+            assert ca == one.last_candidate_counts(n)
+        assert multi.detectBatchImages([], 0.5) == []
+        # device-resident frames and the asynchronous API (whole enqueues go round-robin over the engines)
+        d = torch.from_numpy(np.stack(frames[:8])).cuda()
+        ptrs = [d[i].data_ptr() for i in range(8)]
+        want = _key(one.detect_device(ptrs, [448] * 8, [448] * 8, 0.5))
+        assert _key(multi.detect_device(ptrs, [448] * 8, [448] * 8, 0.5)) == want
+        t = [multi.enqueue_device(ptrs, [448] * 8, [448] * 8, 0.5) for _ in range(7)]
+        for x in t:
+            assert _key(multi.wait(x, 8)) == want
+        t = [multi.enqueue_host(frames[:8], 0.5) for _ in range(4)]
+        for x in t:
+            assert _key(multi.wait(x, 8)) == want
+        # an error in one slice surfaces as the call's error and leaves the handle usable
+        with pytest.raises(rfa._lib.RFError):
+            multi.detectBatchImages(frames[:5] + [np.zeros((4000, 4000, 3), np.uint8)], 0.5)
+        assert _key(multi.detectBatchImages(frames[:5], 0.5)) == _key(one.detectBatchImages(frames[:5], 0.5))
+        multi.close()
+    with pytest.raises(rfa._lib.RFError):
+        rfa.RetinaFace(ASSETS, "net3", 0.4, precision=FP16, net_hw=(448, 448), model_stem="mnet25", devices=[0, 99])
+
+
+def test_device_frames_unaligned_pointer_odd_step_and_roi(rfa, oracles, base_frame):
+    """Device-resident frames exactly as the stem's descriptor path sees them: a frame pointer that is not dword aligned, a row
+    step that is not a multiple of 4, and an ROI of a larger device image (step > cols*3, last row ends before the allocation
+    does).  Host frames never exercise this: they are repacked into aligned staging memory."""
+    import torch
+    hw = (352, 608)
+    od = oracles["mnet-deconv-0517"]
+    for prec in (FP16, FP32):
+        det = engine(rfa, "mnet-deconv-0517", prec, hw)
+        full = np.ascontiguousarray(base_frame[100:100 + hw[0], 400:400 + hw[1]])
+        ref = od.detect(full, 0.5, 0.4, net_hw=hw)
+        assert len(ref.detections) >= 2
+        # (a) odd base address + odd step: the frame starts 1 byte into a buffer whose rows are cols*3 + 7 bytes apart
+        step = hw[1] * 3 + 7
+        back = torch.zeros(hw[0] * step + 64, dtype=torch.uint8, device="cuda")
+        host = np.zeros((hw[0], step), np.uint8)
+        host[:, :hw[1] * 3] = full.reshape(hw[0], -1)
+        back[1:1 + hw[0] * step] = torch.from_numpy(host.reshape(-1)).cuda()
+        ptr = back.data_ptr() + 1
+        assert ptr % 4 == 1 and step % 4 != 0
+        compare(det.detect_device([ptr], [hw[0]], [hw[1]], 0.5, steps=[step])[0], ref.rows(), ref.anchor_indices(), prec)
+        # (b) ROI of a larger device image, placed so that the ROI's last row is the image's last row and ends well before the
+        # end of that row: a descriptor sized rows*step would reach past the allocation's end
+        big = np.zeros((hw[0] + 40, hw[1] + 100, 3), np.uint8)
+        big[40:, 30:30 + hw[1]] = full
+        dbig = torch.from_numpy(big).cuda()
+        roi_ptr = dbig.data_ptr() + (40 * big.shape[1] + 30) * 3
+        compare(det.detect_device([roi_ptr], [hw[0]], [hw[1]], 0.5, steps=[big.shape[1] * 3])[0], ref.rows(), ref.anchor_indices(), prec)
+        torch.cuda.synchronize()
+
+
+def test_error_paths_leave_the_handle_usable(rfa):
+    """A bad frame in a LATER chunk of a synchronous call (the earlier chunks are already in flight), repeated more often than the
+    ticket pool is deep; rf_wait with a NULL result array; enqueue of more than max_batch images."""
+    import ctypes as C
+    from retinaface_amd.frames import synth_frames
+    det = rfa.RetinaFace(ASSETS, "net3", 0.4, precision=FP16, net_hw=(448, 448), model_stem="mnet25")
+    frames = synth_frames(448, 448, 20, config=17)
+    good = _key(det.detectBatchImages(frames, 0.5))
+    lib = det._lib
+    n = 20
+    ptrs = (C.c_void_p * n)(*[f.ctypes.data for f in frames])
+    rows, cols = (C.c_int * n)(*[448] * n), (C.c_int * n)(*[448] * n)
+    steps = (C.c_int * n)(*([448 * 3] * 19 + [100]))                # last frame (third chunk): step < cols*3
+    out = (rfa._lib.rf_face * (n * 256))()
+    counts = (C.c_int * n)()
+    for _ in range(4 * det.num_slots()):
+        assert lib.rf_detect_batch(det._h, ptrs, rows, cols, steps, n, 0.5, out, 256, counts) == rfa._lib.RF_ERR_INVALID_ARG
+    assert _key(det.detectBatchImages(frames, 0.5)) == good
+    import torch
+    d = torch.from_numpy(np.stack(frames[:8])).cuda()
+    t = det.enqueue_device([d[i].data_ptr() for i in range(8)], [448] * 8, [448] * 8, 0.5)
+    assert lib.rf_wait(det._h, t, None, 256, counts) == rfa._lib.RF_ERR_INVALID_ARG        # NULL out with cap > 0
+    assert lib.rf_wait(det._h, t, out, 256, counts) == 0 and list(counts[:8]) == [len(r) for r in good[:8]]
+    with pytest.raises(rfa._lib.RFError):
+        det.enqueue_device([d[0].data_ptr()] * 9, [448] * 9, [448] * 9, 0.5)
+    # calls from another host thread bind the engine's device themselves
+    import threading
+    res = {}
+    th = threading.Thread(target=lambda: res.update(r=_key(det.detectBatchImages(frames, 0.5))))
+    th.start()
+    th.join()
+    assert res["r"] == good
+    det.close()
 
 
 @pytest.mark.parametrize("prec", [FP32, FP16])

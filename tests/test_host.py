@@ -180,6 +180,86 @@ def test_pack_index_math_host_emulation(tmp_path):
     assert out.returncode == 0 and "ok" in out.stdout, out.stdout
 
 
+def test_staging_copier_and_shard_rule_host_unit(tmp_path):
+    exe = str(tmp_path / "test_copier")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-pthread", "-o", exe, os.path.join(ROOT, "tests", "csrc", "test_copier.cpp")])
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0 and "ok" in out.stdout, out.stdout
+
+
+def test_bench_self_launches_n_ranks_and_gathers_results():
+    """`bench.py --gpus 2` with no launcher around it must start 2 ranks itself (round 1 ignored N), run the sharded loop with
+    the result all_gather inside the timed region and report n_gpus == 2.  --dry swaps the HIP engine for a stub and RCCL for
+    gloo; everything else (self-launch, rendezvous on 127.0.0.1, step agreement, gather, MAX over ranks, JSON) is the real path."""
+    import json
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry", "--steps", "100", "--warmup", "10"],
+                         capture_output=True, text=True, env=env, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["steps"] >= 100 and j["scaling"] == "weak" and j["metric"] == "faces/sec"
+    g = j["result_gather"]
+    assert g["records_gathered"] == g["expected"] == 2 * 8 * j["steps"] and g["gathers_in_timed_region"] >= 1
+    # under an external launcher the rank count must agree with --gpus
+    env2 = dict(env, WORLD_SIZE="3", RANK="0", LOCAL_RANK="0")
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry"], capture_output=True, text=True,
+                         env=env2, timeout=120)
+    assert bad.returncode != 0 and "WORLD_SIZE=3" in (bad.stderr + bad.stdout)
+
+
+def test_rfw_reader_rejects_corrupt_files(built_lib, tmp_path):
+    """Dims / counts inside a .rfw are checked against the bytes that are left before anything is sized by them."""
+    import struct
+    good = open(os.path.join(ASSETS, "mnet25.rfw"), "rb").read()
+    h = C.c_void_p()
+
+    def create(blob):
+        d = tmp_path / f"m{len(os.listdir(tmp_path))}"
+        d.mkdir()
+        (d / "mnet25.rfw").write_bytes(blob)
+        o = _lib.rf_options()
+        o.struct_size = C.sizeof(_lib.rf_options)
+        o.model_stem = b"mnet25"
+        return built_lib.rf_create(str(d).encode(), b"net3", 0.4, C.byref(o), C.byref(h))
+
+    assert create(good[:len(good) // 2]) == _lib.RF_ERR_MODEL                 # truncated
+    pos = good.index(struct.pack("<IIII", 8, 3, 3, 3))                        # conv0 weight dims (O, I, kh, kw)
+    for dims in ((65536, 65536, 65536, 65536), (0, 3, 3, 3), (8, 3, 3, 1 << 30)):
+        assert create(good[:pos] + struct.pack("<IIII", *dims) + good[pos + 16:]) == _lib.RF_ERR_MODEL, dims
+    nl_pos = 4 + 4 + 4 + len(b"") + 0                                         # layer count follows name / input name / shape
+    huge = bytearray(good)
+    # the layer count is the first u32 after the header strings and the 4 input dims: find it by parsing
+    p = 8
+    for _ in range(2):
+        (n,) = struct.unpack_from("<I", good, p)
+        p += 4 + n
+    p += 16
+    struct.pack_into("<I", huge, p, 0x7fffffff)
+    assert create(bytes(huge)) == _lib.RF_ERR_MODEL
+    # without a GPU a well-formed file still gets as far as "no HIP device"
+    assert create(good) in (_lib.RF_ERR_HIP, 0)
+    if h.value:
+        built_lib.rf_destroy(h)
+
+
+def test_options_struct_of_abi_1_is_still_accepted(built_lib):
+    """A caller compiled against ABI 1 passes rf_options up to `coalesce`; the later fields default."""
+    o = _lib.rf_options()
+    o.struct_size = _lib.rf_options.copy_threads.offset
+    o.model_stem = b"mnet25"
+    h = C.c_void_p()
+    st = built_lib.rf_create(ASSETS.encode(), b"net3", 0.4, C.byref(o), C.byref(h))
+    assert st in (0, _lib.RF_ERR_HIP), built_lib.rf_last_error(None)           # parsed; fails only for want of a GPU
+    if h.value:
+        built_lib.rf_destroy(h)
+    o.struct_size = 12
+    assert built_lib.rf_create(ASSETS.encode(), b"net3", 0.4, C.byref(o), C.byref(h)) == _lib.RF_ERR_INVALID_ARG
+
+
 def test_synthetic_frames_are_seeded_and_net_sized():
     from retinaface_amd.frames import FACE_BOXES, load_base_frame, synth_frames
     base = load_base_frame()
