@@ -73,7 +73,7 @@ typedef struct rf_options {
                                    images (default 16, max 32; 1 = off).  A merged launch starts when it is full or when one of
                                    its tickets is waited for.  rf_num_slots() = lanes * coalesce. */
     /* ---- fields added in ABI 2 (a caller compiled against ABI 1 passes the shorter struct_size and gets the defaults) ---- */
-    int32_t copy_threads;       /* host threads (the caller's included) that stage host frames into pinned memory; 0 = min(8, cores/4) */
+    int32_t copy_threads;       /* host threads (the caller's included) that stage host frames into pinned memory; 0 = min(12, cores/4) */
     int32_t n_devices;          /* > 1: one engine per entry of devices[], every rf_detect_batch* call is sharded by image over them */
     const int32_t *devices;     /* HIP device ordinals (0-based; an ordinal may repeat); NULL / n_devices <= 1: `device` above */
 } rf_options;

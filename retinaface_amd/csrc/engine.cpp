@@ -136,7 +136,7 @@ public:
         lanes_.resize(opt_.lanes);
         for (auto &l : lanes_) build_lane(l, plan);
         const int hw = (int)std::thread::hardware_concurrency();
-        const int helpers = opt_.copy_threads > 0 ? opt_.copy_threads - 1 : std::max(0, std::min(8, hw / 4) - 1);
+        const int helpers = opt_.copy_threads > 0 ? opt_.copy_threads - 1 : std::max(0, std::min(12, hw / 4) - 1);
         copier_.reset(new ParallelCopier(helpers));
     }
 
@@ -550,6 +550,21 @@ private:
             first_block = 1;
             dw_w_.push_back(DwW{0, 0});
             pw_w_.push_back(GemmW{0, 0});
+            if constexpr (std::is_same<T, half_t>::value) {
+                if (stem2_variant()) {
+                    // stem2 also runs the first stride-2 block: conv3 taps [9][16] fp32, conv4 as a standard packed 32 x 16 GEMM
+                    const auto &b1 = plan.blocks[1];
+                    std::vector<float> dw1((size_t)9 * 16);
+                    for (int ch = 0; ch < 16; ch++)
+                        for (int t = 0; t < 9; t++) dw1[(size_t)t * 16 + ch] = b1.dw.w[(size_t)ch * 9 + t];
+                    stem2_dw_ = DwW{arena_.put(dw1), arena_.put(b1.dw.b)};
+                    stem2_pw_.w = arena_.put(pack_gemm<half_t>(b1.pw.w, b1.pw.cout, 16, 32, 8));
+                    stem2_pw_.b = arena_.put(b1.pw.b);
+                    first_block = 2;
+                    dw_w_.push_back(DwW{0, 0});
+                    pw_w_.push_back(GemmW{0, 0});
+                }
+            }
         }
         float s_prev = 1.f;
         if constexpr (kInt8) s_prev = scale_of(plan, plan.blocks[0].pw.out_blob);
@@ -645,7 +660,37 @@ private:
         T *cur = nullptr;
         size_t first_block = 0;
         int c = 8;
-        if constexpr (sizeof(T) <= 2) {
+        bool fused2 = false;
+        if constexpr (std::is_same<T, half_t>::value) fused2 = stem2_variant() != 0;
+        if (fused2) {
+            if constexpr (std::is_same<T, half_t>::value) {
+                // fp16 engine: preprocess + conv0 + blocks 0 and 1 (conv1..conv4) are ONE launch (stem2_kernel): the 224^2 x 16 map of
+                // the net never exists in HBM
+                const auto &b0 = plan.blocks[0], &b1 = plan.blocks[1];
+                const int h4 = H / 4, w4 = W / 4;
+                T *out = act(b1.pw.out_blob, h4, w4, b1.pw.cout);
+                Stem2Params sp;
+                sp.frames = L.d_frames + mb; sp.out = out;
+                sp.w0 = arena_.ptr<half_t>(c0_hi_); sp.b0 = arena_.ptr<float>(c0_b_);
+                sp.dw0_w = arena_.ptr<float>(stem_dw_.w); sp.dw0_b = arena_.ptr<float>(stem_dw_.b);
+                sp.pw0_w = arena_.ptr<half_t>(stem_pw_.w); sp.pw0_b = arena_.ptr<float>(stem_pw_.b);
+                sp.dw1_w = arena_.ptr<float>(stem2_dw_.w); sp.dw1_b = arena_.ptr<float>(stem2_dw_.b);
+                sp.pw1_w = arena_.ptr<half_t>(stem2_pw_.w); sp.pw1_b = arena_.ptr<float>(stem2_pw_.b);
+                sp.n = 0; sp.net_h = H; sp.net_w = W;
+                OpInfo op;
+                op.name = "pre+" + plan.conv0.name + "+" + b0.dw.name + "+" + b0.pw.name + "+" + b1.dw.name + "+" + b1.pw.name;
+                op.kernel = "stem2";
+                op.alg_u8_in = 3.0 * P;
+                // layer-wise accounting: every covered layer's input + output elements, fused or not
+                op.alg_elems_in = 8.0 * h * w + 8.0 * h * w + 16.0 * h * w + 16.0 * h4 * w4;                       // conv1, conv2, conv3, conv4 inputs
+                op.alg_elems_out = 8.0 * h * w + 8.0 * h * w + 16.0 * h * w + 16.0 * h4 * w4 + 32.0 * h4 * w4;     // conv0 .. conv4 outputs
+                op.macs = (plan.conv0.macs_per_out_pixel() + b0.dw.macs_per_out_pixel() + b0.pw.macs_per_out_pixel()) * h * w +
+                          (b1.dw.macs_per_out_pixel() + b1.pw.macs_per_out_pixel()) * h4 * w4;
+                op.launch = [sp](hipStream_t s, int n) { Stem2Params q = sp; q.n = n; launch_stem2(s, q); };
+                L.ops.push_back(op);
+                cur = out; c = b1.pw.cout; first_block = 2; h = h4; w = w4;
+            }
+        } else if constexpr (sizeof(T) <= 2) {
             // fp16 / int8 engines: preprocess + conv0 + the first depthwise/pointwise block are ONE launch (stem_kernel);
             // it computes in fp16 and stores its 16-channel output in the engine's storage type
             const auto &blk = plan.blocks[0];
@@ -1025,11 +1070,23 @@ private:
             if (stage_need) {
                 uint8_t *hbase = s.h_stage + s.stage_used, *dbase = s.d_stage + s.stage_used;
                 if (all_registered) {
-                    // caller buffers pinned with rf_host_register: the DMA engine reads them in place
-                    for (int i = 0; i < n; i++)
-                        if (!empty[i])
+                    // caller buffers pinned with rf_host_register: the DMA engine reads them in place.  Frames with dense rows
+                    // that follow each other in memory (a ring of camera buffers) and in the staging block go as ONE copy.
+                    for (int i = 0; i < n; i++) {
+                        if (empty[i]) continue;
+                        const size_t fb = (size_t)rows[i] * cols[i] * 3;
+                        if (steps[i] != cols[i] * 3) {
                             RF_HIP(hipMemcpy2DAsync(dbase + off[i], (size_t)cols[i] * 3, frames[i], (size_t)steps[i], (size_t)cols[i] * 3,
                                                     (size_t)rows[i], hipMemcpyHostToDevice, s.stream));
+                            continue;
+                        }
+                        size_t run = fb;
+                        int j = i + 1;
+                        while (j < n && !empty[j] && steps[j] == cols[j] * 3 && frames[j] == frames[i] + run && off[j] == off[i] + run)
+                            run += (size_t)rows[j] * cols[j] * 3, j++;
+                        RF_HIP(hipMemcpyAsync(dbase + off[i], frames[i], run, hipMemcpyHostToDevice, s.stream));
+                        i = j - 1;
+                    }
                 } else {
                     copy_jobs_.clear();
                     for (int i = 0; i < n; i++)
@@ -1089,8 +1146,8 @@ private:
     std::vector<hipEvent_t> prof_ev_;
     Arena arena_;
     size_t c0_w_ = 0, c0_b_ = 0, c0_hi_ = 0;
-    DwW stem_dw_{0, 0};
-    GemmW stem_pw_{0, 0};
+    DwW stem_dw_{0, 0}, stem2_dw_{0, 0};
+    GemmW stem_pw_{0, 0}, stem2_pw_{0, 0};
     float aggr_a_lat_[2] = {1.f, 1.f}, aggr_a_up_[2] = {1.f, 1.f};
     std::map<std::string, float> act_scale_;    // int8: blob -> scale (debug accessors dequantise)
     std::vector<DwW> dw_w_;

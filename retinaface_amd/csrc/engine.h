@@ -34,7 +34,7 @@ struct EngineOptions {
                                      // persistent and pipeline tile t+1's loads under tile t's compute, which pays off once
                                      // a launch holds several tiles per resident workgroup (measured: 4 -> 16 = +8 %)
     bool keep_outputs = false;
-    int copy_threads = 0;            // threads (caller's included) that stage host frames into pinned memory; 0 = min(8, cores / 4)
+    int copy_threads = 0;            // threads (caller's included) that stage host frames into pinned memory; 0 = min(12, cores / 4)
     std::vector<int> devices;        // more than one entry: one engine per device, batches sharded by image (multi.cpp)
     std::string model_stem = "mnet-deconv-0517";
 };

@@ -63,6 +63,18 @@ struct StemParams {
 };
 template <typename TO> void launch_stem(hipStream_t s, const StemParams<TO> &p);
 
+// ---- K_a'' (fp16 engine): K_a' fused with the first stride-2 block (conv3 depthwise + conv4 pointwise): net / 4 map, 32 channels.
+struct Stem2Params {
+    const FrameDesc *frames; half_t *out;          // out: [n][net_h/4][net_w/4][32]
+    const half_t *w0; const float *b0;
+    const float *dw0_w; const float *dw0_b; const half_t *pw0_w; const float *pw0_b;
+    const float *dw1_w; const float *dw1_b;        // conv3: taps [9][16] fp32, bias [16]
+    const half_t *pw1_w; const float *pw1_b;       // conv4: 32 x 16, MFMA-fragment packed (K padded to 32), bias [32]
+    int n, net_h, net_w;
+};
+void launch_stem2(hipStream_t s, const Stem2Params &p);
+int stem2_variant();      // 0 = off (K_a' + a separate dwpw<16,32,s2> launch), 1 = 7x8 tiles, 2 = 7x16 (probe knob RF_STEM2)
+
 // ---- K_b: depthwise 3x3 (+BN+ReLU) -> pointwise 1x1 (+BN+ReLU), the intermediate never leaves LDS.
 //      has_dw = false gives a plain 1x1 conv (+bias, +ReLU): the FPN laterals.
 template <typename T>

@@ -83,7 +83,7 @@ constexpr int kThreads = 256;   // 4 wavefronts
 // boundaries of the launch whose tile count equals g_trace_key (tile counts identify a launch; grids are derived)
 constexpr int kTraceSlots = 12, kTraceBlocks = 8192;
 __device__ unsigned long long g_trace[kTraceBlocks * kTraceSlots];
-__device__ int g_trace_kernel = 0;        // 2 = dwpw, 3 = conv3x3
+__device__ int g_trace_kernel = 0;        // 2 = dwpw, 3 = conv3x3, 4 = stem2
 __device__ unsigned g_trace_key = 0;      // 0 = any launch of that kernel family
 #define RF_TRACE_KEY(expr) const unsigned rf_trace_key = (unsigned)(expr)
 #define RF_TRACE(kid, slot)                                                                                  \
@@ -390,7 +390,8 @@ __device__ __forceinline__ void store_acc(T *s_out, f32x4 mult, f32x4 bv, ACC ac
     float v[4];
 #pragma unroll
     for (int r = 0; r < 4; r++) {
-        v[r] = fmaf((float)acc[r], mult[r], bv[r]);
+        if constexpr (sizeof(T) == 1) v[r] = fmaf((float)acc[r], mult[r], bv[r]);
+        else v[r] = (float)acc[r] + bv[r];           // mult == 1 for fp16 / fp32: fma(a, 1, b) == a + b exactly
         if (relu) v[r] = fmaxf(v[r], 0.f);
     }
     if constexpr (sizeof(T) == 2) {
@@ -662,6 +663,306 @@ template void launch_stem<half_t>(hipStream_t, const StemParams<half_t> &);
 template void launch_stem<int8_t>(hipStream_t, const StemParams<int8_t> &);
 
 // =============================================================================================
+// K_a'' stem2 (fp16 engine): K_a' + the first stride-2 block (conv3 depthwise s2 + conv4 pointwise 16 -> 32) in ONE launch.
+//   The 224^2 x 16 map between them was the largest tensor of the net (1.6 MB per 448^2 image, written once and read once:
+//   414 MB of the ~1.96 GB a 128-image launch moved through HBM) and its consumer dwpw<16,32,s2> ran at the measured HBM copy
+//   rate -- the only way to make that faster is not to move the bytes.  Here the map lives in LDS only.
+//   Tile = 7 x TW outputs of conv4 (112^2 map)  <-  (15 x (2TW+1)) conv2 pixels  <-  (17 x (2TW+3)) conv0 pixels
+//        <-  (35 x (4TW+7)) input pixels.  TW = 8: 255 conv2 pixels = one pass of the 256 threads, 20 KB of LDS.
+//   Phases (one barrier between each):  1 stage BGRX patch | 2 conv0 on MFMA -> fp32 tile | 3 depthwise conv1 (fp32, hi/lo
+//   out) | 4 pointwise conv2 on MFMA -> fp16 tile (zero outside the map: it is conv3's padding) | 5 depthwise conv3 stride 2
+//   | 6 pointwise conv4 on MFMA | 7 coalesced NHWC store.  Numerics of phases 1-4 are exactly K_a' (same rounding points).
+// =============================================================================================
+template <int TW_> struct Stem2Cfg {
+    static constexpr int TH = 7, TW = TW_, P4 = TH * TW;                // conv4 output tile
+    static constexpr int R2H = 2 * TH + 1, R2W = 2 * TW + 1, N2 = R2H * R2W;     // conv2 pixels the tile needs
+    static constexpr int R0H = R2H + 2, R0W = R2W + 2, N0 = R0H * R0W;           // conv0 / conv1-input pixels
+    static constexpr int T0 = (N0 + 15) / 16, T2 = (N2 + 15) / 16, T4 = (P4 + 15) / 16;   // MFMA pixel tiles of conv0 / conv2 / conv4
+    static constexpr int IR = 2 * R0H + 1, IPX = 2 * R0W + 1;                    // input rows / pixels per row
+    static constexpr int GRP = (IPX + 3) / 4, ROWD = GRP * 4;                    // staging groups of 4 pixels, dwords per staged row
+    static constexpr int LDA1 = 24, LDO = 40;                                    // conv3 result / output tile row pitch (fp16 elements)
+    static constexpr int IN_BYTES = IR * ROWD * 4, A_BYTES = T2 * 16 * 32;       // region A: patch -> conv1 result (hi|lo, 32 B / pixel)
+    static constexpr int A1_BYTES = T4 * 16 * LDA1 * 2, OUT_BYTES = T4 * 16 * LDO * 2;   //           -> conv3 result + output tile
+    static constexpr int C0_BYTES = T0 * 16 * 32, C2_BYTES = T2 * 16 * 32;       // region B: fp32 conv0 tile -> fp16 conv2 tile
+    static constexpr int MAX3(int a, int b, int c) { return a > b ? (a > c ? a : c) : (b > c ? b : c); }
+    static constexpr int REGION_A = MAX3(IN_BYTES, A_BYTES, A1_BYTES + OUT_BYTES);
+    static constexpr int REGION_B = C0_BYTES > C2_BYTES ? C0_BYTES : C2_BYTES;
+    static constexpr int LDS_BYTES = REGION_A + REGION_B + 9 * 8 * 4 + 9 * 16 * 4;
+    static constexpr int OCC = LDS_BYTES <= 23 * 1024 ? 7 : (160 * 1024 / LDS_BYTES);
+    static_assert(REGION_A % 16 == 0 && REGION_B % 16 == 0 && A1_BYTES % 16 == 0, "LDS carve must stay 16-byte aligned");
+};
+
+struct Stem2Args {
+    const FrameDesc *frames; half_t *out;           // out: [n][ho4][wo4][32]
+    const half_t *w0; const float *b0;              // conv0 (as StemArgs)
+    const float *dw0_w; const float *dw0_b; const half_t *pw0_w; const float *pw0_b;     // conv1 / conv2 (as StemArgs)
+    const float *dw1_w; const float *dw1_b;         // conv3 taps [9][16] fp32, bias [16]
+    const half_t *pw1_w; const float *pw1_b;        // conv4: 32 x 16 packed (K padded to 32), bias [32]
+    int ho, wo, ho4, wo4, tiles_x, tiles_y, nblk;   // ho x wo = conv0 / conv2 map (net / 2), ho4 x wo4 = conv4 map (net / 4)
+};
+
+template <int TW_>
+__global__ __launch_bounds__(kThreads, (Stem2Cfg<TW_>::OCC)) void stem2_kernel(Stem2Args a) {
+    typedef Stem2Cfg<TW_> C;
+    typedef half_t T;
+    typedef Mma<T> M;
+    typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+    constexpr int TW = C::TW, P4 = C::P4, R2W = C::R2W, N2 = C::N2, R0W = C::R0W, N0 = C::N0;
+    constexpr int ROWD = C::ROWD, GRP = C::GRP, IR = C::IR, LDA1 = C::LDA1, LDO = C::LDO;
+    __shared__ __attribute__((aligned(16))) unsigned char s_raw[C::LDS_BYTES];
+    uint32_t *s_in = (uint32_t *)s_raw;                          // BGRX patch                      (phases 1-2)
+    T *s_a = (T *)s_raw;                                         // conv1 result hi|lo              (phases 3-4)
+    T *s_a1 = (T *)s_raw;                                        // conv3 result                    (phases 5-6)
+    T *s_out = (T *)(s_raw + C::A1_BYTES);                       // conv4 tile                      (phases 6-7)
+    float *s_c0 = (float *)(s_raw + C::REGION_A);                // fp32 conv0 tile                 (phases 2-3)
+    T *s_c2 = (T *)(s_raw + C::REGION_A);                        // fp16 conv2 tile                 (phases 4-5)
+    float *s_dw0 = (float *)(s_raw + C::REGION_A + C::REGION_B);
+    float *s_dw1 = s_dw0 + 9 * 8;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int bid = xcd_remap(blockIdx.x, a.nblk);
+    const int tx = bid % a.tiles_x;
+    const int ty = (bid / a.tiles_x) % a.tiles_y;
+    const int img = bid / (a.tiles_x * a.tiles_y);
+    const int oy0 = ty * C::TH, ox0 = tx * TW;                   // tile origin in the conv4 map
+    const FrameDesc fd = a.frames[img];
+    const int kb = lane >> 4;
+    RF_TRACE_KEY(a.nblk);
+    RF_TRACE(4, 0);
+
+    // ---- phase 0: operands that depend only on kernel arguments
+    const f16x8 *wf = (const f16x8 *)a.w0 + lane;
+    const f16x8 w_hi1 = wf[0], w_lo1 = wf[64], w_hi2 = wf[128], w_lo2 = wf[192];
+    const f32x4 b0 = lane < 32 ? *(const f32x4 *)(a.b0 + kb * 4) : vzero<f32x4, 4>();
+    // (the operands of phases 4 and 6 are loaded one phase ahead of their use, not here: 24 more live registers across the
+    // conv0 / depthwise phases would push the kernel under 7 workgroups per CU)
+
+    // ---- phase 1: stage the u8 patch as BGRX dwords (K_a' phase 1; the patch now starts 5 pixels left of / above the first
+    //      conv0 pixel's centre, so an item can lie entirely or partly left of the frame)
+    {
+        const int iy0 = 4 * oy0 - 5;                                  // input row of patch row 0
+        const int bx0 = (4 * ox0 - 5) * 3;                            // input byte column of patch pixel 0
+        const uintptr_t fp = (uintptr_t)fd.ptr;
+        const int delta = (int)(fp & 3);
+        const unsigned fbytes = ((unsigned)delta + (unsigned)(fd.rows - 1) * (unsigned)fd.step + (unsigned)fd.cols * 3u + 3u) & ~3u;
+        const auto rs = image_rsrc((const uint8_t *)(fp & ~(uintptr_t)3), fbytes);
+        const int row_bytes = fd.cols * 3;
+#pragma unroll 1
+        for (int i = tid; i < IR * GRP; i += kThreads) {
+            const int r = i / GRP, g = i % GRP;
+            const int iy = iy0 + r;
+            const int off = bx0 + 12 * g;                              // byte column of the item's first byte (may be negative)
+            const int neg = off < 0 ? -off : 0;                        // bytes of the item that lie left of the row: 0, 3, 15 (or more)
+            const bool row_ok = (unsigned)iy < (unsigned)fd.rows && neg < 12 && off < row_bytes;
+            const int A = delta + iy * fd.step + (off < 0 ? 0 : off);  // a partly-left item is fetched from the row start and shifted
+            const u32x4 d = __builtin_amdgcn_raw_buffer_load_b128(rs, row_ok ? (A & ~3) : (int)kOobOffset, 0, 0);
+            const uint32_t sh = (uint32_t)(A & 3);
+            uint32_t w0 = __builtin_amdgcn_alignbyte(d[1], d[0], sh);
+            uint32_t w1 = __builtin_amdgcn_alignbyte(d[2], d[1], sh);
+            uint32_t w2 = __builtin_amdgcn_alignbyte(d[3], d[2], sh);
+            if (neg) {                                                 // move byte b of the fetched 12 to position b + neg (neg = 3 here)
+                const uint32_t ls = (uint32_t)(4 - (neg & 3)) & 3u;    // alignbyte shift that moves bytes up by (neg & 3)
+                uint32_t n0 = w0, n1 = w1, n2 = w2;
+                if (neg & 3) {
+                    n2 = __builtin_amdgcn_alignbyte(w2, w1, ls);
+                    n1 = __builtin_amdgcn_alignbyte(w1, w0, ls);
+                    n0 = __builtin_amdgcn_alignbyte(w0, 0u, ls);
+                }
+                if (neg >= 8) { n2 = n0; n1 = 0u; n0 = 0u; }
+                else if (neg >= 4) { n2 = n1; n1 = n0; n0 = 0u; }
+                w0 = n0; w1 = n1; w2 = n2;
+            }
+            if (off < 0 || off + 12 > row_bytes) {                     // left / right border of the frame: clear outside bytes
+                const int lo = neg, hi = row_bytes - off < 12 ? row_bytes - off : 12;
+                auto bmask = [](int nb) -> uint32_t { return nb <= 0 ? 0u : (nb >= 4 ? 0xffffffffu : (1u << (8 * nb)) - 1u); };
+                w0 &= bmask(hi) & ~bmask(lo);
+                w1 &= bmask(hi - 4) & ~bmask(lo - 4);
+                w2 &= bmask(hi - 8) & ~bmask(lo - 8);
+            }
+            uint4 o4;
+            o4.x = w0 & 0x00ffffffu;
+            o4.y = ((w0 >> 24) | (w1 << 8)) & 0x00ffffffu;
+            o4.z = ((w1 >> 16) | (w2 << 16)) & 0x00ffffffu;
+            o4.w = w2 >> 8;
+            *(uint4 *)(s_in + r * ROWD + g * 4) = o4;
+        }
+    }
+    if (tid < 18) *(f32x4 *)(s_dw0 + tid * 4) = *(const f32x4 *)(a.dw0_w + tid * 4);
+    else if (tid >= 64 && tid < 64 + 36) *(f32x4 *)(s_dw1 + (tid - 64) * 4) = *(const f32x4 *)(a.dw1_w + (tid - 64) * 4);
+    RF_TRACE(4, 1);
+    __syncthreads();
+
+    // ---- phase 2: conv0 on the (R0H x R0W) region, K = 4*(3*ky + kx) + c4 (K_a' phase 2)
+    {
+        const int ppA = 2 * kb, ppB = 2 * kb + 1;
+        const int offA = (ppA / 3) * ROWD + ppA % 3, offB = (ppB / 3) * ROWD + ppB % 3, offC = 2 * ROWD + 2;
+#pragma unroll 1
+        for (int t = wave; t < C::T0; t += 4) {
+            const int q = t * 16 + (lane & 15);
+            const int hy = q / R0W, hx = q % R0W;
+            const uint32_t *pp = s_in + (2 * hy) * ROWD + 2 * hx;
+            const bool valid = q < N0;
+            const uint32_t vA = valid ? pp[offA] : 0u, vB = valid ? pp[offB] : 0u;
+            const uint32_t vC = (valid && kb == 0) ? pp[offC] : 0u;
+            f16x8 x1, x2 = vzero<f16x8, 8>();
+            u8x4_to_f16(vA, x1, 0);
+            u8x4_to_f16(vB, x1, 4);
+            u8x4_to_f16(vC, x2, 0);
+            f32x4 acc = b0;                                   // bias rides in the accumulator (lanes >= 32 hold padding rows)
+            acc = M::mma(w_hi1, x1, acc);
+            acc = M::mma(w_lo1, x1, acc);
+            acc = M::mma(w_hi2, x2, acc);
+            acc = M::mma(w_lo2, x2, acc);
+            if (lane < 32) {
+                // conv0 pixels outside its own map are the ZERO PADDING of the depthwise conv, not conv0(zero input)
+                const int cy = 2 * oy0 - 2 + hy, cx = 2 * ox0 - 2 + hx;
+                const bool inside = (unsigned)cy < (unsigned)a.ho && (unsigned)cx < (unsigned)a.wo;
+                f32x4 h;
+#pragma unroll
+                for (int r = 0; r < 4; r++) h[r] = inside ? fmaxf(acc[r], 0.f) : 0.f;
+                *(f32x4 *)(s_c0 + q * 8 + c0_half(q, kb) * 4) = h;
+            }
+        }
+    }
+    RF_TRACE(4, 2);
+    __syncthreads();
+
+    // ---- phase 3: depthwise conv1 on the (R2H x R2W) region, fp32, result as fp16 hi + lo (K_a' phase 3)
+    {
+        float dw_bias[8];
+#pragma unroll
+        for (int e = 0; e < 8; e++) dw_bias[e] = a.dw0_b[e];
+#pragma unroll 1
+        for (int i = tid; i < C::T2 * 16; i += kThreads) {
+            const int ry = i / R2W, rx = i % R2W;
+            float acc[8];
+#pragma unroll
+            for (int e = 0; e < 8; e++) acc[e] = dw_bias[e];
+            if (i < N2) {
+#pragma unroll
+                for (int ky = 0; ky < 3; ky++)
+#pragma unroll
+                    for (int kx = 0; kx < 3; kx++) {
+                        const int q = (ry + ky) * R0W + rx + kx;
+                        const f32x4 x0 = *(const f32x4 *)(s_c0 + q * 8 + c0_half(q, 0) * 4);
+                        const f32x4 x1 = *(const f32x4 *)(s_c0 + q * 8 + c0_half(q, 1) * 4);
+                        const f32x4 w0 = *(const f32x4 *)(s_dw0 + (ky * 3 + kx) * 8), w1 = *(const f32x4 *)(s_dw0 + (ky * 3 + kx) * 8 + 4);
+#pragma unroll
+                        for (int e = 0; e < 4; e++) { acc[e] = fmaf(x0[e], w0[e], acc[e]); acc[e + 4] = fmaf(x1[e], w1[e], acc[e + 4]); }
+                    }
+            }
+            f16x8 hi, lo;
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                const float v = fmaxf(acc[e], 0.f);
+                hi[e] = (half_t)v;
+                lo[e] = (half_t)(v - (float)hi[e]);
+            }
+            *(f16x8 *)(s_a + i * 16) = hi;           // region A: the staged patch is dead since the barrier after phase 2
+            *(f16x8 *)(s_a + i * 16 + 8) = lo;
+        }
+    }
+    const f16x8 pw0_frag = ((const f16x8 *)a.pw0_w)[lane];            // phase 4's operands: requested before the barrier
+    const f32x4 pw0_bias = *(const f32x4 *)(a.pw0_b + kb * 4);
+    RF_TRACE(4, 3);
+    __syncthreads();
+
+    // ---- phase 4: pointwise conv2 (8 -> 16) on MFMA, K slots [W_hi x_hi | W_hi x_lo | W_lo x_hi | 0]; the result tile is fp16
+    //      (the rounding point the un-fused engine had in HBM).  Pixels outside the 224^2 map are conv3's zero padding.
+#pragma unroll 1
+    for (int t = wave; t < C::T2; t += 4) {
+        const int i = t * 16 + (lane & 15);
+        const M::Frag x = kb < 3 ? *(const M::Frag *)(s_a + i * 16 + (kb & 1) * 8) : M::zero();
+        const f32x4 acc = M::mma(pw0_frag, x, pw0_bias);
+        const int ry = i / R2W, rx = i % R2W;
+        const int y2 = 2 * oy0 - 1 + ry, x2 = 2 * ox0 - 1 + rx;
+        const bool inside = i < N2 && (unsigned)y2 < (unsigned)a.ho && (unsigned)x2 < (unsigned)a.wo;
+        f16x4 h;
+#pragma unroll
+        for (int r = 0; r < 4; r++) h[r] = inside ? (half_t)fmaxf(acc[r], 0.f) : (half_t)0;
+        *(f16x4 *)(s_c2 + i * 16 + kb * 4) = h;
+    }
+    RF_TRACE(4, 4);
+    __syncthreads();
+
+    // ---- phase 5: depthwise conv3, stride 2, pad 1: one output pixel x 4 channels per thread (fp32 taps, fp32 accumulate)
+    {
+        const int cq = tid & 3;
+        const f32x4 bias = *(const f32x4 *)(a.dw1_b + cq * 4);
+#pragma unroll 1
+        for (int p = tid >> 2; p < C::T4 * 16; p += kThreads / 4) {
+            const int py = p / TW, px = p % TW;
+            f32x4 acc = bias;
+            if (p < P4) {
+#pragma unroll
+                for (int ky = 0; ky < 3; ky++)
+#pragma unroll
+                    for (int kx = 0; kx < 3; kx++) {
+                        const f16x4 x = *(const f16x4 *)(s_c2 + ((2 * py + ky) * R2W + 2 * px + kx) * 16 + cq * 4);
+                        const f32x4 w = *(const f32x4 *)(s_dw1 + (ky * 3 + kx) * 16 + cq * 4);
+#pragma unroll
+                        for (int e = 0; e < 4; e++) acc[e] = fmaf((float)x[e], w[e], acc[e]);
+                    }
+            }
+            f16x4 h;
+#pragma unroll
+            for (int e = 0; e < 4; e++) h[e] = (half_t)fmaxf(acc[e], 0.f);
+            *(f16x4 *)(s_a1 + p * LDA1 + cq * 4) = h;        // region A again: the conv1 result is dead since the barrier after phase 4
+        }
+    }
+    const f16x8 pw1_frag0 = ((const f16x8 *)a.pw1_w)[lane], pw1_frag1 = ((const f16x8 *)a.pw1_w)[64 + lane];      // phase 6's operands
+    const f32x4 pw1_bias0 = *(const f32x4 *)(a.pw1_b + kb * 4), pw1_bias1 = *(const f32x4 *)(a.pw1_b + 16 + kb * 4);
+    RF_TRACE(4, 5);
+    __syncthreads();
+
+    // ---- phase 6: pointwise conv4 (16 -> 32) on MFMA: 2 channel tiles x T4 pixel tiles, K = 16 of 32
+#pragma unroll 1
+    for (int pr = wave; pr < 2 * C::T4; pr += 4) {
+        const int ct = pr & 1, pt = pr >> 1;
+        const M::Frag x = kb < 2 ? *(const M::Frag *)(s_a1 + (pt * 16 + (lane & 15)) * LDA1 + kb * 8) : M::zero();
+        const f32x4 acc = M::mma(ct ? pw1_frag1 : pw1_frag0, x, ct ? pw1_bias1 : pw1_bias0);
+        f16x4 h;
+#pragma unroll
+        for (int r = 0; r < 4; r++) h[r] = (half_t)fmaxf(acc[r], 0.f);
+        *(f16x4 *)(s_out + (pt * 16 + (lane & 15)) * LDO + ct * 16 + kb * 4) = h;
+    }
+    RF_TRACE(4, 6);
+    __syncthreads();
+
+    // ---- phase 7: tile -> HBM, 16 B per lane; rows below the map fall outside the descriptor, columns need the test
+    {
+        const auto ro = image_rsrc(a.out + (size_t)img * a.ho4 * a.wo4 * 32, (unsigned)(a.ho4 * a.wo4 * 32) * 2u);
+        const int obase = (oy0 * a.wo4 + ox0) * 32 * 2;
+        for (int i = tid; i < P4 * 4; i += kThreads) {
+            const int p = i >> 2, cv = i & 3;
+            const int py = p / TW, px = p % TW;
+            const unsigned off = ox0 + px < a.wo4 ? (unsigned)(((py * a.wo4 + px) * 32 + cv * 8) * 2 + obase) : kOobOffset;
+            buf_store16(ro, off, *(const f16x8 *)(s_out + p * LDO + cv * 8));
+        }
+    }
+    RF_TRACE(4, 7);
+}
+
+int stem2_variant() {
+    static int v = -1;
+    if (v < 0) { const char *e = getenv("RF_STEM2"); v = e ? atoi(e) : 1; }      // probe knob: 1 = 7x8 tiles, 2 = 7x16
+    return v;
+}
+
+void launch_stem2(hipStream_t s, const Stem2Params &p) {
+    Stem2Args a;
+    a.frames = p.frames; a.out = p.out; a.w0 = p.w0; a.b0 = p.b0;
+    a.dw0_w = p.dw0_w; a.dw0_b = p.dw0_b; a.pw0_w = p.pw0_w; a.pw0_b = p.pw0_b;
+    a.dw1_w = p.dw1_w; a.dw1_b = p.dw1_b; a.pw1_w = p.pw1_w; a.pw1_b = p.pw1_b;
+    a.ho = p.net_h / 2; a.wo = p.net_w / 2; a.ho4 = p.net_h / 4; a.wo4 = p.net_w / 4;
+    const int tw = stem2_variant() == 2 ? 16 : 8;
+    a.tiles_x = (a.wo4 + tw - 1) / tw; a.tiles_y = (a.ho4 + 6) / 7;
+    a.nblk = p.n * a.tiles_x * a.tiles_y;
+    if (tw == 16) hipLaunchKernelGGL(stem2_kernel<16>, dim3(a.nblk), dim3(kThreads), 0, s, a);
+    else hipLaunchKernelGGL(stem2_kernel<8>, dim3(a.nblk), dim3(kThreads), 0, s, a);
+}
+
+// =============================================================================================
 // K_b  depthwise 3x3 + BN + ReLU  ->  pointwise 1x1 + BN + ReLU   (13 backbone pairs, prototxt :55-1193)
 //      HAS_DW = false: plain 1x1 + bias + ReLU.
 //      LAT = true: the FPN lateral that taps this block's output (rf_c1_red_conv / rf_c2_lateral / rf_c3_lateral,
@@ -674,7 +975,7 @@ template void launch_stem<int8_t>(hipStream_t, const StemParams<int8_t> &);
 //   phase 4  bias + ReLU, through LDS so the NHWC store is 16 B per lane and fully coalesced
 //   phase 5  (LAT) second GEMM 64 x COUT on the LDS-resident output tile, same epilogue
 // =============================================================================================
-template <typename T, int CIN, int COUT, int STRIDE, bool HAS_DW, int TH, int TW> struct DwPwCfg {
+template <typename T, int CIN, int COUT, int STRIDE, bool HAS_DW, int TH, int TW, bool PADROW = false> struct DwPwCfg {
     typedef typename DwWeight<T>::type DW;
     typedef Mma<T> M;
     static constexpr int VEC = Vec<T>::N;
@@ -690,8 +991,13 @@ template <typename T, int CIN, int COUT, int STRIDE, bool HAS_DW, int TH, int TW
     // and the stencil was ~45 % of their VALU instructions.  Needs the (group, pixel-tile) pairs to split over 4 waves.
     static constexpr bool DWMMA = HAS_DW && sizeof(T) == 2 && CIN % 16 == 0 && ((CIN / 16) * (P / 16)) % 4 == 0 &&
                                   (CIN >= 64 || (P / 16) % (4 / (CIN / 16 > 0 ? CIN / 16 : 1)) == 0);
-    static constexpr int LDIN = DWMMA ? (CIN * sizeof(T) >= 256 ? CIN + VEC : lds_row<T>(CIN)) : CIN;   // halo rows padded: the B-fragment reads stride by pixel
-    static constexpr size_t IN_BYTES = sizeof(T) * (size_t)(HR * HC * LDIN);
+    // Halo tile as the depthwise MFMA's B operand: pixel pitch 32 mod 64 bytes and (TW = 8, stride 1: a 16-pixel MFMA tile spans
+    // two halo rows) a row pitch that is a multiple of the 256-byte bank row make every B-fragment ds_read_b128 conflict-free
+    // (see Conv3Cfg::ROWP).  The halo tile is written with contiguous 128-byte runs, so unlike s_a / s_out it has no write-side
+    // preference.  PADROW = false keeps the round-1 layout (probe knob RF_DWPAD=0).
+    static constexpr int LDIN = DWMMA ? (!PADROW && CIN * sizeof(T) >= 256 ? CIN + VEC : lds_row<T>(CIN)) : CIN;
+    static constexpr int ROWP = PADROW && DWMMA && TW == 8 && STRIDE == 1 ? (HC * LDIN * (int)sizeof(T) + 255) / 256 * 256 / (int)sizeof(T) : HC * LDIN;
+    static constexpr size_t IN_BYTES = sizeof(T) * (size_t)(HR * ROWP);
     static constexpr size_t DW_BYTES = HAS_DW && !DWMMA ? sizeof(DW) * (size_t)(9 * CIN) : 0;
     static constexpr size_t A_BYTES = sizeof(T) * (size_t)(P * LDA);
     static constexpr size_t O_BYTES = sizeof(T) * (size_t)(P * LDO);
@@ -733,14 +1039,14 @@ struct DwPwArgs {
     int hin, win, hout, wout, tiles_x, tiles_y, nblk;     // nblk = tiles in the launch (the grid may be smaller)
 };
 
-template <typename T, int CIN, int COUT, int STRIDE, bool HAS_DW, int TH, int TW, bool LAT>
-__global__ __launch_bounds__(kThreads, (DwPwCfg<T, CIN, COUT, STRIDE, HAS_DW, TH, TW>::template occ<LAT>())) void dwpw_kernel(DwPwArgs<T> a) {
-    typedef DwPwCfg<T, CIN, COUT, STRIDE, HAS_DW, TH, TW> C;
+template <typename T, int CIN, int COUT, int STRIDE, bool HAS_DW, int TH, int TW, bool LAT, bool PADROW>
+__global__ __launch_bounds__(kThreads, (DwPwCfg<T, CIN, COUT, STRIDE, HAS_DW, TH, TW, PADROW>::template occ<LAT>())) void dwpw_kernel(DwPwArgs<T> a) {
+    typedef DwPwCfg<T, CIN, COUT, STRIDE, HAS_DW, TH, TW, PADROW> C;
     typedef typename Vec<T>::type V;
     typedef Mma<T> M;
     typedef typename M::Frag Frag;
     typedef typename C::WS WS;
-    constexpr int VEC = C::VEC, P = C::P, HC = C::HC, LDA = C::LDA, LDO = C::LDO, LDIN = C::LDIN;
+    constexpr int VEC = C::VEC, P = C::P, HC = C::HC, LDA = C::LDA, LDO = C::LDO, LDIN = C::LDIN, ROWP = C::ROWP;
     constexpr int CPV = CIN / VEC, PT = C::PT, KCH = C::KCH, NPF = C::NPF;
     constexpr bool STAT = C::STAT, DWMMA = C::DWMMA;
     typedef typename C::DW DW;
@@ -815,12 +1121,12 @@ __global__ __launch_bounds__(kThreads, (DwPwCfg<T, CIN, COUT, STRIDE, HAS_DW, TH
         for (int pi = 0; pi < PW; pi++) {
             const int pt = NG >= 4 ? pi : wave / NG + pi * (4 / NG);
             const int p = acc_pixel(pt, lane);
-            dpix[pi] = ((p / TW) * STRIDE * HC + (p % TW) * STRIDE) * LDIN + ((lane >> 4) & 1) * 8;
+            dpix[pi] = (p / TW) * STRIDE * ROWP + (p % TW) * STRIDE * LDIN + ((lane >> 4) & 1) * 8;
         }
 #pragma unroll
         for (int kc = 0; kc < DKCH; kc++) {
             const int tap = kc * 2 + (lane >> 5);                   // k = tap*16 + c; lanes 32..63 hold the chunk's second tap
-            dtap[kc] = tap < 9 ? ((tap / 3) * HC + tap % 3) * LDIN : -1;
+            dtap[kc] = tap < 9 ? (tap / 3) * ROWP + (tap % 3) * LDIN : -1;
         }
     }
 
@@ -894,7 +1200,7 @@ __global__ __launch_bounds__(kThreads, (DwPwCfg<T, CIN, COUT, STRIDE, HAS_DW, TH
         for (int k = 0; k < NPF; k++) {
             const int i = tid + k * kThreads;
             if (i < C::STAGE_ITEMS) {
-                if constexpr (HAS_DW) *(V *)(s_in + (i / CPV) * LDIN + (i % CPV) * VEC) = pre[k];
+                if constexpr (HAS_DW) *(V *)(s_in + ((i / CPV) / HC) * ROWP + ((i / CPV) % HC) * LDIN + (i % CPV) * VEC) = pre[k];
                 else *(V *)(s_a + (i / CPV) * LDA + (i % CPV) * VEC) = pre[k];
             }
         }
@@ -956,7 +1262,7 @@ __global__ __launch_bounds__(kThreads, (DwPwCfg<T, CIN, COUT, STRIDE, HAS_DW, TH
                 V xs[9];               // all nine taps requested before the first is used: one LDS round trip, not nine
 #pragma unroll
                 for (int k9 = 0; k9 < 9; k9++)
-                    xs[k9] = *(const V *)(s_in + ((py * STRIDE + k9 / 3) * HC + px * STRIDE + k9 % 3) * LDIN + cv * VEC);
+                    xs[k9] = *(const V *)(s_in + (py * STRIDE + k9 / 3) * ROWP + (px * STRIDE + k9 % 3) * LDIN + cv * VEC);
 #pragma unroll
                 for (int k9 = 0; k9 < 9; k9++) {
                     const DW *wv = s_dw + k9 * CIN + cv * VEC;
@@ -1029,10 +1335,10 @@ __global__ __launch_bounds__(kThreads, (DwPwCfg<T, CIN, COUT, STRIDE, HAS_DW, TH
     if (p_img >= 0) store_tile(p_img, p_oy0, p_ox0);
 }
 
-template <typename T, int CIN, int COUT, int STRIDE, bool HAS_DW, int TH, int TW, bool LAT>
+template <typename T, int CIN, int COUT, int STRIDE, bool HAS_DW, int TH, int TW, bool LAT, bool PADROW>
 static void dwpw_launch(hipStream_t s, const DwPwParams<T> *p, int tiles_x, int tiles_y) {
-    typedef DwPwCfg<T, CIN, COUT, STRIDE, HAS_DW, TH, TW> C;
-    auto kern = dwpw_kernel<T, CIN, COUT, STRIDE, HAS_DW, TH, TW, LAT>;
+    typedef DwPwCfg<T, CIN, COUT, STRIDE, HAS_DW, TH, TW, PADROW> C;
+    auto kern = dwpw_kernel<T, CIN, COUT, STRIDE, HAS_DW, TH, TW, LAT, PADROW>;
     static int resident_cache[kMaxDevices] = {};
     const int resident = kernel_residency(resident_cache, kern, C::LDS_BYTES);
     DwPwArgs<T> a{p->in, p->out, p->dw_w, p->dw_b, p->dw_mma, p->pw_w, p->pw_b, p->lat_w, p->lat_b, p->lat_out, p->pw_m, p->lat_m,
@@ -1041,18 +1347,27 @@ static void dwpw_launch(hipStream_t s, const DwPwParams<T> *p, int tiles_x, int 
     hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), C::LDS_BYTES, s, a);
 }
 
-template <typename T, int CIN, int COUT, int STRIDE, bool HAS_DW, int TH, int TW>
+static int dwpw_padrow() {
+    static int v = -1;
+    if (v < 0) { const char *e = getenv("RF_DWPAD"); v = e ? atoi(e) : 1; }        // probe knob: 0 = round-1 halo layout
+    return v;
+}
+
+template <typename T, int CIN, int COUT, int STRIDE, bool HAS_DW, int TH, int TW, bool PADROW = false>
 static TileInfo dwpw_dispatch(hipStream_t s, const DwPwParams<T> *p, int hout, int wout) {
-    typedef DwPwCfg<T, CIN, COUT, STRIDE, HAS_DW, TH, TW> C;
+    typedef DwPwCfg<T, CIN, COUT, STRIDE, HAS_DW, TH, TW, PADROW> C;
+    if constexpr (!PADROW && sizeof(T) == 2 && HAS_DW && STRIDE == 1 && TW == 8 && CIN >= 32) {
+        if (p && dwpw_padrow()) return dwpw_dispatch<T, CIN, COUT, STRIDE, HAS_DW, TH, TW, true>(s, p, hout, wout);
+    }
     int tiles_x = (wout + TW - 1) / TW, tiles_y = (hout + TH - 1) / TH;
     TileInfo ti{TH, TW, C::LDS_BYTES, tiles_x * tiles_y};
     if (!p) return ti;
     if (p->lat_out) {
         // laterals tap the outputs of blocks 4 (64ch), 10 (128ch) and 12 (256ch)
-        if constexpr (HAS_DW && STRIDE == 1 && CIN == COUT && COUT >= 64) dwpw_launch<T, CIN, COUT, STRIDE, HAS_DW, TH, TW, true>(s, p, tiles_x, tiles_y);
+        if constexpr (HAS_DW && STRIDE == 1 && CIN == COUT && COUT >= 64) dwpw_launch<T, CIN, COUT, STRIDE, HAS_DW, TH, TW, true, PADROW>(s, p, tiles_x, tiles_y);
         else throw LaunchUnsupported("fused lateral: only stride-1 blocks with cin == cout >= 64 have a kernel instance");
     } else {
-        dwpw_launch<T, CIN, COUT, STRIDE, HAS_DW, TH, TW, false>(s, p, tiles_x, tiles_y);
+        dwpw_launch<T, CIN, COUT, STRIDE, HAS_DW, TH, TW, false, PADROW>(s, p, tiles_x, tiles_y);
     }
     return ti;
 }
@@ -1069,6 +1384,13 @@ static TileInfo dwpw_select(hipStream_t s, const DwPwParams<T> *p, int cin, int 
     RF_DWPW(32, 64, 2, true, 4, 8)
     RF_DWPW(64, 64, 1, true, 4, 8)
     RF_DWPW(64, 128, 2, true, 4, 8)
+    if constexpr (sizeof(T) == 2) {
+        static int v128 = -1;
+        if (v128 < 0) { const char *e = getenv("RF_TILE128"); v128 = e ? atoi(e) : 0; }        // probe knob (tools/probes)
+        if (v128 == 1) { RF_DWPW(128, 128, 1, true, 8, 8) }
+        if (v128 == 2) { RF_DWPW(128, 128, 1, true, 4, 16) }
+        if (v128 == 3) { RF_DWPW(128, 128, 1, true, 8, 16) }
+    }
     RF_DWPW(128, 128, 1, true, 4, 8)
     RF_DWPW(128, 256, 2, true, 4, 8)
     RF_DWPW(256, 256, 1, true, 4, 8)
@@ -1103,31 +1425,43 @@ template TileInfo dwpw_tile_info<int8_t>(int, int, int, bool, int, int);
 //   One launch can cover up to 3 FPN levels (same conv shape, different maps / weights): the SSH module of
 //   strides 32, 16 and 8 is 3 launches, not 9.
 // =============================================================================================
-template <typename T, int CIN, int COUT, int TH, int TW> struct Conv3Cfg {
+template <typename T, int CIN, int COUT, int TH, int TW, bool ALLC = false, bool PADROW = false> struct Conv3Cfg {
     typedef Mma<T> M;
     static constexpr int VEC = Vec<T>::N;
     static constexpr int P = TH * TW;
     static constexpr int HR = TH + 2, HC = TW + 2;
     static constexpr int LDI = lds_row<T>(CIN);
     static constexpr int LDO = lds_row<T>(COUT) > COUT ? lds_row<T>(COUT) : COUT + VEC;
-    static constexpr size_t IN_BYTES = sizeof(T) * (size_t)(HR * HC * LDI);
+    // Halo-row pitch.  A B-fragment ds_read_b128 covers 16 pixels; with TW = 8 those are 8 pixels of one halo row and 8 of the
+    // next.  The read is conflict-free when the 16 pixel offsets are those of 16 CONSECUTIVE pixels modulo the 256-byte bank row
+    // (pixel pitch = 32 mod 64 bytes: lds_row): pad the row pitch to a multiple of 256 bytes so that "next row" == "+8 pixels".
+    static constexpr int ROWP = PADROW && TW == 8 ? (HC * LDI * (int)sizeof(T) + 255) / 256 * 256 / (int)sizeof(T) : HC * LDI;
+    static constexpr size_t IN_BYTES = sizeof(T) * (size_t)(HR * ROWP);
     static constexpr size_t O_BYTES = sizeof(T) * (size_t)(P * LDO);
     // persistent + software pipelined like K_b: tile t+G is staged while tile t's result is still being stored, so the
     // halo tile and the result tile are separate LDS regions (and the GEMM -> epilogue barrier disappears)
     static constexpr size_t LDS_BYTES = IN_BYTES + O_BYTES;
     static_assert(IN_BYTES % 16 == 0, "LDS carve must stay 16-byte aligned");
-    // wave split: output-channel tiles first.  3 channel tiles (the merged 64->48 SSH conv) run on 3 of the 4 waves: each
-    // keeps one tile's whole weight share in registers; the 4th wave only stages and stores.
     static constexpr int NT = COUT / 16, PT = P / 16;
-    static constexpr bool ODD = NT == 3;
-    typedef WaveSplit<ODD ? 4 : NT, PT> WS;
-    static constexpr int WN = ODD ? 3 : WS::WN, WP = ODD ? 1 : WS::WP, NI = ODD ? 1 : WS::NI, NJ = ODD ? PT : WS::NJ;
     static constexpr int KTOT = 9 * CIN;
     static constexpr int KCH = (KTOT + M::K - 1) / M::K;
-    static constexpr bool STAT = sizeof(T) <= 2 && NI * KCH <= 18;          // weights stationary in registers (see DwPwCfg)
+    // Wave split.  ALLC ("all channels"): every wave owns ALL output-channel tiles of its own pixel tiles, the whole weight
+    // matrix stationary in its registers (64 -> 64: 4 x 18 A fragments = 288 VGPRs, one workgroup per CU).  A B fragment is then
+    // read from LDS ONCE per workgroup and feeds NT MFMAs; with the channel tiles split over the waves instead (the round-1
+    // layout, kept for the fp32 parity engine) every wave re-read every pixel's fragments: one 1 KB ds_read_b128 per MFMA, which
+    // made these kernels LDS-bound at 9-25 % of the MFMA rate (SQ counters, profiles/r01_pmc_sq_n128_448_fp16.json).
+    // !ALLC: output-channel tiles first; 3 channel tiles (the merged 64->48 SSH conv) run on 3 of the 4 waves.
+    static constexpr bool ODD = !ALLC && NT == 3;
+    typedef WaveSplit<(ODD || ALLC) ? 4 : NT, PT> WS;
+    static constexpr int WN = ALLC ? 1 : (ODD ? 3 : WS::WN), WP = ALLC ? 4 : (ODD ? 1 : WS::WP);
+    static constexpr int NI = ALLC ? NT : (ODD ? 1 : WS::NI), NJ = ALLC ? PT / 4 : (ODD ? PT : WS::NJ);
+    static_assert(!ALLC || (PT % 4 == 0 && PT >= 4), "ALLC needs the pixel tiles to split over 4 waves");
+    static constexpr int WREGS = NI * KCH * 4;                              // VGPRs of stationary weights per lane
+    static constexpr bool STAT = sizeof(T) <= 2 && (ALLC ? WREGS <= 300 : NI * KCH <= 18);
     static constexpr int STAGE_ITEMS = HR * HC * (CIN / VEC);
     static constexpr int NPF = (STAGE_ITEMS + kThreads - 1) / kThreads;
-    static constexpr int OCC = sizeof(T) <= 2 ? (CIN >= 64 ? 3 : 5) : 1;    // 64-channel input: 72 weight VGPRs -> 170-VGPR budget; else 102
+    // register budget -> workgroups per CU (512 / 256 / 168 / 128 / 96 VGPRs per lane at 1 / 2 / 3 / 4 / 5)
+    static constexpr int OCC = sizeof(T) > 2 ? 1 : ALLC ? (WREGS > 160 ? 1 : WREGS > 64 ? 2 : 5) : (CIN >= 64 ? 3 : 5);
     static constexpr int GFRAGS = 12;                                      // streamed case only
 };
 
@@ -1144,13 +1478,13 @@ struct Conv3Args {
     Conv3Level<T> lv[3];
 };
 
-template <typename T, int CIN, int COUT, int TH, int TW, bool UPADD>
-__global__ __launch_bounds__(kThreads, (Conv3Cfg<T, CIN, COUT, TH, TW>::OCC)) void conv3x3_kernel(Conv3Args<T> a) {
-    typedef Conv3Cfg<T, CIN, COUT, TH, TW> C;
+template <typename T, int CIN, int COUT, int TH, int TW, bool UPADD, bool ALLC, bool PADROW>
+__global__ __launch_bounds__(kThreads, (Conv3Cfg<T, CIN, COUT, TH, TW, ALLC, PADROW>::OCC)) void conv3x3_kernel(Conv3Args<T> a) {
+    typedef Conv3Cfg<T, CIN, COUT, TH, TW, ALLC, PADROW> C;
     typedef typename Vec<T>::type V;
     typedef Mma<T> M;
     typedef typename M::Frag Frag;
-    constexpr int VEC = C::VEC, P = C::P, HC = C::HC, LDI = C::LDI, LDO = C::LDO;
+    constexpr int VEC = C::VEC, P = C::P, HC = C::HC, LDI = C::LDI, LDO = C::LDO, ROWP = C::ROWP;
     constexpr int CPV = CIN / VEC, KTOT = C::KTOT, KCH = C::KCH, NPF = C::NPF;
     constexpr int WN = C::WN, WP = C::WP, NI = C::NI, NJ = C::NJ;
     constexpr bool STAT = C::STAT;
@@ -1170,7 +1504,7 @@ __global__ __launch_bounds__(kThreads, (Conv3Cfg<T, CIN, COUT, TH, TW>::OCC)) vo
     RF_TRACE(3, 0);
 
     // ---- once per workgroup: this wave's weight share and biases
-    const int wn = C::ODD ? wave : wave % WN, wp = C::ODD ? 0 : wave / WN;
+    const int wn = C::ODD ? wave : wave % WN, wp = C::ODD ? 0 : wave / WN;      // ALLC: wn = 0, wp = wave
     const bool gemm_wave = !C::ODD || wave < 3;
     const int wnc = gemm_wave ? wn : 0;            // the idle wave reads tile 0's constants and never uses them
     Frag wst[STAT ? NI : 1][STAT ? KCH : 1];
@@ -1265,7 +1599,7 @@ __global__ __launch_bounds__(kThreads, (Conv3Cfg<T, CIN, COUT, TH, TW>::OCC)) vo
 #pragma unroll
     for (int j = 0; j < NJ; j++) {
         const int p = acc_pixel(wp + j * WP, lane);
-        pbase[j] = ((p / TW) * HC + p % TW) * LDI;
+        pbase[j] = (p / TW) * ROWP + (p % TW) * LDI;
     }
 
     // tile loop:  stage(t) | fetch(t+G) issued | store(t-1) | barrier | GEMM(t) | epilogue(t) -> s_out | barrier
@@ -1295,7 +1629,7 @@ __global__ __launch_bounds__(kThreads, (Conv3Cfg<T, CIN, COUT, TH, TW>::OCC)) vo
 #pragma unroll
                     for (int e = 0; e < VEC; e++) v[e] = ok ? to_T<T>(fmaf((float)v[e], a_lat, sacc[e] * a_up)) : to_T<T>(0.f);
                 }
-                *(V *)(s_in + (i / CPV) * LDI + (i % CPV) * VEC) = v;
+                *(V *)(s_in + ((i / CPV) / HC) * ROWP + ((i / CPV) % HC) * LDI + (i % CPV) * VEC) = v;
             }
         }
         RF_TRACE(3, 9);
@@ -1318,7 +1652,7 @@ __global__ __launch_bounds__(kThreads, (Conv3Cfg<T, CIN, COUT, TH, TW>::OCC)) vo
             auto xf = [&](int j, int kc) -> Frag {
                 const int kb = kc * M::K + (lane >> 4) * M::KPL;      // k = tap*CIN + c, KPL consecutive c of one tap
                 const int tap = kb / CIN, c = kb % CIN;
-                const int koff = ((tap / 3) * HC + tap % 3) * LDI + c;
+                const int koff = (tap / 3) * ROWP + (tap % 3) * LDI + c;
                 return kb < KTOT ? *(const Frag *)(s_in + pbase[j] + koff) : M::zero();
             };
             if constexpr (STAT) {
@@ -1343,10 +1677,10 @@ __global__ __launch_bounds__(kThreads, (Conv3Cfg<T, CIN, COUT, TH, TW>::OCC)) vo
     RF_TRACE(3, 7);
 }
 
-template <typename T, int CIN, int COUT, int TH, int TW, bool UPADD>
+template <typename T, int CIN, int COUT, int TH, int TW, bool UPADD, bool ALLC, bool PADROW>
 static void conv3_launch(hipStream_t s, Conv3Args<T> &a, int nlv, int total_tiles) {
-    typedef Conv3Cfg<T, CIN, COUT, TH, TW> C;
-    auto kern = conv3x3_kernel<T, CIN, COUT, TH, TW, UPADD>;
+    typedef Conv3Cfg<T, CIN, COUT, TH, TW, ALLC, PADROW> C;
+    auto kern = conv3x3_kernel<T, CIN, COUT, TH, TW, UPADD, ALLC, PADROW>;
     static int resident_cache[kMaxDevices] = {};
     const int resident = kernel_residency(resident_cache, kern, C::LDS_BYTES);
     // grid: persistent size for the whole launch, shared out to the levels in proportion to their tiles
@@ -1365,9 +1699,9 @@ static void conv3_launch(hipStream_t s, Conv3Args<T> &a, int nlv, int total_tile
     hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), C::LDS_BYTES, s, a);
 }
 
-template <typename T, int CIN, int COUT, int TH, int TW>
+template <typename T, int CIN, int COUT, int TH, int TW, bool ALLC = false, bool PADROW = false>
 static TileInfo conv3_dispatch(hipStream_t s, const Conv3Params<T> *p, int nlv, int h, int w) {
-    typedef Conv3Cfg<T, CIN, COUT, TH, TW> C;
+    typedef Conv3Cfg<T, CIN, COUT, TH, TW, ALLC, PADROW> C;
     TileInfo ti{TH, TW, C::LDS_BYTES, ((w + TW - 1) / TW) * ((h + TH - 1) / TH)};
     if (!p) return ti;
     Conv3Args<T> a;
@@ -1380,16 +1714,40 @@ static TileInfo conv3_dispatch(hipStream_t s, const Conv3Params<T> *p, int nlv, 
         if (l < nlv) total += q.n * tiles_x * tiles_y;
     }
     if (p[0].up) {
-        if constexpr (CIN == 64 && COUT == 64) conv3_launch<T, CIN, COUT, TH, TW, true>(s, a, nlv, total);
+        if constexpr (CIN == 64 && COUT == 64) conv3_launch<T, CIN, COUT, TH, TW, true, ALLC, PADROW>(s, a, nlv, total);
         else throw LaunchUnsupported("fused upsample + add: only the 64 -> 64 aggregation conv has a kernel instance");
     } else {
-        conv3_launch<T, CIN, COUT, TH, TW, false>(s, a, nlv, total);
+        conv3_launch<T, CIN, COUT, TH, TW, false, ALLC, PADROW>(s, a, nlv, total);
     }
     return ti;
 }
 
+// probe knob (tools/probes): RF_CONV3=0 selects the round-1 wave split (channel tiles over the waves) for A/B measurements
+static int conv3_variant() {
+    static int v = -1;
+    if (v < 0) { const char *e = getenv("RF_CONV3"); v = e ? atoi(e) : -1; }
+    return v;
+}
+
 template <typename T>
 static TileInfo conv3_select(hipStream_t s, const Conv3Params<T> *p, int nlv, int cin, int cout, int h, int w) {
+    if constexpr (sizeof(T) <= 2) {
+        // fp16 / int8: every wave owns all output channels of its pixels (Conv3Cfg ALLC), 8x8 tiles
+        const int v = conv3_variant();
+        if (v >= 1) {
+            if (cin == 64 && cout == 64) return v == 2 ? conv3_dispatch<T, 64, 64, 4, 16, true>(s, p, nlv, h, w) : conv3_dispatch<T, 64, 64, 8, 8, true>(s, p, nlv, h, w);
+            if (cin == 64 && cout == 48) return v == 2 ? conv3_dispatch<T, 64, 48, 8, 16, true>(s, p, nlv, h, w) : conv3_dispatch<T, 64, 48, 8, 8, true>(s, p, nlv, h, w);
+            if (cin == 16 && cout == 32) return conv3_dispatch<T, 16, 32, 8, 8, true>(s, p, nlv, h, w);
+            if (cin == 16 && cout == 16) return conv3_dispatch<T, 16, 16, 8, 8, true>(s, p, nlv, h, w);
+            return TileInfo{0, 0, 0, 0};
+        }
+        if (v == -1) {          // round-1 wave split, halo rows padded to the bank row (conflict-free B-fragment reads)
+            if (cin == 64 && cout == 64) return conv3_dispatch<T, 64, 64, 4, 8, false, true>(s, p, nlv, h, w);
+            if (cin == 16 && cout == 32) return conv3_dispatch<T, 16, 32, 8, 8, false, true>(s, p, nlv, h, w);
+            if (cin == 64 && cout == 48) return conv3_dispatch<T, 64, 48, 8, 8, false, true>(s, p, nlv, h, w);
+            if (cin == 16 && cout == 16) return conv3_dispatch<T, 16, 16, 8, 8, false, true>(s, p, nlv, h, w);
+        }
+    }
     // single-level small maps (stride 32 / 16 at 448^2: 14x14, 28x28) get 4x8 tiles for more workgroups where the
     // channel tiles still split over 4 waves (COUT % 32 == 0); everything else 8x8
     const bool small = nlv == 1 && (size_t)h * w <= 32 * 32;
