@@ -295,7 +295,7 @@ public:
         std::vector<T> tmp(cnt);
         RF_HIP(hipMemcpy(tmp.data(), (const T *)ai.ptr + (size_t)(last_first_image_ + image) * cnt, cnt * sizeof(T),
                          hipMemcpyDeviceToHost));
-        for (size_t i = 0; i < cnt; i++) dst[i] = Cast<T>::to(tmp[i]) * ai.scale;
+        for (size_t i = 0; i < cnt; i++) dst[i] = Cast<T>::to(tmp[i]) * (ai.scale.empty() ? 1.f : ai.scale[i % ai.c]);      // NHWC: channel = i % c
         return (long)cnt;
     }
 
@@ -361,7 +361,7 @@ public:
 private:
     static constexpr size_t kNone = (size_t)-1;
     struct GemmW { size_t w, b, m = kNone; };          // m: int8 requantisation multipliers (absent otherwise)
-    struct DwW { size_t w, b, mma = 0; };
+    struct DwW { size_t w, b, mma = 0, m = kNone; };     // m: int8 depthwise-on-MFMA tap scales
 
     struct Lane {
         hipStream_t stream = nullptr;
@@ -434,27 +434,55 @@ private:
             if (kv.first == blob) return kv.second;
         throw Unsupported("int8: the calibration table has no scale for tensor '" + blob + "'");
     }
+    // Per-channel activation scales (an extension of the TensorRT cache format: besides `tensor: hex` lines, which every reader
+    // takes as the per-tensor scale, tools/calibrate_int8.py writes `tensor#<c>: hex` lines).  A GEMM's per-input-channel scale
+    // folds into its weights and its per-output-channel scale into the requantisation multiplier (put_gemm), so per-channel
+    // activations cost nothing at run time; a per-tensor table (the one the reference ships) is broadcast.
+    typedef std::vector<float> Sc;
+    Sc scales_of(const Plan &plan, const std::string &blob, int channels) const {
+        Sc v(channels, 1.f);
+        if constexpr (!kInt8) return v;
+        bool per_channel = false;
+        for (const auto &kv : plan.int8_scales)
+            if (kv.first == blob + "#0") { per_channel = true; break; }
+        if (!per_channel) { std::fill(v.begin(), v.end(), scale_of(plan, blob)); return v; }
+        for (int c = 0; c < channels; c++) v[c] = scale_of(plan, blob + "#" + std::to_string(c));
+        return v;
+    }
+    static Sc slice(const Sc &v, int lo, int hi) { return Sc(v.begin() + lo, v.begin() + hi); }
+    static Sc concat(Sc a, const Sc &b) { a.insert(a.end(), b.begin(), b.end()); return a; }
+    static Sc cmax(const Sc &a, const Sc &b, const Sc &c) {
+        Sc v(a.size());
+        for (size_t i = 0; i < a.size(); i++) v[i] = std::max(a[i], std::max(b[i], c[i]));
+        return v;
+    }
     const float *mult_ptr(const GemmW &g) const { return g.m == kNone ? nullptr : arena_.ptr<float>(g.m); }
 
     // fp16 / fp32: weights as they are.  int8: per-output-channel symmetric weight quantisation (w_scale = amax / 127, what
     // TensorRT does with a per-tensor activation table); the epilogue computes acc * mult + bias with
     //   mult[c] = w_scale[c] * in_scale / out_scale[c],  bias[c] = b[c] / out_scale[c]     (out_scale = 1: real output)
-    GemmW put_gemm(const FoldedConv &f, float in_scale = 1.f, const std::vector<float> &out_scale = {}) {
-        const int ktot = f.k * f.k * (f.cin / f.group);
+    GemmW put_gemm(const FoldedConv &f, const Sc &in_scale = {}, const Sc &out_scale = {}) {
+        const int cin_g = f.cin / f.group;
+        const int ktot = f.k * f.k * cin_g;
         GemmW g;
         if constexpr (!kInt8) {
             g.w = arena_.put(pack_gemm<T>(f.w, f.cout, ktot, mma_k<T>(), mma_kpl<T>()));
             g.b = arena_.put(f.b);
         } else {
-            std::vector<float> q(f.w.size()), mult(f.cout), bias(f.cout);
+            if (!in_scale.empty() && (int)in_scale.size() != cin_g) throw ModelError("int8: input scale count does not match " + f.name);
+            if (!out_scale.empty() && (int)out_scale.size() != f.cout) throw ModelError("int8: output scale count does not match " + f.name);
+            std::vector<float> ws_in(f.w), q(f.w.size()), mult(f.cout), bias(f.cout);
+            if (!in_scale.empty())
+                for (int o = 0; o < f.cout; o++)
+                    for (int k = 0; k < ktot; k++) ws_in[(size_t)o * ktot + k] *= in_scale[k % cin_g];       // k = tap*cin + c
             for (int o = 0; o < f.cout; o++) {
                 float amax = 0.f;
-                for (int k = 0; k < ktot; k++) amax = std::max(amax, std::fabs(f.w[(size_t)o * ktot + k]));
+                for (int k = 0; k < ktot; k++) amax = std::max(amax, std::fabs(ws_in[(size_t)o * ktot + k]));
                 const float ws = amax > 0.f ? amax / 127.f : 1.f;
                 for (int k = 0; k < ktot; k++)
-                    q[(size_t)o * ktot + k] = std::min(127.f, std::max(-127.f, std::nearbyintf(f.w[(size_t)o * ktot + k] / ws)));
-                const float os = out_scale.empty() ? 1.f : out_scale[out_scale.size() == 1 ? 0 : o];
-                mult[o] = ws * in_scale / os;
+                    q[(size_t)o * ktot + k] = std::min(127.f, std::max(-127.f, std::nearbyintf(ws_in[(size_t)o * ktot + k] / ws)));
+                const float os = out_scale.empty() ? 1.f : out_scale[o];
+                mult[o] = ws / os;
                 bias[o] = f.b[o] / os;
             }
             g.w = arena_.put(pack_gemm<T>(q, f.cout, ktot, mma_k<T>(), mma_kpl<T>()));
@@ -466,17 +494,17 @@ private:
 
     // depthwise weights [c][3][3][1] -> [tap][c].  int8: fp32 weights pre-scaled so the stencil maps input quanta straight to
     // output quanta: w * in_scale / mid_scale, b / mid_scale
-    DwW put_dw(const FoldedConv &dw, float in_scale = 1.f, float mid_scale = 1.f) {
+    DwW put_dw(const FoldedConv &dw, const Sc &in_scale = {}, const Sc &mid_scale = {}) {
         const int c = dw.cout;
         std::vector<DWT> w((size_t)9 * c);
         std::vector<float> b(dw.b);
         for (int ch = 0; ch < c; ch++)
             for (int t = 0; t < 9; t++) {
                 float v = dw.w[(size_t)ch * 9 + t];
-                if constexpr (kInt8) w[(size_t)t * c + ch] = v * in_scale / mid_scale;
+                if constexpr (kInt8) w[(size_t)t * c + ch] = v * in_scale[ch] / mid_scale[ch];
                 else w[(size_t)t * c + ch] = Cast<DWT>::from(v);
             }
-        if constexpr (kInt8) for (auto &v : b) v /= mid_scale;
+        if constexpr (kInt8) for (int ch = 0; ch < c; ch++) b[ch] /= mid_scale[ch];
         DwW r{arena_.put(w), arena_.put(b), 0};
         if constexpr (std::is_same<T, half_t>::value) {
             // the same taps as diagonal MFMA A fragments (pack.h dw_mma_dword): [c/16][5][64] dwords
@@ -492,6 +520,35 @@ private:
                         for (int kc = 0; kc < kDwMmaChunks; kc++) mm[((size_t)g * kDwMmaChunks + kc) * 64 + lane] = dw_mma_dword(kc, lane, w9);
                     }
                 r.mma = arena_.put(mm);
+            }
+        }
+        if constexpr (kInt8) {
+            // int8 engine: the taps (already in output quanta per input quantum) as 15-bit integers w = 128*hi + lo with a
+            // per-channel scale, hi / lo as diagonal i8 MFMA A fragments (pack.h dw_mma_dword_i8): [c/16][3][hi, lo][64] dwords
+            if (c % 16 == 0) {
+                std::vector<float> ws(c, 1.f);
+                std::vector<int8_t> hi((size_t)9 * c), lo((size_t)9 * c);
+                for (int ch = 0; ch < c; ch++) {
+                    float amax = 0.f;
+                    for (int t = 0; t < 9; t++) amax = std::max(amax, std::fabs((float)w[(size_t)t * c + ch]));
+                    ws[ch] = amax > 0.f ? amax / (float)kDwI8Range : 1.f;
+                    for (int t = 0; t < 9; t++) {
+                        const int wi = (int)std::lrintf((float)w[(size_t)t * c + ch] / ws[ch]);
+                        dw_i8_split(std::max(-kDwI8Range, std::min(kDwI8Range, wi)), &hi[(size_t)t * c + ch], &lo[(size_t)t * c + ch]);
+                    }
+                }
+                std::vector<uint32_t> mm((size_t)(c / 16) * kDwMmaChunksI8 * 2 * 64);
+                for (int g = 0; g < c / 16; g++)
+                    for (int lane = 0; lane < 64; lane++) {
+                        int8_t h9[9], l9[9];
+                        for (int t = 0; t < 9; t++) { h9[t] = hi[(size_t)t * c + g * 16 + (lane & 15)]; l9[t] = lo[(size_t)t * c + g * 16 + (lane & 15)]; }
+                        for (int kc = 0; kc < kDwMmaChunksI8; kc++) {
+                            mm[(((size_t)g * kDwMmaChunksI8 + kc) * 2 + 0) * 64 + lane] = dw_mma_dword_i8(kc, lane, h9);
+                            mm[(((size_t)g * kDwMmaChunksI8 + kc) * 2 + 1) * 64 + lane] = dw_mma_dword_i8(kc, lane, l9);
+                        }
+                    }
+                r.mma = arena_.put(mm);
+                r.m = arena_.put(ws);
             }
         }
         return r;
@@ -539,9 +596,9 @@ private:
             }
             stem_pw_.w = arena_.put(pwf);
             if constexpr (kInt8) {
-                const float os = scale_of(plan, b0.pw.out_blob);
-                std::vector<float> b(b0.pw.b), m(b0.pw.cout, 1.f / os);
-                for (auto &v : b) v /= os;
+                const Sc os = scales_of(plan, b0.pw.out_blob, b0.pw.cout);
+                std::vector<float> b(b0.pw.b), m(b0.pw.cout);
+                for (int o = 0; o < b0.pw.cout; o++) { m[o] = 1.f / os[o]; b[o] /= os[o]; }
                 stem_pw_.b = arena_.put(b);
                 stem_pw_.m = arena_.put(m);
             } else {
@@ -566,59 +623,67 @@ private:
                 }
             }
         }
-        float s_prev = 1.f;
-        if constexpr (kInt8) s_prev = scale_of(plan, plan.blocks[0].pw.out_blob);
-        float s_tap[3] = {1.f, 1.f, 1.f};            // scale of the block outputs the laterals tap (blocks 12, 10, 4)
+        Sc s_prev = scales_of(plan, plan.blocks[0].pw.out_blob, plan.blocks[0].pw.cout);
+        Sc s_tap[3];                                  // scales of the block outputs the laterals tap (blocks 12, 10, 4)
         for (size_t i = first_block; i < plan.blocks.size(); i++) {
             const auto &blk = plan.blocks[i];
-            float s_mid = 1.f, s_out = 1.f;
-            if constexpr (kInt8) { s_mid = scale_of(plan, blk.dw.out_blob); s_out = scale_of(plan, blk.pw.out_blob); }
+            const Sc s_mid = scales_of(plan, blk.dw.out_blob, blk.dw.cout), s_out = scales_of(plan, blk.pw.out_blob, blk.pw.cout);
             dw_w_.push_back(put_dw(blk.dw, s_prev, s_mid));
-            pw_w_.push_back(put_gemm(blk.pw, s_mid, {s_out}));
+            pw_w_.push_back(put_gemm(blk.pw, s_mid, s_out));
             s_prev = s_out;
+            if constexpr (kInt8) act_scale_[blk.pw.out_blob] = s_out;
             if (i == 12) s_tap[0] = s_out;
             if (i == 10) s_tap[1] = s_out;
             if (i == 4) s_tap[2] = s_out;
         }
-        float s_lat[3] = {1.f, 1.f, 1.f}, s_feat[3] = {1.f, 1.f, 1.f};
-        for (int i = 0; i < 3; i++) {
-            if constexpr (kInt8) s_lat[i] = scale_of(plan, plan.lateral[i].out_blob);
-            lat_w_[i] = put_gemm(plan.lateral[i], s_tap[i], {s_lat[i]});
+        if constexpr (kInt8) act_scale_[plan.blocks[0].pw.out_blob] = scales_of(plan, plan.blocks[0].pw.out_blob, plan.blocks[0].pw.cout);
+        // FPN.  The fused "lateral + upsample(coarser)" staging adds two int8 tensors and requantises to the `_plus` scale:
+        //   q_plus = round(q_lat * s_lat / s_plus + blend(q_up) * s_up / s_plus).
+        // With a per-tensor table the two ratios are scalars (a_lat, a_up).  With per-channel scales the three tensors of each
+        // add are given ONE common per-channel scale (the largest of their calibrated ones, as for concat inputs), so the ratios
+        // are 1 and the kernel needs no per-channel multipliers.
+        Sc s_lat[3], s_feat[3], s_plus[2], s_aggr[2];
+        bool per_channel = false;
+        if constexpr (kInt8)
+            for (const auto &kv : plan.int8_scales) per_channel = per_channel || kv.first == "_plus0#0";
+        for (int i = 0; i < 3; i++) s_lat[i] = scales_of(plan, plan.lateral[i].out_blob, 64);
+        for (int i = 0; i < 2; i++) {
+            s_plus[i] = scales_of(plan, i == 0 ? "_plus0" : "_plus1", 64);
+            s_aggr[i] = scales_of(plan, plan.aggr[i].out_blob, 64);
         }
+        if (per_channel) {
+            // add 0: {c3 lateral (= P3), c2 lateral, _plus0};  add 1: {c2 aggr (= P2), c1 lateral, _plus1}
+            s_lat[0] = s_lat[1] = s_plus[0] = cmax(s_lat[0], s_lat[1], s_plus[0]);
+            s_aggr[0] = s_lat[2] = s_plus[1] = cmax(s_aggr[0], s_lat[2], s_plus[1]);
+        }
+        for (int i = 0; i < 3; i++) lat_w_[i] = put_gemm(plan.lateral[i], s_tap[i], s_lat[i]);
         s_feat[0] = s_lat[0];
         for (int i = 0; i < 2; i++) {
-            float s_plus = 1.f, s_out = 1.f;
             if constexpr (kInt8) {
-                s_plus = scale_of(plan, i == 0 ? "_plus0" : "_plus1");
-                s_out = scale_of(plan, plan.aggr[i].out_blob);
-                aggr_a_lat_[i] = s_lat[i + 1] / s_plus;
-                aggr_a_up_[i] = s_feat[i] / s_plus;
+                aggr_a_lat_[i] = per_channel ? 1.f : s_lat[i + 1][0] / s_plus[i][0];
+                aggr_a_up_[i] = per_channel ? 1.f : s_feat[i][0] / s_plus[i][0];
             }
-            aggr_w_[i] = put_gemm(plan.aggr[i], s_plus, {s_out});
-            s_feat[i + 1] = s_out;
+            aggr_w_[i] = put_gemm(plan.aggr[i], s_plus[i], s_aggr[i]);
+            s_feat[i + 1] = s_aggr[i];
         }
         for (int i = 0; i < 3; i++) {
             const SshModule &m = plan.ssh[i];
             std::string pre = "rf_c" + std::to_string(3 - i) + "_det_";
-            float s_cat = 1.f, s_c1 = 1.f, s_c31 = 1.f;
-            if constexpr (kInt8) {
-                s_cat = scale_of(plan, pre + "concat_relu");          // the three concat inputs share one scale
-                s_c1 = scale_of(plan, pre + "context_conv1_relu");
-                s_c31 = scale_of(plan, pre + "context_conv3_1_relu");
-            }
-            std::vector<float> oa(48, s_cat), ob(32, s_cat);
-            for (int c = 32; c < 48; c++) oa[c] = s_c1;
-            for (int c = 16; c < 32; c++) ob[c] = s_c31;
-            ssh_w_[i][0] = put_gemm(m.conv_a, s_feat[i], oa);
-            ssh_w_[i][1] = put_gemm(m.conv_b, s_c1, ob);
-            ssh_w_[i][2] = put_gemm(m.conv_c, s_c31, {s_cat});
+            // the three concat inputs are quantised with the concat tensor's scales (per tensor: one shared scale, as in the
+            // TensorRT table; per channel: each branch writes its slice with that slice's scales)
+            const Sc s_cat = scales_of(plan, pre + "concat_relu", 64);
+            const Sc s_c1 = scales_of(plan, pre + "context_conv1_relu", 16), s_c31 = scales_of(plan, pre + "context_conv3_1_relu", 16);
+            ssh_w_[i][0] = put_gemm(m.conv_a, s_feat[i], concat(slice(s_cat, 0, 32), s_c1));
+            ssh_w_[i][1] = put_gemm(m.conv_b, s_c1, concat(slice(s_cat, 32, 48), s_c31));
+            ssh_w_[i][2] = put_gemm(m.conv_c, s_c31, slice(s_cat, 48, 64));
             ssh_w_[i][3] = put_gemm(m.head, s_cat, {});              // heads are dequantised to real logits / deltas
-            act_scale_[pre + "concat_relu"] = s_cat;
-            act_scale_[pre + "context_conv1_relu"] = s_c1;
-            act_scale_[pre + "context_conv3_1_relu"] = s_c31;
+            if constexpr (kInt8) {
+                act_scale_[pre + "concat_relu"] = s_cat;
+                act_scale_[pre + "context_conv1_relu"] = s_c1;
+                act_scale_[pre + "context_conv3_1_relu"] = s_c31;
+            }
         }
         if constexpr (kInt8) {
-            for (const auto &blk : plan.blocks) act_scale_[blk.pw.out_blob] = scale_of(plan, blk.pw.out_blob);
             for (int i = 0; i < 3; i++) act_scale_[plan.lateral[i].out_blob] = s_lat[i];
             for (int i = 0; i < 2; i++) act_scale_[plan.aggr[i].out_blob] = s_feat[i + 1];
         }
@@ -652,7 +717,7 @@ private:
         auto act = [&](const std::string &name, int h, int w, int c) {
             T *p = dalloc<T>((size_t)mb * h * w * c);
             auto sc = act_scale_.find(name);
-            L.acts[name] = ActInfo{p, h, w, c, sc == act_scale_.end() ? 1.f : sc->second};
+            L.acts[name] = ActInfo{p, h, w, c, sc == act_scale_.end() ? std::vector<float>() : sc->second};
             return p;
         };
         // activations: one buffer per reference blob that survives fusion (288 GB of HBM: nothing is recycled)
@@ -738,6 +803,7 @@ private:
             p.in = cur; p.out = out;
             p.dw_w = arena_.ptr<DWT>(dw_w_[i].w); p.dw_b = arena_.ptr<float>(dw_w_[i].b);
             if (dw_w_[i].mma) p.dw_mma = arena_.ptr<uint32_t>(dw_w_[i].mma);
+            if (dw_w_[i].m != kNone) p.dw_m = arena_.ptr<float>(dw_w_[i].m);
             p.pw_w = arena_.ptr<T>(pw_w_[i].w); p.pw_b = arena_.ptr<float>(pw_w_[i].b); p.pw_m = mult_ptr(pw_w_[i]);
             p.n = 0; p.hin = h; p.win = w; p.hout = ho; p.wout = wo;
             p.cin = c; p.cout = blk.pw.cout; p.stride = blk.dw.stride; p.has_dw = true;
@@ -1149,7 +1215,7 @@ private:
     DwW stem_dw_{0, 0}, stem2_dw_{0, 0};
     GemmW stem_pw_{0, 0}, stem2_pw_{0, 0};
     float aggr_a_lat_[2] = {1.f, 1.f}, aggr_a_up_[2] = {1.f, 1.f};
-    std::map<std::string, float> act_scale_;    // int8: blob -> scale (debug accessors dequantise)
+    std::map<std::string, std::vector<float>> act_scale_;    // int8: blob -> per-channel scales (debug accessors dequantise)
     std::vector<DwW> dw_w_;
     std::vector<GemmW> pw_w_;
     GemmW lat_w_[3], aggr_w_[2], ssh_w_[3][4];

@@ -39,7 +39,7 @@ struct EngineOptions {
     std::string model_stem = "mnet-deconv-0517";
 };
 
-struct ActInfo { void *ptr; int h, w, c; float scale = 1.f; };
+struct ActInfo { void *ptr; int h, w, c; std::vector<float> scale; };      // scale: empty, or one per channel (int8)
 
 struct OpInfo {
     std::string name;            // reference layer name(s) the launch covers

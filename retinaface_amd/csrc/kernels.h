@@ -88,6 +88,7 @@ struct DwPwParams {
     const float *pw_b;    // [cout]
     const T *lat_w = nullptr; const float *lat_b = nullptr; T *lat_out = nullptr;   // optional fused FPN lateral (cout -> 64)
     const float *pw_m = nullptr, *lat_m = nullptr;   // int8: requantisation multipliers per output channel
+    const float *dw_m = nullptr;                     // int8 depthwise on MFMA: per-channel scale of the 15-bit integer taps
     int n, hin, win, hout, wout;
     int cin, cout, stride;
     bool has_dw;

@@ -407,8 +407,17 @@ __device__ __forceinline__ void store_acc(T *s_out, f32x4 mult, f32x4 bv, ACC ac
         *(f32x4 *)(s_out + p * LDO + c0) = f;
     } else {
         uint32_t packed = 0;
+        if (relu) {
+            // ReLU'd quanta are 0..127: clamp with one v_med3, round to nearest even (as rintf), then v_cvt_pk_u8_f32 converts the
+            // now integral value and drops it into its byte -- 3 instructions per value instead of ~7 (clamp pair, convert, mask,
+            // shift, or); the int8 epilogues were a third of these kernels' VALU work
 #pragma unroll
-        for (int r = 0; r < 4; r++) packed |= ((uint32_t)(uint8_t)to_T<int8_t>(v[r])) << (8 * r);
+            for (int r = 0; r < 4; r++)
+                packed = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_rintf(__builtin_amdgcn_fmed3f(v[r], 0.f, 127.f)), r, packed);
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; r++) packed |= ((uint32_t)(uint8_t)to_T<int8_t>(v[r])) << (8 * r);
+        }
         *(uint32_t *)(s_out + p * LDO + c0) = packed;
     }
 }
@@ -989,7 +998,8 @@ template <typename T, int CIN, int COUT, int STRIDE, bool HAS_DW, int TH, int TW
     // fp16 engine: the depthwise stencil runs on the matrix cores as a diagonal-weight 3x3 conv per 16-channel group (see
     // pack.h dw_mma_dword): these kernels are VALU-issue bound (SQ counters: VALU busy 70-100 % of issue cycles, MFMA < 10 %)
     // and the stencil was ~45 % of their VALU instructions.  Needs the (group, pixel-tile) pairs to split over 4 waves.
-    static constexpr bool DWMMA = HAS_DW && sizeof(T) == 2 && CIN % 16 == 0 && ((CIN / 16) * (P / 16)) % 4 == 0 &&
+    // int8 engine: the same with v_mfma_i32_16x16x64_i8 and 15-bit taps split over two fragments (pack.h dw_mma_dword_i8).
+    static constexpr bool DWMMA = HAS_DW && sizeof(T) <= 2 && CIN % 16 == 0 && ((CIN / 16) * (P / 16)) % 4 == 0 &&
                                   (CIN >= 64 || (P / 16) % (4 / (CIN / 16 > 0 ? CIN / 16 : 1)) == 0);
     // Halo tile as the depthwise MFMA's B operand: pixel pitch 32 mod 64 bytes and (TW = 8, stride 1: a 16-pixel MFMA tile spans
     // two halo rows) a row pitch that is a multiple of the 256-byte bank row make every B-fragment ds_read_b128 conflict-free
@@ -1036,6 +1046,7 @@ struct DwPwArgs {
     const T *in; T *out; const typename DwWeight<T>::type *dw_w; const float *dw_b; const uint32_t *dw_mma; const T *pw_w; const float *pw_b;
     const T *lat_w; const float *lat_b; T *lat_out;
     const float *pw_m, *lat_m;        // int8: per-output-channel requantisation multipliers (nullptr otherwise)
+    const float *dw_m;                // int8 depthwise on MFMA: per-channel tap scale
     int hin, win, hout, wout, tiles_x, tiles_y, nblk;     // nblk = tiles in the launch (the grid may be smaller)
 };
 
@@ -1102,30 +1113,36 @@ __global__ __launch_bounds__(kThreads, (DwPwCfg<T, CIN, COUT, STRIDE, HAS_DW, TH
     }
     // depthwise on MFMA: wave -> (channel group, pixel tile) pairs; per group 5 diagonal A fragments, each kept as ONE dword
     // per lane and expanded to 4 when used
-    constexpr int NG = CIN / 16 > 0 ? CIN / 16 : 1, DKCH = kDwMmaChunks;
+    constexpr bool I8 = sizeof(T) == 1;
+    constexpr int NG = CIN / 16 > 0 ? CIN / 16 : 1, DKCH = I8 ? kDwMmaChunksI8 : kDwMmaChunks;
+    constexpr int DPARTS = I8 ? 2 : 1;                               // int8: hi and lo fragments per chunk
     constexpr int GW = DWMMA ? (NG >= 4 ? NG / 4 : 1) : 1;          // groups per wave
     constexpr int PW = DWMMA ? (NG * PT / 4) / GW : 1;              // pixel tiles per wave and group
-    uint32_t dwv[GW][DKCH];
-    f32x4 dwb4[GW];
+    uint32_t dwv[GW][DKCH][DPARTS];
+    f32x4 dwb4[GW], dwm4[GW];
     int dpix[PW], dtap[DKCH];
-    const int dsel = dw_mma_dword_index(lane);
+    const int dsel = I8 ? dw_mma_dword_index_i8(lane) : dw_mma_dword_index(lane);
     if constexpr (DWMMA) {
 #pragma unroll
         for (int gi = 0; gi < GW; gi++) {
             const int g = NG >= 4 ? wave + 4 * gi : wave % NG;
 #pragma unroll
-            for (int kc = 0; kc < DKCH; kc++) dwv[gi][kc] = a.dw_mma[(g * DKCH + kc) * 64 + lane];
+            for (int kc = 0; kc < DKCH; kc++)
+#pragma unroll
+                for (int hl = 0; hl < DPARTS; hl++) dwv[gi][kc][hl] = a.dw_mma[((g * DKCH + kc) * DPARTS + hl) * 64 + lane];
             dwb4[gi] = *(const f32x4 *)(a.dw_b + acc_cout(g, lane, 0));
+            dwm4[gi] = load_mult(I8 ? a.dw_m : nullptr, acc_cout(g, lane, 0));
         }
 #pragma unroll
         for (int pi = 0; pi < PW; pi++) {
             const int pt = NG >= 4 ? pi : wave / NG + pi * (4 / NG);
             const int p = acc_pixel(pt, lane);
-            dpix[pi] = (p / TW) * STRIDE * ROWP + (p % TW) * STRIDE * LDIN + ((lane >> 4) & 1) * 8;
+            // fp16: a lane's 8 k's are half of a tap's 16 channels; int8: all 16 channels of one tap
+            dpix[pi] = (p / TW) * STRIDE * ROWP + (p % TW) * STRIDE * LDIN + (I8 ? 0 : ((lane >> 4) & 1) * 8);
         }
 #pragma unroll
         for (int kc = 0; kc < DKCH; kc++) {
-            const int tap = kc * 2 + (lane >> 5);                   // k = tap*16 + c; lanes 32..63 hold the chunk's second tap
+            const int tap = I8 ? kc * 4 + (lane >> 4) : kc * 2 + (lane >> 5);      // k = tap*16 + c
             dtap[kc] = tap < 9 ? (tap / 3) * ROWP + (tap % 3) * LDIN : -1;
         }
     }
@@ -1218,33 +1235,46 @@ __global__ __launch_bounds__(kThreads, (DwPwCfg<T, CIN, COUT, STRIDE, HAS_DW, TH
         RF_TRACE(2, 2);
 
         if constexpr (DWMMA) {
-            // ---- phase 2 (fp16): depthwise 3x3 as diagonal-weight implicit GEMM, D[c][pixel] per 16-channel group
-            const f32x4 ones = {1.f, 1.f, 1.f, 1.f};
+            // ---- phase 2 (fp16 / int8): depthwise 3x3 as diagonal-weight implicit GEMM, D[c][pixel] per 16-channel group
 #pragma unroll
             for (int gi = 0; gi < GW; gi++) {
                 const int g = NG >= 4 ? wave + 4 * gi : wave % NG;
-                typename M::Acc dacc[PW];
+                typename M::Acc dacc[DPARTS][PW];
 #pragma unroll
-                for (int pi = 0; pi < PW; pi++) dacc[pi] = vzero<typename M::Acc, 4>();
+                for (int hl = 0; hl < DPARTS; hl++)
+#pragma unroll
+                    for (int pi = 0; pi < PW; pi++) dacc[hl][pi] = vzero<typename M::Acc, 4>();
 #pragma unroll
                 for (int kc = 0; kc < DKCH; kc++) {
                     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-                    u32x4 wa;
-                    uint32_t wd = dwv[gi][kc];
-                    asm volatile("" : "+v"(wd));        // opaque: keeps the 4-dword expansion inside the tile loop (1 VGPR, not 4, per fragment)
+                    Frag af[DPARTS];
 #pragma unroll
-                    for (int d = 0; d < 4; d++) wa[d] = dsel == d ? wd : 0u;
-                    const Frag af = __builtin_bit_cast(Frag, wa);
+                    for (int hl = 0; hl < DPARTS; hl++) {
+                        u32x4 wa;
+                        uint32_t wd = dwv[gi][kc][hl];
+                        asm volatile("" : "+v"(wd));        // opaque: keeps the 4-dword expansion inside the tile loop (1 VGPR, not 4, per fragment)
+#pragma unroll
+                        for (int d = 0; d < 4; d++) wa[d] = dsel == d ? wd : 0u;
+                        af[hl] = __builtin_bit_cast(Frag, wa);
+                    }
 #pragma unroll
                     for (int pi = 0; pi < PW; pi++) {
                         const Frag bf = dtap[kc] >= 0 ? *(const Frag *)(s_in + dpix[pi] + dtap[kc] + g * 16) : M::zero();
-                        dacc[pi] = M::mma(af, bf, dacc[pi]);
+#pragma unroll
+                        for (int hl = 0; hl < DPARTS; hl++) dacc[hl][pi] = M::mma(af[hl], bf, dacc[hl][pi]);
                     }
                 }
 #pragma unroll
                 for (int pi = 0; pi < PW; pi++) {
                     const int pt = NG >= 4 ? pi : wave / NG + pi * (4 / NG);
-                    store_acc<T, LDA>(s_a, ones, dwb4[gi], dacc[pi], g, pt, lane, true);
+                    if constexpr (I8) {
+                        typename M::Acc tot;
+#pragma unroll
+                        for (int r = 0; r < 4; r++) tot[r] = dacc[0][pi][r] * 128 + dacc[DPARTS - 1][pi][r];      // taps = 128*hi + lo
+                        store_acc<T, LDA>(s_a, dwm4[gi], dwb4[gi], tot, g, pt, lane, true);
+                    } else {
+                        store_acc<T, LDA>(s_a, dwm4[gi], dwb4[gi], dacc[0][pi], g, pt, lane, true);
+                    }
                 }
             }
             RF_TRACE(2, 3);
@@ -1341,7 +1371,7 @@ static void dwpw_launch(hipStream_t s, const DwPwParams<T> *p, int tiles_x, int 
     auto kern = dwpw_kernel<T, CIN, COUT, STRIDE, HAS_DW, TH, TW, LAT, PADROW>;
     static int resident_cache[kMaxDevices] = {};
     const int resident = kernel_residency(resident_cache, kern, C::LDS_BYTES);
-    DwPwArgs<T> a{p->in, p->out, p->dw_w, p->dw_b, p->dw_mma, p->pw_w, p->pw_b, p->lat_w, p->lat_b, p->lat_out, p->pw_m, p->lat_m,
+    DwPwArgs<T> a{p->in, p->out, p->dw_w, p->dw_b, p->dw_mma, p->pw_w, p->pw_b, p->lat_w, p->lat_b, p->lat_out, p->pw_m, p->lat_m, p->dw_m,
                   p->hin, p->win, p->hout, p->wout, tiles_x, tiles_y, p->n * tiles_x * tiles_y};
     const int grid = sizeof(T) <= 2 ? persistent_grid(a.nblk, resident) : a.nblk;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), C::LDS_BYTES, s, a);
@@ -1356,7 +1386,7 @@ static int dwpw_padrow() {
 template <typename T, int CIN, int COUT, int STRIDE, bool HAS_DW, int TH, int TW, bool PADROW = false>
 static TileInfo dwpw_dispatch(hipStream_t s, const DwPwParams<T> *p, int hout, int wout) {
     typedef DwPwCfg<T, CIN, COUT, STRIDE, HAS_DW, TH, TW, PADROW> C;
-    if constexpr (!PADROW && sizeof(T) == 2 && HAS_DW && STRIDE == 1 && TW == 8 && CIN >= 32) {
+    if constexpr (!PADROW && sizeof(T) <= 2 && HAS_DW && STRIDE == 1 && TW == 8 && CIN >= 32) {
         if (p && dwpw_padrow()) return dwpw_dispatch<T, CIN, COUT, STRIDE, HAS_DW, TH, TW, true>(s, p, hout, wout);
     }
     int tiles_x = (wout + TW - 1) / TW, tiles_y = (hout + TH - 1) / TH;

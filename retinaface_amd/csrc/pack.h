@@ -65,6 +65,28 @@ RF_HD inline uint32_t dw_mma_dword(int kc, int lane, const uint16_t *w9) {
 RF_HD inline int dw_mma_dword_index(int lane) { return ((lane & 15) & 7) >> 1; }
 constexpr int kDwMmaChunks = 5;
 
+// The same for the int8 engine (v_mfma_i32_16x16x64_i8, K = 64 = 4 taps x 16 channels per chunk, 144 -> 3 chunks): lane l of A
+// fragment (group g, chunk kc) holds row c' = l & 15, columns k = (l >> 4)*16 + e, e < 16, i.e. tap kc*4 + (l >> 4), all 16
+// channels: one non-zero BYTE (e == c') -> dword (c' >> 2) of the 4-dword fragment, byte (c' & 3).  The taps are 15-bit
+// integers w = 128*hi + lo carried by TWO such fragments (hi, lo in [-127, 127]): acc = 128*acc_hi + acc_lo, so the depthwise
+// weights lose nothing to 8-bit quantisation (the round-1 engine ran this stencil in fp32 on the VALU for that reason).
+RF_HD inline uint32_t dw_mma_dword_i8(int kc, int lane, const int8_t *w9) {
+    const int c = lane & 15, tap = kc * 4 + (lane >> 4);
+    if (tap >= 9) return 0u;
+    return (uint32_t)(uint8_t)w9[tap] << (8 * (c & 3));
+}
+RF_HD inline int dw_mma_dword_index_i8(int lane) { return (lane & 15) >> 2; }
+constexpr int kDwMmaChunksI8 = 3;
+// w (real, in output quanta per input quantum) -> 15-bit integer split; scale = amax / kDwI8Range per channel
+constexpr int kDwI8Range = 127 * 128;
+RF_HD inline void dw_i8_split(int w_int, int8_t *hi, int8_t *lo) {
+    int h = (w_int >= 0 ? w_int + 64 : w_int - 64) / 128;          // round to nearest multiple of 128
+    if (h > 127) h = 127;
+    if (h < -127) h = -127;
+    *hi = (int8_t)h;
+    *lo = (int8_t)(w_int - 128 * h);                               // [-64, 64] (up to +-127 only when h saturates; it cannot: |w| <= 16256)
+}
+
 // Stem pointwise (8 -> 16 channels) as ONE v_mfma_f32_16x16x32_f16 with fp32-grade operands: the depthwise result reaches the
 // MFMA as an fp16 pair x = x_hi + x_lo (B operand: K group 0 = x_hi, 1 = x_lo, 2 = x_hi, 3 = 0) and the weight as w = w_hi + w_lo
 // (A operand: K group 0 = w_hi, 1 = w_hi, 2 = w_lo, 3 = 0), so D = w_hi x_hi + w_hi x_lo + w_lo x_hi (the dropped w_lo x_lo term is

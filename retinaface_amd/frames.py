@@ -59,11 +59,14 @@ def _rescale(p: np.ndarray, num: int, den: int) -> np.ndarray:
     return p
 
 
-def synth_frames(h: int, w: int, n: int, config: int = 0, base: np.ndarray = None) -> List[np.ndarray]:
-    """n seeded BGR uint8 frames of h x w with 1..6 pasted faces each."""
+def synth_frames(h: int, w: int, n: int, config: int = 0, base: np.ndarray = None, faces=None) -> List[np.ndarray]:
+    """n seeded BGR uint8 frames of h x w with 1..6 pasted faces each.  `faces` restricts the patches to a subset of the six
+    fixture faces (indices into FACE_BOXES): the int8 calibration set and the held-out int8 parity frames use disjoint subsets."""
     if base is None:
         base = load_base_frame()
     patches = _patches(base)
+    if faces is not None:
+        patches = [patches[i] for i in faces]
     frames = []
     for i in range(n):
         rng = np.random.default_rng(1000 * config + i)

