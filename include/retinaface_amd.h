@@ -83,10 +83,19 @@ typedef struct rf_engine *rf_handle;
 /* RetinaFace::RetinaFace(string &model, string network = "net3", float nms = 0.4)
  * (RetinaFace.h:66, RetinaFace.cpp:205-337).  model_dir holds either <stem>.rfw (this repo's packed
  * model, the analogue of the reference's serialized-engine cache, trtnetbase.cpp:205-243) or
- * <stem>.prototxt + <stem>.caffemodel (+ <stem>.table.int8).  Only network == "net3" has an anchor
- * configuration in the reference (RetinaFace.cpp:245-271); others return RF_ERR_UNSUPPORTED. */
+ * <stem>.prototxt + <stem>.caffemodel (+ <stem>.table.int8).  `network` is the reference's preset name: "net3" (2 anchors per
+ * cell, what the shipped models carry), "net3a" (ratios {1, 1.5}: 4 anchors per cell; needs a model whose heads have 8 / 16 / 40
+ * channels, otherwise RF_ERR_MODEL -- the reference would read past its score blob), and the presets the reference constructs
+ * without anchors ("ssh", "vgg", "net4" ... and unknown names): accepted, every detect call returns zero faces as there. */
 int rf_create(const char *model_dir, const char *network, float nms_threshold,
               const rf_options *options, rf_handle *out_handle);
+
+/* Host-only (no GPU): what the constructor's `network` preset means (RetinaFace.cpp:209-271).  Writes the base anchors
+ * (x1, y1, x2, y2) of one stride (32, 16 or 8) in the reference's order -- ratios outer, scales inner -- and returns their count A:
+ * 2 for "net3", 4 for "net3a", 0 for the presets the reference leaves without ratios / without an anchor configuration ("ssh",
+ * "vgg", "net4", "net5", "net5a", "net6": they construct and then find no faces), RF_ERR_INVALID_ARG for a bad stride.
+ * Names the reference does not know behave like "ssh" there (it prints "network setting error" and goes on): also 0. */
+int rf_preset_anchors(const char *network, int stride, float *out4, int cap_boxes);
 
 /* RetinaFace::~RetinaFace() (RetinaFace.cpp:339-345) -- unlike the reference this frees everything. */
 void rf_destroy(rf_handle h);

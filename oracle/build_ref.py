@@ -70,6 +70,11 @@ def _load() -> C.CDLL:
         f32p, u8p = C.POINTER(C.c_float), C.POINTER(C.c_uint8)
         l.rfref_create.restype = C.c_int
         l.rfref_create.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_float, _FWD, C.c_void_p]
+        l.rfref_create_net.restype = C.c_int
+        l.rfref_create_net.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, _FWD, C.c_void_p]
+        l.rfref_num_levels.restype = C.c_int
+        l.rfref_base_anchors.restype = C.c_int
+        l.rfref_base_anchors.argtypes = [C.c_int, C.POINTER(C.c_float), C.c_int]
         l.rfref_destroy.restype = None
         l.rfref_set_output.restype = None
         l.rfref_set_output.argtypes = [C.c_char_p, C.c_int, f32p, C.c_size_t]
@@ -106,7 +111,7 @@ class ReferenceRetinaFace:
     Only one instance may exist at a time (the harness keeps a single global, like the reference's main.cpp)."""
 
     def __init__(self, net_h: int, net_w: int, forward: Optional[Callable[[np.ndarray], Sequence[Sequence[np.ndarray]]]] = None,
-                 nms: float = 0.4, max_batch: int = 8, model_dir: str = "unused"):
+                 nms: float = 0.4, max_batch: int = 8, model_dir: str = "unused", network: str = "net3", head_anchors: int = 2):
         self._l = _load()
         self.net_h, self.net_w, self.max_batch = net_h, net_w, max_batch
         self._forward = forward
@@ -122,10 +127,20 @@ class ReferenceRetinaFace:
                 self.set_heads(i, outs[i])
 
         self._cb = _FWD(_cb)          # keep alive
-        self._l.rfref_create(model_dir.encode(), net_h, net_w, max_batch, nms, self._cb, None)
+        self._l.rfref_create_net(model_dir.encode(), network.encode(), head_anchors, net_h, net_w, max_batch, nms, self._cb, None)
 
     def close(self):
         self._l.rfref_destroy()
+
+    def num_levels(self) -> int:
+        """Strides the constructor gave an anchor configuration (0 for the fmc != 3 presets)."""
+        return self._l.rfref_num_levels()
+
+    def base_anchors(self, stride: int) -> np.ndarray:
+        """_anchors_fpn["stride<S>"] as built by the constructor for its `network` preset: (A, 4); A = 0 without ratios."""
+        out = np.zeros((16, 4), np.float32)
+        n = self._l.rfref_base_anchors(stride, _fp(out), 16)
+        return out[:max(n, 0)].copy()
 
     def set_heads(self, image: int, heads9: Sequence[np.ndarray]):
         for name, a in zip(HEAD_BLOBS, heads9):

@@ -48,13 +48,13 @@ void TrtRetinaFaceNet::buildTrtContext(const std::string &, const std::string &,
     blobs_.clear();
     static const int strides[3] = {32, 16, 8};     // output order of model/mnet-deconv-0517.prototxt
     static const struct { const char *stem; int c; } kinds[3] = {
-        {"face_rpn_cls_prob_reshape_stride", 4}, {"face_rpn_bbox_pred_stride", 8}, {"face_rpn_landmark_pred_stride", 20}};
+        {"face_rpn_cls_prob_reshape_stride", 2}, {"face_rpn_bbox_pred_stride", 4}, {"face_rpn_landmark_pred_stride", 10}};   // x anchors per cell
     for (int s = 0; s < 3; ++s)
         for (int k = 0; k < 3; ++k) {
             TrtBlob b;
             b.layer_name = std::string(kinds[k].stem) + std::to_string(strides[s]);
             b.layer_index = (int)blobs_.size();
-            b.outputDims.d[0] = kinds[k].c;
+            b.outputDims.d[0] = kinds[k].c * cfg_.head_anchors;
             b.outputDims.d[1] = cfg_.net_h / strides[s];
             b.outputDims.d[2] = cfg_.net_w / strides[s];
             b.outputSize = b.outputDims.c() * b.outputDims.h() * b.outputDims.w();
@@ -110,15 +110,32 @@ extern "C" {
 
 typedef void (*rfref_forward_fn)(const float *input, int n, int h, int w, void *user);
 
-int rfref_create(const char *model_dir, int net_h, int net_w, int max_batch, float nms, rfref_forward_fn fwd, void *user) {
+// `network`: the constructor's preset name (RetinaFace.cpp:209-243).  head_anchors = A of the stand-in engine's output blobs
+// (channels 2A / 4A / 10A; the shipped models have A = 2).
+int rfref_create_net(const char *model_dir, const char *network, int head_anchors, int net_h, int net_w, int max_batch, float nms,
+                     rfref_forward_fn fwd, void *user) {
     delete g_rf;
     g_rf = nullptr;
     RefShimConfig &c = ref_shim_config();
     c.net_h = net_h; c.net_w = net_w; c.max_batch = max_batch; c.forward = fwd; c.user = user;
+    c.head_anchors = head_anchors;
     g_primary = nullptr;
     std::string m(model_dir);
-    g_rf = new RetinaFace(m, "net3", nms);        // RetinaFace.cpp:205
+    g_rf = new RetinaFace(m, network, nms);       // RetinaFace.cpp:205
     return 0;
+}
+int rfref_create(const char *model_dir, int net_h, int net_w, int max_batch, float nms, rfref_forward_fn fwd, void *user) {
+    return rfref_create_net(model_dir, "net3", 2, net_h, net_w, max_batch, nms, fwd, user);
+}
+
+// what the constructor made of the preset: strides with an anchor configuration, and the base anchors of one of them
+int rfref_num_levels() { return (int)g_rf->_feat_stride_fpn.size(); }
+int rfref_base_anchors(int stride, float *out4, int cap_boxes) {
+    auto it = g_rf->_anchors_fpn.find("stride" + std::to_string(stride));
+    if (it == g_rf->_anchors_fpn.end()) return -1;
+    const std::vector<anchor_box> &a = it->second;
+    for (size_t i = 0; i < a.size() && (int)i < cap_boxes; ++i) { out4[4 * i] = a[i].x1; out4[4 * i + 1] = a[i].y1; out4[4 * i + 2] = a[i].x2; out4[4 * i + 3] = a[i].y2; }
+    return (int)a.size();
 }
 
 void rfref_destroy() { delete g_rf; g_rf = nullptr; }

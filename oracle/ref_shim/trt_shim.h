@@ -26,6 +26,7 @@ struct TrtBlob {
 // set by the harness (ref_harness.cpp) before a RetinaFace is constructed
 struct RefShimConfig {
     int net_h = 448, net_w = 448, max_batch = 8;
+    int head_anchors = 2;       // A: the stand-in engine's output blobs carry 2A / 4A / 10A channels (shipped models: 2)
     // input: n x 3 x H x W float, as the reference wrote it; the callee fills blobs through TrtRetinaFaceNet::set_output
     void (*forward)(const float *input, int n, int h, int w, void *user) = nullptr;
     void *user = nullptr;

@@ -77,9 +77,18 @@ def generate_anchors(base_size: int, ratios: Sequence[float], scales: Sequence[i
     return np.array(anchors, dtype=np.float32)         # [A, 4]
 
 
-def base_anchors() -> Dict[int, np.ndarray]:
-    """generate_anchors_fpn, RetinaFace.cpp:105-125, with the net3 cfg of :245-268."""
-    return {s: generate_anchors(ANCHOR_BASE_SIZE, ANCHOR_RATIOS, ANCHOR_SCALES[s])
+# `network` presets of the constructor (RetinaFace.cpp:209-271): only "net3" / "net3a" set ratios; every other name leaves the
+# ratio list empty (-> zero anchors per stride) or, for fmc != 3, the whole cfg empty (-> no strides): either way no faces.
+PRESET_RATIOS = {"net3": (1.0,), "net3a": (1.0, 1.5)}
+
+
+def preset_ratios(network: str) -> Tuple[float, ...]:
+    return PRESET_RATIOS.get(network, ())
+
+
+def base_anchors(ratios: Sequence[float] = ANCHOR_RATIOS) -> Dict[int, np.ndarray]:
+    """generate_anchors_fpn, RetinaFace.cpp:105-125, with the fmc == 3 cfg of :245-268 and the preset's ratios."""
+    return {s: generate_anchors(ANCHOR_BASE_SIZE, ratios, ANCHOR_SCALES[s]).reshape(-1, 4)
             for s in FEAT_STRIDES}
 
 
@@ -96,13 +105,13 @@ def anchors_plane(height: int, width: int, stride: int, base: np.ndarray) -> np.
     return out.reshape(-1, 4)
 
 
-def anchor_offsets(net_h: int, net_w: int) -> Dict[int, int]:
+def anchor_offsets(net_h: int, net_w: int, anchors_per_cell: int = 2) -> Dict[int, int]:
     """Global anchor index = offset(stride) + a*h*w + iy*w + ix, strides visited 32,16,8
     (visiting order of RetinaFace.cpp:667,:1000)."""
     offs, acc = {}, 0
     for s in FEAT_STRIDES:
         offs[s] = acc
-        acc += 2 * (net_h // s) * (net_w // s)
+        acc += anchors_per_cell * (net_h // s) * (net_w // s)
     offs["total"] = acc  # type: ignore[index]
     return offs
 
@@ -194,12 +203,12 @@ class Detection:
 
 
 def decode(heads: Dict[str, np.ndarray], net_h: int, net_w: int, threshold: float,
-           image: int = 0) -> List[Detection]:
+           image: int = 0, ratios: Sequence[float] = ANCHOR_RATIOS) -> List[Detection]:
     """The threshold scan + regression loop, RetinaFace.cpp:666-724 (== :999-1072).
     `heads` maps the 9 output blob names to NCHW arrays; anchors come from anchors_plane
     on the blob's own H x W as at :301 / :1035."""
     thr = f32(threshold)
-    base = base_anchors()
+    base = base_anchors(ratios)
     out: List[Detection] = []
     goff = 0
     for s in FEAT_STRIDES:
@@ -211,8 +220,11 @@ def decode(heads: Dict[str, np.ndarray], net_h: int, net_w: int, threshold: floa
         score = prob.reshape(-1)[prob.size // 2:]            # second half of the blob, :671-674
         bbox_f = bbox.reshape(-1)
         lmk_f = lmk.reshape(-1)
+        num_anchor = base[s].shape[0]                        # _num_anchors[key], :297
+        if num_anchor == 0:
+            continue                                         # a preset without ratios: the a-loop of :684 runs zero times
+        assert prob.shape[0] == 2 * num_anchor, "the reference would read past the score blob here"
         anchors = anchors_plane(h, w, s, base[s])
-        num_anchor = base[s].shape[0]
         for idx in np.nonzero(score > thr)[0]:               # same visiting order as the a/j loops
             a, j = divmod(int(idx), count)
             conf = score[j + count * a]

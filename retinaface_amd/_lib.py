@@ -38,6 +38,7 @@ _PP = C.POINTER
 SYMBOLS = {
     "rf_abi_version": (C.c_int, []),
     "rf_create": (C.c_int, [C.c_char_p, C.c_char_p, C.c_float, _PP(rf_options), _PP(C.c_void_p)]),
+    "rf_preset_anchors": (C.c_int, [C.c_char_p, C.c_int, _PP(C.c_float), C.c_int]),
     "rf_destroy": (None, [C.c_void_p]),
     "rf_last_error": (C.c_char_p, [C.c_void_p]),
     "rf_get_net_size": (C.c_int, [C.c_void_p, _PP(C.c_int), _PP(C.c_int), _PP(C.c_int)]),

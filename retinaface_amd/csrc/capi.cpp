@@ -83,6 +83,17 @@ int rf_create(const char *model_dir, const char *network, float nms_threshold, c
     });
 }
 
+int rf_preset_anchors(const char *network, int stride, float *out4, int cap_boxes) {
+    if (!network || (stride != 32 && stride != 16 && stride != 8) || (cap_boxes > 0 && !out4)) return RF_ERR_INVALID_ARG;
+    std::vector<float> ratios;
+    (void)rf::network_preset(network, &ratios);
+    float base[4][4] = {};
+    rf::preset_base_anchors(ratios, stride == 32 ? 0 : stride == 16 ? 1 : 2, base);
+    const int a = 2 * (int)ratios.size();
+    for (int i = 0; i < a && i < cap_boxes; i++) memcpy(out4 + 4 * i, base[i], 4 * sizeof(float));
+    return a;
+}
+
 void rf_destroy(rf_handle h) { delete h; }
 
 const char *rf_last_error(rf_handle h) { return h ? h->error.c_str() : g_create_error.c_str(); }

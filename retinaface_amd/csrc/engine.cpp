@@ -89,19 +89,45 @@ template <typename T> std::vector<T> pack_gemm(const std::vector<float> &w, int 
 template <typename T> constexpr int mma_k() { return sizeof(T) == 1 ? 64 : sizeof(T) == 2 ? 32 : 4; }
 template <typename T> constexpr int mma_kpl() { return sizeof(T) == 1 ? 16 : sizeof(T) == 2 ? 8 : 1; }
 
-// base anchor of generate_anchors(base_size 16, ratios {1.0}, scales {scale}) -- RetinaFace.cpp:34-103
-void base_anchor(int scale, float out[4]) {
-    float w = 15.f - 0.f + 1, h = 15.f - 0.f + 1;
+// one base anchor of generate_anchors(base_size 16, ratios {.., ratio, ..}, scales {.., scale, ..}) -- RetinaFace.cpp:9-103, with
+// the reference's float / double rounding points (`0.5 * (w - 1)` is double arithmetic stored to float; sqrt / round on floats)
+void base_anchor(int scale, float ratio, float out[4]) {
+    float w = 15.f - 0.f + 1, h = 15.f - 0.f + 1;                                   // _whctrs of (0, 0, 15, 15)
     float xc = 0.f + 0.5 * (w - 1), yc = 0.f + 0.5 * (h - 1);
-    float size = w * h, sc = size / 1.0f;
-    float w2 = std::round(std::sqrt(sc)), h2 = std::round(w2 * 1.0f);
+    float size = w * h, sc = size / ratio;                                          // _ratio_enum, :34-51
+    float w2 = std::round(std::sqrt(sc)), h2 = std::round(w2 * ratio);
     float rx1 = xc - 0.5 * (w2 - 1), ry1 = yc - 0.5 * (h2 - 1), rx2 = xc + 0.5 * (w2 - 1), ry2 = yc + 0.5 * (h2 - 1);
-    w = rx2 - rx1 + 1; h = ry2 - ry1 + 1;
+    w = rx2 - rx1 + 1; h = ry2 - ry1 + 1;                                           // _scale_enum, :53-68
     xc = rx1 + 0.5 * (w - 1); yc = ry1 + 0.5 * (h - 1);
     w = w * scale; h = h * scale;
     out[0] = xc - 0.5 * (w - 1); out[1] = yc - 0.5 * (h - 1);
     out[2] = xc + 0.5 * (w - 1); out[3] = yc + 0.5 * (h - 1);
 }
+
+}  // namespace
+
+// The reference constructor's `network` presets (RetinaFace.cpp:209-271).  Only fmc == 3 presets get an anchor configuration
+// (strides 32 / 16 / 8, scales {32,16} {8,4} {2,1}, base 16) and only "net3" / "net3a" give it ratios: "ssh" / "vgg" set pixel
+// means that are never applied and leave `_ratio` empty, net4 / net5 / net5a / net6 print "please reconfig anchor_cfg", any
+// other name prints "network setting error" -- all of those construct fine and then find no faces, because post-processing
+// loops over zero anchors.  Returns false for names the reference does not know (its behaviour is the same as for "ssh").
+bool network_preset(const std::string &network, std::vector<float> *ratios) {
+    ratios->clear();
+    if (network == "net3") { *ratios = {1.0f}; return true; }
+    if (network == "net3a") { *ratios = {1.0f, 1.5f}; return true; }
+    for (const char *k : {"ssh", "vgg", "net4", "net5", "net5a", "net6"})
+        if (network == k) return true;
+    return false;
+}
+
+void preset_base_anchors(const std::vector<float> &ratios, int level, float out[][4]) {
+    static const int scales[3][2] = {{32, 16}, {8, 4}, {2, 1}};
+    int a = 0;
+    for (float r : ratios)                              // generate_anchors: ratios outer, scales inner (:86-91)
+        for (int s = 0; s < 2; s++) base_anchor(scales[level][s], r, out[a++]);
+}
+
+namespace {
 
 // One lane = one independent copy of everything a batch touches while in flight: stream(s), activation buffers,
 // candidate buffers, pinned host descriptor / result blocks and the captured hipGraphs.  Batches on different
@@ -109,9 +135,11 @@ void base_anchor(int scale, float out[4]) {
 template <typename T>
 class EngineImpl final : public Engine {
 public:
-    EngineImpl(const Plan &plan, float nms, const EngineOptions &opt) {
+    EngineImpl(const Plan &plan, float nms, const EngineOptions &opt, const std::vector<float> &ratios) {
         opt_ = opt;
         nms_threshold_ = nms;
+        ratios_ = ratios;
+        na_ = 2 * (int)ratios.size();              // anchors per cell: 2 scales x the preset's ratios; 0 = nothing to decode
         net_h_ = opt.net_h > 0 ? opt.net_h : plan.net_h;
         net_w_ = opt.net_w > 0 ? opt.net_w : plan.net_w;
         if (net_h_ <= 0 || net_w_ <= 0 || net_h_ % 32 || net_w_ % 32)
@@ -132,6 +160,7 @@ public:
         RF_HIP(hipGetDeviceCount(&ndev));
         if (device_ < 0 || device_ >= ndev) throw ArgError("device ordinal " + std::to_string(device_) + " out of range (" + std::to_string(ndev) + " devices)");
         DeviceGuard guard(device_);                  // the caller's current device is put back when construction ends
+        head_a_ = plan.anchors_per_cell;
         upload_weights(plan);
         lanes_.resize(opt_.lanes);
         for (auto &l : lanes_) build_lane(l, plan);
@@ -262,7 +291,7 @@ public:
         DeviceGuard guard(device_);
         static const char *kinds[3] = {"face_rpn_cls_prob_reshape_stride", "face_rpn_bbox_pred_stride",
                                        "face_rpn_landmark_pred_stride"};
-        static const int chans[3] = {4, 8, 20};
+        const int chans[3] = {2 * head_a_, 4 * head_a_, 10 * head_a_};
         Lane &l = lanes_[last_lane_];
         for (int si = 0; si < 3; si++)
             for (int k = 0; k < 3; k++) {
@@ -884,22 +913,22 @@ private:
             hp.in = cat; hp.w = arena_.ptr<T>(ssh_w_[i][3].w); hp.b = arena_.ptr<float>(ssh_w_[i][3].b);
             hp.m = mult_ptr(ssh_w_[i][3]);
             hp.n = 0; hp.h = fh; hp.w_ = fw; hp.stride = strides_[i]; hp.anchor_offset = anchor_off;
-            static const int scales[3][2] = {{32, 16}, {8, 4}, {2, 1}};
-            base_anchor(scales[i][0], hp.base[0]);
-            base_anchor(scales[i][1], hp.base[1]);
+            hp.num_anchors = na_;
+            memset(hp.base, 0, sizeof(hp.base));
+            preset_base_anchors(ratios_, i, hp.base);
             hp.net_h = H; hp.net_w = W; hp.params = L.d_params;
             hp.cand = L.d_cand; hp.cand_count = L.d_cand_count; hp.cap = opt_.max_candidates;
             hp.dump_prob = hp.dump_bbox = hp.dump_lmk = nullptr;
             if (opt_.keep_outputs) {
-                static const int chans[3] = {4, 8, 20};
+                const int chans[3] = {2 * head_a_, 4 * head_a_, 10 * head_a_};
                 for (int k = 0; k < 3; k++) L.d_dump[i][k] = dalloc<float>((size_t)mb * chans[k] * fh * fw);
                 hp.dump_prob = L.d_dump[i][0]; hp.dump_bbox = L.d_dump[i][1]; hp.dump_lmk = L.d_dump[i][2];
             }
             op_h.name += (op_h.name.empty() ? "" : " | ") + m.head.name;
             op_h.alg_elems_in += 3.0 * 64 * fh * fw;
-            op_h.alg_elems_out += 32.0 * fh * fw;
+            op_h.alg_elems_out += 16.0 * head_a_ * fh * fw;
             op_h.macs += m.head.macs_per_out_pixel() * fh * fw;
-            anchor_off += 2 * fh * fw;
+            anchor_off += na_ * fh * fw;
         }
         op_a.launch = [lv_a](hipStream_t s, int n) { Level3 q = lv_a; for (auto &p : q.p) p.n = n; launch_conv3x3<T>(s, q.p, 3); };
         op_b.launch = [lv_b](hipStream_t s, int n) { Level3 q = lv_b; for (auto &p : q.p) p.n = n; launch_conv3x3<T>(s, q.p, 3); };
@@ -1205,6 +1234,8 @@ private:
 
     // ------------------------------------------------------------------------------------------ state
     int device_ = 0;
+    std::vector<float> ratios_;                // the network preset's anchor ratios (empty: a preset without anchors)
+    int na_ = 2, head_a_ = 2;                  // anchors per cell the preset decodes / the model's heads carry
     std::unique_ptr<ParallelCopier> copier_;
     std::vector<ParallelCopier::Job> copy_jobs_;
     struct HostRange { uintptr_t base; size_t bytes; bool owned; };
@@ -1239,19 +1270,22 @@ private:
 
 std::unique_ptr<Engine> Engine::create_single(const std::string &model_dir, const std::string &network, float nms,
                                               const EngineOptions &opt) {
-    // Only "net3" has an anchor configuration in the reference (RetinaFace.cpp:215-217, 245-271); the other
-    // presets print "please reconfig anchor_cfg" and leave cfg empty.
-    if (network != "net3") throw Unsupported("network preset '" + network + "' has no anchor configuration (only net3)");
+    std::vector<float> ratios;
+    (void)network_preset(network, &ratios);       // unknown names behave like "ssh": constructed, no anchors (RetinaFace.cpp:237-239)
     Model model = load_model_dir(model_dir, opt.model_stem);      // host-only steps first: their errors do not need a GPU
     Plan plan = compile_plan(model);
+    if (!ratios.empty() && 2 * (int)ratios.size() != plan.anchors_per_cell)
+        // the reference would index past the end of the score blob here (RetinaFace.cpp:669-694 with _num_anchors != blob channels / 2)
+        throw ModelError("network preset '" + network + "' decodes " + std::to_string(2 * ratios.size()) + " anchors per cell but the model's "
+                         "heads carry " + std::to_string(plan.anchors_per_cell));
     if (opt.precision == RF_PRECISION_INT8 && plan.int8_scales.empty())
         throw Unsupported("int8 precision needs a calibration table (<stem>.table.int8, or scales inside the .rfw)");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) throw HipError("no HIP device available");
     switch (opt.precision) {
-        case RF_PRECISION_FP16: return std::unique_ptr<Engine>(new EngineImpl<half_t>(plan, nms, opt));
-        case RF_PRECISION_FP32: return std::unique_ptr<Engine>(new EngineImpl<float>(plan, nms, opt));
-        case RF_PRECISION_INT8: return std::unique_ptr<Engine>(new EngineImpl<int8_t>(plan, nms, opt));
+        case RF_PRECISION_FP16: return std::unique_ptr<Engine>(new EngineImpl<half_t>(plan, nms, opt, ratios));
+        case RF_PRECISION_FP32: return std::unique_ptr<Engine>(new EngineImpl<float>(plan, nms, opt, ratios));
+        case RF_PRECISION_INT8: return std::unique_ptr<Engine>(new EngineImpl<int8_t>(plan, nms, opt, ratios));
         default: throw ArgError("unknown precision");
     }
 }

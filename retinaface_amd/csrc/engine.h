@@ -51,6 +51,11 @@ struct OpInfo {
     std::function<void(hipStream_t, int)> launch;   // (stream, n_images)
 };
 
+// the constructor's `network` presets (RetinaFace.cpp:209-271): anchor ratios of a preset (empty = no anchors), and the base
+// anchors of FPN level 0 / 1 / 2 (strides 32 / 16 / 8) for those ratios, 2 per ratio
+bool network_preset(const std::string &network, std::vector<float> *ratios);
+void preset_base_anchors(const std::vector<float> &ratios, int level, float out[][4]);
+
 class Engine {
 public:
     // opt.devices.size() > 1 gives the image-sharding multi-device engine (multi.cpp), otherwise one single-device engine

@@ -117,10 +117,11 @@ template <typename T> void launch_conv3x3(hipStream_t s, const Conv3Params<T> *l
 template <typename T>
 struct HeadParams {
     const T *in;                          // [n][h][w][64] = rf_cX_det_concat_relu
-    const T *w; const float *b;           // packed 32x64, bias[32]: cls 0..3, bbox 4..11, landmark 12..31
+    const T *w; const float *b;           // packed 16A x 64, bias[16A]: cls [0, 2A) (background A | foreground A), bbox [2A, 6A), landmark [6A, 16A)
     const float *m = nullptr;             // int8: per-channel dequantisation multiplier (w_scale * in_scale)
     int n, h, w_, stride, anchor_offset;  // anchor_offset = global index of (a=0, iy=0, ix=0) of this stride
-    float base[2][4];                     // the 2 base anchors of this stride (RetinaFace.cpp:34-103)
+    int num_anchors = 2;                  // A: anchors per cell, 2 ("net3") or 4 ("net3a"); 0 = a preset without anchors: no candidates
+    float base[4][4];                     // the A base anchors of this stride (RetinaFace.cpp:34-103)
     int net_h, net_w;
     const RunParams *params;
     Candidate *cand; int *cand_count; int cap;

@@ -1817,9 +1817,8 @@ template TileInfo conv3x3_tile_info<int8_t>(int, int, int, int);
 //   One launch covers the heads of all three strides.
 // =============================================================================================
 constexpr int HEAD_P = 64;          // pixels per workgroup (flat, row-major)
-constexpr int HEAD_LDO = 33;        // fp32 result tile row stride (32 + 1: conflict-free column reads)
 
-__device__ __forceinline__ void decode_anchor(const float *__restrict__ o /*32 head outputs of this pixel*/, int a,
+__device__ __forceinline__ void decode_anchor(const float *__restrict__ o /*16A head outputs of this pixel*/, int a, int na,
                                               float ax1, float ay1, float ax2, float ay2, int net_w, int net_h,
                                               float conf, int anchor_index, Candidate *dst) {
 #pragma clang fp contract(off)
@@ -1828,7 +1827,7 @@ __device__ __forceinline__ void decode_anchor(const float *__restrict__ o /*32 h
     const float height = ay2 - ay1 + 1.f;
     const float ctr_x = (float)((double)ax1 + 0.5 * ((double)width - 1.0));
     const float ctr_y = (float)((double)ay1 + 0.5 * ((double)height - 1.0));
-    const float *d = o + 4 + a * 4;
+    const float *d = o + 2 * na + a * 4;
     const float pred_ctr_x = d[0] * width + ctr_x;
     const float pred_ctr_y = d[1] * height + ctr_y;
     const float pred_w = expf(d[2]) * width;
@@ -1845,7 +1844,7 @@ __device__ __forceinline__ void decode_anchor(const float *__restrict__ o /*32 h
     dst->score = conf;
     dst->x1 = x1; dst->y1 = y1; dst->x2 = x2; dst->y2 = y2;
     // landmark_pred, RetinaFace.cpp:418-432 (not clipped)
-    const float *l = o + 12 + a * 10;
+    const float *l = o + 6 * na + a * 10;
 #pragma unroll
     for (int k = 0; k < 5; k++) {
         dst->px[k] = l[2 * k] * width + ctr_x;
@@ -1858,7 +1857,7 @@ template <typename T>
 struct HeadLevel {
     const T *in; const T *w; const float *b; const float *m;
     float *dump_prob, *dump_bbox, *dump_lmk;
-    float base[2][4];
+    float base[4][4];
     int hw, w_, stride, anchor_offset, blocks_per_image, blk_begin;
 };
 template <typename T>
@@ -1870,14 +1869,14 @@ struct HeadArgs {
     int nblk;
 };
 
-template <typename T>
+template <typename T, int NA>
 __global__ __launch_bounds__(kThreads) void head_kernel(HeadArgs<T> a) {
     typedef typename Vec<T>::type V;
     typedef Mma<T> M;
-    constexpr int VEC = Vec<T>::N, CIN = 64, COUT = 32, P = HEAD_P, LDA = lds_row<T>(CIN);
+    constexpr int VEC = Vec<T>::N, CIN = 64, COUT = 16 * NA, P = HEAD_P, LDA = lds_row<T>(CIN), LDOH = COUT + 1;
     constexpr int CPV = CIN / VEC;
     __shared__ __attribute__((aligned(16))) T s_a[P * LDA];
-    __shared__ float s_o[P * HEAD_LDO];
+    __shared__ float s_o[P * LDOH];               // fp32 result tile, row pitch 16A + 1: conflict-free column reads
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -1889,7 +1888,7 @@ __global__ __launch_bounds__(kThreads) void head_kernel(HeadArgs<T> a) {
     const int p0 = (bid % L.blocks_per_image) * P;
     const int hw = L.hw;
 
-    constexpr int NT = COUT / 16, PT = P / 16;       // 2 x 4 tiles: waves = 2 (cout) x 2 (pixel halves)
+    constexpr int NT = COUT / 16, PT = P / 16;       // A = 2: waves = 2 (cout) x 2 (pixel halves); A = 4: 4 (cout) x 1
     typedef WaveSplit<NT, PT> WS;
     constexpr int KCH = CIN / M::K;
     const int wn = wave % WS::WN, wp = wave / WS::WN;
@@ -1920,36 +1919,37 @@ __global__ __launch_bounds__(kThreads) void head_kernel(HeadArgs<T> a) {
         const int p = acc_pixel(wp + j * WS::WP, lane);
         const int c0 = acc_cout(wn, lane, 0);
 #pragma unroll
-        for (int r = 0; r < 4; r++) s_o[p * HEAD_LDO + c0 + r] = fmaf((float)acc[0][j][r], mult[r], bias[r]);
+        for (int r = 0; r < 4; r++) s_o[p * LDOH + c0 + r] = fmaf((float)acc[0][j][r], mult[r], bias[r]);
     }
     __syncthreads();
 
-    if (tid < 2 * P) {
+    if (tid < NA * P) {
         const int p = tid % P, an = tid / P;          // anchor index a is wave-uniform
         const int gp = p0 + p;
         if (gp < hw) {
-            const float *o = s_o + p * HEAD_LDO;
-            // Softmax over the pair (channel a, channel 2+a): Caffe subtracts the max, exponentiates, normalises
-            const float s0 = o[an], s1 = o[2 + an];
+            const float *o = s_o + p * LDOH;
+            // Softmax over the pair (channel a, channel A+a) -- Reshape (2, -1) puts the A background maps first, then the A
+            // foreground maps: Caffe subtracts the max, exponentiates, normalises
+            const float s0 = o[an], s1 = o[NA + an];
             const float m = fmaxf(s0, s1);
             const float e0 = expf(s0 - m), e1 = expf(s1 - m);
             const float sum = e0 + e1;
             const float conf = e1 / sum;
             if (L.dump_prob) {
                 const size_t shw = (size_t)hw;
-                L.dump_prob[((size_t)img * 4 + an) * shw + gp] = e0 / sum;
-                L.dump_prob[((size_t)img * 4 + 2 + an) * shw + gp] = conf;
+                L.dump_prob[((size_t)img * 2 * NA + an) * shw + gp] = e0 / sum;
+                L.dump_prob[((size_t)img * 2 * NA + NA + an) * shw + gp] = conf;
 #pragma unroll
-                for (int c = 0; c < 4; c++) L.dump_bbox[((size_t)img * 8 + an * 4 + c) * shw + gp] = o[4 + an * 4 + c];
+                for (int c = 0; c < 4; c++) L.dump_bbox[((size_t)img * 4 * NA + an * 4 + c) * shw + gp] = o[2 * NA + an * 4 + c];
 #pragma unroll
-                for (int c = 0; c < 10; c++) L.dump_lmk[((size_t)img * 20 + an * 10 + c) * shw + gp] = o[12 + an * 10 + c];
+                for (int c = 0; c < 10; c++) L.dump_lmk[((size_t)img * 10 * NA + an * 10 + c) * shw + gp] = o[6 * NA + an * 10 + c];
             }
             if (conf > threshold) {                    // "if (conf <= threshold) continue", RetinaFace.cpp:693
                 const int iy = gp / L.w_, ix = gp % L.w_;
                 const float sx = (float)(ix * L.stride), sy = (float)(iy * L.stride);
                 const int slot = atomicAdd(&a.cand_count[img], 1);
                 if (slot < a.cap)
-                    decode_anchor(o, an, L.base[an][0] + sx, L.base[an][1] + sy, L.base[an][2] + sx, L.base[an][3] + sy,
+                    decode_anchor(o, an, NA, L.base[an][0] + sx, L.base[an][1] + sy, L.base[an][2] + sx, L.base[an][3] + sy,
                                   a.net_w, a.net_h, conf, L.anchor_offset + an * hw + gp,
                                   a.cand + (size_t)img * a.cap + slot);
             }
@@ -1966,7 +1966,7 @@ template <typename T> void launch_head(hipStream_t s, const HeadParams<T> *level
         HeadLevel<T> &L = a.lv[l];
         L.in = p.in; L.w = p.w; L.b = p.b; L.m = p.m;
         L.dump_prob = p.dump_prob; L.dump_bbox = p.dump_bbox; L.dump_lmk = p.dump_lmk;
-        for (int i = 0; i < 2; i++) for (int j = 0; j < 4; j++) L.base[i][j] = p.base[i][j];
+        for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) L.base[i][j] = p.base[i][j];
         L.hw = p.h * p.w_; L.w_ = p.w_; L.stride = p.stride; L.anchor_offset = p.anchor_offset;
         L.blocks_per_image = (L.hw + HEAD_P - 1) / HEAD_P;
         L.blk_begin = l < nlevels ? blk : 0x7fffffff;
@@ -1976,7 +1976,12 @@ template <typename T> void launch_head(hipStream_t s, const HeadParams<T> *level
     a.net_h = p0.net_h; a.net_w = p0.net_w; a.params = p0.params;
     a.cand = p0.cand; a.cand_count = p0.cand_count; a.cap = p0.cap;
     a.nblk = blk;
-    hipLaunchKernelGGL(head_kernel<T>, dim3(a.nblk), dim3(kThreads), 0, s, a);
+    // a preset without an anchor configuration (RetinaFace.cpp:225-271: "ssh", "vgg", net4/5/6 ...) has nothing to decode: the
+    // reference's post-processing loops over zero anchors, so no candidate is ever produced
+    if (p0.num_anchors == 0 || a.nblk == 0) return;
+    if (p0.num_anchors == 4) hipLaunchKernelGGL((head_kernel<T, 4>), dim3(a.nblk), dim3(kThreads), 0, s, a);
+    else if (p0.num_anchors == 2) hipLaunchKernelGGL((head_kernel<T, 2>), dim3(a.nblk), dim3(kThreads), 0, s, a);
+    else throw LaunchUnsupported("heads: 2 or 4 anchors per cell");
 }
 template void launch_head<half_t>(hipStream_t, const HeadParams<half_t> *, int);
 template void launch_head<float>(hipStream_t, const HeadParams<float> *, int);

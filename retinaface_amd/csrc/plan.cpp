@@ -222,8 +222,13 @@ Plan compile_plan(const Model &m) {
         FoldedConv cls = fold_conv(m, "face_rpn_cls_score_" + st, false);
         FoldedConv box = fold_conv(m, "face_rpn_bbox_pred_" + st, false);
         FoldedConv lmk = fold_conv(m, "face_rpn_landmark_pred_" + st, false);
-        expect(cls.k == 1 && cls.cin == 64 && cls.cout == 4 && box.cout == 8 && lmk.cout == 20,
-               "heads of " + st + " are not 1x1 64->4/8/20");
+        // A anchors per cell: cls 2A (background A | foreground A), bbox 4A, landmark 10A.  A = 2 for the models the reference
+        // ships (network "net3"); "net3a" (ratios {1, 1.5}, RetinaFace.cpp:219-221) needs a model with A = 4.
+        const int A = cls.cout / 2;
+        expect(cls.k == 1 && cls.cin == 64 && (A == 2 || A == 4) && cls.cout == 2 * A && box.cout == 4 * A && lmk.cout == 10 * A,
+               "heads of " + st + " are not 1x1 64 -> 2A / 4A / 10A with A = 2 or 4");
+        expect(p.anchors_per_cell == 0 || p.anchors_per_cell == A, "the strides disagree on the number of anchors per cell");
+        p.anchors_per_cell = A;
         expect(m.get("face_rpn_cls_score_" + st).bottoms.at(0) == cat_out &&
                    m.get("face_rpn_bbox_pred_" + st).bottoms.at(0) == cat_out &&
                    m.get("face_rpn_landmark_pred_" + st).bottoms.at(0) == cat_out, "heads of " + st + " do not read " + cat_out);

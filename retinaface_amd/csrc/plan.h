@@ -29,7 +29,7 @@ struct SshModule {           // one per stride, SURVEY.md App. A "SSH context mo
     FoldedConv conv_a;       // det_conv1 (32, ReLU comes from concat_relu) || context_conv1 (16, ReLU)   64 -> 48
     FoldedConv conv_b;       // context_conv2 (16) || context_conv3_1 (16, ReLU)                            16 -> 32
     FoldedConv conv_c;       // context_conv3_2 (16)                                                        16 -> 16
-    FoldedConv head;         // cls_score (4) || bbox_pred (8) || landmark_pred (20), 1x1                   64 -> 32
+    FoldedConv head;         // cls_score (2A) || bbox_pred (4A) || landmark_pred (10A), 1x1                64 -> 16A
 };
 
 struct Plan {
@@ -40,6 +40,7 @@ struct Plan {
     FoldedConv lateral[3];                // [0] rf_c3_lateral (256->64), [1] rf_c2_lateral (128->64), [2] rf_c1_red_conv (64->64)
     FoldedConv aggr[2];                   // [0] rf_c2_aggr, [1] rf_c1_aggr  (input = lateral + bilinear x2 upsample of the coarser level)
     SshModule ssh[3];                     // strides 32, 16, 8
+    int anchors_per_cell = 0;             // A: head channels are 2A | 4A | 10A (2 for the shipped models)
     // TensorRT calibration cache: tensor (blob) name -> per-tensor activation scale, real ~= q * scale (SURVEY App. B.7;
     // consumed by the int8 engine).  Empty when the model carries no table.
     std::vector<std::pair<std::string, float>> int8_scales;

@@ -185,28 +185,62 @@ def _match(got, ref_rows):
     return [max([iou_plus1(g.rect, r[1:5]) for g in got] or [0.0]) for r in ref_rows]
 
 
+# int8 bars per model (per face, vs the fp32 CPU oracle): minimum IoU, minimum anchor-index agreement rate over the set, |dscore|.
+#   0517  : the TensorRT cache the reference ships (per tensor, calibrated by its authors at 320 x 320 on their own data).
+#   mnet25: the reference ships none; assets/mnet25.table.int8 comes from tools/calibrate_int8.py --per-channel --rule amax on 48
+#           frames that show only fixture faces 0, 2, 4 (the others greyed out) -- the held-out frames below use faces 1, 3, 5 and
+#           other seeds.  Per-channel activation scales are what lifts the worst face from 0.90 (round 1, per tensor) to >= 0.95.
+INT8_BAR = {"mnet-deconv-0517": dict(iou=0.93, heldout_iou=0.87, anchors=0.78, score=0.03),
+            "mnet25": dict(iou=0.95, heldout_iou=0.95, anchors=0.90, score=0.03)}
+
+
+def _int8_stats(res, refs):
+    """Per set: (same face count everywhere, worst per-face IoU, anchor agreement rate, max |dscore|)."""
+    ious, same_anchor, faces, ds, same = [], 0, 0, 0.0, True
+    for got, ref in zip(res, refs):
+        same &= len(got) == len(ref)
+        for r_rect, r_score, r_idx in ref:
+            faces += 1
+            best = max(got, key=lambda a: iou_plus1(a.rect, r_rect)) if got else None
+            ious.append(iou_plus1(best.rect, r_rect) if best else 0.0)
+            same_anchor += bool(best) and best.anchor_index == r_idx
+            ds = max(ds, abs(best.score - r_score) if best else 1.0)
+    return same, min(ious), same_anchor / max(faces, 1), ds
+
+
 @pytest.mark.parametrize("stem", STEMS)
-def test_int8_engine_against_the_fp32_oracle(rfa, oracles, base_frame, crop448, stem):
-    """int8 engine (TensorRT-style: per-tensor activation scales from a calibration table, per-channel weight scales, i8 MFMA).
-    Quantisation noise moves boxes by ~1 px and can hand the NMS win to a neighbouring anchor, so the bar is stated per face,
-    not per anchor: same number of faces, every oracle face matched with IoU >= 0.93, scores within 0.03.  0517 uses the
-    TensorRT table the reference ships.  mnet25 has none in the reference: assets/mnet25.table.int8 is generated by
-    tools/calibrate_int8.py (99.999th-percentile rule on 48 calibration frames; measured worst IoU 0.916 on synthetic frames,
-    0.977 on the reference image -- with the borrowed 0517 table it was 0.912 / 0.903), bar IoU >= 0.90."""
+def test_int8_engine_against_the_fp32_oracle(rfa, oracles, base_frame, stem):
+    """int8 engine (TensorRT-style symmetric quantisation, i8 MFMA for every contraction incl. the depthwise stencil with 15-bit
+    taps).  Quantisation noise moves boxes by ~1 px and can hand the NMS win to a neighbouring anchor, so the bar is per face:
+    same number of faces on every frame, every oracle face matched above the model's IoU bar, and the anchor-index agreement
+    rate is reported and bounded (INT8_BAR).  Three sets: the golden synthetic batch, HELD-OUT synthetic frames (faces and seeds
+    the calibration never saw) at batch 32 = BASELINE configs[2]'s shape, and the reference photo at 1280 x 896."""
     from retinaface_amd.frames import synth_frames
+    bar = INT8_BAR[stem]
     det = engine(rfa, stem, INT8, (448, 448))
     g = golden(f"synth448_{stem}.npz")
     res = det.detectBatchImages(synth_frames(448, 448, 8, config=1), 0.5)
-    min_iou = 0.93 if stem == "mnet-deconv-0517" else 0.90
-    for i in range(8):
-        ref = g[f"det05_{i}"]
-        assert len(res[i]) == len(ref), (i, len(res[i]), len(ref))
-        assert min(_match(res[i], ref)) >= min_iou
-        assert max(abs(a.score - r[0]) for a, r in zip(res[i], ref)) <= 0.03
+    refs = [[(r[1:5], r[0], int(i)) for r, i in zip(g[f"det05_{k}"], g[f"idx05_{k}"])] for k in range(8)]
+    same, worst, agree, ds = _int8_stats(res, refs)
+    assert same and worst >= bar["iou"] and agree >= bar["anchors"] and ds <= bar["score"], (stem, same, worst, agree, ds)
+    # held-out, batch 32 in one call (configs[2]: int8, 448 x 448, batch 32)
+    held = synth_frames(448, 448, 32, config=300, faces=[1, 3, 5])
+    det32 = engine(rfa, stem, INT8, (448, 448), max_batch=32)
+    res = det32.detectBatchImages(held, 0.5)
+    refs = []
+    for f in held:
+        o = oracles[stem].detect(f, 0.5, 0.4, net_hw=(448, 448))
+        refs.append([(d.rect, d.score, d.anchor_index) for d in o.detections])
+    same, worst, agree, ds = _int8_stats(res, refs)
+    assert same and worst >= bar["heldout_iou"] and agree >= bar["anchors"] and ds <= bar["score"], (stem, same, worst, agree, ds)
+    # batch composition must not matter in int8 either: the same frames through the batch-8 engine
+    res8 = det.detectBatchImages(held, 0.5)
+    assert _key(res8) == _key(res)
     big = engine(rfa, stem, INT8, (896, 1280), max_batch=2)
     got = big.detect(base_frame, 0.5)
-    ref = golden(f"fixture_{stem}.npz")["det"]
-    assert len(got) == 6 and min(_match(got, ref)) >= min_iou
+    gf = golden(f"fixture_{stem}.npz")
+    same, worst, agree, ds = _int8_stats([got], [[(r[1:5], r[0], int(i)) for r, i in zip(gf["det"], gf["det_idx"])]])
+    assert same and len(got) == 6 and worst >= bar["iou"] and ds <= bar["score"], (stem, worst, agree, ds)
 
 
 def test_int8_layers_stay_within_quantisation_noise(rfa, oracles, crop448):
@@ -480,6 +514,74 @@ def test_device_frames_unaligned_pointer_odd_step_and_roi(rfa, oracles, base_fra
         roi_ptr = dbig.data_ptr() + (40 * big.shape[1] + 30) * 3
         compare(det.detect_device([roi_ptr], [hw[0]], [hw[1]], 0.5, steps=[big.shape[1] * 3])[0], ref.rows(), ref.anchor_indices(), prec)
         torch.cuda.synchronize()
+
+
+def _widen_heads_to_4_anchors(net):
+    """A 4-anchors-per-cell model for the "net3a" preset (the reference ships none): every head of the mnet25 graph is widened
+    from A = 2 to A = 4 -- anchors 2, 3 reuse the filters of anchors 0, 1 with their class logits scaled by 0.9 (no score ties,
+    which std::sort would order arbitrarily in the reference).  cls layout is [background A | foreground A]."""
+    import copy
+    net = copy.deepcopy(net)
+    for s in (32, 16, 8):
+        cls = net.layer(f"face_rpn_cls_score_stride{s}")
+        w, b = cls.blobs[0], cls.blobs[1].reshape(-1)
+        bg, fg = w[0:2], w[2:4]
+        cls.blobs[0] = np.concatenate([bg, 0.9 * bg, fg, 0.9 * fg]).astype(np.float32)
+        cls.blobs[1] = np.concatenate([b[0:2], 0.9 * b[0:2], b[2:4], 0.9 * b[2:4]]).astype(np.float32).reshape(cls.blobs[1].shape[:-1] + (8,))
+        cls.num_output = 8
+        back = net.layer(f"face_rpn_cls_prob_reshape_stride{s}")     # Reshape(., 2A, -1, .) after the 2-class softmax
+        back.reshape_dims = [8 if d == 4 else d for d in back.reshape_dims]
+        for name, per in ((f"face_rpn_bbox_pred_stride{s}", 8), (f"face_rpn_landmark_pred_stride{s}", 20)):
+            l = net.layer(name)
+            l.blobs[0] = np.concatenate([l.blobs[0], l.blobs[0]]).astype(np.float32)
+            b1 = l.blobs[1].reshape(-1)
+            l.blobs[1] = np.concatenate([b1, b1]).astype(np.float32).reshape(l.blobs[1].shape[:-1] + (2 * per,))
+            l.num_output = 2 * per
+    return net
+
+
+def test_network_presets(rfa, nets, crop448, tmp_path):
+    """The constructor's `network` argument (RetinaFace.cpp:209-271).  Presets the reference leaves without anchors construct and
+    find nothing; "net3a" (ratios {1, 1.5}: 4 anchors per cell) refuses a 2-anchor model (the reference would read past its score
+    blob) and, on a model widened to 4 anchors, decodes exactly what the reference's own postProcess decodes from the same
+    blobs -- same anchor indices (now over 4 x h x w per stride), fp32 boxes within 1e-5 IoU."""
+    from oracle import build_ref
+    from oracle import retinaface_post as post
+    from oracle.caffe_forward import CaffeNet
+    from oracle.caffe_io import write_rfw
+    for preset in ("ssh", "vgg", "net5", "net6", "typo"):
+        det = rfa.RetinaFace(ASSETS, preset, 0.4, precision=FP16, net_hw=(448, 448), model_stem="mnet25")
+        assert det.detect(crop448, 0.5) == [] and det.last_candidate_counts(1) == [0]
+        assert det.detectBatchImages([crop448] * 3, 0.01) == [[], [], []]
+        det.close()
+    with pytest.raises(rfa._lib.RFError) as e:
+        rfa.RetinaFace(ASSETS, "net3a", 0.4, precision=FP16, net_hw=(448, 448), model_stem="mnet25")
+    assert e.value.status == rfa._lib.RF_ERR_MODEL
+    wide = _widen_heads_to_4_anchors(nets["mnet25"])
+    write_rfw(wide, str(tmp_path / "mnet25.rfw"))
+    with pytest.raises(rfa._lib.RFError):                           # and the other way round: a 4-anchor model under "net3"
+        rfa.RetinaFace(str(tmp_path), "net3", 0.4, precision=FP32, net_hw=(448, 448), model_stem="mnet25")
+    ratios = post.preset_ratios("net3a")
+    blobs = CaffeNet(wide).forward(preprocess_trt_identity(crop448, 448, 448))
+    heads = {n: blobs[n] for st in HEAD_STRIDES for n in head_names(st)}
+    assert heads["face_rpn_cls_prob_reshape_stride32"].shape[1] == 8
+    for thr in (0.5, 0.05):
+        want = post.nms(list(post.decode(heads, 448, 448, thr, ratios=ratios)), 0.4)
+        assert len(want) >= 2
+        if build_ref.available():                                   # the reference's own decode + NMS on the same blobs
+            ref = build_ref.ReferenceRetinaFace(448, 448, max_batch=1, network="net3a", head_anchors=4)
+            ref.set_heads(0, [heads[n][0] for n in build_ref.HEAD_BLOBS])
+            faces = ref.postprocess(0, thr)
+            ref.close()
+            assert np.array_equal(faces, np.stack([d.as_row() for d in want]))
+        for prec in (FP32, FP16):
+            det = rfa.RetinaFace(str(tmp_path), "net3a", 0.4, precision=prec, net_hw=(448, 448), model_stem="mnet25", keep_outputs=True)
+            got = det.detect(crop448, thr)
+            compare(got, np.stack([d.as_row() for d in want]), [d.anchor_index for d in want], prec)
+            if prec == FP32:
+                for n in heads:
+                    assert np.abs(det.get_output(n) - heads[n][0]).max() <= 5e-5, n
+            det.close()
 
 
 def test_error_paths_leave_the_handle_usable(rfa):

@@ -187,3 +187,73 @@ def test_live_detect_end_to_end():
             assert np.array_equal(per_image[i], od.detect(f, 0.3, 0.4, net_hw=(H, W)).rows())
     finally:
         ref.close()
+
+
+# ------------------------------------------------------------------------------------------------ network presets
+
+PRESETS = ("net3", "net3a", "ssh", "vgg", "net4", "net5", "net5a", "net6", "no-such-network")
+# net3a's base anchors as the reference's constructor builds them (minted from oracle/_ref, kept here so the pin also holds
+# where the reference build is absent): ratio 1.0 then ratio 1.5 (13 x 20 seed window), scales large then small
+NET3A = {32: [[-248, -248, 263, 263], [-120, -120, 135, 135], [-200, -312, 215, 327], [-96, -152, 111, 167]],
+         16: [[-56, -56, 71, 71], [-24, -24, 39, 39], [-44, -72, 59, 87], [-18, -32, 33, 47]],
+         8: [[-8, -8, 23, 23], [0, 0, 15, 15], [-5, -12, 20, 27], [1.5, -2, 13.5, 17]]}
+
+
+def _product_anchors(network, stride):
+    import ctypes as C
+    from retinaface_amd import _lib
+    lib = _lib.load_library()
+    out = np.zeros((8, 4), np.float32)
+    n = lib.rf_preset_anchors(network.encode(), stride, out.ctypes.data_as(C.POINTER(C.c_float)), 8)
+    assert n >= 0
+    return out[:n]
+
+
+@pytest.mark.parametrize("network", PRESETS)
+def test_network_presets_product_vs_python_restatement(network):
+    """rf_preset_anchors (the product's host code) == the numpy restatement of generate_anchors_fpn for the preset's ratios,
+    bit for bit; presets without ratios / anchor configuration give zero anchors."""
+    ratios = post.preset_ratios(network)
+    base = post.base_anchors(ratios)
+    for s in post.FEAT_STRIDES:
+        got = _product_anchors(network, s)
+        assert got.shape == (2 * len(ratios), 4) and np.array_equal(got, base[s]), (network, s, got, base[s])
+    if network == "net3a":
+        for s in post.FEAT_STRIDES:
+            assert np.array_equal(base[s], np.array(NET3A[s], np.float32)), (s, base[s])
+
+
+@live
+@pytest.mark.parametrize("network", PRESETS)
+def test_live_network_presets_against_the_reference_constructor(network):
+    """The reference's own constructor run with each preset name (RetinaFace.cpp:205-271): its `_anchors_fpn` must equal the
+    product's rf_preset_anchors; presets it leaves unconfigured end up with no strides or no anchors, and its postProcess then
+    returns no faces whatever the blobs hold."""
+    ratios = post.preset_ratios(network)
+    a = max(2 * len(ratios), 2)
+    ref = build_ref.ReferenceRetinaFace(64, 64, max_batch=1, network=network, head_anchors=a)
+    try:
+        fmc3 = network not in ("net4", "net5", "net5a", "net6")
+        assert ref.num_levels() == (3 if fmc3 else 0)
+        for s in post.FEAT_STRIDES:
+            got = ref.base_anchors(s)
+            assert got.shape[0] == (2 * len(ratios) if fmc3 else 0)
+            assert np.array_equal(got, _product_anchors(network, s)), (network, s)
+        # blobs full of confident foreground: decoded only where the preset has anchors
+        rng = np.random.default_rng(5)
+        heads = []
+        for s in post.FEAT_STRIDES:
+            h = 64 // s
+            prob = rng.permutation(np.linspace(0.55, 0.99, 2 * a * h * h).astype(np.float32)).reshape(2 * a, h, h)    # distinct: std::sort ties are undefined
+            heads += [prob, rng.normal(0, 0.2, (4 * a, h, h)).astype(np.float32), rng.normal(0, 0.2, (10 * a, h, h)).astype(np.float32)]
+        ref.set_heads(0, heads)
+        faces = ref.postprocess(0, 0.5)
+        if ratios:
+            hd = {n: x[None] for n, x in zip(build_ref.HEAD_BLOBS, heads)}
+            want = post.nms(list(post.decode(hd, 64, 64, 0.5, ratios=ratios)), 0.4)
+            assert len(faces) == len(want) > 0
+            assert np.array_equal(faces, np.stack([d.as_row() for d in want]))
+        else:
+            assert len(faces) == 0
+    finally:
+        ref.close()

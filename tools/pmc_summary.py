@@ -2,7 +2,7 @@
 """Combine the two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE -- they do not fit one pass, MI355X_MICROARCH.md
 "rocprofv3 PMC slots") into per-kernel HBM bytes per launch.  gfx950 correction from the same guide: FETCH_SIZE
 reports exactly half the bytes of a wide coalesced read stream, so it is doubled; WRITE_SIZE is used as reported
-(uncalibrated per the guide).  Usage: pmc_summary.py fetch.db write.db out.json [images_per_launch]"""
+(uncalibrated per the guide).  Usage: pmc_summary.py fetch.db write.db out.json [images_per_launch [workload_key, e.g. 448x448_fp16]]"""
 import json
 import re
 import sqlite3
@@ -10,16 +10,17 @@ import sys
 
 
 def descriptor(mangled: str) -> str:
-    """Same kernel-instance string as rf_profile reports (engine.cpp OpInfo.kernel)."""
-    m = re.search(r"dwpw_kernelI(?:DF16_|f)Li(\d+)ELi(\d+)ELi(\d+)ELb(\d)ELi(\d+)ELi(\d+)ELb(\d)E", mangled)
+    """Same kernel-instance string as rf_profile reports (engine.cpp OpInfo.kernel); template tails added in later rounds
+    (padded-row / wave-split booleans) are ignored."""
+    m = re.search(r"dwpw_kernelI(?:DF16_|f|a)Li(\d+)ELi(\d+)ELi(\d+)ELb(\d)ELi(\d+)ELi(\d+)ELb(\d)E", mangled)
     if m:
         cin, cout, st, dw, th, tw, lat = m.groups()
         return f"dwpw<{cin},{cout},s{st}{',lat' if lat == '1' else ''}>"
-    m = re.search(r"conv3x3_kernelI(?:DF16_|f)Li(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELb(\d)E", mangled)
+    m = re.search(r"conv3x3_kernelI(?:DF16_|f|a)Li(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELb(\d)E", mangled)
     if m:
         cin, cout, th, tw, up = m.groups()
         return f"conv3x3<{cin},{cout},{th}x{tw}{',up' if up == '1' else ''}>"
-    for k in ("stem", "conv0", "head", "nms"):
+    for k in ("stem2", "stem", "conv0", "head", "nms", "resize_area", "resize_bilinear"):
         if k + "_kernel" in mangled:
             return k
     return mangled
@@ -32,7 +33,7 @@ def per_kernel(db_path, counter):
     return {(r[0], r[1]): (r[2], r[3]) for r in rows}
 
 
-def main(fetch_db, write_db, out, images_per_launch=8):
+def main(fetch_db, write_db, out, images_per_launch=8, workload_key="448x448_fp16"):
     f = per_kernel(fetch_db, "FETCH_SIZE")
     w = per_kernel(write_db, "WRITE_SIZE")
     res = []
@@ -45,13 +46,17 @@ def main(fetch_db, write_db, out, images_per_launch=8):
         res.append({"kernel": descriptor(name), "symbol": name, "grid_threads": grid, "launches_sampled": f.get(key, (0, 0))[0],
                     "fetch_size_bytes_raw": fk, "fetch_bytes_corrected_x2": 2 * fk, "write_size_bytes": wk,
                     "hbm_bytes_per_launch": 2 * fk + wk})
-    json.dump({"note": f"per launch of {images_per_launch} images, 448x448, fp16, eager launches (tools/probes/pmc_probe.py; PMC collection "
+    total = sum(r["hbm_bytes_per_launch"] for r in res)
+    json.dump({"note": f"per launch of {images_per_launch} images, {workload_key}, eager launches (tools/probes/pmc_probe.py; PMC collection "
                        "faults under hipGraph replay); FETCH_SIZE doubled per MI355X_MICROARCH.md section HBM",
-               "images_per_launch": int(images_per_launch), "kernels": res}, open(out, "w"), indent=1)
+               "workload_key": workload_key, "images_per_launch": int(images_per_launch),
+               "hbm_bytes_all_kernels_per_launch": total, "hbm_bytes_per_image": total / int(images_per_launch),
+               "kernels": res}, open(out, "w"), indent=1)
+    print(f"total {total / 1e6:.1f} MB per launch of {images_per_launch} images = {total / int(images_per_launch) / 1e6:.2f} MB per image")
     for r in res:
         print(f"{r['kernel'][:90]:90s} grid {r['grid_threads']:8d}  fetch*2 {r['fetch_bytes_corrected_x2'] / 1e6:8.3f} MB  "
               f"write {r['write_size_bytes'] / 1e6:8.3f} MB")
 
 
 if __name__ == "__main__":
-    main(*sys.argv[1:5])
+    main(*sys.argv[1:6])
