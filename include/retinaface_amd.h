@@ -76,6 +76,10 @@ typedef struct rf_options {
     int32_t copy_threads;       /* host threads (the caller's included) that stage host frames into pinned memory; 0 = min(12, cores/4) */
     int32_t n_devices;          /* > 1: one engine per entry of devices[], every rf_detect_batch* call is sharded by image over them */
     const int32_t *devices;     /* HIP device ordinals (0-based; an ordinal may repeat); NULL / n_devices <= 1: `device` above */
+    int32_t plan_cache;         /* 0 / 1 (default): keep the packed weight image next to the model as <stem>.<precision>.rfplan -- the
+                                   analogue of the reference's serialized-engine cache (trtnetbase.cpp:205-243): later rf_create calls
+                                   read it back (one file read + one hipMemcpy, no parse / BN fold / packing) as long as the model files'
+                                   hash, the precision and the library build match; 2 = neither read nor write it */
 } rf_options;
 
 typedef struct rf_engine *rf_handle;
@@ -207,6 +211,11 @@ int rf_convert_model(const char *prototxt, const char *caffemodel, const char *i
  * w is [cout][k][k][cin/group], b is [cout].  Returns RF_OK or an error; pass NULL buffers to query dims. */
 int rf_plan_folded(const char *model_dir, const char *stem, const char *op, float *w, size_t cap_w,
                    float *b, size_t cap_b, int dims[4]);
+
+/* Host-only test hook: the host half of rf_create (plan cache or model -> packed weight image) for <model_dir>/<stem> at a
+ * precision, with the cache file at cache_path (NULL = the default place).  Returns 1 when the image came from the cache, 0 when it was
+ * built from the model (and the cache written), or a negative rf_status. */
+int rf_plan_cache_probe(const char *model_dir, const char *stem, int precision, const char *cache_path, size_t *image_bytes);
 
 int rf_abi_version(void);
 

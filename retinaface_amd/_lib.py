@@ -30,7 +30,8 @@ class rf_options(C.Structure):
                 ("max_batch", C.c_int32), ("device", C.c_int32), ("max_candidates", C.c_int32),
                 ("max_detections", C.c_int32), ("use_graph", C.c_int32), ("keep_outputs", C.c_int32),
                 ("model_stem", C.c_char_p), ("lanes", C.c_int32), ("coalesce", C.c_int32),
-                ("copy_threads", C.c_int32), ("n_devices", C.c_int32), ("devices", C.POINTER(C.c_int32))]
+                ("copy_threads", C.c_int32), ("n_devices", C.c_int32), ("devices", C.POINTER(C.c_int32)),
+                ("plan_cache", C.c_int32)]
 
 
 # every symbol include/retinaface_amd.h declares: name -> (restype, argtypes)
@@ -66,6 +67,7 @@ SYMBOLS = {
     "rf_profile": (C.c_int, [C.c_void_p, _PP(C.c_void_p), C.c_int, C.c_int, C.c_int, _PP(C.c_char_p), _PP(C.c_char_p),
                              _PP(C.c_float), _PP(C.c_double), _PP(C.c_double)]),
     "rf_convert_model": (C.c_int, [C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p]),
+    "rf_plan_cache_probe": (C.c_int, [C.c_char_p, C.c_char_p, C.c_int, C.c_char_p, _PP(C.c_size_t)]),
     "rf_plan_folded": (C.c_int, [C.c_char_p, C.c_char_p, C.c_char_p, _PP(C.c_float), C.c_size_t, _PP(C.c_float),
                                  C.c_size_t, _PP(C.c_int)]),
 }

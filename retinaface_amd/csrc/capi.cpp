@@ -73,6 +73,7 @@ int rf_create(const char *model_dir, const char *network, float nms_threshold, c
             eo.copy_threads = o->copy_threads;
             if (o->n_devices < 0 || (o->n_devices > 0 && !o->devices)) throw rf::ArgError("n_devices / devices mismatch");
             for (int i = 0; i < o->n_devices; i++) eo.devices.push_back(o->devices[i]);
+            eo.plan_cache = o->plan_cache != 2;
         }
         auto eng = rf::Engine::create(model_dir, network ? network : "net3", nms_threshold, eo);
         rf_engine *h = new rf_engine;
@@ -280,6 +281,17 @@ int rf_convert_model(const char *prototxt, const char *caffemodel, const char *i
         (void)rf::compile_plan(m);      // refuse to pack a graph the engine cannot run
         rf::save_rfw(m, out_rfw);
         return RF_OK;
+    });
+}
+
+int rf_plan_cache_probe(const char *model_dir, const char *stem, int precision, const char *cache_path, size_t *image_bytes) {
+    return guarded(nullptr, [&]() -> int {
+        if (!model_dir) throw rf::ArgError("null argument");
+        rf::EngineOptions eo;
+        eo.precision = precision;
+        if (stem && *stem) eo.model_stem = stem;
+        if (cache_path && *cache_path) eo.plan_cache_path = cache_path;
+        return rf::plan_cache_probe(model_dir, eo, image_bytes);
     });
 }
 

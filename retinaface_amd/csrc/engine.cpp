@@ -9,6 +9,7 @@
 
 #include "copier.h"
 #include "pack.h"
+#include "weights.h"
 
 namespace rf {
 
@@ -39,55 +40,6 @@ public:
 private:
     int dev_, prev_ = 0;
 };
-
-template <typename T> struct Cast;
-template <> struct Cast<float> { static float from(float v) { return v; } static float to(float v) { return v; } };
-template <> struct Cast<half_t> {
-    static half_t from(float v) { return (half_t)v; }
-    static float to(half_t v) { return (float)v; }
-};
-template <> struct Cast<int8_t> {            // values are already integers in [-127, 127] (quantised on the host)
-    static int8_t from(float v) { return (int8_t)std::lrintf(v); }
-    static float to(int8_t v) { return (float)v; }
-};
-
-// Device memory arena for the read-only weights: one allocation, 256-byte aligned sub-buffers.
-class Arena {
-public:
-    size_t reserve(size_t bytes) {
-        size_t off = host_.size();
-        host_.resize(off + ((bytes + 255) / 256) * 256, 0);
-        return off;
-    }
-    template <typename U> size_t put(const std::vector<U> &v) {
-        size_t off = reserve(v.size() * sizeof(U));
-        memcpy(host_.data() + off, v.data(), v.size() * sizeof(U));
-        return off;
-    }
-    void upload() {
-        RF_HIP(hipMalloc(&dev_, host_.size() ? host_.size() : 256));
-        RF_HIP(hipMemcpy(dev_, host_.data(), host_.size(), hipMemcpyHostToDevice));
-    }
-    template <typename U> const U *ptr(size_t off) const { return (const U *)((const char *)dev_ + off); }
-    void release() { if (dev_) (void)hipFree(dev_); dev_ = nullptr; }
-    size_t bytes() const { return host_.size(); }
-private:
-    std::vector<unsigned char> host_;
-    void *dev_ = nullptr;
-};
-
-// GEMM-shaped weights [cout][k_total] -> MFMA A-fragment order (pack.h), zero padded to whole K chunks
-template <typename T> std::vector<T> pack_gemm(const std::vector<float> &w, int cout, int k_total, int K, int KPL) {
-    int kch = k_chunks_for(k_total, K);
-    std::vector<T> out((size_t)(cout / 16) * kch * 64 * KPL, Cast<T>::from(0.f));
-    for (int o = 0; o < cout; o++)
-        for (int k = 0; k < k_total; k++)
-            out[packed_weight_index(o, k, kch, K, KPL)] = Cast<T>::from(w[(size_t)o * k_total + k]);
-    return out;
-}
-
-template <typename T> constexpr int mma_k() { return sizeof(T) == 1 ? 64 : sizeof(T) == 2 ? 32 : 4; }
-template <typename T> constexpr int mma_kpl() { return sizeof(T) == 1 ? 16 : sizeof(T) == 2 ? 8 : 1; }
 
 // one base anchor of generate_anchors(base_size 16, ratios {.., ratio, ..}, scales {.., scale, ..}) -- RetinaFace.cpp:9-103, with
 // the reference's float / double rounding points (`0.5 * (w - 1)` is double arithmetic stored to float; sqrt / round on floats)
@@ -133,9 +85,19 @@ namespace {
 // candidate buffers, pinned host descriptor / result blocks and the captured hipGraphs.  Batches on different
 // lanes overlap on the GPU (most kernels of a batch-8 pass fill only a fraction of the 256 CUs); weights are shared.
 template <typename T>
-class EngineImpl final : public Engine {
+class EngineImpl final : public Engine, private WeightPack<T> {
+    typedef WeightPack<T> WP;
+    using typename WP::GemmW;
+    using typename WP::DwW;
+    using WP::kNone;
+    using WP::arena_; using WP::c0_w_; using WP::c0_b_; using WP::c0_hi_; using WP::stem_dw_; using WP::stem2_dw_; using WP::stem_pw_;
+    using WP::stem2_pw_; using WP::aggr_a_lat_; using WP::aggr_a_up_; using WP::act_scale_; using WP::dw_w_; using WP::pw_w_; using WP::lat_w_;
+    using WP::aggr_w_; using WP::ssh_w_; using WP::head_a_; using WP::mult_ptr;
 public:
-    EngineImpl(const Plan &plan, float nms, const EngineOptions &opt, const std::vector<float> &ratios) {
+    // `plan` may be a skeleton (no weights): everything weight-related comes packed in `pack` (built from the model or read from
+    // the plan cache, weights.h)
+    EngineImpl(const Plan &plan, WeightPack<T> &&pack, float nms, const EngineOptions &opt, const std::vector<float> &ratios)
+        : WeightPack<T>(std::move(pack)) {
         opt_ = opt;
         nms_threshold_ = nms;
         ratios_ = ratios;
@@ -160,8 +122,7 @@ public:
         RF_HIP(hipGetDeviceCount(&ndev));
         if (device_ < 0 || device_ >= ndev) throw ArgError("device ordinal " + std::to_string(device_) + " out of range (" + std::to_string(ndev) + " devices)");
         DeviceGuard guard(device_);                  // the caller's current device is put back when construction ends
-        head_a_ = plan.anchors_per_cell;
-        upload_weights(plan);
+        try { arena_.upload(); } catch (const std::exception &e) { throw HipError(e.what()); }
         lanes_.resize(opt_.lanes);
         for (auto &l : lanes_) build_lane(l, plan);
         const int hw = (int)std::thread::hardware_concurrency();
@@ -388,10 +349,6 @@ public:
     }
 
 private:
-    static constexpr size_t kNone = (size_t)-1;
-    struct GemmW { size_t w, b, m = kNone; };          // m: int8 requantisation multipliers (absent otherwise)
-    struct DwW { size_t w, b, mma = 0, m = kNone; };     // m: int8 depthwise-on-MFMA tap scales
-
     struct Lane {
         hipStream_t stream = nullptr;
         hipEvent_t time_ev[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -457,268 +414,6 @@ private:
     static constexpr bool kInt8 = sizeof(T) == 1;
     typedef typename DwWeightT<T>::type DWT;
 
-    // per-tensor activation scale of a reference blob (TensorRT calibration cache)
-    float scale_of(const Plan &plan, const std::string &blob) const {
-        for (const auto &kv : plan.int8_scales)
-            if (kv.first == blob) return kv.second;
-        throw Unsupported("int8: the calibration table has no scale for tensor '" + blob + "'");
-    }
-    // Per-channel activation scales (an extension of the TensorRT cache format: besides `tensor: hex` lines, which every reader
-    // takes as the per-tensor scale, tools/calibrate_int8.py writes `tensor#<c>: hex` lines).  A GEMM's per-input-channel scale
-    // folds into its weights and its per-output-channel scale into the requantisation multiplier (put_gemm), so per-channel
-    // activations cost nothing at run time; a per-tensor table (the one the reference ships) is broadcast.
-    typedef std::vector<float> Sc;
-    Sc scales_of(const Plan &plan, const std::string &blob, int channels) const {
-        Sc v(channels, 1.f);
-        if constexpr (!kInt8) return v;
-        bool per_channel = false;
-        for (const auto &kv : plan.int8_scales)
-            if (kv.first == blob + "#0") { per_channel = true; break; }
-        if (!per_channel) { std::fill(v.begin(), v.end(), scale_of(plan, blob)); return v; }
-        for (int c = 0; c < channels; c++) v[c] = scale_of(plan, blob + "#" + std::to_string(c));
-        return v;
-    }
-    static Sc slice(const Sc &v, int lo, int hi) { return Sc(v.begin() + lo, v.begin() + hi); }
-    static Sc concat(Sc a, const Sc &b) { a.insert(a.end(), b.begin(), b.end()); return a; }
-    static Sc cmax(const Sc &a, const Sc &b, const Sc &c) {
-        Sc v(a.size());
-        for (size_t i = 0; i < a.size(); i++) v[i] = std::max(a[i], std::max(b[i], c[i]));
-        return v;
-    }
-    const float *mult_ptr(const GemmW &g) const { return g.m == kNone ? nullptr : arena_.ptr<float>(g.m); }
-
-    // fp16 / fp32: weights as they are.  int8: per-output-channel symmetric weight quantisation (w_scale = amax / 127, what
-    // TensorRT does with a per-tensor activation table); the epilogue computes acc * mult + bias with
-    //   mult[c] = w_scale[c] * in_scale / out_scale[c],  bias[c] = b[c] / out_scale[c]     (out_scale = 1: real output)
-    GemmW put_gemm(const FoldedConv &f, const Sc &in_scale = {}, const Sc &out_scale = {}) {
-        const int cin_g = f.cin / f.group;
-        const int ktot = f.k * f.k * cin_g;
-        GemmW g;
-        if constexpr (!kInt8) {
-            g.w = arena_.put(pack_gemm<T>(f.w, f.cout, ktot, mma_k<T>(), mma_kpl<T>()));
-            g.b = arena_.put(f.b);
-        } else {
-            if (!in_scale.empty() && (int)in_scale.size() != cin_g) throw ModelError("int8: input scale count does not match " + f.name);
-            if (!out_scale.empty() && (int)out_scale.size() != f.cout) throw ModelError("int8: output scale count does not match " + f.name);
-            std::vector<float> ws_in(f.w), q(f.w.size()), mult(f.cout), bias(f.cout);
-            if (!in_scale.empty())
-                for (int o = 0; o < f.cout; o++)
-                    for (int k = 0; k < ktot; k++) ws_in[(size_t)o * ktot + k] *= in_scale[k % cin_g];       // k = tap*cin + c
-            for (int o = 0; o < f.cout; o++) {
-                float amax = 0.f;
-                for (int k = 0; k < ktot; k++) amax = std::max(amax, std::fabs(ws_in[(size_t)o * ktot + k]));
-                const float ws = amax > 0.f ? amax / 127.f : 1.f;
-                for (int k = 0; k < ktot; k++)
-                    q[(size_t)o * ktot + k] = std::min(127.f, std::max(-127.f, std::nearbyintf(ws_in[(size_t)o * ktot + k] / ws)));
-                const float os = out_scale.empty() ? 1.f : out_scale[o];
-                mult[o] = ws / os;
-                bias[o] = f.b[o] / os;
-            }
-            g.w = arena_.put(pack_gemm<T>(q, f.cout, ktot, mma_k<T>(), mma_kpl<T>()));
-            g.b = arena_.put(bias);
-            g.m = arena_.put(mult);
-        }
-        return g;
-    }
-
-    // depthwise weights [c][3][3][1] -> [tap][c].  int8: fp32 weights pre-scaled so the stencil maps input quanta straight to
-    // output quanta: w * in_scale / mid_scale, b / mid_scale
-    DwW put_dw(const FoldedConv &dw, const Sc &in_scale = {}, const Sc &mid_scale = {}) {
-        const int c = dw.cout;
-        std::vector<DWT> w((size_t)9 * c);
-        std::vector<float> b(dw.b);
-        for (int ch = 0; ch < c; ch++)
-            for (int t = 0; t < 9; t++) {
-                float v = dw.w[(size_t)ch * 9 + t];
-                if constexpr (kInt8) w[(size_t)t * c + ch] = v * in_scale[ch] / mid_scale[ch];
-                else w[(size_t)t * c + ch] = Cast<DWT>::from(v);
-            }
-        if constexpr (kInt8) for (int ch = 0; ch < c; ch++) b[ch] /= mid_scale[ch];
-        DwW r{arena_.put(w), arena_.put(b), 0};
-        if constexpr (std::is_same<T, half_t>::value) {
-            // the same taps as diagonal MFMA A fragments (pack.h dw_mma_dword): [c/16][5][64] dwords
-            if (c % 16 == 0) {
-                std::vector<uint32_t> mm((size_t)(c / 16) * kDwMmaChunks * 64);
-                for (int g = 0; g < c / 16; g++)
-                    for (int lane = 0; lane < 64; lane++) {
-                        uint16_t w9[9];
-                        for (int t = 0; t < 9; t++) {
-                            half_t h = w[(size_t)t * c + g * 16 + (lane & 15)];
-                            std::memcpy(&w9[t], &h, 2);
-                        }
-                        for (int kc = 0; kc < kDwMmaChunks; kc++) mm[((size_t)g * kDwMmaChunks + kc) * 64 + lane] = dw_mma_dword(kc, lane, w9);
-                    }
-                r.mma = arena_.put(mm);
-            }
-        }
-        if constexpr (kInt8) {
-            // int8 engine: the taps (already in output quanta per input quantum) as 15-bit integers w = 128*hi + lo with a
-            // per-channel scale, hi / lo as diagonal i8 MFMA A fragments (pack.h dw_mma_dword_i8): [c/16][3][hi, lo][64] dwords
-            if (c % 16 == 0) {
-                std::vector<float> ws(c, 1.f);
-                std::vector<int8_t> hi((size_t)9 * c), lo((size_t)9 * c);
-                for (int ch = 0; ch < c; ch++) {
-                    float amax = 0.f;
-                    for (int t = 0; t < 9; t++) amax = std::max(amax, std::fabs((float)w[(size_t)t * c + ch]));
-                    ws[ch] = amax > 0.f ? amax / (float)kDwI8Range : 1.f;
-                    for (int t = 0; t < 9; t++) {
-                        const int wi = (int)std::lrintf((float)w[(size_t)t * c + ch] / ws[ch]);
-                        dw_i8_split(std::max(-kDwI8Range, std::min(kDwI8Range, wi)), &hi[(size_t)t * c + ch], &lo[(size_t)t * c + ch]);
-                    }
-                }
-                std::vector<uint32_t> mm((size_t)(c / 16) * kDwMmaChunksI8 * 2 * 64);
-                for (int g = 0; g < c / 16; g++)
-                    for (int lane = 0; lane < 64; lane++) {
-                        int8_t h9[9], l9[9];
-                        for (int t = 0; t < 9; t++) { h9[t] = hi[(size_t)t * c + g * 16 + (lane & 15)]; l9[t] = lo[(size_t)t * c + g * 16 + (lane & 15)]; }
-                        for (int kc = 0; kc < kDwMmaChunksI8; kc++) {
-                            mm[(((size_t)g * kDwMmaChunksI8 + kc) * 2 + 0) * 64 + lane] = dw_mma_dword_i8(kc, lane, h9);
-                            mm[(((size_t)g * kDwMmaChunksI8 + kc) * 2 + 1) * 64 + lane] = dw_mma_dword_i8(kc, lane, l9);
-                        }
-                    }
-                r.mma = arena_.put(mm);
-                r.m = arena_.put(ws);
-            }
-        }
-        return r;
-    }
-
-    void upload_weights(const Plan &plan) {
-        if constexpr (kInt8)
-            if (plan.int8_scales.empty()) throw Unsupported("int8 precision needs a calibration table (<stem>.table.int8)");
-        c0_w_ = arena_.put(plan.conv0.w);
-        c0_b_ = arena_.put(plan.conv0.b);
-        size_t first_block = 0;
-        if constexpr (sizeof(T) <= 2) {
-            // stem kernel (fp16 and int8 engines): conv0 as 16 x 64 A fragments, K = 4*(3*ky + kx) + c4 with c4 = B, G, R, pad
-            // (the frame's own byte order: net channel c is frame channel 2-c), fp16 hi + lo so the sum carries ~22 mantissa
-            // bits.  Layout: [hi k<32 | lo k<32 | hi k>=32 | lo k>=32][lane 64][8]
-            std::vector<half_t> frag(4 * 64 * 8, (half_t)0);
-            for (int half = 0; half < 2; half++)
-                for (int lane = 0; lane < 64; lane++)
-                    for (int el = 0; el < 8; el++) {
-                        int row = lane & 15, k = half * 32 + (lane >> 4) * 8 + el;
-                        int tap = k / 4, c4 = k % 4;
-                        if (row >= 8 || tap >= 9 || c4 == 3) continue;
-                        float w = plan.conv0.w[(size_t)row * 27 + tap * 3 + (2 - c4)];
-                        half_t h = (half_t)w;
-                        frag[((half * 2 + 0) * 64 + lane) * 8 + el] = h;
-                        frag[((half * 2 + 1) * 64 + lane) * 8 + el] = (half_t)(w - (float)h);
-                    }
-            c0_hi_ = arena_.put(frag);
-            // the stem computes its depthwise + pointwise block in fp16 whatever the storage type of its OUTPUT
-            const auto &b0 = plan.blocks[0];
-            std::vector<float> dw((size_t)9 * 8);                  // taps stay fp32 (see the stem kernel's header)
-            for (int ch = 0; ch < 8; ch++)
-                for (int t = 0; t < 9; t++) dw[(size_t)t * 8 + ch] = b0.dw.w[(size_t)ch * 9 + t];
-            stem_dw_ = DwW{arena_.put(dw), arena_.put(b0.dw.b)};
-            // pointwise 16 x 8: one A fragment whose K slots are [w_hi | w_hi | w_lo | 0] (pack.h stem_pw_slot)
-            std::vector<half_t> pwf((size_t)64 * 8, (half_t)0);
-            for (int lane = 0; lane < 64; lane++) {
-                int row = 0, use_lo = 0;
-                if (!stem_pw_slot(lane, &row, &use_lo)) continue;
-                for (int e = 0; e < 8; e++) {
-                    const float w = b0.pw.w[(size_t)row * 8 + e];
-                    const half_t hi = (half_t)w;
-                    pwf[(size_t)lane * 8 + e] = use_lo ? (half_t)(w - (float)hi) : hi;
-                }
-            }
-            stem_pw_.w = arena_.put(pwf);
-            if constexpr (kInt8) {
-                const Sc os = scales_of(plan, b0.pw.out_blob, b0.pw.cout);
-                std::vector<float> b(b0.pw.b), m(b0.pw.cout);
-                for (int o = 0; o < b0.pw.cout; o++) { m[o] = 1.f / os[o]; b[o] /= os[o]; }
-                stem_pw_.b = arena_.put(b);
-                stem_pw_.m = arena_.put(m);
-            } else {
-                stem_pw_.b = arena_.put(b0.pw.b);
-            }
-            first_block = 1;
-            dw_w_.push_back(DwW{0, 0});
-            pw_w_.push_back(GemmW{0, 0});
-            if constexpr (std::is_same<T, half_t>::value) {
-                if (stem2_variant()) {
-                    // stem2 also runs the first stride-2 block: conv3 taps [9][16] fp32, conv4 as a standard packed 32 x 16 GEMM
-                    const auto &b1 = plan.blocks[1];
-                    std::vector<float> dw1((size_t)9 * 16);
-                    for (int ch = 0; ch < 16; ch++)
-                        for (int t = 0; t < 9; t++) dw1[(size_t)t * 16 + ch] = b1.dw.w[(size_t)ch * 9 + t];
-                    stem2_dw_ = DwW{arena_.put(dw1), arena_.put(b1.dw.b)};
-                    stem2_pw_.w = arena_.put(pack_gemm<half_t>(b1.pw.w, b1.pw.cout, 16, 32, 8));
-                    stem2_pw_.b = arena_.put(b1.pw.b);
-                    first_block = 2;
-                    dw_w_.push_back(DwW{0, 0});
-                    pw_w_.push_back(GemmW{0, 0});
-                }
-            }
-        }
-        Sc s_prev = scales_of(plan, plan.blocks[0].pw.out_blob, plan.blocks[0].pw.cout);
-        Sc s_tap[3];                                  // scales of the block outputs the laterals tap (blocks 12, 10, 4)
-        for (size_t i = first_block; i < plan.blocks.size(); i++) {
-            const auto &blk = plan.blocks[i];
-            const Sc s_mid = scales_of(plan, blk.dw.out_blob, blk.dw.cout), s_out = scales_of(plan, blk.pw.out_blob, blk.pw.cout);
-            dw_w_.push_back(put_dw(blk.dw, s_prev, s_mid));
-            pw_w_.push_back(put_gemm(blk.pw, s_mid, s_out));
-            s_prev = s_out;
-            if constexpr (kInt8) act_scale_[blk.pw.out_blob] = s_out;
-            if (i == 12) s_tap[0] = s_out;
-            if (i == 10) s_tap[1] = s_out;
-            if (i == 4) s_tap[2] = s_out;
-        }
-        if constexpr (kInt8) act_scale_[plan.blocks[0].pw.out_blob] = scales_of(plan, plan.blocks[0].pw.out_blob, plan.blocks[0].pw.cout);
-        // FPN.  The fused "lateral + upsample(coarser)" staging adds two int8 tensors and requantises to the `_plus` scale:
-        //   q_plus = round(q_lat * s_lat / s_plus + blend(q_up) * s_up / s_plus).
-        // With a per-tensor table the two ratios are scalars (a_lat, a_up).  With per-channel scales the three tensors of each
-        // add are given ONE common per-channel scale (the largest of their calibrated ones, as for concat inputs), so the ratios
-        // are 1 and the kernel needs no per-channel multipliers.
-        Sc s_lat[3], s_feat[3], s_plus[2], s_aggr[2];
-        bool per_channel = false;
-        if constexpr (kInt8)
-            for (const auto &kv : plan.int8_scales) per_channel = per_channel || kv.first == "_plus0#0";
-        for (int i = 0; i < 3; i++) s_lat[i] = scales_of(plan, plan.lateral[i].out_blob, 64);
-        for (int i = 0; i < 2; i++) {
-            s_plus[i] = scales_of(plan, i == 0 ? "_plus0" : "_plus1", 64);
-            s_aggr[i] = scales_of(plan, plan.aggr[i].out_blob, 64);
-        }
-        if (per_channel) {
-            // add 0: {c3 lateral (= P3), c2 lateral, _plus0};  add 1: {c2 aggr (= P2), c1 lateral, _plus1}
-            s_lat[0] = s_lat[1] = s_plus[0] = cmax(s_lat[0], s_lat[1], s_plus[0]);
-            s_aggr[0] = s_lat[2] = s_plus[1] = cmax(s_aggr[0], s_lat[2], s_plus[1]);
-        }
-        for (int i = 0; i < 3; i++) lat_w_[i] = put_gemm(plan.lateral[i], s_tap[i], s_lat[i]);
-        s_feat[0] = s_lat[0];
-        for (int i = 0; i < 2; i++) {
-            if constexpr (kInt8) {
-                aggr_a_lat_[i] = per_channel ? 1.f : s_lat[i + 1][0] / s_plus[i][0];
-                aggr_a_up_[i] = per_channel ? 1.f : s_feat[i][0] / s_plus[i][0];
-            }
-            aggr_w_[i] = put_gemm(plan.aggr[i], s_plus[i], s_aggr[i]);
-            s_feat[i + 1] = s_aggr[i];
-        }
-        for (int i = 0; i < 3; i++) {
-            const SshModule &m = plan.ssh[i];
-            std::string pre = "rf_c" + std::to_string(3 - i) + "_det_";
-            // the three concat inputs are quantised with the concat tensor's scales (per tensor: one shared scale, as in the
-            // TensorRT table; per channel: each branch writes its slice with that slice's scales)
-            const Sc s_cat = scales_of(plan, pre + "concat_relu", 64);
-            const Sc s_c1 = scales_of(plan, pre + "context_conv1_relu", 16), s_c31 = scales_of(plan, pre + "context_conv3_1_relu", 16);
-            ssh_w_[i][0] = put_gemm(m.conv_a, s_feat[i], concat(slice(s_cat, 0, 32), s_c1));
-            ssh_w_[i][1] = put_gemm(m.conv_b, s_c1, concat(slice(s_cat, 32, 48), s_c31));
-            ssh_w_[i][2] = put_gemm(m.conv_c, s_c31, slice(s_cat, 48, 64));
-            ssh_w_[i][3] = put_gemm(m.head, s_cat, {});              // heads are dequantised to real logits / deltas
-            if constexpr (kInt8) {
-                act_scale_[pre + "concat_relu"] = s_cat;
-                act_scale_[pre + "context_conv1_relu"] = s_c1;
-                act_scale_[pre + "context_conv3_1_relu"] = s_c31;
-            }
-        }
-        if constexpr (kInt8) {
-            for (int i = 0; i < 3; i++) act_scale_[plan.lateral[i].out_blob] = s_lat[i];
-            for (int i = 0; i < 2; i++) act_scale_[plan.aggr[i].out_blob] = s_feat[i + 1];
-        }
-        arena_.upload();
-    }
-
     void build_lane(Lane &L, const Plan &plan) {
         const int mb = cap_images_;           // images per launch: max_batch * coalesce
         const int H = net_h_, W = net_w_;
@@ -765,11 +460,11 @@ private:
                 T *out = act(b1.pw.out_blob, h4, w4, b1.pw.cout);
                 Stem2Params sp;
                 sp.frames = L.d_frames + mb; sp.out = out;
-                sp.w0 = arena_.ptr<half_t>(c0_hi_); sp.b0 = arena_.ptr<float>(c0_b_);
-                sp.dw0_w = arena_.ptr<float>(stem_dw_.w); sp.dw0_b = arena_.ptr<float>(stem_dw_.b);
-                sp.pw0_w = arena_.ptr<half_t>(stem_pw_.w); sp.pw0_b = arena_.ptr<float>(stem_pw_.b);
-                sp.dw1_w = arena_.ptr<float>(stem2_dw_.w); sp.dw1_b = arena_.ptr<float>(stem2_dw_.b);
-                sp.pw1_w = arena_.ptr<half_t>(stem2_pw_.w); sp.pw1_b = arena_.ptr<float>(stem2_pw_.b);
+                sp.w0 = arena_.template ptr<half_t>(c0_hi_); sp.b0 = arena_.template ptr<float>(c0_b_);
+                sp.dw0_w = arena_.template ptr<float>(stem_dw_.w); sp.dw0_b = arena_.template ptr<float>(stem_dw_.b);
+                sp.pw0_w = arena_.template ptr<half_t>(stem_pw_.w); sp.pw0_b = arena_.template ptr<float>(stem_pw_.b);
+                sp.dw1_w = arena_.template ptr<float>(stem2_dw_.w); sp.dw1_b = arena_.template ptr<float>(stem2_dw_.b);
+                sp.pw1_w = arena_.template ptr<half_t>(stem2_pw_.w); sp.pw1_b = arena_.template ptr<float>(stem2_pw_.b);
                 sp.n = 0; sp.net_h = H; sp.net_w = W;
                 OpInfo op;
                 op.name = "pre+" + plan.conv0.name + "+" + b0.dw.name + "+" + b0.pw.name + "+" + b1.dw.name + "+" + b1.pw.name;
@@ -791,9 +486,9 @@ private:
             T *out = act(blk.pw.out_blob, h, w, blk.pw.cout);
             StemParams<T> sp;
             sp.frames = L.d_frames + mb; sp.out = out;
-            sp.w0 = arena_.ptr<half_t>(c0_hi_); sp.b0 = arena_.ptr<float>(c0_b_);
-            sp.dw_w = arena_.ptr<float>(stem_dw_.w); sp.dw_b = arena_.ptr<float>(stem_dw_.b);
-            sp.pw_w = arena_.ptr<half_t>(stem_pw_.w); sp.pw_b = arena_.ptr<float>(stem_pw_.b);
+            sp.w0 = arena_.template ptr<half_t>(c0_hi_); sp.b0 = arena_.template ptr<float>(c0_b_);
+            sp.dw_w = arena_.template ptr<float>(stem_dw_.w); sp.dw_b = arena_.template ptr<float>(stem_dw_.b);
+            sp.pw_w = arena_.template ptr<half_t>(stem_pw_.w); sp.pw_b = arena_.template ptr<float>(stem_pw_.b);
             sp.pw_m = mult_ptr(stem_pw_);
             sp.n = 0; sp.net_h = H; sp.net_w = W;
             OpInfo op;
@@ -814,7 +509,7 @@ private:
             op.alg_u8_in = 3.0 * P;
             op.alg_elems_out = 8.0 * h * w;
             op.macs = plan.conv0.macs_per_out_pixel() * h * w;
-            const float *wp = arena_.ptr<float>(c0_w_), *bp = arena_.ptr<float>(c0_b_);
+            const float *wp = arena_.template ptr<float>(c0_w_), *bp = arena_.template ptr<float>(c0_b_);
             const FrameDesc *fr = L.d_frames + mb;
             T *o = cur;
             op.launch = [=](hipStream_t s, int n) { launch_conv0<T>(s, fr, o, wp, bp, n, H, W); };
@@ -830,10 +525,10 @@ private:
                 throw ModelError("no kernel instance for depthwise/pointwise block " + blk.dw.name);
             DwPwParams<T> p;
             p.in = cur; p.out = out;
-            p.dw_w = arena_.ptr<DWT>(dw_w_[i].w); p.dw_b = arena_.ptr<float>(dw_w_[i].b);
-            if (dw_w_[i].mma) p.dw_mma = arena_.ptr<uint32_t>(dw_w_[i].mma);
-            if (dw_w_[i].m != kNone) p.dw_m = arena_.ptr<float>(dw_w_[i].m);
-            p.pw_w = arena_.ptr<T>(pw_w_[i].w); p.pw_b = arena_.ptr<float>(pw_w_[i].b); p.pw_m = mult_ptr(pw_w_[i]);
+            p.dw_w = arena_.template ptr<DWT>(dw_w_[i].w); p.dw_b = arena_.template ptr<float>(dw_w_[i].b);
+            if (dw_w_[i].mma) p.dw_mma = arena_.template ptr<uint32_t>(dw_w_[i].mma);
+            if (dw_w_[i].m != kNone) p.dw_m = arena_.template ptr<float>(dw_w_[i].m);
+            p.pw_w = arena_.template ptr<T>(pw_w_[i].w); p.pw_b = arena_.template ptr<float>(pw_w_[i].b); p.pw_m = mult_ptr(pw_w_[i]);
             p.n = 0; p.hin = h; p.win = w; p.hout = ho; p.wout = wo;
             p.cin = c; p.cout = blk.pw.cout; p.stride = blk.dw.stride; p.has_dw = true;
             OpInfo op;
@@ -846,7 +541,7 @@ private:
             if (li >= 0) {          // the lateral 1x1 is computed from this block's output tile while it is in LDS
                 const FoldedConv &lf = plan.lateral[li];
                 lat[li] = act(lf.out_blob, ho, wo, 64);
-                p.lat_w = arena_.ptr<T>(lat_w_[li].w); p.lat_b = arena_.ptr<float>(lat_w_[li].b); p.lat_out = lat[li];
+                p.lat_w = arena_.template ptr<T>(lat_w_[li].w); p.lat_b = arena_.template ptr<float>(lat_w_[li].b); p.lat_out = lat[li];
                 p.lat_m = mult_ptr(lat_w_[li]);
                 op.name += "+" + lf.name;
                 op.kernel.insert(op.kernel.size() - 1, ",lat");
@@ -866,7 +561,7 @@ private:
             feat[i + 1] = act(plan.aggr[i].out_blob, fh, fw, 64);
             Conv3Params<T> p;
             p.in = lat[i + 1]; p.in_ld = 64; p.in_off = 0; p.up = feat[i];
-            p.w = arena_.ptr<T>(aggr_w_[i].w); p.b = arena_.ptr<float>(aggr_w_[i].b); p.m = mult_ptr(aggr_w_[i]);
+            p.w = arena_.template ptr<T>(aggr_w_[i].w); p.b = arena_.template ptr<float>(aggr_w_[i].b); p.m = mult_ptr(aggr_w_[i]);
             p.a_lat = aggr_a_lat_[i]; p.a_up = aggr_a_up_[i];
             p.out0 = feat[i + 1]; p.ld0 = 64; p.off0 = 0; p.n0 = 64; p.out1 = nullptr; p.ld1 = 0; p.off1 = 0;
             p.n = 0; p.h = fh; p.w_ = fw; p.cin = 64; p.cout = 64;
@@ -898,7 +593,7 @@ private:
             auto fill = [&](Conv3Params<T> &p, OpInfo &op, const FoldedConv &f, const GemmW &gw, const T *in, int cin, T *o0,
                             int ld0, int off0, int n0, T *o1, int ld1, int off1, int nlayers) {
                 p.in = in; p.in_ld = cin; p.in_off = 0; p.up = nullptr;
-                p.w = arena_.ptr<T>(gw.w); p.b = arena_.ptr<float>(gw.b); p.m = mult_ptr(gw);
+                p.w = arena_.template ptr<T>(gw.w); p.b = arena_.template ptr<float>(gw.b); p.m = mult_ptr(gw);
                 p.out0 = o0; p.ld0 = ld0; p.off0 = off0; p.n0 = n0; p.out1 = o1; p.ld1 = ld1; p.off1 = off1;
                 p.n = 0; p.h = fh; p.w_ = fw; p.cin = cin; p.cout = f.cout;
                 op.name += (op.name.empty() ? "" : " | ") + f.name;
@@ -910,7 +605,7 @@ private:
             fill(lv_b.p[i], op_b, m.conv_b, ssh_w_[i][1], ctx1, 16, cat, 64, 32, 16, ctx31, 16, 0, 2);
             fill(lv_c.p[i], op_c, m.conv_c, ssh_w_[i][2], ctx31, 16, cat, 64, 48, 16, nullptr, 0, 0, 1);
             HeadParams<T> &hp = hl.p[i];
-            hp.in = cat; hp.w = arena_.ptr<T>(ssh_w_[i][3].w); hp.b = arena_.ptr<float>(ssh_w_[i][3].b);
+            hp.in = cat; hp.w = arena_.template ptr<T>(ssh_w_[i][3].w); hp.b = arena_.template ptr<float>(ssh_w_[i][3].b);
             hp.m = mult_ptr(ssh_w_[i][3]);
             hp.n = 0; hp.h = fh; hp.w_ = fw; hp.stride = strides_[i]; hp.anchor_offset = anchor_off;
             hp.num_anchors = na_;
@@ -1235,21 +930,12 @@ private:
     // ------------------------------------------------------------------------------------------ state
     int device_ = 0;
     std::vector<float> ratios_;                // the network preset's anchor ratios (empty: a preset without anchors)
-    int na_ = 2, head_a_ = 2;                  // anchors per cell the preset decodes / the model's heads carry
+    int na_ = 2;                               // anchors per cell the preset decodes (head_a_: what the model's heads carry)
     std::unique_ptr<ParallelCopier> copier_;
     std::vector<ParallelCopier::Job> copy_jobs_;
     struct HostRange { uintptr_t base; size_t bytes; bool owned; };
     std::vector<HostRange> registered_;       // rf_host_register ranges (pinned caller memory; owned = pinned by this engine)
     std::vector<hipEvent_t> prof_ev_;
-    Arena arena_;
-    size_t c0_w_ = 0, c0_b_ = 0, c0_hi_ = 0;
-    DwW stem_dw_{0, 0}, stem2_dw_{0, 0};
-    GemmW stem_pw_{0, 0}, stem2_pw_{0, 0};
-    float aggr_a_lat_[2] = {1.f, 1.f}, aggr_a_up_[2] = {1.f, 1.f};
-    std::map<std::string, std::vector<float>> act_scale_;    // int8: blob -> per-channel scales (debug accessors dequantise)
-    std::vector<DwW> dw_w_;
-    std::vector<GemmW> pw_w_;
-    GemmW lat_w_[3], aggr_w_[2], ssh_w_[3][4];
     std::vector<void *> dev_allocs_, host_allocs_;
     const int strides_[3] = {32, 16, 8};
 
@@ -1268,24 +954,78 @@ private:
 
 }  // namespace
 
-std::unique_ptr<Engine> Engine::create_single(const std::string &model_dir, const std::string &network, float nms,
-                                              const EngineOptions &opt) {
-    std::vector<float> ratios;
-    (void)network_preset(network, &ratios);       // unknown names behave like "ssh": constructed, no anchors (RetinaFace.cpp:237-239)
-    Model model = load_model_dir(model_dir, opt.model_stem);      // host-only steps first: their errors do not need a GPU
-    Plan plan = compile_plan(model);
+std::string plan_cache_path(const std::string &model_dir, const std::string &stem, int precision) {
+    static const char *names[3] = {"fp32", "fp16", "int8"};
+    return model_dir + "/" + stem + "." + names[precision < 0 || precision > 2 ? 1 : precision] + ".rfplan";
+}
+
+// Host-only half of engine start-up: the packed weight image and the plan skeleton, from the plan cache when it matches the
+// model files, otherwise from the model (and then the cache is (re)written, best effort: a read-only model directory is fine).
+template <typename T>
+void prepare_pack(const std::string &model_dir, const EngineOptions &opt, Plan *plan, WeightPack<T> *pack, bool *from_cache) {
+    PlanCacheKey key;
+    key.build = 1469598103934665603ull;
+    for (const char *c = __DATE__ " " __TIME__ " " __FILE__; *c; c++) { key.build ^= (unsigned char)*c; key.build *= 1099511628211ull; }
+    key.precision = opt.precision;
+    key.stem2 = std::is_same<T, half_t>::value ? stem2_variant() : 0;
+    const std::string path = opt.plan_cache_path.empty() ? plan_cache_path(model_dir, opt.model_stem, opt.precision) : opt.plan_cache_path;
+    *from_cache = false;
+    if (opt.plan_cache) {
+        key.source_hash = model_source_hash(model_dir, opt.model_stem);        // throws IoError when the model is missing
+        std::string bytes;
+        if (read_file_if_exists(path, &bytes)) {
+            try {
+                if (load_plan_cache<T>(bytes, key, plan, pack)) { *from_cache = true; return; }
+            } catch (const IoError &) { /* damaged cache file: rebuild below and overwrite it */ }
+            *plan = Plan();
+            *pack = WeightPack<T>();
+        }
+    }
+    Model model = load_model_dir(model_dir, opt.model_stem);
+    *plan = compile_plan(model);
+    if (opt.precision == RF_PRECISION_INT8 && plan->int8_scales.empty())
+        throw Unsupported("int8 precision needs a calibration table (<stem>.table.int8, or scales inside the .rfw)");
+    pack->pack(*plan);
+    if (opt.plan_cache) write_file_best_effort(path, save_plan_cache<T>(key, *plan, *pack));
+}
+
+template <typename T>
+static std::unique_ptr<Engine> make_engine(const std::string &model_dir, const std::string &network, float nms, const EngineOptions &opt,
+                                           const std::vector<float> &ratios) {
+    Plan plan;
+    WeightPack<T> pack;
+    bool from_cache = false;
+    prepare_pack<T>(model_dir, opt, &plan, &pack, &from_cache);       // host-only steps first: their errors do not need a GPU
     if (!ratios.empty() && 2 * (int)ratios.size() != plan.anchors_per_cell)
         // the reference would index past the end of the score blob here (RetinaFace.cpp:669-694 with _num_anchors != blob channels / 2)
         throw ModelError("network preset '" + network + "' decodes " + std::to_string(2 * ratios.size()) + " anchors per cell but the model's "
                          "heads carry " + std::to_string(plan.anchors_per_cell));
-    if (opt.precision == RF_PRECISION_INT8 && plan.int8_scales.empty())
-        throw Unsupported("int8 precision needs a calibration table (<stem>.table.int8, or scales inside the .rfw)");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) throw HipError("no HIP device available");
+    return std::unique_ptr<Engine>(new EngineImpl<T>(plan, std::move(pack), nms, opt, ratios));
+}
+
+// test hook (host only): build / validate the plan cache of one model without creating an engine
+int plan_cache_probe(const std::string &model_dir, const EngineOptions &opt, size_t *arena_bytes) {
+    Plan plan;
+    bool hit = false;
     switch (opt.precision) {
-        case RF_PRECISION_FP16: return std::unique_ptr<Engine>(new EngineImpl<half_t>(plan, nms, opt, ratios));
-        case RF_PRECISION_FP32: return std::unique_ptr<Engine>(new EngineImpl<float>(plan, nms, opt, ratios));
-        case RF_PRECISION_INT8: return std::unique_ptr<Engine>(new EngineImpl<int8_t>(plan, nms, opt, ratios));
+        case RF_PRECISION_FP16: { WeightPack<half_t> p; prepare_pack<half_t>(model_dir, opt, &plan, &p, &hit); if (arena_bytes) *arena_bytes = p.arena_.bytes(); break; }
+        case RF_PRECISION_FP32: { WeightPack<float> p; prepare_pack<float>(model_dir, opt, &plan, &p, &hit); if (arena_bytes) *arena_bytes = p.arena_.bytes(); break; }
+        case RF_PRECISION_INT8: { WeightPack<int8_t> p; prepare_pack<int8_t>(model_dir, opt, &plan, &p, &hit); if (arena_bytes) *arena_bytes = p.arena_.bytes(); break; }
+        default: throw ArgError("unknown precision");
+    }
+    return hit ? 1 : 0;
+}
+
+std::unique_ptr<Engine> Engine::create_single(const std::string &model_dir, const std::string &network, float nms,
+                                              const EngineOptions &opt) {
+    std::vector<float> ratios;
+    (void)network_preset(network, &ratios);       // unknown names behave like "ssh": constructed, no anchors (RetinaFace.cpp:237-239)
+    switch (opt.precision) {
+        case RF_PRECISION_FP16: return make_engine<half_t>(model_dir, network, nms, opt, ratios);
+        case RF_PRECISION_FP32: return make_engine<float>(model_dir, network, nms, opt, ratios);
+        case RF_PRECISION_INT8: return make_engine<int8_t>(model_dir, network, nms, opt, ratios);
         default: throw ArgError("unknown precision");
     }
 }

@@ -35,6 +35,8 @@ struct EngineOptions {
                                      // a launch holds several tiles per resident workgroup (measured: 4 -> 16 = +8 %)
     bool keep_outputs = false;
     int copy_threads = 0;            // threads (caller's included) that stage host frames into pinned memory; 0 = min(12, cores / 4)
+    bool plan_cache = true;          // read / write <model_dir>/<stem>.<precision>.rfplan (packed weight image, weights.h)
+    std::string plan_cache_path;     // explicit cache file instead (tests)
     std::vector<int> devices;        // more than one entry: one engine per device, batches sharded by image (multi.cpp)
     std::string model_stem = "mnet-deconv-0517";
 };
@@ -55,6 +57,9 @@ struct OpInfo {
 // anchors of FPN level 0 / 1 / 2 (strides 32 / 16 / 8) for those ratios, 2 per ratio
 bool network_preset(const std::string &network, std::vector<float> *ratios);
 void preset_base_anchors(const std::vector<float> &ratios, int level, float out[][4]);
+
+// host-only test hook: runs the host half of engine start-up (plan cache or model -> packed image); 1 = served from the cache
+int plan_cache_probe(const std::string &model_dir, const EngineOptions &opt, size_t *arena_bytes);
 
 class Engine {
 public:

@@ -28,7 +28,7 @@ bool Model::scale_of(const std::string &tensor, float *scale) const {
     return false;
 }
 
-static std::string slurp(const std::string &path, bool binary) {
+std::string slurp(const std::string &path, bool binary) {
     std::ifstream f(path, binary ? std::ios::binary : std::ios::in);
     if (!f) throw IoError("cannot open '" + path + "'");
     std::ostringstream ss;
@@ -486,7 +486,7 @@ Model load_rfw(const std::string &path) {
     return m;
 }
 
-static bool file_exists(const std::string &p) {
+bool file_exists(const std::string &p) {
     FILE *f = fopen(p.c_str(), "rb");
     if (!f) return false;
     fclose(f);
@@ -505,6 +505,44 @@ Model load_model_dir(const std::string &dir, const std::string &stem) {
     else if (file_exists(dir + "/mnet-deconv-0517.table.int8"))
         attach_int8_table(m, dir + "/mnet-deconv-0517.table.int8");
     return m;
+}
+
+}  // namespace rf
+
+// ------------------------------------------------------------------------------------------
+// plan-cache support (weights.h): validity key of a model directory, small file helpers
+// ------------------------------------------------------------------------------------------
+namespace rf {
+
+static void fnv1a(uint64_t &h, const std::string &bytes) {
+    for (unsigned char c : bytes) { h ^= c; h *= 1099511628211ull; }
+}
+
+uint64_t model_source_hash(const std::string &dir, const std::string &stem) {
+    const std::string base = dir + "/" + stem;
+    uint64_t h = 1469598103934665603ull;
+    if (file_exists(base + ".rfw")) { fnv1a(h, slurp(base + ".rfw", true)); return h; }
+    if (!file_exists(base + ".prototxt") || !file_exists(base + ".caffemodel"))
+        throw IoError("no model in '" + dir + "': need " + stem + ".rfw or " + stem + ".prototxt + " + stem + ".caffemodel");
+    fnv1a(h, slurp(base + ".prototxt", true));
+    fnv1a(h, slurp(base + ".caffemodel", true));
+    if (file_exists(base + ".table.int8")) fnv1a(h, slurp(base + ".table.int8", true));
+    else if (file_exists(dir + "/mnet-deconv-0517.table.int8")) fnv1a(h, slurp(dir + "/mnet-deconv-0517.table.int8", true));
+    return h;
+}
+
+bool read_file_if_exists(const std::string &path, std::string *bytes) {
+    if (!file_exists(path)) return false;
+    try { *bytes = slurp(path, true); } catch (const IoError &) { return false; }
+    return true;
+}
+
+void write_file_best_effort(const std::string &path, const std::string &bytes) {
+    const std::string tmp = path + ".tmp" + std::to_string((unsigned long)(uintptr_t)&bytes & 0xffffff);
+    FILE *f = fopen(tmp.c_str(), "wb");
+    if (!f) return;                                    // read-only model directory: run without a cache
+    const bool ok = fwrite(bytes.data(), 1, bytes.size(), f) == bytes.size();
+    if (fclose(f) != 0 || !ok || rename(tmp.c_str(), path.c_str()) != 0) (void)remove(tmp.c_str());
 }
 
 }  // namespace rf

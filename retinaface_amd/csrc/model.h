@@ -60,4 +60,9 @@ void save_rfw(const Model &m, const std::string &path);
 // hard-codes that one table: trtnetbase.cpp:13).
 Model load_model_dir(const std::string &dir, const std::string &stem);
 
+// FNV-1a 64 over the bytes of exactly the files load_model_dir would read for (dir, stem): the plan cache's validity key
+uint64_t model_source_hash(const std::string &dir, const std::string &stem);
+bool read_file_if_exists(const std::string &path, std::string *bytes);
+void write_file_best_effort(const std::string &path, const std::string &bytes);      // tmp file + rename; failures are ignored
+
 }  // namespace rf

@@ -584,6 +584,26 @@ def test_network_presets(rfa, nets, crop448, tmp_path):
             det.close()
 
 
+def test_engine_from_the_plan_cache_equals_engine_from_the_model(rfa, tmp_path):
+    """Warm start (packed weight image read back from <stem>.<precision>.rfplan) gives bit-identical detections to a cold start and
+    to an engine that never touches the cache, in every precision."""
+    import shutil
+    from retinaface_amd.frames import synth_frames
+    shutil.copy(os.path.join(ASSETS, "mnet25.rfw"), tmp_path / "mnet25.rfw")
+    frames = synth_frames(448, 448, 4, config=23)
+    for prec, name in ((FP16, "fp16"), (FP32, "fp32"), (INT8, "int8")):
+        nocache = rfa.RetinaFace(str(tmp_path), "net3", 0.4, precision=prec, net_hw=(448, 448), model_stem="mnet25", plan_cache=False)
+        want = _key(nocache.detectBatchImages(frames, 0.5))
+        nocache.close()
+        assert not (tmp_path / f"mnet25.{name}.rfplan").exists()
+        for run in ("cold", "warm"):
+            det = rfa.RetinaFace(str(tmp_path), "net3", 0.4, precision=prec, net_hw=(448, 448), model_stem="mnet25")
+            assert (tmp_path / f"mnet25.{name}.rfplan").exists()
+            assert _key(det.detectBatchImages(frames, 0.5)) == want, (name, run)
+            det.close()
+        assert rfa._lib.load_library().rf_plan_cache_probe(str(tmp_path).encode(), b"mnet25", prec, None, None) == 1
+
+
 def test_error_paths_leave_the_handle_usable(rfa):
     """A bad frame in a LATER chunk of a synchronous call (the earlier chunks are already in flight), repeated more often than the
     ticket pool is deep; rf_wait with a NULL result array; enqueue of more than max_batch images."""

@@ -130,8 +130,12 @@ def _create(lib, model_dir, network=b"net3", **kw):
 def test_error_paths_without_a_gpu(built_lib, tmp_path):
     st, msg = _create(built_lib, str(tmp_path).encode())
     assert st == _lib.RF_ERR_IO and "mnet-deconv-0517" in msg
+    # presets the reference constructs without anchors are accepted (they detect nothing, as there): only the GPU is missing here
     st, msg = _create(built_lib, ASSETS.encode(), network=b"net5")
-    assert st == _lib.RF_ERR_UNSUPPORTED
+    assert st in (_lib.RF_ERR_HIP, 0), msg
+    # "net3a" decodes 4 anchors per cell, the shipped models carry 2: refused on the host (the reference would read out of bounds)
+    st, msg = _create(built_lib, ASSETS.encode(), network=b"net3a")
+    assert st == _lib.RF_ERR_MODEL and "anchors per cell" in msg
     st, msg = _create(built_lib, ASSETS.encode(), precision=7)
     assert st == _lib.RF_ERR_INVALID_ARG
     bad = tmp_path / "mnet-deconv-0517.rfw"
@@ -357,9 +361,15 @@ def test_int8_calibration_math():
     from oracle.caffe_io import read_int8_table
     own = read_int8_table(os.path.join(ROOT, "assets", "mnet25.table.int8"))
     trt = read_int8_table(os.path.join(ROOT, "assets", "mnet-deconv-0517.table.int8"))
-    assert set(own) <= set(trt) and len(own) >= 43
-    ratio = np.array([own[n] / trt[n] for n in own])                         # different weights, same architecture: same ballpark
+    per_tensor = {n: v for n, v in own.items() if "#" not in n}             # `name#c` lines: the per-channel extension
+    assert set(per_tensor) <= set(trt) and len(per_tensor) >= 43
+    ratio = np.array([per_tensor[n] / trt[n] for n in per_tensor])           # different weights, same architecture: same ballpark
     assert 0.3 < np.median(ratio) < 3.0
+    chans = {n.split("#")[0] for n in own if "#" in n}
+    assert chans == set(per_tensor) - {"data"}                               # every tensor also carries per-channel scales ...
+    for n in chans:                                                          # ... none above its tensor's, none vanishing
+        pc = np.array([v for k, v in own.items() if k.startswith(n + "#")])
+        assert pc.max() <= per_tensor[n] * 1.0001 and pc.min() >= per_tensor[n] / 64.0 * 0.999, n
 
 
 def test_calibration_batch_files_follow_the_reference_layout(tmp_path):
@@ -389,3 +399,42 @@ def test_calibration_batch_files_follow_the_reference_layout(tmp_path):
     a = synth_frames(448, 448, 2, config=9, faces=[0, 2, 4])
     b = synth_frames(448, 448, 2, config=9, faces=[1, 3, 5])
     assert not np.array_equal(a[0], b[0])
+
+
+def test_plan_cache_round_trip_and_invalidation(built_lib, tmp_path):
+    """The packed-weight image cache (<stem>.<precision>.rfplan, the analogue of the reference's serialized-engine cache,
+    trtnetbase.cpp:205-243): built on first use, served afterwards, rebuilt when the model bytes change, when the file is damaged or
+    belongs to another precision; an unwritable location just runs without a cache."""
+    import shutil
+    d = tmp_path / "model"
+    d.mkdir()
+    shutil.copy(os.path.join(ASSETS, "mnet25.rfw"), d / "mnet25.rfw")
+    nbytes = C.c_size_t()
+
+    def probe(prec, path=None):
+        r = built_lib.rf_plan_cache_probe(str(d).encode(), b"mnet25", prec, path.encode() if path else None, C.byref(nbytes))
+        assert r >= 0, built_lib.rf_last_error(None)
+        return r
+
+    for prec, name in ((1, "fp16"), (2, "int8"), (0, "fp32")):
+        assert probe(prec) == 0                                        # built from the model, cache written
+        f = d / f"mnet25.{name}.rfplan"
+        assert f.exists() and f.stat().st_size > nbytes.value > 400_000
+        first = nbytes.value
+        assert probe(prec) == 1 and nbytes.value == first              # served from the cache: same image
+    sizes = {n: (d / f"mnet25.{n}.rfplan").stat().st_size for n in ("fp32", "fp16", "int8")}
+    assert sizes["fp32"] > sizes["fp16"] > sizes["int8"]
+    # another precision's file under this precision's name is not accepted
+    shutil.copy(d / "mnet25.int8.rfplan", d / "mnet25.fp16.rfplan")
+    assert probe(1) == 0 and probe(1) == 1
+    # a damaged cache is rebuilt, not trusted
+    raw = (d / "mnet25.fp16.rfplan").read_bytes()
+    (d / "mnet25.fp16.rfplan").write_bytes(raw[:len(raw) // 2])
+    assert probe(1) == 0 and probe(1) == 1
+    # the model changed (one weight byte): stale cache is ignored and replaced
+    m = bytearray((d / "mnet25.rfw").read_bytes())
+    m[len(m) // 2] ^= 0x01
+    (d / "mnet25.rfw").write_bytes(bytes(m))
+    assert probe(1) == 0 and probe(1) == 1
+    # nowhere to write: still works, never a hit
+    assert probe(1, "/proc/definitely/not/writable.rfplan") == 0 and probe(1, "/proc/definitely/not/writable.rfplan") == 0
