@@ -73,13 +73,17 @@ typedef struct rf_options {
                                    images (default 16, max 32; 1 = off).  A merged launch starts when it is full or when one of
                                    its tickets is waited for.  rf_num_slots() = lanes * coalesce. */
     /* ---- fields added in ABI 2 (a caller compiled against ABI 1 passes the shorter struct_size and gets the defaults) ---- */
-    int32_t copy_threads;       /* host threads (the caller's included) that stage host frames into pinned memory; 0 = min(12, cores/4) */
+    int32_t copy_threads;       /* host threads (the caller's included) that stage host frames into pinned memory; 0 = min(8, cores/4) */
     int32_t n_devices;          /* > 1: one engine per entry of devices[], every rf_detect_batch* call is sharded by image over them */
     const int32_t *devices;     /* HIP device ordinals (0-based; an ordinal may repeat); NULL / n_devices <= 1: `device` above */
     int32_t plan_cache;         /* 0 / 1 (default): keep the packed weight image next to the model as <stem>.<precision>.rfplan -- the
                                    analogue of the reference's serialized-engine cache (trtnetbase.cpp:205-243): later rf_create calls
                                    read it back (one file read + one hipMemcpy, no parse / BN fold / packing) as long as the model files'
                                    hash, the precision and the library build match; 2 = neither read nor write it */
+    int32_t oversize_resize;    /* how a frame LARGER than the net is shrunk: 0 / 1 (default) = aspect-kept area average, the reference's
+                                   NPP build (resizeconvertion.cu:298-311, NPPI_INTER_SUPER: closed source, semantics by definition);
+                                   2 = cv::resize bilinear + one-sided zero padding, the reference's build without NPP
+                                   (RetinaFace.cpp:585-620; OpenCV's published 8-bit fixed-point algorithm, bit-exact to the oracle's) */
 } rf_options;
 
 typedef struct rf_engine *rf_handle;
@@ -114,8 +118,8 @@ int rf_get_net_size(rf_handle h, int *net_h, int *net_w, int *max_batch);
  * (RetinaFace.h:69, RetinaFace.cpp:749-940) and, with n == 1, RetinaFace::detect (RetinaFace.h:70,
  * RetinaFace.cpp:576-747).  Frames are HOST pointers to CV_8UC3 BGR pixels: bgr[i] + y*steps[i] is row y
  * (cv::Mat data/step).  Frames no larger than the net are placed top-left on a zero canvas
- * (resizeconvertion.cu:298-303 with the scale factor clamped to 1); larger frames are area-averaged
- * down first.  Unlike the reference (which returns void and drops faceInfo, RetinaFace.cpp:726-747)
+ * (resizeconvertion.cu:298-303 with the scale factor clamped to 1); larger frames are shrunk first
+ * (options.oversize_resize: area average as in the NPP build, or bilinear as in the build without NPP).  Unlike the reference (which returns void and drops faceInfo, RetinaFace.cpp:726-747)
  * results are returned: out[i*cap_per_image + k], k < min(counts[i], cap_per_image), score-descending,
  * coordinates in network-input pixels (as in the reference).  A NULL/0x0 frame yields count 0
  * (img.empty() early return, RetinaFace.cpp:578-580). */

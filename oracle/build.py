@@ -16,7 +16,8 @@ _OUT = os.path.join(_HERE, "_build", "librf_post_ref.so")
 
 
 def build(force: bool = False) -> str:
-    if force or not os.path.exists(_OUT) or os.path.getmtime(_OUT) < os.path.getmtime(_SRC):
+    newest = max(os.path.getmtime(_SRC), os.path.getmtime(os.path.join(_HERE, "csrc", "cv_resize_linear.h")))
+    if force or not os.path.exists(_OUT) or os.path.getmtime(_OUT) < newest:
         os.makedirs(os.path.dirname(_OUT), exist_ok=True)
         subprocess.check_call(["gcc", "-O2", "-std=c11", "-fPIC", "-shared", "-ffp-contract=off", "-o", _OUT, _SRC, "-lm"])
     return _OUT
@@ -41,6 +42,20 @@ def lib() -> C.CDLL:
         _lib.rfo_anchors_plane.restype = None
         _lib.rfo_anchors_plane.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float)]
     return _lib
+
+
+def cv_resize_linear(img, fx: float, fy: float):
+    """C restatement of cv::resize(img, Size(), fx, fy), INTER_LINEAR, CV_8UC3 (csrc/cv_resize_linear.h)."""
+    import numpy as np
+    l = lib()
+    l.rfo_cv_resize_dsize.argtypes = [C.c_int, C.c_int, C.c_double, C.c_double, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    l.rfo_cv_resize_linear.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_double, C.c_double]
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    dr, dc = C.c_int(), C.c_int()
+    l.rfo_cv_resize_dsize(img.shape[0], img.shape[1], fx, fy, C.byref(dr), C.byref(dc))
+    out = np.empty((dr.value, dc.value, 3), np.uint8)
+    l.rfo_cv_resize_linear(img.ctypes.data, img.shape[0], img.shape[1], out.ctypes.data, fx, fy)
+    return out
 
 
 def decode_nms(heads9, net_h: int, net_w: int, threshold: float, nms_threshold: float, cap: int = 1 << 16):

@@ -199,3 +199,14 @@ int rfo_nms(rfo_face *faces, int32_t *anchor_index, int n, float threshold)
     free(merged);
     return kept;
 }
+
+
+/* ---- oversize frames: OpenCV's bilinear resize, restated in cv_resize_linear.h (exported for the numpy-vs-C agreement test) */
+#include "cv_resize_linear.h"
+
+void rfo_cv_resize_dsize(int rows, int cols, double fx, double fy, int *drows, int *dcols) { cv_resize_dsize(rows, cols, fx, fy, drows, dcols); }
+void rfo_cv_resize_linear(const uint8_t *src, int rows, int cols, uint8_t *dst, double fx, double fy) {
+    int drows, dcols;
+    cv_resize_dsize(rows, cols, fx, fy, &drows, &dcols);
+    cv_resize_linear_8uc3(src, rows, cols, (size_t)cols * 3, dst, drows, dcols, (size_t)dcols * 3, fx, fy);
+}

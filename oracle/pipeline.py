@@ -15,7 +15,7 @@ import numpy as np
 
 from .caffe_forward import CaffeNet, HEAD_STRIDES, head_names
 from .caffe_io import NetSpec
-from .retinaface_post import (Detection, decode, nms, preprocess_caffe, preprocess_trt_identity)
+from .retinaface_post import (Detection, decode, nms, preprocess_caffe, preprocess_trt_cvresize, preprocess_trt_identity)
 
 
 @dataclass
@@ -48,7 +48,10 @@ class OracleDetector:
             chw, hs, ws = preprocess_caffe(img_bgr)
         else:
             hs, ws = net_hw
-            chw = preprocess_trt_identity(img_bgr, hs, ws)
+            # frames that fit: 1:1 on a zero canvas (both TensorRT builds agree); larger frames: the cv::resize branch of the
+            # build without NPP (the one oracle/_ref compiles) -- NPP's area filter is closed source
+            fits = img_bgr.shape[0] <= hs and img_bgr.shape[1] <= ws
+            chw = preprocess_trt_identity(img_bgr, hs, ws) if fits else preprocess_trt_cvresize(img_bgr, hs, ws)
         blobs = self.caffe.forward(chw)
         heads = {n: blobs[n] for s in HEAD_STRIDES for n in head_names(s)}
         cands = decode(heads, hs, ws, threshold)

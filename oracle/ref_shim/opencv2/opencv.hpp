@@ -2,8 +2,9 @@
 // Implements exactly the OpenCV surface the reference's RetinaFace.h / RetinaFace.cpp touch when built
 // with -DUSE_TENSORRT and without USE_NPP: Mat (u8 / f32, interleaved), copyMakeBorder (constant),
 // convertTo (u8 -> f32), cvtColor (BGR<->RGB), split (into pre-allocated planes), tick counters.
-// cv::resize is deliberately absent from the arithmetic: it aborts (OpenCV's interpolation is third-party).
+// cv::resize (bilinear, 8UC3) goes through a restatement of OpenCV's published fixed-point algorithm (oracle/csrc/cv_resize_linear.h).
 #pragma once
+#include "../../csrc/cv_resize_linear.h"
 #include <algorithm>
 #include <cassert>
 #include <chrono>
@@ -156,10 +157,18 @@ inline void split(const Mat &src, std::vector<Mat> &mv) {
     }
 }
 
-inline void resize(const Mat &, Mat &, Size, double = 0, double = 0, int = 1) {
-    fprintf(stderr, "ref_shim: cv::resize is third-party OpenCV arithmetic and is not provided; "
-                    "only frames that fit the network input can go through the reference build\n");
-    abort();
+// cv::resize with an empty dsize and INTER_LINEAR on CV_8UC3 -- the only form the reference uses (RetinaFace.cpp:613,:617) --
+// through the restatement of OpenCV's published algorithm in oracle/csrc/cv_resize_linear.h (a stand-in like everything here).
+inline void resize(const Mat &src, Mat &dst, Size dsize, double fx = 0, double fy = 0, int interpolation = 1) {
+    if (src.type() != CV_8UC3 || dsize.width != 0 || dsize.height != 0 || fx <= 0 || fy <= 0 || interpolation != 1) {
+        fprintf(stderr, "ref_shim: cv::resize is provided for CV_8UC3, Size(), fx, fy, INTER_LINEAR only\n");
+        abort();
+    }
+    int drows = 0, dcols = 0;
+    cv_resize_dsize(src.rows, src.cols, fx, fy, &drows, &dcols);
+    Mat out(drows, dcols, CV_8UC3);
+    cv_resize_linear_8uc3(src.data, src.rows, src.cols, src.step, out.data, drows, dcols, out.step, fx, fy);
+    dst = out;
 }
 
 inline long long getTickCount() {

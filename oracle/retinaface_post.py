@@ -143,6 +143,87 @@ def preprocess_trt_identity(img_bgr: np.ndarray, net_h: int, net_w: int) -> np.n
     return np.ascontiguousarray(chw[None])
 
 
+def cv_resize_linear(img: np.ndarray, fx: float, fy: float) -> np.ndarray:
+    """cv::resize(img, dst, Size(), fx, fy) with the default INTER_LINEAR for CV_8UC3: numpy twin of
+    oracle/csrc/cv_resize_linear.h (OpenCV's published legacy fixed-point path; see that header for the algorithm and for why
+    it is a restatement of a third-party dependency: parity unpinned)."""
+    assert img.dtype == np.uint8 and img.ndim == 3 and img.shape[2] == 3
+    rows, cols = img.shape[:2]
+    dcols, drows = int(np.rint(f64(cols) * f64(fx))), int(np.rint(f64(rows) * f64(fy)))          # cvRound: half to even
+    scale_x, scale_y = f64(1.0) / f64(fx), f64(1.0) / f64(fy)
+
+    def taps(n_dst, n_src, scale, clamp):
+        f = ((np.arange(n_dst, dtype=np.float64) + 0.5) * scale - 0.5).astype(np.float32)
+        s = np.floor(f).astype(np.int64)
+        f = (f - s.astype(np.float32)).astype(np.float32)
+        if clamp:                                                    # columns: fraction forced to 0 at the borders
+            lo, hi = s < 0, s >= n_src - 1
+            f = np.where(lo | hi, f32(0), f)
+            s = np.where(lo, 0, np.where(hi, n_src - 1, s))
+        a0 = np.clip(np.rint((f32(1) - f) * f32(2048)), -32768, 32767).astype(np.int64)
+        a1 = np.clip(np.rint(f * f32(2048)), -32768, 32767).astype(np.int64)
+        return s, a0, a1
+
+    sx, a0, a1 = taps(dcols, cols, scale_x, True)
+    sy, b0, b1 = taps(drows, rows, scale_y, False)
+    sx1 = np.minimum(sx + 1, cols - 1)
+    y0, y1 = np.clip(sy, 0, rows - 1), np.clip(sy + 1, 0, rows - 1)
+    src = img.astype(np.int64)
+    h = src[:, sx] * a0[None, :, None] + src[:, sx1] * a1[None, :, None]            # horizontal pass, all source rows
+    out = (((b0[:, None, None] * (h[y0] >> 4)) >> 16) + ((b1[:, None, None] * (h[y1] >> 4)) >> 16) + 2) >> 2
+    return out.astype(np.uint8)
+
+
+def resize_area_reference(img_bgr: np.ndarray, net_h: int, net_w: int) -> np.ndarray:
+    """Independent statement of what the product's area-average step computes for an oversize frame (the NPP build's
+    NPPI_INTER_SUPER is closed source, so this is a DEFINITION, not a pin): factor f = min(netW / cols, netH / rows) < 1, the
+    destination is floor(cols f) x floor(rows f) pixels top-left on a zero canvas, and destination pixel (y, x) is the mean of
+    the source over the rectangle [x / f, (x + 1) / f) x [y / f, (y + 1) / f) with fractional coverage at the edges.  Written
+    as two coverage matrices (rows and columns) -- a different formulation from the kernel's per-pixel loops."""
+    rows, cols = img_bgr.shape[:2]
+    f = min(f32(net_w) / f32(cols), f32(net_h) / f32(rows))
+    f = f32(min(f, f32(1.0)))
+    dw, dh = int(f32(cols) * f), int(f32(rows) * f)
+    inv = f64(f32(1.0) / f)
+
+    def coverage(n_dst, n_src):
+        lo = np.arange(n_dst, dtype=np.float64) * inv
+        hi = np.minimum((np.arange(n_dst, dtype=np.float64) + 1) * inv, n_src)
+        edges = np.arange(n_src + 1, dtype=np.float64)
+        return np.clip(np.minimum(hi[:, None], edges[None, 1:]) - np.maximum(lo[:, None], edges[None, :-1]), 0, None)
+
+    wy, wx = coverage(dh, rows), coverage(dw, cols)
+    src = img_bgr.astype(np.float64)
+    tmp = (wy @ src.reshape(rows, cols * 3)).reshape(dh, cols, 3)             # rows first, then columns: two small matmuls
+    acc = np.einsum("xc,ycs->yxs", wx, tmp, optimize=True)
+    mean = acc / (wy.sum(1)[:, None, None] * wx.sum(1)[None, :, None])
+    out = np.zeros((net_h, net_w, 3), np.uint8)
+    out[:dh, :dw] = np.clip(np.rint(mean), 0, 255).astype(np.uint8)
+    return out
+
+
+def preprocess_trt_cvresize(img_bgr: np.ndarray, net_h: int, net_w: int) -> np.ndarray:
+    """The TensorRT build WITHOUT NPP (CMake default), RetinaFace.cpp:585-647: scale = max(cols / netW, rows / netH, 1) in float;
+    frames that fit are zero-padded bottom / right to the net size (:621-624, identical to preprocess_trt_identity); larger frames
+    are shrunk by cv::resize(img, Size(), 1 / scale, 1 / scale) (bilinear) and padded on the ONE side that is short (:611-620 --
+    the code assumes the other side came out at exactly the net size, which holds whenever cvRound(side / scale) does)."""
+    rows, cols = img_bgr.shape[:2]
+    sw = f32(f64(1.0) * f64(cols) / f64(net_w))        # `float sw = 1.0 * img.cols / inputW`: double arithmetic, stored to float
+    sh = f32(f64(1.0) * f64(rows) / f64(net_h))
+    scale = sw if sw > sh else sh
+    scale = scale if scale > 1.0 else f32(1.0)
+    if scale > 1:
+        inv = f64(f32(1) / scale)                   # `1 / scale`: int / float -> float, then widened to cv::resize's double fx
+        small = cv_resize_linear(img_bgr, inv, inv)
+        if sw > sh:
+            assert small.shape[1] == net_w, "the reference pads only the bottom here"
+        else:
+            assert small.shape[0] == net_h, "the reference pads only the right side here"
+        assert small.shape[0] <= net_h and small.shape[1] <= net_w
+        img_bgr = small
+    return preprocess_trt_identity(img_bgr, net_h, net_w)
+
+
 # ------------------------------------------------------------------ regression (RetinaFace.cpp:378-432)
 
 def bbox_pred(anchor, regress):

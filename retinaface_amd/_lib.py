@@ -31,7 +31,7 @@ class rf_options(C.Structure):
                 ("max_detections", C.c_int32), ("use_graph", C.c_int32), ("keep_outputs", C.c_int32),
                 ("model_stem", C.c_char_p), ("lanes", C.c_int32), ("coalesce", C.c_int32),
                 ("copy_threads", C.c_int32), ("n_devices", C.c_int32), ("devices", C.POINTER(C.c_int32)),
-                ("plan_cache", C.c_int32)]
+                ("plan_cache", C.c_int32), ("oversize_resize", C.c_int32)]
 
 
 # every symbol include/retinaface_amd.h declares: name -> (restype, argtypes)

@@ -74,6 +74,7 @@ int rf_create(const char *model_dir, const char *network, float nms_threshold, c
             if (o->n_devices < 0 || (o->n_devices > 0 && !o->devices)) throw rf::ArgError("n_devices / devices mismatch");
             for (int i = 0; i < o->n_devices; i++) eo.devices.push_back(o->devices[i]);
             eo.plan_cache = o->plan_cache != 2;
+            eo.resize_bilinear = o->oversize_resize == 2;
         }
         auto eng = rf::Engine::create(model_dir, network ? network : "net3", nms_threshold, eo);
         rf_engine *h = new rf_engine;

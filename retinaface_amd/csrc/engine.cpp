@@ -126,7 +126,7 @@ public:
         lanes_.resize(opt_.lanes);
         for (auto &l : lanes_) build_lane(l, plan);
         const int hw = (int)std::thread::hardware_concurrency();
-        const int helpers = opt_.copy_threads > 0 ? opt_.copy_threads - 1 : std::max(0, std::min(12, hw / 4) - 1);
+        const int helpers = opt_.copy_threads > 0 ? opt_.copy_threads - 1 : std::max(0, std::min(8, hw / 4) - 1);
         copier_.reset(new ParallelCopier(helpers));
     }
 
@@ -273,6 +273,19 @@ public:
     long debug_activation(const std::string &blob, int image, float *dst, size_t cap, int dims[3]) override {
         DeviceGuard guard(device_);
         Lane &l = lanes_[last_lane_];
+        if (blob == "input_canvas") {
+            // the net-sized u8 BGR canvas an OVERSIZE frame was scaled onto (valid when the last launch had one)
+            if (image < 0 || image >= last_n_ || last_first_image_ < 0) throw ArgError("image index out of range");
+            const size_t cnt = (size_t)net_h_ * net_w_ * 3;
+            if (dims) { dims[0] = net_h_; dims[1] = net_w_; dims[2] = 3; }
+            if (!dst) return (long)cnt;
+            if (cap < cnt) throw ArgError("destination too small");
+            RF_HIP(hipStreamSynchronize(l.stream));
+            std::vector<uint8_t> tmp(cnt);
+            RF_HIP(hipMemcpy(tmp.data(), l.d_canvas + (size_t)(last_first_image_ + image) * cnt, cnt, hipMemcpyDeviceToHost));
+            for (size_t i = 0; i < cnt; i++) dst[i] = (float)tmp[i];
+            return (long)cnt;
+        }
         auto it = l.acts.find(blob);
         if (it == l.acts.end()) throw ArgError("unknown activation '" + blob + "'");
         const ActInfo &ai = it->second;
@@ -786,7 +799,10 @@ private:
                 s.h_frames[mb + i] = FrameDesc{s.d_canvas + (size_t)i * net_h_ * net_w_ * 3, net_h_, net_w_, net_w_ * 3, 0};
         }
         RF_HIP(hipMemcpyAsync(s.d_frames, s.h_frames, s.table_bytes, hipMemcpyHostToDevice, s.stream));
-        if (s.need_resize) launch_resize_area(s.stream, s.d_frames, s.d_canvas, n, net_h_, net_w_);
+        if (s.need_resize) {
+            if (opt_.resize_bilinear) launch_resize_bilinear(s.stream, s.d_frames, s.d_canvas, n, net_h_, net_w_);
+            else launch_resize_area(s.stream, s.d_frames, s.d_canvas, n, net_h_, net_w_);
+        }
         const bool eager_timed = s.timed;
         if (eager_timed) RF_HIP(hipEventRecord(s.time_ev[1], s.stream));
         if (opt_.use_graph && s.warmed.count(n)) {

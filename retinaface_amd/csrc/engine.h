@@ -34,7 +34,8 @@ struct EngineOptions {
                                      // persistent and pipeline tile t+1's loads under tile t's compute, which pays off once
                                      // a launch holds several tiles per resident workgroup (measured: 4 -> 16 = +8 %)
     bool keep_outputs = false;
-    int copy_threads = 0;            // threads (caller's included) that stage host frames into pinned memory; 0 = min(12, cores / 4)
+    int copy_threads = 0;            // threads (caller's included) that stage host frames into pinned memory; 0 = min(8, cores / 4): measured best on a 256-thread host, 46 GB/s; more threads contend
+    bool resize_bilinear = false;    // oversize frames: false = area average (the NPP build), true = cv::resize bilinear (the build without NPP)
     bool plan_cache = true;          // read / write <model_dir>/<stem>.<precision>.rfplan (packed weight image, weights.h)
     std::string plan_cache_path;     // explicit cache file instead (tests)
     std::vector<int> devices;        // more than one entry: one engine per device, batches sharded by image (multi.cpp)

@@ -143,6 +143,8 @@ void launch_nms(hipStream_t s, const NmsParams &p);
 // Area-average downscale of an over-size frame onto the net-size u8 canvas (NPPI_INTER_SUPER stand-in,
 // resizeconvertion.cu:298-311; closed-source NPP semantics -> "parity unpinned").
 void launch_resize_area(hipStream_t s, const FrameDesc *src, uint8_t *dst, int n, int net_h, int net_w);
+// The same step in the reference's build without NPP: cv::resize bilinear (RetinaFace.cpp:611-620), OpenCV's fixed-point algorithm.
+void launch_resize_bilinear(hipStream_t s, const FrameDesc *src, uint8_t *dst, int n, int net_h, int net_w);
 
 // LDS bytes / tile geometry chosen for a layer (exposed for tests and DESIGN.md tables)
 struct TileInfo { int th, tw; size_t lds_bytes; int blocks_per_image; };

@@ -2168,6 +2168,71 @@ void launch_resize_area(hipStream_t s, const FrameDesc *src, uint8_t *dst, int n
     hipLaunchKernelGGL(resize_area_kernel, grid, dim3(kThreads), 0, s, src, dst, net_h, net_w);
 }
 
+// =============================================================================================
+// Bilinear downscale for frames larger than the net: the reference's build WITHOUT NPP (CMake default), RetinaFace.cpp:585-620:
+//   scale = max(cols / netW, rows / netH) in float, cv::resize(img, Size(), 1 / scale, 1 / scale)  [OpenCV INTER_LINEAR],
+//   zero padding on the short side.  OpenCV is third party and absent from the reference tree; its published 8-bit fixed-point
+//   algorithm (imgproc/resize.cpp: 11-bit taps, int32 horizontal pass, ((b0*(H0>>4))>>16 + (b1*(H1>>4))>>16 + 2) >> 2 vertical
+//   pass) is implemented here integer for integer, and in double / float exactly where OpenCV uses them (contraction off), so it
+//   is bit-identical to oracle/csrc/cv_resize_linear.h.  Frames that fit are copied 1:1.
+// =============================================================================================
+__device__ __forceinline__ void bilinear_tap(int d, double scale, int n_src, bool clamp, int *s0, int *s1, int *a0, int *a1) {
+#pragma clang fp contract(off)
+    float f = (float)(((double)d + 0.5) * scale - 0.5);
+    int s = (int)floorf(f);
+    f -= (float)s;
+    if (clamp) {
+        if (s < 0) { f = 0.f; s = 0; }
+        if (s >= n_src - 1) { f = 0.f; s = n_src - 1; }
+    }
+    int t0 = (int)rintf((1.f - f) * 2048.f), t1 = (int)rintf(f * 2048.f);
+    *a0 = t0 > 32767 ? 32767 : (t0 < -32768 ? -32768 : t0);
+    *a1 = t1 > 32767 ? 32767 : (t1 < -32768 ? -32768 : t1);
+    const int lo = s < 0 ? 0 : (s < n_src ? s : n_src - 1), hi = s + 1 < 0 ? 0 : (s + 1 < n_src ? s + 1 : n_src - 1);
+    *s0 = lo; *s1 = hi;
+}
+
+__global__ __launch_bounds__(kThreads) void resize_bilinear_kernel(const FrameDesc *__restrict__ src, uint8_t *__restrict__ dst,
+                                                                   int net_h, int net_w) {
+#pragma clang fp contract(off)
+    const int img = blockIdx.z;
+    const FrameDesc fd = src[img];
+    const int x = blockIdx.x * 32 + (threadIdx.x & 31);
+    const int y = blockIdx.y * 8 + (threadIdx.x >> 5);
+    if (x >= net_w || y >= net_h) return;
+    uint8_t *d = dst + ((size_t)img * net_h * net_w + (size_t)y * net_w + x) * 3;
+    if (fd.ptr == nullptr) { d[0] = d[1] = d[2] = 0; return; }
+    // float sw = 1.0 * img.cols / inputW (double arithmetic, stored to float), RetinaFace.cpp:586-589
+    const float sw = (float)(1.0 * (double)fd.cols / (double)net_w), sh = (float)(1.0 * (double)fd.rows / (double)net_h);
+    float scale = sw > sh ? sw : sh;
+    scale = scale > 1.0 ? scale : 1.0f;
+    if (!(scale > 1)) {                                   // fits: copyMakeBorder only (:621-624)
+        if (x >= fd.cols || y >= fd.rows) { d[0] = d[1] = d[2] = 0; return; }
+        const uint8_t *sp = fd.ptr + (size_t)y * fd.step + x * 3;
+        d[0] = sp[0]; d[1] = sp[1]; d[2] = sp[2];
+        return;
+    }
+    const double fx = (double)(1 / scale);                // `1 / scale` is a float division; cv::resize takes it as double
+    const int dcols = (int)__builtin_rint((double)fd.cols * fx), drows = (int)__builtin_rint((double)fd.rows * fx);
+    if (x >= dcols || y >= drows) { d[0] = d[1] = d[2] = 0; return; }
+    const double sc = 1.0 / fx;
+    int x0, x1, a0, a1, y0, y1, b0, b1;
+    bilinear_tap(x, sc, fd.cols, true, &x0, &x1, &a0, &a1);
+    bilinear_tap(y, sc, fd.rows, false, &y0, &y1, &b0, &b1);
+    const uint8_t *r0 = fd.ptr + (size_t)y0 * fd.step, *r1 = fd.ptr + (size_t)y1 * fd.step;
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        const int h0 = r0[3 * x0 + c] * a0 + r0[3 * x1 + c] * a1;
+        const int h1 = r1[3 * x0 + c] * a0 + r1[3 * x1 + c] * a1;
+        d[c] = (uint8_t)((((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2);
+    }
+}
+
+void launch_resize_bilinear(hipStream_t s, const FrameDesc *src, uint8_t *dst, int n, int net_h, int net_w) {
+    dim3 grid((net_w + 31) / 32, (net_h + 7) / 8, n);
+    hipLaunchKernelGGL(resize_bilinear_kernel, grid, dim3(kThreads), 0, s, src, dst, net_h, net_w);
+}
+
 #ifdef RF_KERNEL_TRACE
 extern "C" int rf_trace_select(int kernel_id, unsigned grid) {
     static unsigned long long zeros[kTraceBlocks * kTraceSlots];

@@ -41,7 +41,8 @@ class RetinaFace:
                  net_hw: Optional[tuple] = None, max_batch: int = 8, model_stem: Optional[str] = None,
                  max_candidates: int = 0, max_detections: int = 0, use_graph: bool = True,
                  keep_outputs: bool = False, device: Optional[int] = None, lanes: int = 0, coalesce: int = 0,
-                 devices: Optional[Sequence[int]] = None, copy_threads: int = 0, plan_cache: bool = True):
+                 devices: Optional[Sequence[int]] = None, copy_threads: int = 0, plan_cache: bool = True,
+                 oversize_resize: str = "area"):
         self._lib = _lib.load_library()
         o = rf_options()
         o.struct_size = C.sizeof(rf_options)
@@ -58,6 +59,7 @@ class RetinaFace:
         o.coalesce = coalesce
         o.copy_threads = copy_threads
         o.plan_cache = 1 if plan_cache else 2
+        o.oversize_resize = {"area": 1, "bilinear": 2}[oversize_resize]
         if devices:       # more than one entry: one engine per entry, detectBatchImages sharded by image over them
             self._devices = (C.c_int32 * len(devices))(*devices)
             o.devices, o.n_devices = self._devices, len(devices)

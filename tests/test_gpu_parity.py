@@ -692,6 +692,45 @@ def test_oversize_frame_is_area_averaged_down(rfa, base_frame):
     assert all(abs(x.rect[0] * 2.0 - 2 * y.rect[0]) < 1e-6 for x, y in zip(a, b))
 
 
+def test_oversize_frames_pixel_exact_against_the_oracles(rfa, oracles, base_frame):
+    """What an oversize frame is turned into before the network sees it, compared PIXEL BY PIXEL (debug blob "input_canvas"):
+      * oversize_resize="bilinear" -- the reference's build without NPP: cv::resize + one-sided padding (RetinaFace.cpp:585-620).
+        Bit-exact against oracle.retinaface_post.preprocess_trt_cvresize, which tests/test_reference_pin.py holds equal to the
+        reference's own detect() (through the shim's stand-in for OpenCV); detections equal the oracle pipeline's.
+      * oversize_resize="area" (default) -- the NPP build; NPPI_INTER_SUPER is closed source, so the bar is agreement with an
+        independently written statement of the definition (coverage matrices, float64; the kernel accumulates in fp32): every
+        pixel within 1 level, > 99.5 % identical."""
+    from oracle import retinaface_post as post
+    rng = np.random.default_rng(21)
+    od = oracles["mnet-deconv-0517"]
+    frames = [np.ascontiguousarray(base_frame[:886]),                                       # 886 x 1280 photo -> 448 wide
+              np.ascontiguousarray(np.repeat(np.repeat(base_frame[200:648, 380:828], 2, 0), 2, 1)),      # 896^2 -> 448^2 exactly
+              rng.integers(0, 256, (1080, 1920, 3), dtype=np.uint8),
+              rng.integers(0, 256, (450, 449, 3), dtype=np.uint8),                          # barely oversize
+              np.ascontiguousarray(base_frame[100:400, 300:700])]                          # fits: 1:1 in both modes
+    for mode in ("bilinear", "area"):
+        det = engine(rfa, "mnet-deconv-0517", FP32, (448, 448), oversize_resize=mode, use_graph=False)
+        for k, f in enumerate(frames):
+            got = det.detect(f, 0.5)
+            fits = f.shape[0] <= 448 and f.shape[1] <= 448
+            if fits:
+                ref = od.detect(f, 0.5, 0.4, net_hw=(448, 448))
+                compare(got, ref.rows(), ref.anchor_indices(), FP32)
+                continue
+            canvas = det.debug_activation("input_canvas").astype(np.uint8)
+            if mode == "bilinear":
+                want = post.preprocess_trt_cvresize(f, 448, 448)[0].transpose(1, 2, 0)[:, :, ::-1].astype(np.uint8)
+                assert np.array_equal(canvas, want), (mode, k, int(np.abs(canvas.astype(int) - want).max()))
+                ref = od.detect(f, 0.5, 0.4, net_hw=(448, 448))
+                compare(got, ref.rows(), ref.anchor_indices(), FP32)
+                if k < 2:
+                    assert len(got) >= 1
+            else:
+                want = post.resize_area_reference(f, 448, 448)
+                diff = np.abs(canvas.astype(int) - want)
+                assert diff.max() <= 1 and (diff > 0).mean() < 5e-3, (mode, k, int(diff.max()), float((diff > 0).mean()))
+
+
 def test_cxx_class_drop_in(rfa, tmp_path):
     """The reference's class surface (include/RetinaFace.h) driven from C++ like retinaface/main.cpp does."""
     from retinaface_amd.frames import synth_frames

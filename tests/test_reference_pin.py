@@ -257,3 +257,47 @@ def test_live_network_presets_against_the_reference_constructor(network):
             assert len(faces) == 0
     finally:
         ref.close()
+
+
+# ------------------------------------------------------------------------------------------------ oversize frames
+
+def test_cv_resize_restatements_agree():
+    """numpy twin == C restatement (oracle/csrc/cv_resize_linear.h, through ctypes via the C oracle library) on awkward sizes
+    and factors: both restate OpenCV's published bilinear path (third party, absent here: parity unpinned), they must at least
+    be the same function."""
+    rng = np.random.default_rng(11)
+    for rows, cols, f in ((37, 53, 0.5), (480, 640, 0.7), (1080, 1920, 448 / 1920), (901, 1283, 0.349), (64, 64, 0.9999), (5, 7, 0.31)):
+        img = rng.integers(0, 256, (rows, cols, 3), dtype=np.uint8)
+        a = post.cv_resize_linear(img, f, f)
+        b = cbuild.cv_resize_linear(img, f, f)
+        assert a.shape == b.shape == (int(np.rint(rows * f)), int(np.rint(cols * f)), 3)
+        assert np.array_equal(a, b), (rows, cols, f, int(np.abs(a.astype(int) - b).max()))
+    # exact 2:1 of a constant image stays constant; a ramp stays monotone
+    assert np.all(post.cv_resize_linear(np.full((40, 40, 3), 77, np.uint8), 0.5, 0.5) == 77)
+    ramp = np.repeat(np.arange(200, dtype=np.uint8)[None, :, None], 3, axis=2).repeat(10, axis=0)
+    assert np.all(np.diff(post.cv_resize_linear(ramp, 0.37, 0.37)[0, :, 0].astype(int)) >= 0)
+
+
+@live
+def test_live_reference_detect_on_oversize_frames():
+    """The reference's own detect() (the build without NPP) on frames larger than the net: its scale / cv::resize / one-sided
+    copyMakeBorder branch (RetinaFace.cpp:585-620) must hand the engine exactly the tensor preprocess_trt_cvresize builds.  (The
+    interpolation itself is the shim's stand-in for OpenCV, the same restatement -- what this pins is the reference's branch.)"""
+    rng = np.random.default_rng(3)
+    ref = build_ref.ReferenceRetinaFace(448, 448, max_batch=1)
+    try:
+        for rows, cols in ((448, 896), (896, 448), (1080, 1920), (672, 672), (450, 449)):
+            img = rng.integers(0, 256, (rows, cols, 3), dtype=np.uint8)
+            sw, sh = np.float32(cols) / np.float32(448), np.float32(rows) / np.float32(448)
+            scale = max(sw, sh, np.float32(1))
+            # the reference pads ONE side only and needs the other to land on the net size exactly: keep to frames where it does
+            if int(np.rint(cols * np.float64(np.float32(1) / scale))) != 448 and sw > sh:
+                continue
+            if int(np.rint(rows * np.float64(np.float32(1) / scale))) != 448 and sh >= sw:
+                continue
+            ref.detect(img, 0.5)
+            got = ref.last_input()
+            want = post.preprocess_trt_cvresize(img, 448, 448)
+            assert got.shape == want.shape and np.array_equal(got, want), (rows, cols)
+    finally:
+        ref.close()
