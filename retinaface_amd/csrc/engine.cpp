@@ -491,6 +491,29 @@ private:
                 op.launch = [sp](hipStream_t s, int n) { Stem2Params q = sp; q.n = n; launch_stem2(s, q); };
                 L.ops.push_back(op);
                 cur = out; c = b1.pw.cout; first_block = 2; h = h4; w = w4;
+                if (dwpw2_variant() && plan.blocks.size() > 3 && plan.blocks[2].dw.cout == 32 && plan.blocks[2].pw.cout == 32 &&
+                    plan.blocks[3].dw.stride == 2 && plan.blocks[3].pw.cout == 64) {
+                    // blocks 2 and 3 (conv5..conv8) as ONE launch (dwpw2_kernel): the 112^2 x 32 map between them stays in LDS
+                    const auto &ba = plan.blocks[2], &bb = plan.blocks[3];
+                    T *out2 = act(bb.pw.out_blob, h / 2, w / 2, bb.pw.cout);
+                    DwPw2Params dp;
+                    dp.in = cur; dp.out = out2;
+                    dp.dwa_mma = arena_.template ptr<uint32_t>(dw_w_[2].mma); dp.dwa_b = arena_.template ptr<float>(dw_w_[2].b);
+                    dp.pwa_w = arena_.template ptr<half_t>(pw_w_[2].w); dp.pwa_b = arena_.template ptr<float>(pw_w_[2].b);
+                    dp.dwb_mma = arena_.template ptr<uint32_t>(dw_w_[3].mma); dp.dwb_b = arena_.template ptr<float>(dw_w_[3].b);
+                    dp.pwb_w = arena_.template ptr<half_t>(pw_w_[3].w); dp.pwb_b = arena_.template ptr<float>(pw_w_[3].b);
+                    dp.n = 0; dp.hin = h; dp.win = w;
+                    OpInfo o2;
+                    o2.name = ba.dw.name + "+" + ba.pw.name + "+" + bb.dw.name + "+" + bb.pw.name;
+                    o2.kernel = "dwpw2<32,32,64>";
+                    const double pa = (double)h * w, pb = (double)(h / 2) * (w / 2);
+                    o2.alg_elems_in = 32.0 * pa + 32.0 * pa + 32.0 * pa + 32.0 * pb;          // dw A, pw A, dw B, pw B inputs (layer-wise)
+                    o2.alg_elems_out = 32.0 * pa + 32.0 * pa + 32.0 * pb + 64.0 * pb;
+                    o2.macs = (ba.dw.macs_per_out_pixel() + ba.pw.macs_per_out_pixel()) * pa + (bb.dw.macs_per_out_pixel() + bb.pw.macs_per_out_pixel()) * pb;
+                    o2.launch = [dp](hipStream_t s, int n) { DwPw2Params q = dp; q.n = n; launch_dwpw2(s, q); };
+                    L.ops.push_back(o2);
+                    cur = out2; c = bb.pw.cout; first_block = 4; h /= 2; w /= 2;
+                }
             }
         } else if constexpr (sizeof(T) <= 2) {
             // fp16 / int8 engines: preprocess + conv0 + the first depthwise/pointwise block are ONE launch (stem_kernel);

@@ -95,6 +95,16 @@ struct DwPwParams {
 };
 template <typename T> void launch_dwpw(hipStream_t s, const DwPwParams<T> &p);
 
+// ---- K_b2 (fp16 engine): two backbone blocks, 32 -> 32 stride 1 then 32 -> 64 stride 2, in one launch; the map between them stays in LDS
+struct DwPw2Params {
+    const half_t *in; half_t *out;                 // in [n][hin][win][32], out [n][hin/2][win/2][64]
+    const uint32_t *dwa_mma; const float *dwa_b; const half_t *pwa_w; const float *pwa_b;     // block A: diagonal dw fragments (pack.h), packed pw
+    const uint32_t *dwb_mma; const float *dwb_b; const half_t *pwb_w; const float *pwb_b;     // block B
+    int n, hin, win;
+};
+void launch_dwpw2(hipStream_t s, const DwPw2Params &p);
+int dwpw2_variant();     // probe knob RF_DWPW2: 0 = off
+
 // ---- K_c: dense 3x3 p1 s1 conv as an implicit GEMM on MFMA (+bias +ReLU).  Optional fused input
 //      "lateral + bilinear x2 upsample(coarser)" (Deconvolution k4 s2 p1 + Crop + Eltwise SUM,
 //      prototxt :1553-1592) and an output split into two NHWC destinations (merged sibling convs).

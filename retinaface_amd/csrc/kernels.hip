@@ -1038,6 +1038,7 @@ template <typename T, int CIN, int COUT, int STRIDE, bool HAS_DW, int TH, int TW
     static constexpr int OCC = BIG_MAP ? (LDS_OCC < 1 ? 1 : (LDS_OCC > OCC_CAP ? OCC_CAP : LDS_OCC)) : 1;
     static constexpr int GFRAGS = 12;                      // streamed case only
     // (capping the 128-channel blocks at 128 VGPRs for a 4th workgroup per CU spills 33 registers: 18 -> 37 us, measured)
+    // (round 2 re-tried the 128-VGPR cap with a shallower B prefetch: still 20-28 spills)
     template <bool LAT> static constexpr int occ() { return OCC; }
 };
 
@@ -1244,6 +1245,17 @@ __global__ __launch_bounds__(kThreads, (DwPwCfg<T, CIN, COUT, STRIDE, HAS_DW, TH
                 for (int hl = 0; hl < DPARTS; hl++)
 #pragma unroll
                     for (int pi = 0; pi < PW; pi++) dacc[hl][pi] = vzero<typename M::Acc, 4>();
+                // B fragments (shifted halo reads) run DDEPTH - 1 reads ahead of their MFMAs, as in gemm_stationary: without it
+                // every MFMA waited for its own LDS round trip (21 s_waitcnt for 20 MFMAs in the 128-channel block: this
+                // phase was the longest of the tile, 685 of ~3000 ns in the phase trace)
+                constexpr int NB = DKCH * PW, DDEPTH = NB < 4 ? NB : 4;
+                Frag bq[DDEPTH];
+                auto bload = [&](int idx) -> Frag {
+                    const int kc = idx / PW, pi = idx % PW;
+                    return dtap[kc] >= 0 ? *(const Frag *)(s_in + dpix[pi] + dtap[kc] + g * 16) : M::zero();
+                };
+#pragma unroll
+                for (int d = 0; d < DDEPTH - 1; d++) bq[d] = bload(d);
 #pragma unroll
                 for (int kc = 0; kc < DKCH; kc++) {
                     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -1259,9 +1271,10 @@ __global__ __launch_bounds__(kThreads, (DwPwCfg<T, CIN, COUT, STRIDE, HAS_DW, TH
                     }
 #pragma unroll
                     for (int pi = 0; pi < PW; pi++) {
-                        const Frag bf = dtap[kc] >= 0 ? *(const Frag *)(s_in + dpix[pi] + dtap[kc] + g * 16) : M::zero();
+                        const int idx = kc * PW + pi;
+                        if (idx + DDEPTH - 1 < NB) bq[(idx + DDEPTH - 1) % DDEPTH] = bload(idx + DDEPTH - 1);
 #pragma unroll
-                        for (int hl = 0; hl < DPARTS; hl++) dacc[hl][pi] = M::mma(af[hl], bf, dacc[hl][pi]);
+                        for (int hl = 0; hl < DPARTS; hl++) dacc[hl][pi] = M::mma(af[hl], bq[idx % DDEPTH], dacc[hl][pi]);
                     }
                 }
 #pragma unroll
@@ -1444,6 +1457,232 @@ template void launch_dwpw<int8_t>(hipStream_t, const DwPwParams<int8_t> &);
 template TileInfo dwpw_tile_info<half_t>(int, int, int, bool, int, int);
 template TileInfo dwpw_tile_info<float>(int, int, int, bool, int, int);
 template TileInfo dwpw_tile_info<int8_t>(int, int, int, bool, int, int);
+
+// =============================================================================================
+// K_b2  two backbone blocks in one launch: [depthwise s1 + pointwise CI -> CA] -> [depthwise s2 + pointwise CA -> CB]
+//   (fp16 engine, conv5..conv8: 32 -> 32 at 112^2, then 32 -> 64 down to 56^2).  Both blocks ran at the measured HBM copy rate
+//   (208 + 155 MB per 128-image launch, PMC), so the only way to make them faster is to keep the 112^2 x 32 map between them in
+//   LDS: this kernel reads the first block's input once (103 MB) and writes the second block's output (51 MB).
+//   Tile = 4 x 8 outputs of the second block  <-  9 x 17 = 153 pixels of the first block's output (its stride-2 3x3 window)
+//        <-  11 x 19 = 209 input pixels.  The first block is recomputed on the 1-pixel ring (153 / 128 = 1.2x).
+//   Phases, one barrier between each:  1 halo -> LDS (buffer loads, hardware zero padding) | 2 depthwise A on MFMA (diagonal
+//   fragments, as K_b) | 3 pointwise A, result tile fp16 with ZEROS outside the map (block B's padding) | 4 depthwise B,
+//   stride 2 | 5 pointwise B | 6 coalesced store.  LDS 35 KB (regions reused once their last reader passed a barrier).
+// =============================================================================================
+struct DwPw2Args {
+    const half_t *in; half_t *out;                      // in: [n][hin][win][32], out: [n][hout][wout][64]
+    const uint32_t *dwa_mma; const float *dwa_b; const half_t *pwa_w; const float *pwa_b;
+    const uint32_t *dwb_mma; const float *dwb_b; const half_t *pwb_w; const float *pwb_b;
+    int hin, win, hout, wout, tiles_x, tiles_y, nblk;
+};
+
+__global__ __launch_bounds__(kThreads, 3) void dwpw2_kernel(DwPw2Args a) {
+    typedef half_t T;
+    typedef Mma<T> M;
+    typedef M::Frag Frag;
+    typedef f16x8 V;
+    typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+    constexpr int CI = 32, CB = 64;
+    constexpr int TH = 4, TW = 8, P = TH * TW;                         // block-B outputs per tile
+    constexpr int RH = 2 * TH + 1, RW = 2 * TW + 1, NR = RH * RW;      // block-A outputs the tile needs: 9 x 17 = 153
+    constexpr int HH = RH + 2, HW = RW + 2, NH = HH * HW;              // input halo: 11 x 19 = 209
+    constexpr int PTA = (NR + 15) / 16;                                // 10 MFMA pixel tiles of block A
+    constexpr int UA = PTA / 2;                                        // units (pixel tiles) of block A per wave: 5
+    constexpr int LD = lds_row<T>(32);                                 // 48 halfs = 96 B per pixel: conflict-free B-fragment pitch
+    constexpr int LDO = lds_row<T>(CB);                                // 80
+    constexpr int IN_BYTES = NH * LD * 2, A_BYTES = PTA * 16 * LD * 2, B_BYTES = P * LD * 2, OUT_BYTES = P * LDO * 2;
+    constexpr int NPF = (NH * 4 + kThreads - 1) / kThreads;            // halo items (16 B) per thread: 4
+    static_assert(PTA % 2 == 0 && PTA * 16 * LD * 2 <= IN_BYTES && B_BYTES + OUT_BYTES <= A_BYTES, "region reuse");
+    __shared__ __attribute__((aligned(16))) unsigned char s_raw[IN_BYTES + A_BYTES];
+    T *s_in = (T *)s_raw;                              // halo                       (phases 1-2)
+    T *s_mid = (T *)s_raw;                             // block-A output tile        (phases 3-4)
+    T *s_a = (T *)(s_raw + IN_BYTES);                  // depthwise-A result         (phases 2-3)
+    T *s_b = (T *)(s_raw + IN_BYTES);                  // depthwise-B result         (phases 4-5)
+    T *s_out = (T *)(s_raw + IN_BYTES + B_BYTES);      // output tile                (phases 5-6)
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int G = gridDim.x;
+    const int first = xcd_remap(blockIdx.x, G);
+    const int kb = lane >> 4;
+    const int dsel = dw_mma_dword_index(lane);
+    const f32x4 ones = {1.f, 1.f, 1.f, 1.f};
+    RF_TRACE_KEY(a.nblk);
+    RF_TRACE(5, 0);
+
+    // ---- once per workgroup.  Units are split so that a wave always works on ONE channel group / channel tile (wave & 1) and
+    //      on pixel tiles (wave >> 1) + 2 i: its weights are a handful of registers, loaded here and never again
+    const int g = wave & 1;
+    uint32_t dwa[kDwMmaChunks], dwb[kDwMmaChunks];
+#pragma unroll
+    for (int kc = 0; kc < kDwMmaChunks; kc++) {
+        dwa[kc] = a.dwa_mma[(g * kDwMmaChunks + kc) * 64 + lane];
+        dwb[kc] = a.dwb_mma[(g * kDwMmaChunks + kc) * 64 + lane];
+    }
+    const Frag pwa = ((const Frag *)a.pwa_w)[g * 64 + lane];
+    const Frag pwb = ((const Frag *)a.pwb_w)[wave * 64 + lane];
+    const f32x4 dwa_b = *(const f32x4 *)(a.dwa_b + acc_cout(g, lane, 0)), pwa_b = *(const f32x4 *)(a.pwa_b + acc_cout(g, lane, 0));
+    const f32x4 dwb_b = *(const f32x4 *)(a.dwb_b + acc_cout(g, lane, 0)), pwb_b = *(const f32x4 *)(a.pwb_b + acc_cout(wave, lane, 0));
+    auto dw_frag = [&](uint32_t wd) -> Frag {          // diagonal depthwise A fragment from its one dword per lane
+        typedef uint32_t u32x4_ __attribute__((ext_vector_type(4)));
+        asm volatile("" : "+v"(wd));
+        u32x4_ wa;
+#pragma unroll
+        for (int d = 0; d < 4; d++) wa[d] = dsel == d ? wd : 0u;
+        return __builtin_bit_cast(Frag, wa);
+    };
+    // per-lane constants of the wave's block-A units: region pixel, its halo offset, its coordinates inside the region
+    int pa_base[UA], pa_yx[UA];                                        // pa_yx: (ry << 16 | rx), ry poisoned for tail lanes
+#pragma unroll
+    for (int i = 0; i < UA; i++) {
+        const int p = ((wave >> 1) + 2 * i) * 16 + (lane & 15);
+        const int pc = p < NR ? p : NR - 1;                            // tail lanes recompute the last pixel; never used past NR
+        pa_yx[i] = ((p < NR ? pc / RW : 0x4000) << 16) | (pc % RW);   // poisoned row: fails the inside-the-map test
+        pa_base[i] = ((pc / RW) * HW + pc % RW) * LD + g * 16 + (kb & 1) * 8;
+    }
+    // tap of chunk kc: 2 kc for lanes 0..31, 2 kc + 1 for lanes 32..63 (k = tap*16 + c): two compile-time offsets per chunk,
+    // picked by the lane half when used (this kernel runs at 3 workgroups per CU: the 128-VGPR budget of a 4th spills 37 registers)
+    const bool hi = lane >= 32;
+    auto tap_a = [&](int kc) -> int { const int t0 = 2 * kc, t1 = 2 * kc + 1; return hi ? (t1 < 9 ? ((t1 / 3) * HW + t1 % 3) * LD : -1) : ((t0 / 3) * HW + t0 % 3) * LD; };
+    auto tap_b = [&](int kc) -> int { const int t0 = 2 * kc, t1 = 2 * kc + 1; return hi ? (t1 < 9 ? ((t1 / 3) * RW + t1 % 3) * LD : -1) : ((t0 / 3) * RW + t0 % 3) * LD; };
+    const int pb = (wave >> 1) * 16 + (lane & 15);                     // the wave's block-B pixel
+    const int pb_base = ((pb / TW) * 2 * RW + (pb % TW) * 2) * LD + g * 16 + (kb & 1) * 8;
+
+    // halo of a tile -> registers (unconditional buffer loads; rows / columns outside the map read as zero = depthwise A's padding)
+    V pre[NPF];
+    int koff[NPF], kdx[NPF];
+#pragma unroll
+    for (int k = 0; k < NPF; k++) {
+        int i = tid + k * kThreads;
+        i = i < NH * 4 ? i : NH * 4 - 1;
+        const int pix = i >> 2, cv = i & 3;
+        koff[k] = (((pix / HW) * a.win + pix % HW) * CI + cv * 8) * 2;
+        kdx[k] = pix % HW;
+    }
+    const unsigned in_img_bytes = (unsigned)(a.hin * a.win * CI) * 2u;
+    auto fetch = [&](int tx, int ty, int img) {
+        const auto rs = image_rsrc(a.in + (size_t)img * a.hin * a.win * CI, in_img_bytes);
+        const int iy0 = 2 * ty * TH - 2, ix0 = 2 * tx * TW - 2;
+        const int sbase = (iy0 * a.win + ix0) * CI * 2;
+#pragma unroll
+        for (int k = 0; k < NPF; k++) {
+            const unsigned off = (unsigned)(ix0 + kdx[k]) < (unsigned)a.win ? (unsigned)(koff[k] + sbase) : kOobOffset;
+            pre[k] = buf_load16<V>(rs, off);
+        }
+    };
+    const TileStep step(G, a.tiles_x, a.tiles_y);
+    TileCoord cur(first, a.tiles_x, a.tiles_y), nxt = cur;
+    step.advance(nxt);
+    if (first < a.nblk) fetch(cur.tx, cur.ty, cur.img);
+    __builtin_amdgcn_s_waitcnt(0x0F70);       // vmcnt(0): the once-per-workgroup loads have landed; in the loop only the prefetch is in flight
+
+    for (int t = first; t < a.nblk; t += G) {
+        const int oy0 = cur.ty * TH, ox0 = cur.tx * TW, img = cur.img;
+        // ---- phase 1: prefetched halo -> LDS, next tile's halo requested
+#pragma unroll
+        for (int k = 0; k < NPF; k++) {
+            const int i = tid + k * kThreads;
+            if (i < NH * 4) *(V *)(s_in + (i >> 2) * LD + (i & 3) * 8) = pre[k];
+        }
+        if (t + G < a.nblk) fetch(nxt.tx, nxt.ty, nxt.img);
+        cur = nxt;
+        step.advance(nxt);
+        RF_TRACE(5, 1);
+        __syncthreads();
+
+        // ---- phase 2: depthwise A (3x3, stride 1) on the 153-pixel region: the wave's 5 pixel tiles advance together, so five
+        //      independent accumulators are in flight and each chunk's fragment is expanded once
+        {
+            M::Acc acc[UA];
+#pragma unroll
+            for (int i = 0; i < UA; i++) acc[i] = vzero<M::Acc, 4>();
+#pragma unroll
+            for (int kc = 0; kc < kDwMmaChunks; kc++) {
+                Frag bf[UA];
+#pragma unroll
+                for (int i = 0; i < UA; i++) bf[i] = tap_a(kc) >= 0 ? *(const Frag *)(s_in + pa_base[i] + tap_a(kc)) : M::zero();
+                const Frag af = dw_frag(dwa[kc]);
+#pragma unroll
+                for (int i = 0; i < UA; i++) acc[i] = M::mma(af, bf[i], acc[i]);
+            }
+#pragma unroll
+            for (int i = 0; i < UA; i++) store_acc<T, LD>(s_a, ones, dwa_b, acc[i], g, (wave >> 1) + 2 * i, lane, true);
+        }
+        RF_TRACE(5, 2);
+        __syncthreads();
+
+        // ---- phase 3: pointwise A (CI -> CA, K = 32: one MFMA per pixel tile); outside the map the tile holds block B's zero padding
+        {
+            Frag bf[UA];
+#pragma unroll
+            for (int i = 0; i < UA; i++) bf[i] = *(const Frag *)(s_a + (((wave >> 1) + 2 * i) * 16 + (lane & 15)) * LD + kb * 8);
+#pragma unroll
+            for (int i = 0; i < UA; i++) {
+                const M::Acc acc = M::mma(pwa, bf[i], vzero<M::Acc, 4>());
+                const int y = 2 * oy0 - 1 + (pa_yx[i] >> 16), x = 2 * ox0 - 1 + (pa_yx[i] & 0xffff);
+                const bool inside = (unsigned)y < (unsigned)a.hin && (unsigned)x < (unsigned)a.win;
+                f16x4 h;
+#pragma unroll
+                for (int r = 0; r < 4; r++) h[r] = inside ? (half_t)fmaxf(acc[r] + pwa_b[r], 0.f) : (half_t)0;
+                *(f16x4 *)(s_mid + (((wave >> 1) + 2 * i) * 16 + (lane & 15)) * LD + acc_cout(g, lane, 0)) = h;     // the halo is dead since the last barrier
+            }
+        }
+        RF_TRACE(5, 3);
+        __syncthreads();
+
+        // ---- phase 4: depthwise B (3x3, stride 2) on the 32 output pixels: one (group, pixel tile) unit per wave
+        {
+            M::Acc acc = vzero<M::Acc, 4>();
+            Frag bf[kDwMmaChunks];
+#pragma unroll
+            for (int kc = 0; kc < kDwMmaChunks; kc++) bf[kc] = tap_b(kc) >= 0 ? *(const Frag *)(s_mid + pb_base + tap_b(kc)) : M::zero();
+#pragma unroll
+            for (int kc = 0; kc < kDwMmaChunks; kc++) acc = M::mma(dw_frag(dwb[kc]), bf[kc], acc);
+            store_acc<T, LD>(s_b, ones, dwb_b, acc, g, wave >> 1, lane, true);      // the depthwise-A result is dead since the last barrier
+        }
+        RF_TRACE(5, 4);
+        __syncthreads();
+
+        // ---- phase 5: pointwise B (CA -> CB): wave = output-channel tile, both pixel tiles
+        {
+            Frag bf[2];
+#pragma unroll
+            for (int pt = 0; pt < 2; pt++) bf[pt] = *(const Frag *)(s_b + (pt * 16 + (lane & 15)) * LD + kb * 8);
+#pragma unroll
+            for (int pt = 0; pt < 2; pt++) store_acc<T, LDO>(s_out, ones, pwb_b, M::mma(pwb, bf[pt], vzero<M::Acc, 4>()), wave, pt, lane, true);
+        }
+        RF_TRACE(5, 5);
+        __syncthreads();
+
+        // ---- phase 6: 32 px x 64 ch tile -> HBM: one 16-byte item per thread (s_out is next written after two more barriers)
+        {
+            const auto ro = image_rsrc(a.out + (size_t)img * a.hout * a.wout * CB, (unsigned)(a.hout * a.wout * CB) * 2u);
+            const int p = tid >> 3, cv = tid & 7;
+            const int py = p / TW, px = p % TW;
+            const unsigned off = ox0 + px < a.wout ? (unsigned)((((oy0 + py) * a.wout + ox0 + px) * CB + cv * 8) * 2) : kOobOffset;
+            buf_store16(ro, off, *(const V *)(s_out + p * LDO + cv * 8));
+        }
+        RF_TRACE(5, 6);
+    }
+}
+
+void launch_dwpw2(hipStream_t s, const DwPw2Params &p) {
+    DwPw2Args a;
+    a.in = p.in; a.out = p.out;
+    a.dwa_mma = p.dwa_mma; a.dwa_b = p.dwa_b; a.pwa_w = p.pwa_w; a.pwa_b = p.pwa_b;
+    a.dwb_mma = p.dwb_mma; a.dwb_b = p.dwb_b; a.pwb_w = p.pwb_w; a.pwb_b = p.pwb_b;
+    a.hin = p.hin; a.win = p.win; a.hout = p.hin / 2; a.wout = p.win / 2;
+    a.tiles_x = (a.wout + 7) / 8; a.tiles_y = (a.hout + 3) / 4;
+    a.nblk = p.n * a.tiles_x * a.tiles_y;
+    static int resident_cache[kMaxDevices] = {};
+    const int resident = kernel_residency(resident_cache, dwpw2_kernel, 0);
+    hipLaunchKernelGGL(dwpw2_kernel, dim3(persistent_grid(a.nblk, resident)), dim3(kThreads), 0, s, a);
+}
+
+int dwpw2_variant() {
+    static int v = -1;
+    if (v < 0) { const char *e = getenv("RF_DWPW2"); v = e ? atoi(e) : 1; }      // probe knob: 0 = two separate K_b launches
+    return v;
+}
 
 // =============================================================================================
 // K_c  dense 3x3 p1 s1 convolution + BN + ReLU as implicit GEMM (K = 9*CIN) on MFMA

@@ -46,7 +46,12 @@ def main(fetch_db, write_db, out, images_per_launch=8, workload_key="448x448_fp1
         res.append({"kernel": descriptor(name), "symbol": name, "grid_threads": grid, "launches_sampled": f.get(key, (0, 0))[0],
                     "fetch_size_bytes_raw": fk, "fetch_bytes_corrected_x2": 2 * fk, "write_size_bytes": wk,
                     "hbm_bytes_per_launch": 2 * fk + wk})
-    total = sum(r["hbm_bytes_per_launch"] for r in res)
+    # a kernel instance that runs several times per pass (the four plain 128-channel blocks) shows up once with an average:
+    # weight it by how many times it ran per engine pass
+    base = min((r["launches_sampled"] for r in res if r["launches_sampled"]), default=1)
+    for r in res:
+        r["launches_per_pass"] = max(1, round(r["launches_sampled"] / base)) if r["launches_sampled"] else 1
+    total = sum(r["hbm_bytes_per_launch"] * r["launches_per_pass"] for r in res)
     json.dump({"note": f"per launch of {images_per_launch} images, {workload_key}, eager launches (tools/probes/pmc_probe.py; PMC collection "
                        "faults under hipGraph replay); FETCH_SIZE doubled per MI355X_MICROARCH.md section HBM",
                "workload_key": workload_key, "images_per_launch": int(images_per_launch),

@@ -15,7 +15,7 @@ frames = torch.from_numpy(np.stack(synth_frames(448, 448, 8, config=1))).cuda();
 ptrs = [frames[i % 8].data_ptr() for i in range(8)]
 det = retinaface_amd.RetinaFace(os.path.join(ROOT, "assets"), "net3", 0.4, net_hw=(448, 448), model_stem="mnet25", lanes=1,
                                 coalesce=n // 8, use_graph=False)
-kid = {"dwpw": 2, "conv3": 3, "stem2": 4}[family]
+kid = {"dwpw": 2, "conv3": 3, "stem2": 4, "dwpw2": 5}[family]
 lib.rf_trace_select.argtypes = [C.c_int, C.c_uint]; lib.rf_trace_read.argtypes = [C.c_void_p, C.c_int]
 def run():
     tickets = [det.enqueue_device(ptrs, [448] * 8, [448] * 8, 0.5) for _ in range(n // 8)]
@@ -23,7 +23,7 @@ def run():
 for _ in range(3): run()
 NB, NS, GHZ = 8192, 12, 2.4
 # stamp slots, in program order inside the LAST tile a workgroup walked (slot 0 = workgroup start, 7 = after the loop / lateral)
-ORDER = {"dwpw": [8, 9, 10, 1, 2, 3, 4, 5, 6, 7], "conv3": [8, 9, 10, 1, 2, 3, 5, 6], "stem2": [0, 1, 2, 3, 4, 5, 6, 7]}
+ORDER = {"dwpw": [8, 9, 10, 1, 2, 3, 4, 5, 6, 7], "conv3": [8, 9, 10, 1, 2, 3, 5, 6], "stem2": [0, 1, 2, 3, 4, 5, 6, 7], "dwpw2": [0, 1, 2, 3, 4, 5, 6]}
 LABEL = {8: "tile loop top", 9: "prefetch landed + staged to LDS", 10: "next tile's loads issued", 1: "previous tile's stores issued",
          2: "barrier", 3: "stencil (dwpw) / GEMM (conv3) done", 4: "barrier", 5: "GEMM + epilogue -> LDS", 6: "barrier", 7: "lateral / end"}
 for grid in grids:
@@ -36,6 +36,8 @@ for grid in grids:
     if not len(tr):
         print(f"{family} grid {grid}: no stamps"); continue
     order = ORDER[family]
+    if family == "dwpw2":
+        LABEL.update({1: "1 halo -> LDS", 2: "2 depthwise A", 3: "3 pointwise A", 4: "4 depthwise B", 5: "5 pointwise B", 6: "6 store"})
     if family == "stem2":
         LABEL.update({1: "1 stage patch (arrival at barrier)", 2: "2 conv0 MFMA", 3: "3 depthwise conv1", 4: "4 pointwise conv2 MFMA",
                       5: "5 depthwise conv3 s2", 6: "6 pointwise conv4 MFMA", 7: "7 store"})
