@@ -63,11 +63,13 @@ def parse_args(argv=None):
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--profile-iters", type=int, default=50)
     ap.add_argument("--lanes", type=int, default=0, help="launches in flight (0 = engine default: 3)")
-    ap.add_argument("--coalesce", type=int, default=0, help="enqueued batches merged per launch (0 = engine default: 16)")
+    ap.add_argument("--coalesce", type=int, default=0, help="enqueued batches merged per launch (0 = engine default: 256 / batch)")
     ap.add_argument("--ring-mb", type=float, default=320.0, help="distinct input frames per GPU, in MB (> the 256 MiB MALL)")
     ap.add_argument("--host-seconds", type=float, default=1.5, help="length of the host-frame (PCIe inclusive) measurement; 0 = skip")
     ap.add_argument("--oversubscribe", action="store_true", help="allow more ranks than visible GPUs (ranks share devices)")
     ap.add_argument("--dry", action="store_true", help="no GPU: stub engine, gloo backend (launcher / gather / JSON plumbing only)")
+    ap.add_argument("--timed-only", action="store_true", help="warm-up + timed region only (no burst / latency / host-frame / per-kernel "
+                                                              "passes): the run to put under rocprofv3 --kernel-trace")
     ap.add_argument("--master-port", type=int, default=0)
     return ap.parse_args(argv)
 
@@ -97,7 +99,7 @@ class StubEngine:
     def __init__(self, batch, lanes, coalesce):
         import numpy as np
         self.np = np
-        self.batch, self.lanes, self.coalesce = batch, lanes or 3, coalesce or 16
+        self.batch, self.lanes, self.coalesce = batch, lanes or 3, coalesce or max(1, min(32, 256 // batch))
         self._q = {}
         self._t = 0
         self.last_faces = np.zeros((batch, self.max_detections, 15), np.float32)
@@ -276,7 +278,7 @@ def main() -> int:
     dt = time.perf_counter() - t0
 
     extra = {}
-    if not args.dry:
+    if not args.dry and not args.timed_only:
         # burst: ONE super-batch through an empty pipeline, start to finish (what --steps 16 used to time)
         lat = []
         for _ in range(10):
@@ -338,6 +340,8 @@ def main() -> int:
                                     "records_gathered": int(gather_state["images"].item()), "expected": images_total}
         if args.dry:
             out["dry"] = True
+        elif args.timed_only:
+            out["timed_only"] = True
         else:
             out.update(extra)
             out.update(device_side_report(args, det, frames, B, H, W, per_launch, prec, images_total, world, dt_max))

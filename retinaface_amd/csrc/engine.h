@@ -30,7 +30,7 @@ struct EngineOptions {
     int max_detections = 256;
     bool use_graph = true;
     int lanes = 3;                   // launches in flight (each lane has its own stream + buffers + graphs)
-    int coalesce = 16;               // enqueued batches merged into one launch (max_batch * coalesce images): the kernels are
+    int coalesce = 0;                // enqueued batches merged into one launch (max_batch * coalesce images; 0 = about 256 images of 448 x 448 per launch): the kernels are
                                      // persistent and pipeline tile t+1's loads under tile t's compute, which pays off once
                                      // a launch holds several tiles per resident workgroup (measured: 4 -> 16 = +8 %)
     bool keep_outputs = false;
