@@ -73,7 +73,7 @@ struct Stem2Params {
     int n, net_h, net_w;
 };
 void launch_stem2(hipStream_t s, const Stem2Params &p);
-int stem2_variant();      // 0 = off (K_a' + a separate dwpw<16,32,s2> launch), 1 = 7x8 tiles, 2 = 7x16 (probe knob RF_STEM2)
+int stem2_variant();      // 0 = off (K_a' + a separate dwpw<16,32,s2> launch), 1 = 7x8 tiles, 2 = 7x16, 3 = 7x8 fp16 patch (probe knob RF_STEM2)
 
 // ---- K_b: depthwise 3x3 (+BN+ReLU) -> pointwise 1x1 (+BN+ReLU), the intermediate never leaves LDS.
 //      has_dw = false gives a plain 1x1 conv (+bias, +ReLU): the FPN laterals.

@@ -380,32 +380,55 @@ __device__ __forceinline__ void gemm_stationary(typename Mma<T>::Acc (&acc)[NI][
     }
 }
 
-// epilogue: y = acc * mult + bias (+ReLU), convert, 4 consecutive output channels of one pixel -> LDS tile
-// s_out[pixel][LDO].  fp16 / fp32: mult = 1 (fma(a, 1, b) = a + b exactly).  int8: acc is int32, mult[c] =
-// w_scale[c] * in_scale / out_scale and bias = b / out_scale, so y is already in units of the output quantum.
+// ReLU on the bit pattern: a signed integer max with 0 is max(x, +0) for every float (negative floats, -0 included, have the sign
+// bit set = negative integers).  One v_max_i32 / v_pk_max_i16; fmaxf() costs two instructions wherever the compiler cannot prove
+// its operand canonical (MFMA results), and these kernels are VALU-issue bound.
+__device__ __forceinline__ float relu_f(float x) {
+    const int i = __builtin_bit_cast(int, x);
+    return __builtin_bit_cast(float, i > 0 ? i : 0);
+}
+typedef _Float16 f16x2_ __attribute__((ext_vector_type(2)));
+typedef float f32x2_ __attribute__((ext_vector_type(2)));
+typedef short s16x2_ __attribute__((ext_vector_type(2)));
+// two floats -> packed fp16 (one v_cvt_pk_f16_f32, round to nearest even), optionally ReLU'd AFTER the rounding (rounding is
+// monotonic and keeps the sign, so max(rn(x), 0) == rn(max(x, 0)))
+__device__ __forceinline__ uint32_t pack_f16(float a, float b, bool relu) {
+    const f32x2_ f = {a, b};
+    s16x2_ h = __builtin_bit_cast(s16x2_, __builtin_convertvector(f, f16x2_));
+    const s16x2_ z = {0, 0};
+    if (relu) h = __builtin_elementwise_max(h, z);
+    return __builtin_bit_cast(uint32_t, h);
+}
+
+// Accumulator of a GEMM tile before its first MFMA.  fp16 / fp32 engines: the BIAS (it rides through the MFMA chain as the C
+// operand, so the epilogue has no add); int8: zero (the epilogue is y = acc * mult + bias on the int32 sum).
+template <typename T> __device__ __forceinline__ typename Mma<T>::Acc acc_init(f32x4 bias) {
+    if constexpr (sizeof(T) == 1) return vzero<typename Mma<T>::Acc, 4>();
+    else return bias;
+}
+
+// epilogue: 4 consecutive output channels of one pixel -> LDS tile s_out[pixel][LDO].
+// fp16 / fp32 storage: acc already holds sum + bias (acc_init); ReLU, convert.  int8 storage: y = acc * mult + bias with
+// mult[c] = w_scale[c] * in_scale / out_scale and bias = b / out_scale, so y is in units of the output quantum (acc is the int32
+// sum, or -- the stem -- an fp32 sum WITHOUT bias).
 template <typename T, int LDO, typename ACC>
 __device__ __forceinline__ void store_acc(T *s_out, f32x4 mult, f32x4 bv, ACC acc, int ct, int pt, int lane, bool relu) {
     const int c0 = acc_cout(ct, lane, 0);
     const int p = acc_pixel(pt, lane);
-    float v[4];
-#pragma unroll
-    for (int r = 0; r < 4; r++) {
-        if constexpr (sizeof(T) == 1) v[r] = fmaf((float)acc[r], mult[r], bv[r]);
-        else v[r] = (float)acc[r] + bv[r];           // mult == 1 for fp16 / fp32: fma(a, 1, b) == a + b exactly
-        if (relu) v[r] = fmaxf(v[r], 0.f);
-    }
     if constexpr (sizeof(T) == 2) {
-        typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
-        f16x4 h;
-#pragma unroll
-        for (int r = 0; r < 4; r++) h[r] = (half_t)v[r];
-        *(f16x4 *)(s_out + p * LDO + c0) = h;
+        uint2 h;
+        h.x = pack_f16((float)acc[0], (float)acc[1], relu);
+        h.y = pack_f16((float)acc[2], (float)acc[3], relu);
+        *(uint2 *)(s_out + p * LDO + c0) = h;
     } else if constexpr (sizeof(T) == 4) {
         f32x4 f;
 #pragma unroll
-        for (int r = 0; r < 4; r++) f[r] = v[r];
+        for (int r = 0; r < 4; r++) f[r] = relu ? relu_f((float)acc[r]) : (float)acc[r];
         *(f32x4 *)(s_out + p * LDO + c0) = f;
     } else {
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) v[r] = fmaf((float)acc[r], mult[r], bv[r]);
         uint32_t packed = 0;
         if (relu) {
             // ReLU'd quanta are 0..127: clamp with one v_med3, round to nearest even (as rintf), then v_cvt_pk_u8_f32 converts the
@@ -637,7 +660,10 @@ __global__ __launch_bounds__(kThreads, 7) void stem_kernel(StemArgs<TO> a) {
     // ---- phase 4: pointwise 8 -> 16 (conv2) on MFMA, K padded to 32
     f32x4 acc[1][4];
 #pragma unroll
-    for (int j = 0; j < 4; j++) acc[0][j] = vzero<f32x4, 4>();
+    for (int j = 0; j < 4; j++) {
+        if constexpr (sizeof(TO) == 1) acc[0][j] = vzero<f32x4, 4>();       // int8 output: bias added after the requantising multiply
+        else acc[0][j] = pw_bias;
+    }
     // K slots of the one MFMA: [W_hi x_hi | W_hi x_lo | W_lo x_hi | 0]
     pipe.run(acc, [&](int j, int) -> M::Frag {
         return kb < 3 ? *(const M::Frag *)(s_a + acc_pixel(wave + j * 4, lane) * LDA + (kb & 1) * 8) : M::zero();
@@ -682,7 +708,7 @@ template void launch_stem<int8_t>(hipStream_t, const StemParams<int8_t> &);
 //   out) | 4 pointwise conv2 on MFMA -> fp16 tile (zero outside the map: it is conv3's padding) | 5 depthwise conv3 stride 2
 //   | 6 pointwise conv4 on MFMA | 7 coalesced NHWC store.  Numerics of phases 1-4 are exactly K_a' (same rounding points).
 // =============================================================================================
-template <int TW_> struct Stem2Cfg {
+template <int TW_, bool F16P> struct Stem2Cfg {     // F16P: the staged patch holds fp16 (converted once) instead of u8
     static constexpr int TH = 7, TW = TW_, P4 = TH * TW;                // conv4 output tile
     static constexpr int R2H = 2 * TH + 1, R2W = 2 * TW + 1, N2 = R2H * R2W;     // conv2 pixels the tile needs
     static constexpr int R0H = R2H + 2, R0W = R2W + 2, N0 = R0H * R0W;           // conv0 / conv1-input pixels
@@ -690,14 +716,14 @@ template <int TW_> struct Stem2Cfg {
     static constexpr int IR = 2 * R0H + 1, IPX = 2 * R0W + 1;                    // input rows / pixels per row
     static constexpr int GRP = (IPX + 3) / 4, ROWD = GRP * 4;                    // staging groups of 4 pixels, dwords per staged row
     static constexpr int LDA1 = 24, LDO = 40;                                    // conv3 result / output tile row pitch (fp16 elements)
-    static constexpr int IN_BYTES = IR * ROWD * 4, A_BYTES = T2 * 16 * 32;       // region A: patch -> conv1 result (hi|lo, 32 B / pixel)
+    static constexpr int IN_BYTES = IR * ROWD * (F16P ? 8 : 4), A_BYTES = T2 * 16 * 32;       // region A: patch (4 x fp16 per pixel) -> conv1 result (hi|lo, 32 B / pixel)
     static constexpr int A1_BYTES = T4 * 16 * LDA1 * 2, OUT_BYTES = T4 * 16 * LDO * 2;   //           -> conv3 result + output tile
     static constexpr int C0_BYTES = T0 * 16 * 32, C2_BYTES = T2 * 16 * 32;       // region B: fp32 conv0 tile -> fp16 conv2 tile
     static constexpr int MAX3(int a, int b, int c) { return a > b ? (a > c ? a : c) : (b > c ? b : c); }
     static constexpr int REGION_A = MAX3(IN_BYTES, A_BYTES, A1_BYTES + OUT_BYTES);
     static constexpr int REGION_B = C0_BYTES > C2_BYTES ? C0_BYTES : C2_BYTES;
     static constexpr int LDS_BYTES = REGION_A + REGION_B + 9 * 8 * 4 + 9 * 16 * 4;
-    static constexpr int OCC = LDS_BYTES <= 23 * 1024 ? 7 : (160 * 1024 / LDS_BYTES);
+    static constexpr int OCC = LDS_BYTES <= 20 * 1024 ? 8 : LDS_BYTES <= 23 * 1024 ? 7 : (160 * 1024 / LDS_BYTES);
     static_assert(REGION_A % 16 == 0 && REGION_B % 16 == 0 && A1_BYTES % 16 == 0, "LDS carve must stay 16-byte aligned");
 };
 
@@ -710,16 +736,21 @@ struct Stem2Args {
     int ho, wo, ho4, wo4, tiles_x, tiles_y, nblk;   // ho x wo = conv0 / conv2 map (net / 2), ho4 x wo4 = conv4 map (net / 4)
 };
 
-template <int TW_>
-__global__ __launch_bounds__(kThreads, (Stem2Cfg<TW_>::OCC)) void stem2_kernel(Stem2Args a) {
-    typedef Stem2Cfg<TW_> C;
+template <int TW_, bool F16P>
+__global__ __launch_bounds__(kThreads, (Stem2Cfg<TW_, F16P>::OCC)) void stem2_kernel(Stem2Args a) {
+    typedef Stem2Cfg<TW_, F16P> C;
     typedef half_t T;
     typedef Mma<T> M;
     typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
-    constexpr int TW = C::TW, P4 = C::P4, R2W = C::R2W, N2 = C::N2, R0W = C::R0W, N0 = C::N0;
+    constexpr int TW = C::TW, P4 = C::P4, R2W = C::R2W, N2 = C::N2, R0W = C::R0W;
     constexpr int ROWD = C::ROWD, GRP = C::GRP, IR = C::IR, LDA1 = C::LDA1, LDO = C::LDO;
+    // fp32 conv0 tile as two channel planes [channels 0-3 | channels 4-7][pixel][4]: 16 consecutive pixels of a plane are 256
+    // contiguous bytes (every ds_read/write_b128 of a 16-lane group is conflict-free) and a depthwise tap is the thread's base
+    // address + a compile-time offset (the XOR-swizzled single plane of K_a' cost ~50 address instructions per pixel here)
+    constexpr int C0_PLANE = C::T0 * 16 * 4;
     __shared__ __attribute__((aligned(16))) unsigned char s_raw[C::LDS_BYTES];
-    uint32_t *s_in = (uint32_t *)s_raw;                          // BGRX patch                      (phases 1-2)
+    uint2 *s_in = (uint2 *)s_raw;                                // BGRX patch, 4 x fp16 per pixel  (phases 1-2)
+    uint32_t *s_in8 = (uint32_t *)s_raw;                         // ... or (!F16P) 4 x u8 per pixel
     T *s_a = (T *)s_raw;                                         // conv1 result hi|lo              (phases 3-4)
     T *s_a1 = (T *)s_raw;                                        // conv3 result                    (phases 5-6)
     T *s_out = (T *)(s_raw + C::A1_BYTES);                       // conv4 tile                      (phases 6-7)
@@ -793,7 +824,19 @@ __global__ __launch_bounds__(kThreads, (Stem2Cfg<TW_>::OCC)) void stem2_kernel(S
             o4.y = ((w0 >> 24) | (w1 << 8)) & 0x00ffffffu;
             o4.z = ((w1 >> 16) | (w2 << 16)) & 0x00ffffffu;
             o4.w = w2 >> 8;
-            *(uint4 *)(s_in + r * ROWD + g * 4) = o4;
+            // u8 -> fp16 HERE, once per input pixel (conv0 reads every pixel 2.25 times on average: converting in phase 2 was
+            // 12 of its 30 VALU instructions per MFMA tile); the X byte becomes the half 0 = the K padding
+            if constexpr (F16P) {
+                f16x8 h01, h23;
+                u8x4_to_f16(o4.x, h01, 0);
+                u8x4_to_f16(o4.y, h01, 4);
+                u8x4_to_f16(o4.z, h23, 0);
+                u8x4_to_f16(o4.w, h23, 4);
+                *(f16x8 *)(s_in + r * ROWD + g * 4) = h01;
+                *(f16x8 *)(s_in + r * ROWD + g * 4 + 2) = h23;
+            } else {
+                *(uint4 *)(s_in8 + r * ROWD + g * 4) = o4;
+            }
         }
     }
     if (tid < 18) *(f32x4 *)(s_dw0 + tid * 4) = *(const f32x4 *)(a.dw0_w + tid * 4);
@@ -809,27 +852,36 @@ __global__ __launch_bounds__(kThreads, (Stem2Cfg<TW_>::OCC)) void stem2_kernel(S
         for (int t = wave; t < C::T0; t += 4) {
             const int q = t * 16 + (lane & 15);
             const int hy = q / R0W, hx = q % R0W;
-            const uint32_t *pp = s_in + (2 * hy) * ROWD + 2 * hx;
-            const bool valid = q < N0;
-            const uint32_t vA = valid ? pp[offA] : 0u, vB = valid ? pp[offB] : 0u;
-            const uint32_t vC = (valid && kb == 0) ? pp[offC] : 0u;
-            f16x8 x1, x2 = vzero<f16x8, 8>();
-            u8x4_to_f16(vA, x1, 0);
-            u8x4_to_f16(vB, x1, 4);
-            u8x4_to_f16(vC, x2, 0);
+            f16x8 x1, x2;
+            if constexpr (F16P) {
+            const uint2 *pp = s_in + (2 * hy) * ROWD + 2 * hx;
+            // No masks on the reads: the pixels q >= N0 of the last MFMA tile read rows past the patch (still inside this
+            // workgroup's LDS; whatever they hold only reaches their own columns of the result, which phase 3 never reads) and
+            // every lane group reads window pixel 8 (a finite fp16), whose K slots 36..63 meet zero weights (weights.h)
+            const uint2 vA = pp[offA], vB = pp[offB], vC = pp[offC];
+            const uint4 u1 = {vA.x, vA.y, vB.x, vB.y}, u2 = {vC.x, vC.y, 0u, 0u};
+            x1 = __builtin_bit_cast(f16x8, u1); x2 = __builtin_bit_cast(f16x8, u2);
+            } else {
+                const uint32_t *pp = s_in8 + (2 * hy) * ROWD + 2 * hx;
+                x2 = vzero<f16x8, 8>();
+                u8x4_to_f16(pp[offA], x1, 0);
+                u8x4_to_f16(pp[offB], x1, 4);
+                u8x4_to_f16(pp[offC], x2, 0);
+            }
             f32x4 acc = b0;                                   // bias rides in the accumulator (lanes >= 32 hold padding rows)
             acc = M::mma(w_hi1, x1, acc);
             acc = M::mma(w_lo1, x1, acc);
             acc = M::mma(w_hi2, x2, acc);
             acc = M::mma(w_lo2, x2, acc);
             if (lane < 32) {
-                // conv0 pixels outside its own map are the ZERO PADDING of the depthwise conv, not conv0(zero input)
+                // conv0 pixels outside its own map are the ZERO PADDING of the depthwise conv, not conv0(zero input):
+                // ReLU and that mask are one clamp to [0, lim]
                 const int cy = 2 * oy0 - 2 + hy, cx = 2 * ox0 - 2 + hx;
-                const bool inside = (unsigned)cy < (unsigned)a.ho && (unsigned)cx < (unsigned)a.wo;
+                const float lim = ((unsigned)cy < (unsigned)a.ho && (unsigned)cx < (unsigned)a.wo) ? __builtin_inff() : 0.f;
                 f32x4 h;
 #pragma unroll
-                for (int r = 0; r < 4; r++) h[r] = inside ? fmaxf(acc[r], 0.f) : 0.f;
-                *(f32x4 *)(s_c0 + q * 8 + c0_half(q, kb) * 4) = h;
+                for (int r = 0; r < 4; r++) h[r] = __builtin_amdgcn_fmed3f(acc[r], 0.f, lim);      // one v_med3_f32: clamp to [0, lim]
+                *(f32x4 *)(s_c0 + kb * C0_PLANE + q * 4) = h;
             }
         }
     }
@@ -852,9 +904,9 @@ __global__ __launch_bounds__(kThreads, (Stem2Cfg<TW_>::OCC)) void stem2_kernel(S
                 for (int ky = 0; ky < 3; ky++)
 #pragma unroll
                     for (int kx = 0; kx < 3; kx++) {
-                        const int q = (ry + ky) * R0W + rx + kx;
-                        const f32x4 x0 = *(const f32x4 *)(s_c0 + q * 8 + c0_half(q, 0) * 4);
-                        const f32x4 x1 = *(const f32x4 *)(s_c0 + q * 8 + c0_half(q, 1) * 4);
+                        const int q = (ry + ky) * R0W + rx + kx;          // = the thread's base pixel + a compile-time tap offset
+                        const f32x4 x0 = *(const f32x4 *)(s_c0 + q * 4);
+                        const f32x4 x1 = *(const f32x4 *)(s_c0 + C0_PLANE + q * 4);
                         const f32x4 w0 = *(const f32x4 *)(s_dw0 + (ky * 3 + kx) * 8), w1 = *(const f32x4 *)(s_dw0 + (ky * 3 + kx) * 8 + 4);
 #pragma unroll
                         for (int e = 0; e < 4; e++) { acc[e] = fmaf(x0[e], w0[e], acc[e]); acc[e + 4] = fmaf(x1[e], w1[e], acc[e + 4]); }
@@ -863,7 +915,7 @@ __global__ __launch_bounds__(kThreads, (Stem2Cfg<TW_>::OCC)) void stem2_kernel(S
             f16x8 hi, lo;
 #pragma unroll
             for (int e = 0; e < 8; e++) {
-                const float v = fmaxf(acc[e], 0.f);
+                const float v = relu_f(acc[e]);
                 hi[e] = (half_t)v;
                 lo[e] = (half_t)(v - (float)hi[e]);
             }
@@ -886,10 +938,10 @@ __global__ __launch_bounds__(kThreads, (Stem2Cfg<TW_>::OCC)) void stem2_kernel(S
         const int ry = i / R2W, rx = i % R2W;
         const int y2 = 2 * oy0 - 1 + ry, x2 = 2 * ox0 - 1 + rx;
         const bool inside = i < N2 && (unsigned)y2 < (unsigned)a.ho && (unsigned)x2 < (unsigned)a.wo;
-        f16x4 h;
-#pragma unroll
-        for (int r = 0; r < 4; r++) h[r] = inside ? (half_t)fmaxf(acc[r], 0.f) : (half_t)0;
-        *(f16x4 *)(s_c2 + i * 16 + kb * 4) = h;
+        uint2 h;
+        h.x = inside ? pack_f16(acc[0], acc[1], true) : 0u;
+        h.y = inside ? pack_f16(acc[2], acc[3], true) : 0u;
+        *(uint2 *)(s_c2 + i * 16 + kb * 4) = h;
     }
     RF_TRACE(4, 4);
     __syncthreads();
@@ -913,10 +965,10 @@ __global__ __launch_bounds__(kThreads, (Stem2Cfg<TW_>::OCC)) void stem2_kernel(S
                         for (int e = 0; e < 4; e++) acc[e] = fmaf((float)x[e], w[e], acc[e]);
                     }
             }
-            f16x4 h;
-#pragma unroll
-            for (int e = 0; e < 4; e++) h[e] = (half_t)fmaxf(acc[e], 0.f);
-            *(f16x4 *)(s_a1 + p * LDA1 + cq * 4) = h;        // region A again: the conv1 result is dead since the barrier after phase 4
+            uint2 h;
+            h.x = pack_f16(acc[0], acc[1], true);
+            h.y = pack_f16(acc[2], acc[3], true);
+            *(uint2 *)(s_a1 + p * LDA1 + cq * 4) = h;        // region A again: the conv1 result is dead since the barrier after phase 4
         }
     }
     const f16x8 pw1_frag0 = ((const f16x8 *)a.pw1_w)[lane], pw1_frag1 = ((const f16x8 *)a.pw1_w)[64 + lane];      // phase 6's operands
@@ -930,10 +982,10 @@ __global__ __launch_bounds__(kThreads, (Stem2Cfg<TW_>::OCC)) void stem2_kernel(S
         const int ct = pr & 1, pt = pr >> 1;
         const M::Frag x = kb < 2 ? *(const M::Frag *)(s_a1 + (pt * 16 + (lane & 15)) * LDA1 + kb * 8) : M::zero();
         const f32x4 acc = M::mma(ct ? pw1_frag1 : pw1_frag0, x, ct ? pw1_bias1 : pw1_bias0);
-        f16x4 h;
-#pragma unroll
-        for (int r = 0; r < 4; r++) h[r] = (half_t)fmaxf(acc[r], 0.f);
-        *(f16x4 *)(s_out + (pt * 16 + (lane & 15)) * LDO + ct * 16 + kb * 4) = h;
+        uint2 h;
+        h.x = pack_f16(acc[0], acc[1], true);
+        h.y = pack_f16(acc[2], acc[3], true);
+        *(uint2 *)(s_out + (pt * 16 + (lane & 15)) * LDO + ct * 16 + kb * 4) = h;
     }
     RF_TRACE(4, 6);
     __syncthreads();
@@ -954,7 +1006,7 @@ __global__ __launch_bounds__(kThreads, (Stem2Cfg<TW_>::OCC)) void stem2_kernel(S
 
 int stem2_variant() {
     static int v = -1;
-    if (v < 0) { const char *e = getenv("RF_STEM2"); v = e ? atoi(e) : 1; }      // probe knob: 1 = 7x8 tiles, 2 = 7x16
+    if (v < 0) { const char *e = getenv("RF_STEM2"); v = e ? atoi(e) : 1; }      // probe knob: 1 = 7x8 tiles, 2 = 7x16, 3 = 7x8 with the patch converted to fp16 at staging (7 workgroups / CU: measured slower)
     return v;
 }
 
@@ -964,11 +1016,13 @@ void launch_stem2(hipStream_t s, const Stem2Params &p) {
     a.dw0_w = p.dw0_w; a.dw0_b = p.dw0_b; a.pw0_w = p.pw0_w; a.pw0_b = p.pw0_b;
     a.dw1_w = p.dw1_w; a.dw1_b = p.dw1_b; a.pw1_w = p.pw1_w; a.pw1_b = p.pw1_b;
     a.ho = p.net_h / 2; a.wo = p.net_w / 2; a.ho4 = p.net_h / 4; a.wo4 = p.net_w / 4;
-    const int tw = stem2_variant() == 2 ? 16 : 8;
+    const int v = stem2_variant();
+    const int tw = v == 2 ? 16 : 8;
     a.tiles_x = (a.wo4 + tw - 1) / tw; a.tiles_y = (a.ho4 + 6) / 7;
     a.nblk = p.n * a.tiles_x * a.tiles_y;
-    if (tw == 16) hipLaunchKernelGGL(stem2_kernel<16>, dim3(a.nblk), dim3(kThreads), 0, s, a);
-    else hipLaunchKernelGGL(stem2_kernel<8>, dim3(a.nblk), dim3(kThreads), 0, s, a);
+    if (tw == 16) hipLaunchKernelGGL((stem2_kernel<16, false>), dim3(a.nblk), dim3(kThreads), 0, s, a);
+    else if (v == 3) hipLaunchKernelGGL((stem2_kernel<8, true>), dim3(a.nblk), dim3(kThreads), 0, s, a);
+    else hipLaunchKernelGGL((stem2_kernel<8, false>), dim3(a.nblk), dim3(kThreads), 0, s, a);
 }
 
 // =============================================================================================
@@ -1244,7 +1298,7 @@ __global__ __launch_bounds__(kThreads, (DwPwCfg<T, CIN, COUT, STRIDE, HAS_DW, TH
 #pragma unroll
                 for (int hl = 0; hl < DPARTS; hl++)
 #pragma unroll
-                    for (int pi = 0; pi < PW; pi++) dacc[hl][pi] = vzero<typename M::Acc, 4>();
+                    for (int pi = 0; pi < PW; pi++) dacc[hl][pi] = acc_init<T>(dwb4[gi]);
                 // B fragments (shifted halo reads) run DDEPTH - 1 reads ahead of their MFMAs, as in gemm_stationary: without it
                 // every MFMA waited for its own LDS round trip (21 s_waitcnt for 20 MFMAs in the 128-channel block: this
                 // phase was the longest of the tile, 685 of ~3000 ns in the phase trace)
@@ -1327,7 +1381,7 @@ __global__ __launch_bounds__(kThreads, (DwPwCfg<T, CIN, COUT, STRIDE, HAS_DW, TH
 #pragma unroll
         for (int i = 0; i < WS::NI; i++)
 #pragma unroll
-            for (int j = 0; j < WS::NJ; j++) acc[i][j] = vzero<typename M::Acc, 4>();
+            for (int j = 0; j < WS::NJ; j++) acc[i][j] = acc_init<T>(pw_bias[i]);
         auto xf = [&](int j, int kc) -> Frag {
             const int kb = kc * M::K + (lane >> 4) * M::KPL;
             const int p = acc_pixel(wp + j * WS::WP, lane);
@@ -1357,7 +1411,7 @@ __global__ __launch_bounds__(kThreads, (DwPwCfg<T, CIN, COUT, STRIDE, HAS_DW, TH
             constexpr int LDL = 64 + VEC;
             typename M::Acc acc2[1][PT];
 #pragma unroll
-            for (int j = 0; j < PT; j++) acc2[0][j] = vzero<typename M::Acc, 4>();
+            for (int j = 0; j < PT; j++) acc2[0][j] = acc_init<T>(lat_bias);
             auto lf = [&](int j, int kc) -> Frag {
                 const int kb = kc * M::K + (lane >> 4) * M::KPL;
                 return *(const Frag *)(s_out + acc_pixel(j, lane) * LDO + kb);
@@ -1481,7 +1535,6 @@ __global__ __launch_bounds__(kThreads, 3) void dwpw2_kernel(DwPw2Args a) {
     typedef Mma<T> M;
     typedef M::Frag Frag;
     typedef f16x8 V;
-    typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
     constexpr int CI = 32, CB = 64;
     constexpr int TH = 4, TW = 8, P = TH * TW;                         // block-B outputs per tile
     constexpr int RH = 2 * TH + 1, RW = 2 * TW + 1, NR = RH * RW;      // block-A outputs the tile needs: 9 x 17 = 153
@@ -1594,7 +1647,7 @@ __global__ __launch_bounds__(kThreads, 3) void dwpw2_kernel(DwPw2Args a) {
         {
             M::Acc acc[UA];
 #pragma unroll
-            for (int i = 0; i < UA; i++) acc[i] = vzero<M::Acc, 4>();
+            for (int i = 0; i < UA; i++) acc[i] = dwa_b;                 // bias rides in the accumulator (acc_init)
 #pragma unroll
             for (int kc = 0; kc < kDwMmaChunks; kc++) {
                 Frag bf[UA];
@@ -1617,13 +1670,13 @@ __global__ __launch_bounds__(kThreads, 3) void dwpw2_kernel(DwPw2Args a) {
             for (int i = 0; i < UA; i++) bf[i] = *(const Frag *)(s_a + (((wave >> 1) + 2 * i) * 16 + (lane & 15)) * LD + kb * 8);
 #pragma unroll
             for (int i = 0; i < UA; i++) {
-                const M::Acc acc = M::mma(pwa, bf[i], vzero<M::Acc, 4>());
+                const M::Acc acc = M::mma(pwa, bf[i], pwa_b);
                 const int y = 2 * oy0 - 1 + (pa_yx[i] >> 16), x = 2 * ox0 - 1 + (pa_yx[i] & 0xffff);
                 const bool inside = (unsigned)y < (unsigned)a.hin && (unsigned)x < (unsigned)a.win;
-                f16x4 h;
-#pragma unroll
-                for (int r = 0; r < 4; r++) h[r] = inside ? (half_t)fmaxf(acc[r] + pwa_b[r], 0.f) : (half_t)0;
-                *(f16x4 *)(s_mid + (((wave >> 1) + 2 * i) * 16 + (lane & 15)) * LD + acc_cout(g, lane, 0)) = h;     // the halo is dead since the last barrier
+                uint2 h;
+                h.x = inside ? pack_f16(acc[0], acc[1], true) : 0u;
+                h.y = inside ? pack_f16(acc[2], acc[3], true) : 0u;
+                *(uint2 *)(s_mid + (((wave >> 1) + 2 * i) * 16 + (lane & 15)) * LD + acc_cout(g, lane, 0)) = h;     // the halo is dead since the last barrier
             }
         }
         RF_TRACE(5, 3);
@@ -1631,7 +1684,7 @@ __global__ __launch_bounds__(kThreads, 3) void dwpw2_kernel(DwPw2Args a) {
 
         // ---- phase 4: depthwise B (3x3, stride 2) on the 32 output pixels: one (group, pixel tile) unit per wave
         {
-            M::Acc acc = vzero<M::Acc, 4>();
+            M::Acc acc = dwb_b;
             Frag bf[kDwMmaChunks];
 #pragma unroll
             for (int kc = 0; kc < kDwMmaChunks; kc++) bf[kc] = tap_b(kc) >= 0 ? *(const Frag *)(s_mid + pb_base + tap_b(kc)) : M::zero();
@@ -1648,7 +1701,7 @@ __global__ __launch_bounds__(kThreads, 3) void dwpw2_kernel(DwPw2Args a) {
 #pragma unroll
             for (int pt = 0; pt < 2; pt++) bf[pt] = *(const Frag *)(s_b + (pt * 16 + (lane & 15)) * LD + kb * 8);
 #pragma unroll
-            for (int pt = 0; pt < 2; pt++) store_acc<T, LDO>(s_out, ones, pwb_b, M::mma(pwb, bf[pt], vzero<M::Acc, 4>()), wave, pt, lane, true);
+            for (int pt = 0; pt < 2; pt++) store_acc<T, LDO>(s_out, ones, pwb_b, M::mma(pwb, bf[pt], pwb_b), wave, pt, lane, true);
         }
         RF_TRACE(5, 5);
         __syncthreads();
@@ -1917,7 +1970,7 @@ __global__ __launch_bounds__(kThreads, (Conv3Cfg<T, CIN, COUT, TH, TW, ALLC, PAD
 #pragma unroll
             for (int i = 0; i < NI; i++)
 #pragma unroll
-                for (int j = 0; j < NJ; j++) acc[i][j] = vzero<typename M::Acc, 4>();
+                for (int j = 0; j < NJ; j++) acc[i][j] = acc_init<T>(bias[i]);
             auto xf = [&](int j, int kc) -> Frag {
                 const int kb = kc * M::K + (lane >> 4) * M::KPL;      // k = tap*CIN + c, KPL consecutive c of one tap
                 const int tap = kb / CIN, c = kb % CIN;
@@ -2129,7 +2182,8 @@ __global__ __launch_bounds__(kThreads) void head_kernel(HeadArgs<T> a) {
 
     constexpr int NT = COUT / 16, PT = P / 16;       // A = 2: waves = 2 (cout) x 2 (pixel halves); A = 4: 4 (cout) x 1
     typedef WaveSplit<NT, PT> WS;
-    constexpr int KCH = CIN / M::K;
+    // fp16 engine: the weights are an fp16 hi + lo pair laid out along K (weights.h): K = 128, both halves read the same 64 inputs
+    constexpr int KCH1 = CIN / M::K, KCH = sizeof(T) == 2 ? 2 * KCH1 : KCH1;
     const int wn = wave % WS::WN, wp = wave / WS::WN;
     GemmPipe<T, 1, WS::NJ, KCH, WS::WN> pipe;
     pipe.init(L.w, wn, lane);
@@ -2150,7 +2204,7 @@ __global__ __launch_bounds__(kThreads) void head_kernel(HeadArgs<T> a) {
 #pragma unroll
     for (int j = 0; j < WS::NJ; j++) acc[0][j] = vzero<typename M::Acc, 4>();
     pipe.run(acc, [&](int j, int kc) -> typename M::Frag {
-        const int kb = kc * M::K + (lane >> 4) * M::KPL;
+        const int kb = (kc % KCH1) * M::K + (lane >> 4) * M::KPL;
         return *(const typename M::Frag *)(s_a + acc_pixel(wp + j * WS::WP, lane) * LDA + kb);
     });
 #pragma unroll

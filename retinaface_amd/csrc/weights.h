@@ -204,6 +204,40 @@ struct WeightPack {
         return g;
     }
 
+    // fp16 engine: per-channel rescaling of a depthwise + pointwise block that costs nothing at run time and takes the rounding of
+    // the nine fp16 taps out of the error budget.  relu(y / t) = relu(y) / t for t > 0, so channel c of the depthwise stage may
+    // produce its output divided by t[c] (taps and bias / t[c]) if column c of the pointwise matrix is multiplied by t[c].  The
+    // taps' RELATIVE rounding errors depend on where they fall between fp16 grid points, i.e. on t: scanning t over one octave
+    // and keeping the best value brings the rms tap error of a channel to 0.2-0.3 of plain rounding (measured on both shipped
+    // models); the pointwise column is rounded afterwards as usual (different numbers, same expected error).  The taps were
+    // ~24 % of what was left of the fp16 engine's box-error variance (tools/fp16_error_budget.py).
+    static void equalize_depthwise(FoldedConv &dw, FoldedConv &pw) {
+        const int c = dw.cout;
+        if (dw.group != c || dw.k != 3 || pw.k != 1 || pw.cin != c) return;
+        auto err2 = [](const float *w9, double t) {
+            double e = 0.0;
+            for (int k = 0; k < 9; k++) {
+                const double v = (double)w9[k] / t;
+                const double q = (double)(float)(half_t)(float)v * t;
+                e += (q - (double)w9[k]) * (q - (double)w9[k]);
+            }
+            return e;
+        };
+        for (int ch = 0; ch < c; ch++) {
+            const float *w9 = &dw.w[(size_t)ch * 9];
+            double best_t = 1.0, best_e = err2(w9, 1.0);
+            if (best_e == 0.0) continue;
+            for (int i = 1; i < 2048; i++) {
+                const double t = 1.0 + i / 2048.0, e = err2(w9, t);
+                if (e < best_e) { best_e = e; best_t = t; }
+            }
+            const float t = (float)best_t;
+            for (int k = 0; k < 9; k++) dw.w[(size_t)ch * 9 + k] = (float)((double)dw.w[(size_t)ch * 9 + k] / best_t);
+            dw.b[ch] = (float)((double)dw.b[ch] / best_t);
+            for (int o = 0; o < pw.cout; o++) pw.w[(size_t)o * c + ch] *= t;
+        }
+    }
+
     // depthwise weights [c][3][3][1] -> [tap][c].  int8: fp32 weights pre-scaled so the stencil maps input quanta straight to
     // output quanta: w * in_scale / mid_scale, b / mid_scale
     DwW put_dw(const FoldedConv &dw, const Sc &in_scale = {}, const Sc &mid_scale = {}) {
@@ -341,8 +375,15 @@ struct WeightPack {
         for (size_t i = first_block; i < plan.blocks.size(); i++) {
             const auto &blk = plan.blocks[i];
             const Sc s_mid = scales_of(plan, blk.dw.out_blob, blk.dw.cout), s_out = scales_of(plan, blk.pw.out_blob, blk.pw.cout);
-            dw_w_.push_back(put_dw(blk.dw, s_prev, s_mid));
-            pw_w_.push_back(put_gemm(blk.pw, s_mid, s_out));
+            if constexpr (std::is_same<T, half_t>::value) {
+                FoldedConv dwq = blk.dw, pwq = blk.pw;
+                equalize_depthwise(dwq, pwq);
+                dw_w_.push_back(put_dw(dwq, s_prev, s_mid));
+                pw_w_.push_back(put_gemm(pwq, s_mid, s_out));
+            } else {
+                dw_w_.push_back(put_dw(blk.dw, s_prev, s_mid));
+                pw_w_.push_back(put_gemm(blk.pw, s_mid, s_out));
+            }
             s_prev = s_out;
             if constexpr (kInt8) act_scale_[blk.pw.out_blob] = s_out;
             if (i == 12) s_tap[0] = s_out;
@@ -389,7 +430,25 @@ struct WeightPack {
             ssh_w_[i][0] = put_gemm(m.conv_a, s_feat[i], concat(slice(s_cat, 0, 32), s_c1));
             ssh_w_[i][1] = put_gemm(m.conv_b, s_c1, concat(slice(s_cat, 32, 48), s_c31));
             ssh_w_[i][2] = put_gemm(m.conv_c, s_c31, slice(s_cat, 48, 64));
-            ssh_w_[i][3] = put_gemm(m.head, s_cat, {});              // heads are dequantised to real logits / deltas
+            if constexpr (std::is_same<T, half_t>::value) {
+                // fp16 engine: head weights as an fp16 hi + lo pair along K (k < 64: rn16(w), k >= 64: rn16(w - hi); the kernel reads
+                // the same 64 activations for both halves).  Box deltas are what the IoU bound is measured on, the heads are
+                // 0.1 % of the MACs, and their weight rounding was ~7 % of the remaining box-error variance.
+                FoldedConv h2 = m.head;
+                const int ci = m.head.cin;
+                h2.cin = 2 * ci;
+                h2.w.assign((size_t)h2.cout * 2 * ci, 0.f);
+                for (int o = 0; o < h2.cout; o++)
+                    for (int k = 0; k < ci; k++) {
+                        const float w = m.head.w[(size_t)o * ci + k];
+                        const float hi = (float)(half_t)w;
+                        h2.w[(size_t)o * 2 * ci + k] = hi;
+                        h2.w[(size_t)o * 2 * ci + ci + k] = w - hi;
+                    }
+                ssh_w_[i][3] = put_gemm(h2);
+            } else {
+                ssh_w_[i][3] = put_gemm(m.head, s_cat, {});          // heads are dequantised to real logits / deltas
+            }
             if constexpr (kInt8) {
                 act_scale_[pre + "concat_relu"] = s_cat;
                 act_scale_[pre + "context_conv1_relu"] = s_c1;
