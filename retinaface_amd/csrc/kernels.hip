@@ -1822,7 +1822,7 @@ __global__ __launch_bounds__(kThreads, (Conv3Cfg<T, CIN, COUT, TH, TW, ALLC, PAD
     const int first = gbid - L.gb_begin, G = L.gsz, ntiles = L.ntiles;
     const int tiles_x = L.tiles_x;
     const int lh = L.h, lw = L.w_;
-    RF_TRACE_KEY(a.lv[0].ntiles);
+    RF_TRACE_KEY(a.lv[0].ntiles + COUT);           // tile count of the first level + output channels: identifies one conv3x3 launch
     RF_TRACE(3, 0);
 
     // ---- once per workgroup: this wave's weight share and biases
