@@ -1934,7 +1934,31 @@ __global__ __launch_bounds__(kThreads, (Conv3Cfg<T, CIN, COUT, TH, TW, ALLC, PAD
             const int i = tid + k * kThreads;
             if (i < C::STAGE_ITEMS) {
                 V v = pre[k];
-                if constexpr (UPADD) {
+                if constexpr (UPADD && sizeof(T) == 2) {
+                    // fp16 engine: the blend in packed fp16 (v_pk_fma_f16, two channels per instruction).  The tap weights 9/16,
+                    // 3/16, 3/16, 1/16 are exact in fp16; the sum is rounded after every step instead of once (the `plus` tensors
+                    // carry 0.2 % of the fp16 engine's box-error variance, tools/fp16_error_budget.py) -- and the blend, which was
+                    // ~40 % of this kernel's VALU instructions in fp32 (8 x (mul + 3 fma_mix + fma + select) + 4 converts per
+                    // 16-byte item), is 4 x (mul + 3 fma + add + select)
+                    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+                    const h2 w0 = {(half_t)0.5625f, (half_t)0.5625f}, w1 = {(half_t)0.1875f, (half_t)0.1875f}, w3 = {(half_t)0.0625f, (half_t)0.0625f};
+                    const bool ok = (pre_ok >> k) & 1u;
+                    uint4 r;
+                    uint32_t *rp = (uint32_t *)&r;
+                    const uint4 lat4 = __builtin_bit_cast(uint4, v), u0 = __builtin_bit_cast(uint4, upv[k][0]), u1 = __builtin_bit_cast(uint4, upv[k][1]),
+                                u2 = __builtin_bit_cast(uint4, upv[k][2]), u3 = __builtin_bit_cast(uint4, upv[k][3]);
+                    const uint32_t *lp = (const uint32_t *)&lat4, *p0 = (const uint32_t *)&u0, *p1 = (const uint32_t *)&u1, *p2 = (const uint32_t *)&u2, *p3 = (const uint32_t *)&u3;
+#pragma unroll
+                    for (int d = 0; d < 4; d++) {
+                        h2 acc = __builtin_bit_cast(h2, p0[d]) * w0;
+                        acc = __builtin_elementwise_fma(__builtin_bit_cast(h2, p1[d]), w1, acc);
+                        acc = __builtin_elementwise_fma(__builtin_bit_cast(h2, p2[d]), w1, acc);
+                        acc = __builtin_elementwise_fma(__builtin_bit_cast(h2, p3[d]), w3, acc);
+                        acc = acc + __builtin_bit_cast(h2, lp[d]);
+                        rp[d] = ok ? __builtin_bit_cast(uint32_t, acc) : 0u;
+                    }
+                    v = __builtin_bit_cast(V, r);
+                } else if constexpr (UPADD) {
                     // the tap weights live in registers (not literals) so that each MAC is one v_fma_mix_f32 on the fp16 tap
                     // instead of a convert + fmac pair: this staging blend is ~half of the kernel's VALU instructions
                     float wq[4] = {0.5625f, 0.1875f, 0.1875f, 0.0625f};
