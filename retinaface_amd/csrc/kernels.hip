@@ -501,24 +501,31 @@ __device__ __forceinline__ void u8x4_to_f16(uint32_t v, f16x8 &dst, int at) {
     dst[at] = lo.h[0]; dst[at + 1] = lo.h[1]; dst[at + 2] = hi.h[0]; dst[at + 3] = hi.h[1];
 }
 
-// fp32 conv0 tile: pixel q = 8 floats (32 B); its two 16-byte halves are swapped on odd (q >> 3), so 16 consecutive pixels
-// read as ds_read_b128 touch every bank once (at a plain 32-byte stride lanes i and i + 8 of a 16-lane group collide)
-__device__ __forceinline__ int c0_half(int q, int half) { return half ^ ((q >> 3) & 1); }
+
+template <typename TO> struct StemCfg {
+    static constexpr int LDA = 16;                    // depthwise result per pixel: 8 x fp16 hi | 8 x fp16 lo (32 B)
+    static constexpr int LDO = 16 + Vec<TO>::N;       // output tile row stride in TO elements (16 B of padding)
+    static constexpr int IN_BYTES = ST_IR * ST_ROWD * 4, A_BYTES = ST_P * LDA * 2;
+    static constexpr int C0_BYTES = ST_PTILES * 16 * 8 * 4, OUT_BYTES = ST_P * LDO * (int)sizeof(TO);
+    static constexpr int REGION_A = IN_BYTES > A_BYTES ? IN_BYTES : A_BYTES;
+    static constexpr int REGION_B = C0_BYTES > OUT_BYTES ? C0_BYTES : OUT_BYTES;
+    static constexpr int LDS_BYTES = REGION_A + REGION_B + 9 * 8 * 4;
+    static constexpr int OCC = LDS_BYTES <= 20 * 1024 ? 8 : 7;     // int8 output: 19.7 KB -> the hardware's 32 waves per CU
+};
 
 template <typename TO>
-__global__ __launch_bounds__(kThreads, 7) void stem_kernel(StemArgs<TO> a) {
+__global__ __launch_bounds__(kThreads, (StemCfg<TO>::OCC)) void stem_kernel(StemArgs<TO> a) {
     typedef half_t T;                                 // compute type of the stem; TO = storage type of its output
     typedef Mma<T> M;
-    constexpr int LDA = 16;                           // depthwise result per pixel: 8 x fp16 hi | 8 x fp16 lo (32 B)
-    constexpr int LDO = 16 + Vec<TO>::N;              // output tile row stride in TO elements (16 B of padding)
-    // LDS (20.8 KB -> 7 workgroups per CU).  Two regions, each reused once the barrier after its last reader has passed:
+    typedef StemCfg<TO> SC;
+    constexpr int LDA = SC::LDA, LDO = SC::LDO;
+    // LDS (19.7 KB with an int8 output tile -> 8 workgroups per CU; 23.8 KB with fp16 -> 6).  Two regions, each reused once the barrier after its last
+    // reader has passed:
     //   region A: staged BGRX patch (phases 1-2)  ->  depthwise result hi/lo (phases 3-4)
     //   region B: fp32 conv0 tile   (phases 2-3)  ->  output tile (phase 4 - store)
-    constexpr int IN_BYTES = ST_IR * ST_ROWD * 4, A_BYTES = ST_P * LDA * 2;
-    constexpr int C0_BYTES = ST_PTILES * 16 * 8 * 4, OUT_BYTES = ST_P * LDO * (int)sizeof(TO);
-    constexpr int REGION_A = IN_BYTES > A_BYTES ? IN_BYTES : A_BYTES;
-    constexpr int REGION_B = C0_BYTES > OUT_BYTES ? C0_BYTES : OUT_BYTES;
-    __shared__ __attribute__((aligned(16))) unsigned char s_raw[REGION_A + REGION_B + 9 * 8 * 4];
+    constexpr int REGION_A = SC::REGION_A, REGION_B = SC::REGION_B;
+    constexpr int C0_PLANE = ST_PTILES * 16 * 4;      // fp32 conv0 tile as two 4-channel planes (see stem2_kernel)
+    __shared__ __attribute__((aligned(16))) unsigned char s_raw[SC::LDS_BYTES];
     uint32_t *s_in = (uint32_t *)s_raw;                                             // BGRX pixels
     T *s_a = (T *)s_raw;
     float *s_c0 = (float *)(s_raw + REGION_A);
@@ -537,13 +544,8 @@ __global__ __launch_bounds__(kThreads, 7) void stem_kernel(StemArgs<TO> a) {
     const f16x8 *wf = (const f16x8 *)a.w0 + lane;
     const f16x8 w_hi1 = wf[0], w_lo1 = wf[64], w_hi2 = wf[128], w_lo2 = wf[192];
     const f32x4 b0 = lane < 32 ? *(const f32x4 *)(a.b0 + (lane >> 4) * 4) : vzero<f32x4, 4>();
-    GemmPipe<T, 1, 4, 1, 1> pipe;
-    pipe.init(a.pw_w, 0, lane);
-    const f32x4 pw_bias = *(const f32x4 *)(a.pw_b + acc_cout(0, lane, 0));
-    const f32x4 pw_mult = load_mult(a.pw_m, acc_cout(0, lane, 0));
-    float dw_bias[8];
-#pragma unroll
-    for (int e = 0; e < 8; e++) dw_bias[e] = a.dw_b[e];
+    // (the operands of phases 3 and 4 are loaded one phase ahead of their use, not here: 20 more live registers across the
+    // staging / conv0 phases cost the 8th workgroup per CU)
 
     // ---- phase 1: stage the u8 patch as BGRX dwords.  One item = 4 pixels = 12 consecutive frame bytes at an arbitrary
     //      alignment, fetched as the 4 aligned dwords that contain them (ONE buffer_load_dwordx4), realigned with
@@ -603,26 +605,27 @@ __global__ __launch_bounds__(kThreads, 7) void stem_kernel(StemArgs<TO> a) {
         const int q = t * 16 + (lane & 15);
         const int hy = q / ST_HC, hx = q % ST_HC;
         const uint32_t *pp = s_in + (2 * hy) * ST_ROWD + 2 * hx;
-        const bool valid = q < ST_NPIX;
-        const uint32_t vA = valid ? pp[offA] : 0u, vB = valid ? pp[offB] : 0u;
-        const uint32_t vC = (valid && kb == 0) ? pp[offC] : 0u;
+        // no masks on the reads (see stem2_kernel phase 2): pixels past the patch only reach result columns nobody reads, and
+        // window pixel 8 in the lane groups kb > 0 meets zero weights
+        const uint32_t vA = pp[offA], vB = pp[offB], vC = pp[offC];
         f16x8 x1, x2 = vzero<f16x8, 8>();
         u8x4_to_f16(vA, x1, 0);
         u8x4_to_f16(vB, x1, 4);
         u8x4_to_f16(vC, x2, 0);
-        f32x4 acc = vzero<f32x4, 4>();
+        f32x4 acc = b0;                                   // bias rides in the accumulator
         acc = M::mma(w_hi1, x1, acc);
         acc = M::mma(w_lo1, x1, acc);
         acc = M::mma(w_hi2, x2, acc);
         acc = M::mma(w_lo2, x2, acc);
         if (lane < 32) {
-            // conv0 pixels outside its own map are the ZERO PADDING of the depthwise conv, not conv0(zero input)
+            // conv0 pixels outside its own map are the ZERO PADDING of the depthwise conv, not conv0(zero input): ReLU and that
+            // mask are one clamp to [0, lim]
             const int cy = oy0 - 1 + hy, cx = ox0 - 1 + hx;
-            const bool inside = cy >= 0 && cy < a.ho && cx >= 0 && cx < a.wo;
+            const float lim = ((unsigned)cy < (unsigned)a.ho && (unsigned)cx < (unsigned)a.wo) ? __builtin_inff() : 0.f;
             f32x4 h;
 #pragma unroll
-            for (int r = 0; r < 4; r++) h[r] = inside ? fmaxf(acc[r] + b0[r], 0.f) : 0.f;
-            *(f32x4 *)(s_c0 + q * 8 + c0_half(q, kb) * 4) = h;
+            for (int r = 0; r < 4; r++) h[r] = __builtin_amdgcn_fmed3f(acc[r], 0.f, lim);
+            *(f32x4 *)(s_c0 + kb * C0_PLANE + q * 4) = h;
         }
     }
     __syncthreads();
@@ -633,14 +636,14 @@ __global__ __launch_bounds__(kThreads, 7) void stem_kernel(StemArgs<TO> a) {
         const int py = tid / ST_TW, px = tid % ST_TW;
         float acc[8];
 #pragma unroll
-        for (int e = 0; e < 8; e++) acc[e] = dw_bias[e];
+        for (int e = 0; e < 8; e++) acc[e] = a.dw_b[e];
 #pragma unroll
         for (int ky = 0; ky < 3; ky++)
 #pragma unroll
             for (int kx = 0; kx < 3; kx++) {
                 const int q = (py + ky) * ST_HC + px + kx;
-                const f32x4 x0 = *(const f32x4 *)(s_c0 + q * 8 + c0_half(q, 0) * 4);
-                const f32x4 x1 = *(const f32x4 *)(s_c0 + q * 8 + c0_half(q, 1) * 4);
+                const f32x4 x0 = *(const f32x4 *)(s_c0 + q * 4);
+                const f32x4 x1 = *(const f32x4 *)(s_c0 + C0_PLANE + q * 4);
                 const f32x4 w0 = *(const f32x4 *)(s_dw + (ky * 3 + kx) * 8), w1 = *(const f32x4 *)(s_dw + (ky * 3 + kx) * 8 + 4);
 #pragma unroll
                 for (int e = 0; e < 4; e++) { acc[e] = fmaf(x0[e], w0[e], acc[e]); acc[e + 4] = fmaf(x1[e], w1[e], acc[e + 4]); }
@@ -648,13 +651,17 @@ __global__ __launch_bounds__(kThreads, 7) void stem_kernel(StemArgs<TO> a) {
         f16x8 hi, lo;
 #pragma unroll
         for (int e = 0; e < 8; e++) {
-            const float v = fmaxf(acc[e], 0.f);
+            const float v = relu_f(acc[e]);
             hi[e] = (half_t)v;
             lo[e] = (half_t)(v - (float)hi[e]);
         }
         *(f16x8 *)(s_a + tid * LDA) = hi;        // region A: the staged patch is dead since the barrier after phase 2
         *(f16x8 *)(s_a + tid * LDA + 8) = lo;
     }
+    GemmPipe<T, 1, 4, 1, 1> pipe;                 // phase 4's operands: requested before the barrier
+    pipe.init(a.pw_w, 0, lane);
+    const f32x4 pw_bias = *(const f32x4 *)(a.pw_b + acc_cout(0, lane, 0));
+    const f32x4 pw_mult = load_mult(a.pw_m, acc_cout(0, lane, 0));
     __syncthreads();
 
     // ---- phase 4: pointwise 8 -> 16 (conv2) on MFMA, K padded to 32
