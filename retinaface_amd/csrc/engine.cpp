@@ -480,7 +480,7 @@ private:
                 sp.w0 = arena_.template ptr<half_t>(c0_hi_); sp.b0 = arena_.template ptr<float>(c0_b_);
                 sp.dw0_w = arena_.template ptr<float>(stem_dw_.w); sp.dw0_b = arena_.template ptr<float>(stem_dw_.b);
                 sp.pw0_w = arena_.template ptr<half_t>(stem_pw_.w); sp.pw0_b = arena_.template ptr<float>(stem_pw_.b);
-                sp.dw1_w = arena_.template ptr<float>(stem2_dw_.w); sp.dw1_b = arena_.template ptr<float>(stem2_dw_.b);
+                sp.dw1_mma = arena_.template ptr<uint32_t>(stem2_dw_.mma); sp.dw1_b = arena_.template ptr<float>(stem2_dw_.b);
                 sp.pw1_w = arena_.template ptr<half_t>(stem2_pw_.w); sp.pw1_b = arena_.template ptr<float>(stem2_pw_.b);
                 sp.n = 0; sp.net_h = H; sp.net_w = W;
                 OpInfo op;

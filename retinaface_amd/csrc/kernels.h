@@ -68,7 +68,7 @@ struct Stem2Params {
     const FrameDesc *frames; half_t *out;          // out: [n][net_h/4][net_w/4][32]
     const half_t *w0; const float *b0;
     const float *dw0_w; const float *dw0_b; const half_t *pw0_w; const float *pw0_b;
-    const float *dw1_w; const float *dw1_b;        // conv3: taps [9][16] fp32, bias [16]
+    const uint32_t *dw1_mma; const float *dw1_b;   // conv3: taps as diagonal MFMA A fragments [5][64] dwords (pack.h), bias [16]
     const half_t *pw1_w; const float *pw1_b;       // conv4: 32 x 16, MFMA-fragment packed (K padded to 32), bias [32]
     int n, net_h, net_w;
 };

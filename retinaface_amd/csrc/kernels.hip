@@ -729,7 +729,7 @@ template <int TW_, bool F16P> struct Stem2Cfg {     // F16P: the staged patch ho
     static constexpr int MAX3(int a, int b, int c) { return a > b ? (a > c ? a : c) : (b > c ? b : c); }
     static constexpr int REGION_A = MAX3(IN_BYTES, A_BYTES, A1_BYTES + OUT_BYTES);
     static constexpr int REGION_B = C0_BYTES > C2_BYTES ? C0_BYTES : C2_BYTES;
-    static constexpr int LDS_BYTES = REGION_A + REGION_B + 9 * 8 * 4 + 9 * 16 * 4;
+    static constexpr int LDS_BYTES = REGION_A + REGION_B + 9 * 8 * 4;
     static constexpr int OCC = LDS_BYTES <= 20 * 1024 ? 8 : LDS_BYTES <= 23 * 1024 ? 7 : (160 * 1024 / LDS_BYTES);
     static_assert(REGION_A % 16 == 0 && REGION_B % 16 == 0 && A1_BYTES % 16 == 0, "LDS carve must stay 16-byte aligned");
 };
@@ -738,7 +738,7 @@ struct Stem2Args {
     const FrameDesc *frames; half_t *out;           // out: [n][ho4][wo4][32]
     const half_t *w0; const float *b0;              // conv0 (as StemArgs)
     const float *dw0_w; const float *dw0_b; const half_t *pw0_w; const float *pw0_b;     // conv1 / conv2 (as StemArgs)
-    const float *dw1_w; const float *dw1_b;         // conv3 taps [9][16] fp32, bias [16]
+    const uint32_t *dw1_mma; const float *dw1_b;    // conv3 taps as diagonal MFMA A fragments [5][64] dwords (pack.h dw_mma_dword), bias [16]
     const half_t *pw1_w; const float *pw1_b;        // conv4: 32 x 16 packed (K padded to 32), bias [32]
     int ho, wo, ho4, wo4, tiles_x, tiles_y, nblk;   // ho x wo = conv0 / conv2 map (net / 2), ho4 x wo4 = conv4 map (net / 4)
 };
@@ -764,7 +764,6 @@ __global__ __launch_bounds__(kThreads, (Stem2Cfg<TW_, F16P>::OCC)) void stem2_ke
     float *s_c0 = (float *)(s_raw + C::REGION_A);                // fp32 conv0 tile                 (phases 2-3)
     T *s_c2 = (T *)(s_raw + C::REGION_A);                        // fp16 conv2 tile                 (phases 4-5)
     float *s_dw0 = (float *)(s_raw + C::REGION_A + C::REGION_B);
-    float *s_dw1 = s_dw0 + 9 * 8;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int bid = xcd_remap(blockIdx.x, a.nblk);
@@ -847,7 +846,6 @@ __global__ __launch_bounds__(kThreads, (Stem2Cfg<TW_, F16P>::OCC)) void stem2_ke
         }
     }
     if (tid < 18) *(f32x4 *)(s_dw0 + tid * 4) = *(const f32x4 *)(a.dw0_w + tid * 4);
-    else if (tid >= 64 && tid < 64 + 36) *(f32x4 *)(s_dw1 + (tid - 64) * 4) = *(const f32x4 *)(a.dw1_w + (tid - 64) * 4);
     RF_TRACE(4, 1);
     __syncthreads();
 
@@ -950,32 +948,47 @@ __global__ __launch_bounds__(kThreads, (Stem2Cfg<TW_, F16P>::OCC)) void stem2_ke
         h.y = inside ? pack_f16(acc[2], acc[3], true) : 0u;
         *(uint2 *)(s_c2 + i * 16 + kb * 4) = h;
     }
+    uint32_t dw1v[kDwMmaChunks];                             // phase 5's operands: requested before the barrier
+#pragma unroll
+    for (int kc = 0; kc < kDwMmaChunks; kc++) dw1v[kc] = a.dw1_mma[kc * 64 + lane];
+    const f32x4 dbias = *(const f32x4 *)(a.dw1_b + kb * 4);
     RF_TRACE(4, 4);
     __syncthreads();
 
-    // ---- phase 5: depthwise conv3, stride 2, pad 1: one output pixel x 4 channels per thread (fp32 taps, fp32 accumulate)
+    // ---- phase 5: depthwise conv3, stride 2, pad 1, on the matrix cores: a dense 3x3 conv 16 -> 16 whose weight matrix is diagonal
+    //      (K = 9 taps x 16 channels -> 5 chunks of 32; pack.h dw_mma_dword, as in K_b).  B fragments are 16-byte reads of the fp16
+    //      conv2 tile at the tap's offset; one pixel tile per wave.  On the VALU this phase was 54 convert + pk_fma instructions
+    //      plus 18 LDS reads per thread; the taps are fp16 here, equalised per channel on the host (weights.h) so that their
+    //      rounding stays out of the error budget.
     {
-        const int cq = tid & 3;
-        const f32x4 bias = *(const f32x4 *)(a.dw1_b + cq * 4);
+        const int dsel = dw_mma_dword_index(lane);
+        const bool hi_tap = lane >= 32;                     // chunk kc carries tap 2 kc (lanes 0..31) and 2 kc + 1 (lanes 32..63)
 #pragma unroll 1
-        for (int p = tid >> 2; p < C::T4 * 16; p += kThreads / 4) {
-            const int py = p / TW, px = p % TW;
-            f32x4 acc = bias;
-            if (p < P4) {
+        for (int pt = wave; pt < C::T4; pt += 4) {
+            const int p = pt * 16 + (lane & 15);
+            const int py = p / TW, px = p % TW;             // p >= P4: reads past the tile's last row (inside this workgroup's LDS), result never stored
+            const T *src = s_c2 + ((2 * py) * R2W + 2 * px) * 16 + (kb & 1) * 8;
+            M::Frag bf[kDwMmaChunks];
 #pragma unroll
-                for (int ky = 0; ky < 3; ky++)
+            for (int kc = 0; kc < kDwMmaChunks; kc++) {
+                const int t0 = 2 * kc, t1 = 2 * kc + 1;
+                const int o0 = ((t0 / 3) * R2W + t0 % 3) * 16, o1 = t1 < 9 ? ((t1 / 3) * R2W + t1 % 3) * 16 : o0;      // tap 9 does not exist: its A columns are zero
+                bf[kc] = *(const M::Frag *)(src + (hi_tap ? o1 : o0));
+            }
+            f32x4 acc = dbias;
 #pragma unroll
-                    for (int kx = 0; kx < 3; kx++) {
-                        const f16x4 x = *(const f16x4 *)(s_c2 + ((2 * py + ky) * R2W + 2 * px + kx) * 16 + cq * 4);
-                        const f32x4 w = *(const f32x4 *)(s_dw1 + (ky * 3 + kx) * 16 + cq * 4);
+            for (int kc = 0; kc < kDwMmaChunks; kc++) {
+                typedef uint32_t u32x4_ __attribute__((ext_vector_type(4)));
+                const uint32_t wd = dw1v[kc];
+                u32x4_ wa;
 #pragma unroll
-                        for (int e = 0; e < 4; e++) acc[e] = fmaf((float)x[e], w[e], acc[e]);
-                    }
+                for (int d = 0; d < 4; d++) wa[d] = dsel == d ? wd : 0u;
+                acc = M::mma(__builtin_bit_cast(M::Frag, wa), bf[kc], acc);
             }
             uint2 h;
             h.x = pack_f16(acc[0], acc[1], true);
             h.y = pack_f16(acc[2], acc[3], true);
-            *(uint2 *)(s_a1 + p * LDA1 + cq * 4) = h;        // region A again: the conv1 result is dead since the barrier after phase 4
+            *(uint2 *)(s_a1 + p * LDA1 + kb * 4) = h;      // region A again: the conv1 result is dead since the barrier after phase 4
         }
     }
     const f16x8 pw1_frag0 = ((const f16x8 *)a.pw1_w)[lane], pw1_frag1 = ((const f16x8 *)a.pw1_w)[64 + lane];      // phase 6's operands
@@ -1021,7 +1034,7 @@ void launch_stem2(hipStream_t s, const Stem2Params &p) {
     Stem2Args a;
     a.frames = p.frames; a.out = p.out; a.w0 = p.w0; a.b0 = p.b0;
     a.dw0_w = p.dw0_w; a.dw0_b = p.dw0_b; a.pw0_w = p.pw0_w; a.pw0_b = p.pw0_b;
-    a.dw1_w = p.dw1_w; a.dw1_b = p.dw1_b; a.pw1_w = p.pw1_w; a.pw1_b = p.pw1_b;
+    a.dw1_mma = p.dw1_mma; a.dw1_b = p.dw1_b; a.pw1_w = p.pw1_w; a.pw1_b = p.pw1_b;
     a.ho = p.net_h / 2; a.wo = p.net_w / 2; a.ho4 = p.net_h / 4; a.wo4 = p.net_w / 4;
     const int v = stem2_variant();
     const int tw = v == 2 ? 16 : 8;

@@ -356,14 +356,13 @@ struct WeightPack {
             pw_w_.push_back(GemmW{0, 0});
             if constexpr (std::is_same<T, half_t>::value) {
                 if (stem2_variant()) {
-                    // stem2 also runs the first stride-2 block: conv3 taps [9][16] fp32, conv4 as a standard packed 32 x 16 GEMM
-                    const auto &b1 = plan.blocks[1];
-                    std::vector<float> dw1((size_t)9 * 16);
-                    for (int ch = 0; ch < 16; ch++)
-                        for (int t = 0; t < 9; t++) dw1[(size_t)t * 16 + ch] = b1.dw.w[(size_t)ch * 9 + t];
-                    stem2_dw_ = DwW{arena_.put(dw1), arena_.put(b1.dw.b)};
-                    stem2_pw_.w = arena_.put(pack_gemm<half_t>(b1.pw.w, b1.pw.cout, 16, 32, 8));
-                    stem2_pw_.b = arena_.put(b1.pw.b);
+                    // stem2 also runs the first stride-2 block: conv3 taps as diagonal MFMA fragments (equalised per channel like every
+                    // other depthwise stage, see equalize_depthwise), conv4 as a standard packed 32 x 16 GEMM
+                    FoldedConv dwq = plan.blocks[1].dw, pwq = plan.blocks[1].pw;
+                    equalize_depthwise(dwq, pwq);
+                    stem2_dw_ = put_dw(dwq);
+                    stem2_pw_.w = arena_.put(pack_gemm<half_t>(pwq.w, pwq.cout, 16, 32, 8));
+                    stem2_pw_.b = arena_.put(pwq.b);
                     first_block = 2;
                     dw_w_.push_back(DwW{0, 0});
                     pw_w_.push_back(GemmW{0, 0});
