@@ -773,6 +773,9 @@ __global__ __launch_bounds__(kThreads, (Stem2Cfg<TW_, F16P>::OCC)) void stem2_ke
     const int oy0 = ty * C::TH, ox0 = tx * TW;                   // tile origin in the conv4 map
     const FrameDesc fd = a.frames[img];
     const int kb = lane >> 4;
+    // the conv0 region [2 oy0 - 2, +R0H) x [2 ox0 - 2, +R0W) (and with it the conv2 region) lies inside the 224^2-type map: no
+    // pixel of this tile is another layer's zero padding
+    const bool interior = 2 * oy0 - 2 >= 0 && 2 * oy0 - 2 + C::R0H <= a.ho && 2 * ox0 - 2 >= 0 && 2 * ox0 - 2 + C::R0W <= a.wo;
     RF_TRACE_KEY(a.nblk);
     RF_TRACE(4, 0);
 
@@ -881,8 +884,12 @@ __global__ __launch_bounds__(kThreads, (Stem2Cfg<TW_, F16P>::OCC)) void stem2_ke
             if (lane < 32) {
                 // conv0 pixels outside its own map are the ZERO PADDING of the depthwise conv, not conv0(zero input):
                 // ReLU and that mask are one clamp to [0, lim]
-                const int cy = 2 * oy0 - 2 + hy, cx = 2 * ox0 - 2 + hx;
-                const float lim = ((unsigned)cy < (unsigned)a.ho && (unsigned)cx < (unsigned)a.wo) ? __builtin_inff() : 0.f;
+                float lim = __builtin_inff();
+                if (!interior) {                                  // wave-uniform: 3 of 4 tiles of a 448^2 frame skip the border test
+                    asm volatile("" ::: "memory");                // (an empty side effect: keeps the compiler from if-converting the branch away)
+                    const int cy = 2 * oy0 - 2 + hy, cx = 2 * ox0 - 2 + hx;
+                    lim = ((unsigned)cy < (unsigned)a.ho && (unsigned)cx < (unsigned)a.wo) ? __builtin_inff() : 0.f;
+                }
                 f32x4 h;
 #pragma unroll
                 for (int r = 0; r < 4; r++) h[r] = __builtin_amdgcn_fmed3f(acc[r], 0.f, lim);      // one v_med3_f32: clamp to [0, lim]
@@ -940,9 +947,13 @@ __global__ __launch_bounds__(kThreads, (Stem2Cfg<TW_, F16P>::OCC)) void stem2_ke
         const int i = t * 16 + (lane & 15);
         const M::Frag x = kb < 3 ? *(const M::Frag *)(s_a + i * 16 + (kb & 1) * 8) : M::zero();
         const f32x4 acc = M::mma(pw0_frag, x, pw0_bias);
-        const int ry = i / R2W, rx = i % R2W;
-        const int y2 = 2 * oy0 - 1 + ry, x2 = 2 * ox0 - 1 + rx;
-        const bool inside = i < N2 && (unsigned)y2 < (unsigned)a.ho && (unsigned)x2 < (unsigned)a.wo;
+        bool inside = i < N2;
+        if (!interior) {
+            asm volatile("" ::: "memory");
+            const int ry = i / R2W, rx = i % R2W;
+            const int y2 = 2 * oy0 - 1 + ry, x2 = 2 * ox0 - 1 + rx;
+            inside = inside && (unsigned)y2 < (unsigned)a.ho && (unsigned)x2 < (unsigned)a.wo;
+        }
         uint2 h;
         h.x = inside ? pack_f16(acc[0], acc[1], true) : 0u;
         h.y = inside ? pack_f16(acc[2], acc[3], true) : 0u;
