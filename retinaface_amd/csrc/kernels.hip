@@ -730,6 +730,9 @@ template <int TW_, bool F16P> struct Stem2Cfg {     // F16P: the staged patch ho
     static constexpr int REGION_A = MAX3(IN_BYTES, A_BYTES, A1_BYTES + OUT_BYTES);
     static constexpr int REGION_B = C0_BYTES > C2_BYTES ? C0_BYTES : C2_BYTES;
     static constexpr int LDS_BYTES = REGION_A + REGION_B + 9 * 8 * 4;
+    // 7 x 8 tiles: 4 waves per workgroup; 7 x 16 tiles: the same work per thread with 8 waves (half the horizontal halo per output,
+    // twice the LDS per workgroup, the same 32 waves per CU)
+    static constexpr int THREADS = TW_ >= 16 ? 512 : 256;
     static constexpr int OCC = LDS_BYTES <= 20 * 1024 ? 8 : LDS_BYTES <= 23 * 1024 ? 7 : (160 * 1024 / LDS_BYTES);
     static_assert(REGION_A % 16 == 0 && REGION_B % 16 == 0 && A1_BYTES % 16 == 0, "LDS carve must stay 16-byte aligned");
 };
@@ -744,8 +747,9 @@ struct Stem2Args {
 };
 
 template <int TW_, bool F16P>
-__global__ __launch_bounds__(kThreads, (Stem2Cfg<TW_, F16P>::OCC)) void stem2_kernel(Stem2Args a) {
+__global__ __launch_bounds__((Stem2Cfg<TW_, F16P>::THREADS), (Stem2Cfg<TW_, F16P>::OCC)) void stem2_kernel(Stem2Args a) {
     typedef Stem2Cfg<TW_, F16P> C;
+    constexpr int NT = C::THREADS, NW = NT / 64;         // threads / waves per workgroup
     typedef half_t T;
     typedef Mma<T> M;
     typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
@@ -797,7 +801,7 @@ __global__ __launch_bounds__(kThreads, (Stem2Cfg<TW_, F16P>::OCC)) void stem2_ke
         const auto rs = image_rsrc((const uint8_t *)(fp & ~(uintptr_t)3), fbytes);
         const int row_bytes = fd.cols * 3;
 #pragma unroll 1
-        for (int i = tid; i < IR * GRP; i += kThreads) {
+        for (int i = tid; i < IR * GRP; i += NT) {
             const int r = i / GRP, g = i % GRP;
             const int iy = iy0 + r;
             const int off = bx0 + 12 * g;                              // byte column of the item's first byte (may be negative)
@@ -857,7 +861,7 @@ __global__ __launch_bounds__(kThreads, (Stem2Cfg<TW_, F16P>::OCC)) void stem2_ke
         const int ppA = 2 * kb, ppB = 2 * kb + 1;
         const int offA = (ppA / 3) * ROWD + ppA % 3, offB = (ppB / 3) * ROWD + ppB % 3, offC = 2 * ROWD + 2;
 #pragma unroll 1
-        for (int t = wave; t < C::T0; t += 4) {
+        for (int t = wave; t < C::T0; t += NW) {
             const int q = t * 16 + (lane & 15);
             const int hy = q / R0W, hx = q % R0W;
             f16x8 x1, x2;
@@ -906,7 +910,7 @@ __global__ __launch_bounds__(kThreads, (Stem2Cfg<TW_, F16P>::OCC)) void stem2_ke
 #pragma unroll
         for (int e = 0; e < 8; e++) dw_bias[e] = a.dw0_b[e];
 #pragma unroll 1
-        for (int i = tid; i < C::T2 * 16; i += kThreads) {
+        for (int i = tid; i < C::T2 * 16; i += NT) {
             const int ry = i / R2W, rx = i % R2W;
             float acc[8];
 #pragma unroll
@@ -943,7 +947,7 @@ __global__ __launch_bounds__(kThreads, (Stem2Cfg<TW_, F16P>::OCC)) void stem2_ke
     // ---- phase 4: pointwise conv2 (8 -> 16) on MFMA, K slots [W_hi x_hi | W_hi x_lo | W_lo x_hi | 0]; the result tile is fp16
     //      (the rounding point the un-fused engine had in HBM).  Pixels outside the 224^2 map are conv3's zero padding.
 #pragma unroll 1
-    for (int t = wave; t < C::T2; t += 4) {
+    for (int t = wave; t < C::T2; t += NW) {
         const int i = t * 16 + (lane & 15);
         const M::Frag x = kb < 3 ? *(const M::Frag *)(s_a + i * 16 + (kb & 1) * 8) : M::zero();
         const f32x4 acc = M::mma(pw0_frag, x, pw0_bias);
@@ -975,7 +979,7 @@ __global__ __launch_bounds__(kThreads, (Stem2Cfg<TW_, F16P>::OCC)) void stem2_ke
         const int dsel = dw_mma_dword_index(lane);
         const bool hi_tap = lane >= 32;                     // chunk kc carries tap 2 kc (lanes 0..31) and 2 kc + 1 (lanes 32..63)
 #pragma unroll 1
-        for (int pt = wave; pt < C::T4; pt += 4) {
+        for (int pt = wave; pt < C::T4; pt += NW) {
             const int p = pt * 16 + (lane & 15);
             const int py = p / TW, px = p % TW;             // p >= P4: reads past the tile's last row (inside this workgroup's LDS), result never stored
             const T *src = s_c2 + ((2 * py) * R2W + 2 * px) * 16 + (kb & 1) * 8;
@@ -1009,7 +1013,7 @@ __global__ __launch_bounds__(kThreads, (Stem2Cfg<TW_, F16P>::OCC)) void stem2_ke
 
     // ---- phase 6: pointwise conv4 (16 -> 32) on MFMA: 2 channel tiles x T4 pixel tiles, K = 16 of 32
 #pragma unroll 1
-    for (int pr = wave; pr < 2 * C::T4; pr += 4) {
+    for (int pr = wave; pr < 2 * C::T4; pr += NW) {
         const int ct = pr & 1, pt = pr >> 1;
         const M::Frag x = kb < 2 ? *(const M::Frag *)(s_a1 + (pt * 16 + (lane & 15)) * LDA1 + kb * 8) : M::zero();
         const f32x4 acc = M::mma(ct ? pw1_frag1 : pw1_frag0, x, ct ? pw1_bias1 : pw1_bias0);
@@ -1025,7 +1029,7 @@ __global__ __launch_bounds__(kThreads, (Stem2Cfg<TW_, F16P>::OCC)) void stem2_ke
     {
         const auto ro = image_rsrc(a.out + (size_t)img * a.ho4 * a.wo4 * 32, (unsigned)(a.ho4 * a.wo4 * 32) * 2u);
         const int obase = (oy0 * a.wo4 + ox0) * 32 * 2;
-        for (int i = tid; i < P4 * 4; i += kThreads) {
+        for (int i = tid; i < P4 * 4; i += NT) {
             const int p = i >> 2, cv = i & 3;
             const int py = p / TW, px = p % TW;
             const unsigned off = ox0 + px < a.wo4 ? (unsigned)(((py * a.wo4 + px) * 32 + cv * 8) * 2 + obase) : kOobOffset;
@@ -1051,7 +1055,7 @@ void launch_stem2(hipStream_t s, const Stem2Params &p) {
     const int tw = v == 2 ? 16 : 8;
     a.tiles_x = (a.wo4 + tw - 1) / tw; a.tiles_y = (a.ho4 + 6) / 7;
     a.nblk = p.n * a.tiles_x * a.tiles_y;
-    if (tw == 16) hipLaunchKernelGGL((stem2_kernel<16, false>), dim3(a.nblk), dim3(kThreads), 0, s, a);
+    if (tw == 16) hipLaunchKernelGGL((stem2_kernel<16, false>), dim3(a.nblk), dim3(Stem2Cfg<16, false>::THREADS), 0, s, a);
     else if (v == 3) hipLaunchKernelGGL((stem2_kernel<8, true>), dim3(a.nblk), dim3(kThreads), 0, s, a);
     else hipLaunchKernelGGL((stem2_kernel<8, false>), dim3(a.nblk), dim3(kThreads), 0, s, a);
 }
