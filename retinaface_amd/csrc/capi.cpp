@@ -9,6 +9,7 @@
 #include <vector>
 
 #include "engine.h"
+#include "weights.h"
 
 namespace {
 thread_local std::string g_create_error;
@@ -310,6 +311,17 @@ int rf_plan_folded(const char *model_dir, const char *stem, const char *op, floa
             return i >= 0 && i < limit ? i : -1;
         };
         int i;
+        // "dw<i>.eq" / "pw<i>.eq": block i as the fp16 engine packs it, after the per-channel depthwise equalisation (weights.h)
+        rf::FoldedConv eq_dw, eq_pw;
+        if (name.size() > 3 && name.compare(name.size() - 3, 3, ".eq") == 0) {
+            const bool want_dw = name.compare(0, 2, "dw") == 0;
+            name.resize(name.size() - 3);
+            if ((i = idx(want_dw ? "dw" : "pw", 13)) < 0) throw rf::ArgError("unknown plan op '" + std::string(op) + "'");
+            eq_dw = p.blocks[i].dw;
+            eq_pw = p.blocks[i].pw;
+            rf::WeightPack<rf::half_t>::equalize_depthwise(eq_dw, eq_pw);
+            f = want_dw ? &eq_dw : &eq_pw;
+        } else
         if (name == "conv0") f = &p.conv0;
         else if ((i = idx("dw", 13)) >= 0 && name.find('.') == std::string::npos) f = &p.blocks[i].dw;
         else if ((i = idx("pw", 13)) >= 0) f = &p.blocks[i].pw;

@@ -127,6 +127,35 @@ def _create(lib, model_dir, network=b"net3", **kw):
     return st, msg
 
 
+@pytest.mark.parametrize("stem,block", [("mnet25", 4), ("mnet-deconv-0517", 7), ("mnet25", 1)])
+def test_depthwise_equalisation_is_exact_and_cuts_the_fp16_tap_error(built_lib, stem, block):
+    """weights.h equalize_depthwise (fp16 engine): channel c of a depthwise stage works at 1 / t[c] scale, column c of the pointwise
+    matrix is multiplied by t[c].  (1) It is a pure re-scaling: taps and bias / t, column * t, 1 <= t < 2, biases of the pointwise
+    stage untouched, and relu(dw(x)) -> pw gives the same result as before.  (2) It does what it is for: the fp16 rounding error of
+    the nine taps (in units of the original weights) drops by more than 2.5x in rms."""
+    dw, db = _folded(built_lib, ASSETS, stem, f"dw{block}")
+    pw, pb = _folded(built_lib, ASSETS, stem, f"pw{block}")
+    dwe, dbe = _folded(built_lib, ASSETS, stem, f"dw{block}.eq")
+    pwe, pbe = _folded(built_lib, ASSETS, stem, f"pw{block}.eq")
+    c = dw.shape[0]
+    d9, e9 = dw.reshape(c, 9).astype(np.float64), dwe.reshape(c, 9).astype(np.float64)
+    live = np.abs(d9).max(1) > 1e-20
+    k = np.abs(d9).argmax(1)
+    t = np.where(live, d9[np.arange(c), k] / np.where(live, e9[np.arange(c), k], 1.0), 1.0)
+    assert (t >= 1.0 - 1e-6).all() and (t < 2.0).all()
+    assert np.allclose(e9 * t[:, None], d9, rtol=2e-7, atol=1e-30)
+    assert np.allclose(dbe.astype(np.float64) * t, db, rtol=2e-7, atol=1e-30)
+    assert np.allclose(pwe.reshape(-1, c), pw.reshape(-1, c).astype(np.float64) * t[None, :], rtol=2e-7) and np.array_equal(pbe, pb)
+    rng = np.random.default_rng(block)
+    x = rng.normal(size=(c, 9))                                     # one 3x3 window per channel
+    y0 = np.maximum((d9 * x).sum(1) + db, 0.0) @ pw.reshape(-1, c).astype(np.float64).T
+    y1 = np.maximum((e9 * x).sum(1) + dbe, 0.0) @ pwe.reshape(-1, c).astype(np.float64).T
+    assert np.allclose(y0, y1, rtol=1e-5, atol=1e-6)
+    err = lambda w, scale: ((w.astype(np.float16).astype(np.float64) - w) * scale[:, None])[live]
+    before, after = err(d9.astype(np.float32), np.ones(c)), err(e9.astype(np.float32), t)
+    assert np.sqrt((after ** 2).mean()) < np.sqrt((before ** 2).mean()) / 2.5, (np.sqrt((before ** 2).mean()), np.sqrt((after ** 2).mean()))
+
+
 def test_error_paths_without_a_gpu(built_lib, tmp_path):
     st, msg = _create(built_lib, str(tmp_path).encode())
     assert st == _lib.RF_ERR_IO and "mnet-deconv-0517" in msg

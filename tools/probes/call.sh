@@ -1,5 +1,6 @@
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out
-RF_STEM2=2 timeout 900 python -m pytest tests -m gpu -q -x -k "fused_op or synthetic or odd_net or fixture" 2>&1 | grep -v "compute time" | tail -3
-for v in 1 2 1 2; do
-RF_STEM2=$v timeout 200 python tools/kbench.py --n 256 --tag cur 2>&1 | grep -E "stem2" | sed "s/^/v$v /"
+for cfg in "3 32" "3 48" "3 64" "2 64" "3 32" "3 64"; do set -- $cfg
+timeout 300 python bench.py --timed-only --lanes $1 --coalesce $2 > gpurun_out/c_b.json 2> gpurun_out/c_b.err
+python -c "
+import json; j=json.load(open('gpurun_out/c_b.json')); print('lanes $1 coalesce $2: img/s %.0f ms/step %.4f steps %d' % (j['images_per_sec'], j['ms_per_step'], j['steps']))" || tail -3 gpurun_out/c_b.err
 done
