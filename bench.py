@@ -140,6 +140,7 @@ def main() -> int:
     if world != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
 
+    shared = False
     if args.dry:
         dev = torch.device("cpu")
     else:
@@ -150,9 +151,14 @@ def main() -> int:
             raise SystemExit(f"bench.py: {world} ranks but only {ndev} visible GPU(s) (one rank per GPU; --oversubscribe to share)")
         torch.cuda.set_device(local_rank % ndev)
         dev = torch.device("cuda", local_rank % ndev)
+        shared = world > ndev
+    # RCCL refuses two ranks on one device ("Duplicate GPU detected"): when ranks share GPUs (--oversubscribe, how the N > 1 path
+    # is exercised on a one-GPU box) the result records travel over gloo from host memory; one rank per GPU uses nccl = RCCL
+    backend = "gloo" if (args.dry or shared) else "nccl"
+    cdev = torch.device("cpu") if backend == "gloo" else dev               # where the collectives' tensors live
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("gloo" if args.dry else "nccl")          # nccl = RCCL on ROCm
+        dist.init_process_group(backend)
 
     from retinaface_amd import shard
 
@@ -196,7 +202,7 @@ def main() -> int:
     # ---- result gather of the sharded call (N > 1): one all_gather of fixed-size records per global super-batch
     rec_w = 1 + GATHER_CAP * shard.RECORD_FLOATS
     gather_state = {"buf": np.zeros((per_launch * B, rec_w), np.float32), "fill": 0, "handle": None, "out": None, "block": None,
-                    "gathers": 0, "images": torch.zeros((), dtype=torch.int64, device=dev)}
+                    "gathers": 0, "images": torch.zeros((), dtype=torch.int64, device=cdev)}
 
     def record_step(counts, n):
         """Append this step's per-image records (count + first GATHER_CAP faces) to the rank's block; all_gather it when the
@@ -225,8 +231,8 @@ def main() -> int:
             if gs["fill"] < gs["buf"].shape[0]:                       # ragged tail: pad to the fixed block size
                 pad = torch.full((gs["buf"].shape[0] - gs["fill"], rec_w), -1.0)
                 block = torch.cat([block, pad])
-            gs["block"] = block.to(dev, non_blocking=True)
-            gs["out"] = torch.empty((world * block.shape[0], rec_w), dtype=torch.float32, device=dev)
+            gs["block"] = block.to(cdev, non_blocking=True)
+            gs["out"] = torch.empty((world * block.shape[0], rec_w), dtype=torch.float32, device=cdev)
             gs["handle"] = dist.all_gather_into_tensor(gs["out"], gs["block"], async_op=True)
             gs["gathers"] += 1
             gs["fill"] = 0
@@ -266,16 +272,29 @@ def main() -> int:
         steps = max(steps, int(np.ceil(args.min_seconds / max(est, 1e-7))))
         steps = -(-steps // slots) * slots                              # whole pipeline fills
     if world > 1:
-        st = torch.tensor([steps], dtype=torch.int64, device=dev)
+        st = torch.tensor([steps], dtype=torch.int64, device=cdev)
         dist.all_reduce(st, op=dist.ReduceOp.MAX)                      # every rank times the same number of steps
         steps = int(st.item())
-    gather_state["gathers"] = 0
-    gather_state["images"].zero_()
-    barrier()
-    t0 = time.perf_counter()
-    faces = run(steps, prepared_ring, do_gather)
-    barrier()
-    dt = time.perf_counter() - t0
+    # The warm-up rate (the driver passes --warmup 5: one cold pipeline fill) can overestimate the step time 20-fold, so the
+    # estimate is checked against the clock: a timed region shorter than 0.8 x --min-seconds is repeated with the step count
+    # scaled from its own rate (every rank takes the same decision from the MAX over ranks).
+    for attempt in range(4):
+        gather_state["gathers"] = 0
+        gather_state["images"].zero_()
+        barrier()
+        t0 = time.perf_counter()
+        faces = run(steps, prepared_ring, do_gather)
+        barrier()
+        dt = time.perf_counter() - t0
+        if args.dry or args.min_seconds <= 0:
+            break
+        dt_all = torch.tensor([dt], dtype=torch.float64, device=cdev)
+        if world > 1:
+            dist.all_reduce(dt_all, op=dist.ReduceOp.MAX)
+        if float(dt_all.item()) >= 0.8 * args.min_seconds:
+            break
+        steps = int(np.ceil(steps * 1.1 * args.min_seconds / max(float(dt_all.item()), 1e-6)))
+        steps = -(-steps // slots) * slots
 
     extra = {}
     if not args.dry and not args.timed_only:
@@ -306,7 +325,7 @@ def main() -> int:
         if args.host_seconds > 0:
             extra["host_frames"] = host_frames(det, frames_np, args, slots, B, run, rank)
 
-    tt = torch.tensor([dt, float(faces)], dtype=torch.float64, device=dev)
+    tt = torch.tensor([dt, float(faces)], dtype=torch.float64, device=cdev)
     if world > 1:
         tmax = tt.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -334,7 +353,8 @@ def main() -> int:
             "faces_per_step": faces_total / steps / world,
         }
         if world > 1:
-            out["result_gather"] = {"collective": "all_gather_into_tensor (RCCL)" if not args.dry else "all_gather_into_tensor (gloo, dry)",
+            out["result_gather"] = {"collective": "all_gather_into_tensor (RCCL)" if backend == "nccl" else
+                                    ("all_gather_into_tensor (gloo, dry)" if args.dry else "all_gather_into_tensor (gloo: ranks share a GPU, RCCL refuses that)"),
                                     "gathers_in_timed_region": gather_state["gathers"],
                                     "bytes_per_rank_per_gather": int(per_launch * B * rec_w * 4),
                                     "records_gathered": int(gather_state["images"].item()), "expected": images_total}
