@@ -1,7 +1,7 @@
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out
-( time timeout 300 python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/c_b1.json 2> gpurun_out/c_b1.err ) 2>&1 | grep real; echo rc $?
+( timeout 900 python -m pytest tests -m gpu -q -x 2>&1 | grep -v "compute time" | tail -4 ) 2>&1
+for i in 1 2; do for v in 0 1; do for l in 3 1; do
+RF_SNAKE=$v timeout 300 python bench.py --timed-only --lanes $l > gpurun_out/c_b.json 2> gpurun_out/c_b.err
 python -c "
-import json; j=json.loads(open('gpurun_out/c_b1.json').read().strip().splitlines()[-1]); print({k:j[k] for k in ('n_gpus','value','images_per_sec','steps','steps_requested','ms_per_step','timed_seconds')}); print(j['roofline']['frac'], j['roofline']['traffic'], j['cpu_baseline']['value'])"
-timeout 300 python bench.py --gpus 2 --oversubscribe --no-cpu-baseline --host-seconds 0 --steps 20 --warmup 5 > gpurun_out/c_b2.json 2> gpurun_out/c_b2.err; echo rc $?
-python -c "
-import json; j=json.loads(open('gpurun_out/c_b2.json').read().strip().splitlines()[-1]); print({k:j[k] for k in ('n_gpus','value','images_per_sec','steps','ms_per_step','timed_seconds')}); print(j['result_gather'])"
+import json; j=json.load(open('gpurun_out/c_b.json')); print('snake $v lanes $l img/s %.0f' % (j['images_per_sec']))"
+done; done; done
