@@ -35,6 +35,12 @@ for cfg in "b8_448_fp16:" "int8_mnet25_b32:--precision int8 --model mnet25 --bat
     [ -n "$f" ] && cp "$f" $O/${TAG}_bench_${name}_kernel_trace.csv
     rm -rf $O/${TAG}_ktrace_$name
 done
+# the same with ONE lane: no other launch shares the chip, so these averages are the ones that agree with the HIP-event figures
+rm -rf $O/${TAG}_ktrace_lanes1
+timeout 300 rocprofv3 --kernel-trace --stats -d $O/${TAG}_ktrace_lanes1 -o kt --output-format csv -- python $R/bench.py --timed-only --lanes 1 --steps 2000 --min-seconds 0.5 > $O/${TAG}_ktrace_lanes1.log 2>&1
+f=$(find $O/${TAG}_ktrace_lanes1 -name "*kernel_stats.csv" | head -1)
+[ -n "$f" ] && cp "$f" $O/${TAG}_bench_b8_448_fp16_kernel_trace_lanes1.csv
+rm -rf $O/${TAG}_ktrace_lanes1
 cd $R
 bash tools/profile_round.sh ${TAG}_n256_448_fp16 256 fp16 mnet25 448 448 8 sq 2>&1 | tail -24
 bash tools/profile_round.sh ${TAG}_n32_1280x896_fp16 32 fp16 mnet25 896 1280 1 2>&1 | tail -2
