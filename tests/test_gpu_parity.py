@@ -244,6 +244,25 @@ def test_int8_engine_against_the_fp32_oracle(rfa, oracles, base_frame, stem):
     assert same and len(got) == 6 and worst >= bar["iou"] and ds <= bar["score"], (stem, worst, agree, ds)
 
 
+def test_int8_integer_blend_is_bit_identical_to_the_fp32_blend(rfa):
+    """int8 engine, per-channel table (mnet25): the fused upsample + add runs in packed 16-bit integer arithmetic.  Every
+    intermediate of the fp32 form is exact and both round half to even, so the two must agree bit for bit: same detections
+    (scores, boxes, landmarks, anchors) with the integer blend and with RF_BLEND_FP32=1 (the knob is read at launch-build time)."""
+    from retinaface_amd.frames import synth_frames
+    frames = synth_frames(448, 448, 8, config=7)
+    res = []
+    for force_fp32 in (False, True):
+        if force_fp32:
+            os.environ["RF_BLEND_FP32"] = "1"
+        try:
+            det = rfa.RetinaFace(ASSETS, "net3", 0.4, precision=INT8, net_hw=(448, 448), model_stem="mnet25")
+            res.append(_key(det.detectBatchImages(frames, 0.5)))
+            det.close()
+        finally:
+            os.environ.pop("RF_BLEND_FP32", None)
+    assert res[0] == res[1] and sum(len(r) for r in res[0]) > 0
+
+
 def test_int8_layers_stay_within_quantisation_noise(rfa, oracles, crop448):
     """Every int8 activation, dequantised with its table scale, vs the oracle blob: a wrong index or scale shows up as an
     error of the order of the range; quantisation noise stays within a few percent of it."""
