@@ -13,8 +13,10 @@ Tolerances (stated once, used everywhere):
   post-processing alone (decode + NMS given the GPU's own head blobs, vs the plain-C restatement):
                 anchor indices and scores bit-exact, coordinates within 1e-4 px (expf ulp)
 """
+import json
 import os
 import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -131,6 +133,37 @@ def test_synthetic_batch8_against_golden(rfa, stem, prec):
         for i in range(8):
             compare(res[i], g[f"det{tag}_{i}"], g[f"idx{tag}_{i}"], prec)
             assert abs(ncand[i] - int(g[f"ncand{tag}_{i}"])) <= TOL[prec]["ncand"]
+
+
+@pytest.mark.parametrize("knob", ["RF_STEM2=0", "RF_STEM2=2", "RF_STEM2=3", "RF_DWPW2=0", "RF_CONV3=0"])
+def test_probe_knob_kernel_variants_stay_correct(rfa, knob):
+    """The measured-and-rejected kernel variants DESIGN.md cites stay selectable (RF_* probe knobs, read once per process): each
+    is held to the same fp16 parity bar as the default path, in a subprocess so that the knob is seen at library start-up.
+    RF_STEM2=0: K_a' stem + separate dwpw<16,32,s2>; 2: 7x16 tiles, 8 waves; 3: fp16 patch; RF_DWPW2=0: blocks 2 and 3 as two
+    launches; RF_CONV3=0: 3x3 convs without the bank-row padding."""
+    code = (
+        "import sys, json; sys.path.insert(0, %r)\n"
+        "import retinaface_amd\n"
+        "from retinaface_amd.frames import synth_frames\n"
+        "det = retinaface_amd.RetinaFace(%r, 'net3', 0.4, precision=1, net_hw=(448, 448), model_stem='mnet25')\n"
+        "res = det.detectBatchImages(synth_frames(448, 448, 8, config=1), 0.5)\n"
+        "print('RESULT ' + json.dumps([[[d.anchor_index] + [float(v) for v in d.as_row()] for d in r] for r in res]))\n"
+    ) % (ROOT, ASSETS)
+    env = dict(os.environ)
+    k, v = knob.split("=")
+    env[k] = v
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("RESULT ")][-1]
+    res = json.loads(line[len("RESULT "):])
+    g = golden("synth448_mnet25.npz")
+    t = TOL[FP16]
+    for i in range(8):
+        ref_rows, ref_idx = g[f"det05_{i}"], g[f"idx05_{i}"]
+        assert [int(r[0]) for r in res[i]] == list(ref_idx), (knob, i)
+        for got, ref in zip(res[i], ref_rows):
+            assert iou_plus1(got[2:6], ref[1:5]) >= 1 - t["iou"], (knob, i)
+            assert abs(got[1] - ref[0]) <= t["score"]
 
 
 @pytest.mark.parametrize("thr", [0.5, 0.1, 0.02, 0.004, 0.0015])
