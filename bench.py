@@ -99,7 +99,7 @@ class StubEngine:
     def __init__(self, batch, lanes, coalesce):
         import numpy as np
         self.np = np
-        self.batch, self.lanes, self.coalesce = batch, lanes or 3, coalesce or max(1, min(32, 256 // batch))
+        self.batch, self.lanes, self.coalesce = batch, lanes or 3, coalesce or max(1, min(256, 256 // batch))
         self._q = {}
         self._t = 0
         self.last_faces = np.zeros((batch, self.max_detections, 15), np.float32)

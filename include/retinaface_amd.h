@@ -70,7 +70,7 @@ typedef struct rf_options {
     int32_t lanes;              /* launches that may be in flight at once (default 3): each lane owns a stream, its
                                    activation buffers and its hipGraphs */
     int32_t coalesce;           /* rf_enqueue_batch_device() batches merged into ONE launch of up to max_batch*coalesce
-                                   images (default: about 256 images of 448 x 448 worth of pixels per launch, clamped to [1, 32]; 1 = off).  A merged launch starts when it is full or when one of
+                                   images (default: about 256 images of 448 x 448 worth of pixels per launch, clamped to [1, 256]; 1 = off).  A merged launch starts when it is full or when one of
                                    its tickets is waited for.  rf_num_slots() = lanes * coalesce. */
     /* ---- fields added in ABI 2 (a caller compiled against ABI 1 passes the shorter struct_size and gets the defaults) ---- */
     int32_t copy_threads;       /* host threads (the caller's included) that stage host frames into pinned memory; 0 = min(8, cores/4) */

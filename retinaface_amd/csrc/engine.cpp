@@ -84,6 +84,8 @@ namespace {
 // One lane = one independent copy of everything a batch touches while in flight: stream(s), activation buffers,
 // candidate buffers, pinned host descriptor / result blocks and the captured hipGraphs.  Batches on different
 // lanes overlap on the GPU (most kernels of a batch-8 pass fill only a fraction of the 256 CUs); weights are shared.
+constexpr int kMaxCoalesce = 256;       // enqueues merged into one launch: a batch-1 caller still fills a 256-image super-batch
+
 template <typename T>
 class EngineImpl final : public Engine, private WeightPack<T> {
     typedef WeightPack<T> WP;
@@ -115,8 +117,8 @@ public:
         // default super-batch: ~256 images of 448 x 448 worth of pixels per launch whatever the batch size (measured: 8 x 32 and 32 x 8 beat 8 x 16 / 32 x 4 by
         // 2-4 %; every persistent kernel then has several tiles per resident workgroup)
         if (opt_.coalesce == 0)
-            opt_.coalesce = (int)std::max<long>(1, std::min<long>(32, 256L * 448 * 448 / ((long)std::max(opt_.max_batch, 1) * net_h_ * net_w_)));
-        if (opt_.coalesce < 1 || opt_.coalesce > 32) throw ArgError("coalesce must be in [1, 32]");
+            opt_.coalesce = (int)std::max<long>(1, std::min<long>(kMaxCoalesce, 256L * 448 * 448 / ((long)std::max(opt_.max_batch, 1) * net_h_ * net_w_)));
+        if (opt_.coalesce < 1 || opt_.coalesce > kMaxCoalesce) throw ArgError("coalesce must be in [1, 256]");
         if (opt_.copy_threads < 0 || opt_.copy_threads > 64) throw ArgError("copy_threads must be in [0, 64]");
         cap_images_ = opt_.max_batch * opt_.coalesce;
         tickets_.resize(4 * opt_.lanes * opt_.coalesce + 8);
