@@ -121,6 +121,10 @@ public:
         if (opt_.coalesce < 1 || opt_.coalesce > kMaxCoalesce) throw ArgError("coalesce must be in [1, 256]");
         if (opt_.copy_threads < 0 || opt_.copy_threads > 64) throw ArgError("copy_threads must be in [0, 64]");
         cap_images_ = opt_.max_batch * opt_.coalesce;
+        // every lane owns activation buffers for a full super-batch (~13 MB per 448 x 448 image in fp16): refuse sizes that can only
+        // end in an out-of-memory error three allocations later
+        if ((long)cap_images_ * net_h_ * net_w_ > 2048L * 448 * 448)
+            throw ArgError("max_batch x coalesce = " + std::to_string(cap_images_) + " images per launch: more than 2048 images of 448 x 448 worth of pixels");
         tickets_.resize(4 * opt_.lanes * opt_.coalesce + 8);
         if (opt_.device >= 0) device_ = opt_.device;
         else RF_HIP(hipGetDevice(&device_));
@@ -238,11 +242,13 @@ public:
 
     int last_anchor_indices(int image, int32_t *out, int cap) const override {
         if (image < 0 || image >= last_n_) throw ArgError("image index out of range");
+        if (cap > 0 && !out) throw ArgError("null argument");
         int n = (int)last_anchor_[image].size();
         for (int i = 0; i < std::min(n, cap); i++) out[i] = last_anchor_[image][i];
         return n;
     }
     int last_candidate_counts(int *counts, int n) const override {
+        if (n > 0 && !counts) throw ArgError("null argument");
         for (int i = 0; i < std::min(n, last_n_); i++) counts[i] = last_cand_counts_[i];
         return last_n_;
     }
