@@ -690,6 +690,16 @@ def test_error_paths_leave_the_handle_usable(rfa):
     th.join()
     assert res["r"] == good
     det.close()
+    # a super-batch that could only end in an out-of-memory error is refused as an argument error, and a batch-1 caller may
+    # coalesce up to 256 enqueues (the cap was 32)
+    with pytest.raises(rfa._lib.RFError):
+        rfa.RetinaFace(ASSETS, "net3", 0.4, precision=FP16, net_hw=(448, 448), model_stem="mnet25", max_batch=64, coalesce=256)
+    one = rfa.RetinaFace(ASSETS, "net3", 0.4, precision=FP16, net_hw=(448, 448), model_stem="mnet25", max_batch=1)
+    assert one.num_slots() == 3 * 256
+    tickets = [one.enqueue_device([d[i % 8].data_ptr()], [448], [448], 0.5) for i in range(300)]       # more than one super-batch
+    got = [one.wait(t, 1) for t in tickets]
+    assert [_key([g[0]])[0] for g in got[:8]] == [good[i] for i in range(8)] and _key([got[299][0]])[0] == good[299 % 8]
+    one.close()
 
 
 @pytest.mark.parametrize("prec", [FP32, FP16])
