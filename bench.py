@@ -70,6 +70,8 @@ def parse_args(argv=None):
     ap.add_argument("--dry", action="store_true", help="no GPU: stub engine, gloo backend (launcher / gather / JSON plumbing only)")
     ap.add_argument("--timed-only", action="store_true", help="warm-up + timed region only (no burst / latency / host-frame / per-kernel "
                                                               "passes): the run to put under rocprofv3 --kernel-trace")
+    ap.add_argument("--no-pmc", action="store_true", help="do not run the two rocprofv3 --pmc passes that measure roofline.traffic "
+                                                          "(the newest committed PMC summary under profiles/ is joined instead)")
     ap.add_argument("--master-port", type=int, default=0)
     return ap.parse_args(argv)
 
@@ -433,6 +435,46 @@ def host_frames(det, frames_np, args, slots, B, run, rank):
     return res
 
 
+def measure_traffic(args, n_img, B, H, W):
+    """HBM bytes per launch and kernel instance, measured now: two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE: they do not fit
+    one pass) over tools/probes/pmc_probe.py = eager launches of the same engine configuration at the same launch size, corrected
+    as MI355X_MICROARCH.md prescribes (tools/pmc_summary.py: FETCH_SIZE x 2).  Counter passes carry no trace flag.  Returns
+    {kernel instance: bytes per launch} or None when rocprofv3 is not there / fails (the caller falls back to profiles/)."""
+    import shutil
+    import subprocess
+    import tempfile
+    if args.no_pmc or shutil.which("rocprofv3") is None:
+        return None
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    try:
+        import pmc_summary
+        tmp = tempfile.mkdtemp(prefix="rf_pmc_", dir="/tmp")
+        env = dict(os.environ, TMPDIR="/tmp")
+        dbs = {}
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(tmp, counter)
+            cmd = ["rocprofv3", "--pmc", counter, "-d", out, "-o", "pmc", "--", sys.executable, os.path.join(ROOT, "tools", "probes", "pmc_probe.py"),
+                   str(n_img), args.precision, args.model, str(H), str(W), str(B)]
+            r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=240)
+            found = [os.path.join(d, f) for d, _, fs in os.walk(out) for f in fs if f.endswith(".db")]
+            if r.returncode != 0 or not found:
+                return None
+            dbs[counter] = found[0]
+        f, w = pmc_summary.per_kernel(dbs["FETCH_SIZE"], "FETCH_SIZE"), pmc_summary.per_kernel(dbs["WRITE_SIZE"], "WRITE_SIZE")
+        res = {}
+        for key in set(f) | set(w):
+            name = key[0]
+            if not name.startswith("_ZN2rf") and "rf::" not in name:
+                continue
+            b = 2 * f.get(key, (0, 0.0))[1] * 1024.0 + w.get(key, (0, 0.0))[1] * 1024.0
+            k = pmc_summary.descriptor(name)
+            res[k] = max(res.get(k, 0.0), b)          # the two conv3x3<64,64,up> launches share a name: the dominant kernel is never one of them
+        shutil.rmtree(tmp, ignore_errors=True)
+        return res or None
+    except Exception:  # noqa: BLE001
+        return None
+
+
 def device_side_report(args, det, frames, B, H, W, per_launch, prec, images_total, world, dt_max):
     """pre / infer / post split, per-kernel HIP-event timing and the roofline object."""
     import numpy as np
@@ -458,10 +500,13 @@ def device_side_report(args, det, frames, B, H, W, per_launch, prec, images_tota
     # corrected as MI355X_MICROARCH.md prescribes; tools/pmc_summary.py).  PMC collection cannot run inside this process: the
     # newest committed summary for this (frame, precision, launch size) is joined by kernel instance; otherwise null.
     traffic, traffic_src = None, None
+    measured = measure_traffic(args, n_prof, B, H, W)
+    if measured and dom["kernel"] in measured:
+        traffic, traffic_src = measured[dom["kernel"]], "measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (two passes, FETCH x 2)"
     key = f"{H}x{W}_{args.precision}"
     cand = sorted((f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith(".json") and "pmc_hbm_traffic" in f),
                   reverse=True)
-    for f in cand:
+    for f in ([] if traffic is not None else cand):
         try:
             j = json.load(open(os.path.join(ROOT, "profiles", f)))
         except Exception:  # noqa: BLE001
