@@ -500,7 +500,7 @@ def device_side_report(args, det, frames, B, H, W, per_launch, prec, images_tota
     # corrected as MI355X_MICROARCH.md prescribes; tools/pmc_summary.py).  PMC collection cannot run inside this process: the
     # newest committed summary for this (frame, precision, launch size) is joined by kernel instance; otherwise null.
     traffic, traffic_src = None, None
-    measured = measure_traffic(args, n_prof, B, H, W)
+    measured = measure_traffic(args, n_prof, B, H, W) if world == 1 else None      # N > 1: the other ranks are waiting at the barrier
     if measured and dom["kernel"] in measured:
         traffic, traffic_src = measured[dom["kernel"]], "measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (two passes, FETCH x 2)"
     key = f"{H}x{W}_{args.precision}"
