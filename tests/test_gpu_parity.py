@@ -826,6 +826,20 @@ def test_cxx_class_drop_in(rfa, tmp_path):
     assert lines[-1] == ["empty", "0"]
 
 
+def test_c_serving_loop_example(rfa):
+    """examples/serve.c: a plain-C serving loop on the C ABI alone -- a pinned ring of host frames (rf_host_register), rf_num_slots()
+    batches in flight through rf_enqueue_batch / rf_wait; and the same binary with two device ordinals (both 0 on this box):
+    rf_detect_batch sharded by image over two engines."""
+    exe = os.path.join(ROOT, "retinaface_amd", "lib", "rf_serve")
+    assert os.path.exists(exe), "build() makes rf_serve"
+    for extra, ndev in (([], 1), (["0"], 1), (["0", "0"], 2)):
+        out = subprocess.run([exe, ASSETS, "mnet25", "fp16", "448", "448", "8", "0.5"] + extra, capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stderr[-1000:]
+        line = [l for l in out.stdout.splitlines() if l.startswith("rf_serve:")][-1]
+        images = int(line.split()[1])
+        assert images > 0 and images % 8 == 0 and f"{ndev} device" in line, line
+
+
 def test_profile_accounting_matches_baseline_md(rfa):
     """rf_profile's per-launch algorithmic bytes / MACs sum to BASELINE.md section 2's per-image figures:
     B = 3P + 2(E - 3P) = 27 615 616 B (fp16, 448^2), MACs = 481 764 864."""
