@@ -445,6 +445,9 @@ def measure_traffic(args, n_img, B, H, W):
     import tempfile
     if args.no_pmc or shutil.which("rocprofv3") is None:
         return None
+    # already running under a profiler (someone is tracing this very bench run): do not nest a second one
+    if any(k.startswith(("ROCPROF", "ROCP_", "ROCTRACER", "ROCTX")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", ""):
+        return None
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     try:
         import pmc_summary
@@ -455,7 +458,7 @@ def measure_traffic(args, n_img, B, H, W):
             out = os.path.join(tmp, counter)
             cmd = ["rocprofv3", "--pmc", counter, "-d", out, "-o", "pmc", "--", sys.executable, os.path.join(ROOT, "tools", "probes", "pmc_probe.py"),
                    str(n_img), args.precision, args.model, str(H), str(W), str(B)]
-            r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=240)
+            r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=120)
             found = [os.path.join(d, f) for d, _, fs in os.walk(out) for f in fs if f.endswith(".db")]
             if r.returncode != 0 or not found:
                 return None
