@@ -193,7 +193,8 @@ long rf_get_output(rf_handle h, const char *blob_name, int image, float *dst, si
 /* Test / profiling hooks (no reference equivalent).
  * rf_debug_activation: copy an internal NHWC activation of the last batch, converted to fp32, by the
  *   name of the reference blob it corresponds to (e.g. "mobilenet0_relu10_fwd", "rf_c2_aggr_relu").
- *   dims = {H, W, C}.  Returns floats written (or needed if dst == NULL), negative on error.
+ *   dims = {H, W, C}.  Returns floats written (or needed if dst == NULL), negative on error.  int8 engine: values are
+ *   dequantised with the tensor's scale(s); "<blob>#raw" returns the stored quanta themselves (-127..127 as floats).
  * rf_profile: time every launch of the hot path on the engine's own stream with HIP events (each launch repeated
  *   back to back between one event pair so the event overhead is amortised), `iters` passes over a batch of n
  *   net-sized device frames; returns the number of launches, fills names (reference layers covered), kernels

@@ -298,8 +298,12 @@ public:
             for (size_t i = 0; i < cnt; i++) dst[i] = (float)tmp[i];
             return (long)cnt;
         }
-        auto it = l.acts.find(blob);
-        if (it == l.acts.end()) throw ArgError("unknown activation '" + blob + "'");
+        // "<blob>#raw": the stored values themselves (int8 engine: the quanta, not multiplied by the tensor's scale)
+        bool raw = false;
+        std::string key = blob;
+        if (key.size() > 4 && key.compare(key.size() - 4, 4, "#raw") == 0) { raw = true; key.resize(key.size() - 4); }
+        auto it = l.acts.find(key);
+        if (it == l.acts.end()) throw ArgError("unknown activation '" + key + "'");
         const ActInfo &ai = it->second;
         if (image < 0 || image >= last_n_ || last_first_image_ < 0) throw ArgError("image index out of range");
         size_t cnt = (size_t)ai.h * ai.w * ai.c;
@@ -310,7 +314,7 @@ public:
         std::vector<T> tmp(cnt);
         RF_HIP(hipMemcpy(tmp.data(), (const T *)ai.ptr + (size_t)(last_first_image_ + image) * cnt, cnt * sizeof(T),
                          hipMemcpyDeviceToHost));
-        for (size_t i = 0; i < cnt; i++) dst[i] = Cast<T>::to(tmp[i]) * (ai.scale.empty() ? 1.f : ai.scale[i % ai.c]);      // NHWC: channel = i % c
+        for (size_t i = 0; i < cnt; i++) dst[i] = Cast<T>::to(tmp[i]) * (raw || ai.scale.empty() ? 1.f : ai.scale[i % ai.c]);      // NHWC: channel = i % c
         return (long)cnt;
     }
 

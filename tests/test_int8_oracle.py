@@ -1,0 +1,112 @@
+"""Pin the integer-exact int8 oracle (oracle/int8_forward.py) on the CPU: known answers for its float epilogue, its two conv
+back-ends against each other, its upsample + add against the Caffe-semantics deconvolution of the fp32 oracle, and the whole
+int8 network against the fp32 oracle (quantisation noise only).  The GPU engine is then held BIT-exact to it (-m gpu)."""
+import numpy as np
+import pytest
+
+from conftest import STEMS
+from oracle import int8_forward as i8
+from oracle.caffe_forward import _deconv2d_numpy
+from oracle.retinaface_post import decode, iou_plus1, nms, preprocess_trt_identity
+
+
+def _requant(acc, mult, bias, relu=True):
+    acc = np.asarray(acc, np.int32).reshape(1, -1, 1)
+    n = acc.shape[1]
+    out = np.empty((1, n, 1), np.int8)
+    for k in range(n):      # one channel per call so every entry can have its own (mult, bias)
+        a = np.ascontiguousarray(acc[:, k:k + 1])
+        o = i8.Int8Net._requant(a, np.array([mult[k]], np.float32), np.array([bias[k]], np.float32), relu)
+        out[0, k, 0] = o[0, 0, 0]
+    return out.reshape(-1).tolist()
+
+
+def test_requantisation_known_answers():
+    """y = fmaf(acc, mult, bias) with ONE rounding, then round-half-even of the clamped value."""
+    f = float.fromhex
+    # ties go to the even integer; negative -> 0 (ReLU); saturation at 127; -127 floor without ReLU
+    assert _requant([5, 7, 9, -3, 1000, 254], [0.5] * 6, [0.0] * 6) == [2, 4, 4, 0, 127, 127]
+    assert _requant([-5, -7, -1000, 5], [0.5] * 4, [0.0] * 4, relu=False) == [-2, -4, -127, 2]
+    # vectors where fl(fl(acc * mult) + bias) and fmaf(acc, mult, bias) land on different sides of k + 0.5 (found by search):
+    # the oracle and the kernels (v_fma_f32) take the fused value
+    cases = [(95164, f("0x1.391236p-7"), f("-0x1.a7db4ep+9"), 61, 62), (129121, f("0x1.472a02p-10"), f("-0x1.7a96aap+6"), 66, 67),
+             (180870, f("0x1.b88268p-9"), f("-0x1.232f8ep+9"), 25, 26), (150071, f("0x1.ed08d6p-8"), f("-0x1.fac014p+9"), 115, 116)]
+    for acc, m, b, fused, unfused in cases:
+        assert _requant([acc], [m], [b]) == [fused]
+        two_step = np.float32(np.float32(np.float32(acc) * np.float32(m)) + np.float32(b))
+        assert int(np.rint(two_step)) == unfused
+    # int32 -> float conversion of the accumulator rounds to nearest even above 2**24 (15-bit depthwise taps reach 1.9e7)
+    assert _requant([2 ** 24 + 1, 2 ** 24 + 3], [2.0 ** -18] * 2, [0.0] * 2) == [64, 64]
+
+
+def test_integer_blend_equals_caffe_deconv_plus_eltwise(nets):
+    """rfi8_upadd mode 1 (integers, round half to even on the total) == rint(Deconvolution(k4 s2 p1 g, bilinear weights) + Crop +
+    Eltwise SUM) computed with the fp32 oracle's own transposed convolution on the same quanta; mode 0 (fp32 form) with unit
+    scale ratios agrees with it bit for bit, and with non-unit ratios follows fmaf(lat, a_lat, blend * a_up)."""
+    rng = np.random.default_rng(5)
+    net = i8.Int8Net(nets["mnet25"])
+    h, w, c = 10, 14, 64
+    lat = rng.integers(0, 128, (h, w, c)).astype(np.int8)
+    up = rng.integers(0, 128, (h // 2, w // 2, c)).astype(np.int8)
+    k1 = np.array([0.25, 0.75, 0.75, 0.25], np.float32)
+    wdec = np.tile(np.outer(k1, k1)[None, None], (c, 1, 1, 1)).astype(np.float32)          # [cin][cout/g = 1][4][4]
+    dec = _deconv2d_numpy(up.transpose(2, 0, 1)[None].astype(np.float32), wdec, None, 2, 1, c)[0].transpose(1, 2, 0)
+    want = np.minimum(np.rint(dec.astype(np.float64) + lat), 127).astype(np.int8)         # multiples of 1/16: exact, half to even
+    out = np.empty_like(lat)
+    i8.lib().rfi8_upadd(lat.ctypes.data, up.ctypes.data, h, w, c, 1.0, 1.0, 1, out.ctypes.data)
+    assert np.array_equal(out, want)
+    out0 = np.empty_like(lat)
+    i8.lib().rfi8_upadd(lat.ctypes.data, up.ctypes.data, h, w, c, 1.0, 1.0, 0, out0.ctypes.data)
+    assert np.array_equal(out0, want)
+    a_lat, a_up = np.float32(0.7312), np.float32(1.318)
+    i8.lib().rfi8_upadd(lat.ctypes.data, up.ctypes.data, h, w, c, float(a_lat), float(a_up), 0, out0.ctypes.data)
+    real = lat.astype(np.float64) * float(a_lat) + dec.astype(np.float64) * float(a_up)
+    assert np.abs(out0 - np.clip(real, -127, 127)).max() <= 0.5 + 1e-4
+    assert net.per_channel and net.a_lat == [1.0, 1.0]
+
+
+@pytest.mark.parametrize("stem", STEMS)
+def test_int8_conv_backends_agree_exactly(nets, stem):
+    """float64 BLAS convolution (exact: every partial sum is an integer below 2**53) vs the plain C loops, every activation of
+    the network, on random quanta at a 64 x 96 net size."""
+    rng = np.random.default_rng(11)
+    x = rng.integers(0, 128, (32, 48, 16)).astype(np.int8)
+    a = i8.Int8Net(nets[stem], backend="blas").forward_from("mobilenet0_relu2_fwd", x)
+    b = i8.Int8Net(nets[stem], backend="c").forward_from("mobilenet0_relu2_fwd", x)
+    assert set(a) == set(b) and len(a) > 40
+    for k in a:
+        if k == "__heads__":
+            for hk in a[k]:
+                assert np.array_equal(a[k][hk], b[k][hk]), hk
+        else:
+            assert a[k].dtype == np.int8 and np.array_equal(a[k], b[k]), k
+    # later starting points continue identically (the engine's fused front end hands over at relu4)
+    c = i8.Int8Net(nets[stem]).forward_from("mobilenet0_relu4_fwd", a["mobilenet0_relu4_fwd"])
+    assert all(np.array_equal(c[k], a[k]) for k in c if k != "__heads__")
+
+
+@pytest.mark.parametrize("stem", STEMS)
+def test_int8_oracle_tracks_the_fp32_oracle(nets, oracles, stem):
+    """The int8 definition is sane: fed the fp32 oracle's own first block output, it finds the same faces (IoU / anchor
+    agreement at the level the engine's INT8_BAR documents) and every layer stays within a few percent of the range."""
+    from retinaface_amd.frames import synth_frames
+    q = i8.Int8Net(nets[stem])
+    ious, same_anchor, faces = [], 0, 0
+    for f in synth_frames(448, 448, 4, config=300, faces=[1, 3, 5]):
+        blobs = oracles[stem].forward(preprocess_trt_identity(f, 448, 448), keep_all=True)
+        x = q.quantise_blob("mobilenet0_relu2_fwd", blobs["mobilenet0_relu2_fwd"][0].transpose(1, 2, 0))
+        acts = q.forward_from("mobilenet0_relu2_fwd", x)
+        for n in ("mobilenet0_relu10_fwd", "mobilenet0_relu26_fwd", "rf_c1_aggr_relu", "rf_c2_det_concat_relu"):
+            r = blobs[n][0].transpose(1, 2, 0)
+            a = acts[n].astype(np.float32) * q.scale_of_blob[n]
+            assert np.abs(a - np.minimum(r, a.max())).mean() <= 0.035 * max(1.0, float(np.abs(r).max())), n
+        heads = {k: v[None] for k, v in acts["__heads__"].items()}
+        got = nms(list(decode(heads, 448, 448, 0.5)), 0.4)
+        ref = oracles[stem].detect(f, 0.5, 0.4, net_hw=(448, 448)).detections
+        assert len(got) == len(ref)
+        for r in ref:
+            best = max(got, key=lambda g: iou_plus1(g.rect, r.rect))
+            ious.append(iou_plus1(best.rect, r.rect))
+            same_anchor += best.anchor_index == r.anchor_index
+            faces += 1
+    assert faces >= 4 and min(ious) >= 0.85 and same_anchor / faces >= 0.5, (min(ious), same_anchor, faces)
