@@ -131,10 +131,27 @@ public:
         int ndev = 0;
         RF_HIP(hipGetDeviceCount(&ndev));
         if (device_ < 0 || device_ >= ndev) throw ArgError("device ordinal " + std::to_string(device_) + " out of range (" + std::to_string(ndev) + " devices)");
+        if (device_ >= kMaxDevices) throw ArgError("device ordinal " + std::to_string(device_) + ": at most " + std::to_string(kMaxDevices) + " devices per process");
+        // device frames are checked for residency whenever another device exists they could live on (RF_FORCE_SCATTER: test knob,
+        // treats every device frame as foreign so the scatter path runs on a one-GPU box)
+        force_scatter_ = getenv("RF_FORCE_SCATTER") != nullptr;
+        check_residency_ = ndev > 1 || force_scatter_;
         DeviceGuard guard(device_);                  // the caller's current device is put back when construction ends
         try { arena_.upload(); } catch (const std::exception &e) { throw HipError(e.what()); }
+        // Lanes are built on first use: a caller that only makes synchronous calls of <= max_batch images keeps re-using lane 0 and
+        // never pays for the other lanes' activation buffers (~13 MB per 448 x 448 image in fp16 x the super-batch size).  Lane 0
+        // is built now; if its buffers do not fit the device (a small or shared GPU) the super-batch is halved until they do.
+        plan_ = plan;
+        for (auto *f : {&plan_.conv0, &plan_.lateral[0], &plan_.lateral[1], &plan_.lateral[2], &plan_.aggr[0], &plan_.aggr[1]}) { f->w.clear(); f->w.shrink_to_fit(); }
         lanes_.resize(opt_.lanes);
-        for (auto &l : lanes_) build_lane(l, plan);
+        for (;;) {
+            try { ensure_lane(0); break; }
+            catch (const HipError &) {
+                if (opt_.coalesce == 1) throw;
+                opt_.coalesce = std::max(1, opt_.coalesce / 2);
+                cap_images_ = opt_.max_batch * opt_.coalesce;
+            }
+        }
         const int hw = (int)std::thread::hardware_concurrency();
         const int helpers = opt_.copy_threads > 0 ? opt_.copy_threads - 1 : std::max(0, std::min(8, hw / 4) - 1);
         copier_.reset(new ParallelCopier(helpers));
@@ -143,15 +160,7 @@ public:
     ~EngineImpl() override {
         DeviceGuard guard(device_);
         for (auto &r : registered_) if (r.owned) (void)hipHostUnregister((void *)r.base);
-        for (auto &l : lanes_) {
-            if (l.stream) (void)hipStreamSynchronize(l.stream);
-            for (auto &kv : l.graphs) (void)hipGraphExecDestroy(kv.second);
-            for (hipEvent_t e : l.time_ev) (void)hipEventDestroy(e);
-            if (l.done) (void)hipEventDestroy(l.done);
-            if (l.d_stage) (void)hipFree(l.d_stage);
-            if (l.h_stage) (void)hipHostFree(l.h_stage);
-            if (l.stream) (void)hipStreamDestroy(l.stream);
-        }
+        for (auto &l : lanes_) free_lane(l);
         for (void *p : dev_allocs_) (void)hipFree(p);
         for (void *p : host_allocs_) (void)hipHostFree(p);
         arena_.release();
@@ -379,6 +388,8 @@ public:
 
 private:
     struct Lane {
+        bool built = false;
+        std::vector<void *> dev_allocs, host_allocs;      // what build_lane allocated for this lane
         hipStream_t stream = nullptr;
         hipEvent_t time_ev[4] = {nullptr, nullptr, nullptr, nullptr};
         hipEvent_t done = nullptr;
@@ -429,15 +440,56 @@ private:
     template <typename U> U *dalloc(size_t count) {
         void *p = nullptr;
         RF_HIP(hipMalloc(&p, std::max<size_t>(count * sizeof(U), 256)));
-        dev_allocs_.push_back(p);
+        (building_ ? building_->dev_allocs : dev_allocs_).push_back(p);
         return (U *)p;
     }
     template <typename U> U *halloc(size_t count) {
         void *p = nullptr;
         RF_HIP(hipHostMalloc(&p, std::max<size_t>(count * sizeof(U), 256), hipHostMallocDefault));
-        host_allocs_.push_back(p);
+        (building_ ? building_->host_allocs : host_allocs_).push_back(p);
         memset(p, 0, std::max<size_t>(count * sizeof(U), 256));
         return (U *)p;
+    }
+
+    void free_lane(Lane &l) {
+        if (l.stream) (void)hipStreamSynchronize(l.stream);
+        for (auto &kv : l.graphs) (void)hipGraphExecDestroy(kv.second);
+        for (hipEvent_t &e : l.time_ev) { if (e) (void)hipEventDestroy(e); e = nullptr; }
+        if (l.done) (void)hipEventDestroy(l.done);
+        if (l.d_stage) (void)hipFree(l.d_stage);
+        if (l.h_stage) (void)hipHostFree(l.h_stage);
+        if (l.stream) (void)hipStreamDestroy(l.stream);
+        for (void *p : l.dev_allocs) (void)hipFree(p);
+        for (void *p : l.host_allocs) (void)hipHostFree(p);
+        l = Lane();
+    }
+
+    // build lane k if it has not been used yet; a failed build releases what it had allocated and rethrows
+    void ensure_lane(int k) {
+        Lane &l = lanes_[k];
+        if (l.built) return;
+        building_ = &l;
+        try { build_lane(l, plan_); }
+        catch (...) { building_ = nullptr; (void)hipGetLastError(); free_lane(l); throw; }
+        building_ = nullptr;
+        l.built = true;
+    }
+
+    // Which lane opens the next super-batch: an idle lane that exists (a synchronous caller therefore stays on lane 0), else a
+    // lane that has not been built yet (if its buffers do not fit the device any more the engine simply runs with fewer lanes),
+    // else the oldest busy one (its results are harvested first).
+    int pick_lane() {
+        const int L = (int)lanes_.size();
+        for (int k = 0; k < L; k++) {
+            const int l = (next_lane_ + k) % L;
+            if (lanes_[l].built && !lanes_[l].busy) return l;
+        }
+        for (int l = 0; l < L; l++)
+            if (!lanes_[l].built) {
+                try { ensure_lane(l); return l; }
+                catch (const HipError &) { if (l == 0) throw; lanes_.resize(l); next_lane_ %= l; break; }      // lanes l.. were never built: drop them
+            }
+        return next_lane_ % (int)lanes_.size();
     }
 
     static constexpr bool kInt8 = sizeof(T) == 1;
@@ -491,7 +543,8 @@ private:
                 sp.frames = L.d_frames + mb; sp.out = out;
                 sp.w0 = arena_.template ptr<half_t>(c0_hi_); sp.b0 = arena_.template ptr<float>(c0_b_);
                 sp.dw0_w = arena_.template ptr<float>(stem_dw_.w); sp.dw0_b = arena_.template ptr<float>(stem_dw_.b);
-                sp.pw0_w = arena_.template ptr<half_t>(stem_pw_.w); sp.pw0_b = arena_.template ptr<float>(stem_pw_.b);
+                sp.pw0_w = arena_.template ptr<half_t>(stem_pw_.w); sp.pw0_b = arena_.template ptr<float>(WP::stem2_c2_b_);
+                sp.c2_floor = arena_.template ptr<uint32_t>(WP::stem2_c2_floor_); sp.c3_floor = arena_.template ptr<uint32_t>(WP::stem2_c3_floor_);
                 sp.dw1_mma = arena_.template ptr<uint32_t>(stem2_dw_.mma); sp.dw1_b = arena_.template ptr<float>(stem2_dw_.b);
                 sp.pw1_w = arena_.template ptr<half_t>(stem2_pw_.w); sp.pw1_b = arena_.template ptr<float>(stem2_pw_.b);
                 sp.n = 0; sp.net_h = H; sp.net_w = W;
@@ -728,6 +781,23 @@ private:
         L.stage_cap = want;
     }
 
+    // Where a caller's "device" frame lives (rf_detect_batch_device / rf_enqueue_batch_device).  -1: readable in place by this
+    // engine's kernels (its own device's memory, or pinned / managed host memory); >= 0: the ordinal of ANOTHER device of the
+    // node -- the frame is then scattered to this device over xGMI before the launch (submit()).  Anything the runtime does not
+    // know as device-accessible memory is refused here instead of faulting inside a kernel.
+    int foreign_device_of(const uint8_t *p) const {
+        hipPointerAttribute_t attr;
+        memset(&attr, 0, sizeof(attr));
+        if (hipPointerGetAttributes(&attr, p) != hipSuccess) {
+            (void)hipGetLastError();
+            throw ArgError("device frame pointer is not known to the HIP runtime (host memory passed to a *_device entry point?)");
+        }
+        if (attr.type == hipMemoryTypeUnregistered) throw ArgError("device frame pointer is unregistered host memory");
+        if (attr.type == hipMemoryTypeHost || attr.type == hipMemoryTypeManaged) return -1;
+        if (attr.device == device_) return force_scatter_ ? device_ : -1;
+        return attr.device;
+    }
+
     bool is_registered(const uint8_t *p, size_t bytes) const {
         for (const auto &r : registered_)
             if ((uintptr_t)p >= r.base && (uintptr_t)p + bytes <= r.base + r.bytes) return true;
@@ -871,6 +941,7 @@ private:
         size_t stage_need = 0;
         std::vector<char> empty(n, 0);
         std::vector<size_t> off(n, 0);
+        std::vector<int> src_dev(n, -1);          // device frames: >= 0 = resident on that OTHER device, staged by a peer copy
         for (int i = 0; i < n; i++) {
             check_frame(frames[i], rows[i], cols[i], steps[i]);
             empty[i] = !frames[i] || rows[i] <= 0 || cols[i] <= 0;      // img.empty(), RetinaFace.cpp:578-580
@@ -880,6 +951,12 @@ private:
                 off[i] = stage_need;
                 stage_need += align256((size_t)rows[i] * cols[i] * 3);
                 all_registered = all_registered && is_registered(frames[i], (size_t)(rows[i] - 1) * steps[i] + (size_t)cols[i] * 3);
+            } else if (check_residency_) {
+                src_dev[i] = foreign_device_of(frames[i]);
+                if (src_dev[i] >= 0) {            // the rows keep the caller's step: one contiguous span, one peer copy
+                    off[i] = stage_need;
+                    stage_need += align256((size_t)(rows[i] - 1) * steps[i] + (size_t)cols[i] * 3);
+                }
             }
         }
         const bool eager_timed = sync_call && !opt_.use_graph;
@@ -893,11 +970,11 @@ private:
         }
         const int id = alloc_ticket();
         if (pending_lane_ < 0) {
-            const int lane = next_lane_;
+            const int lane = pick_lane();
             Lane &s = lanes_[lane];
             harvest(s);                       // waits for the previous super-batch on this lane, if any
             if (stage_need) ensure_stage(s, stage_need);
-            next_lane_ = (next_lane_ + 1) % (int)lanes_.size();
+            next_lane_ = (lane + 1) % (int)lanes_.size();
             s.n_images = 0;
             s.stage_used = 0;
             s.threshold = threshold;
@@ -914,7 +991,16 @@ private:
         try {
             if (stage_need) {
                 uint8_t *hbase = s.h_stage + s.stage_used, *dbase = s.d_stage + s.stage_used;
-                if (all_registered) {
+                if (on_device) {
+                    // the batch split of a multi-GPU node: frames resident on another device cross xGMI as one peer copy each
+                    // (SDMA, on this lane's stream: it overlaps the compute of the super-batches in flight on the other lanes)
+                    for (int i = 0; i < n; i++)
+                        if (!empty[i] && src_dev[i] >= 0) {
+                            RF_HIP(hipMemcpyPeerAsync(dbase + off[i], device_, frames[i], src_dev[i],
+                                                      (size_t)(rows[i] - 1) * steps[i] + (size_t)cols[i] * 3, s.stream));
+                            scattered_frames_++;
+                        }
+                } else if (all_registered) {
                     // caller buffers pinned with rf_host_register: the DMA engine reads them in place.  Frames with dense rows
                     // that follow each other in memory (a ring of camera buffers) and in the staging block go as ONE copy.
                     for (int i = 0; i < n; i++) {
@@ -950,7 +1036,8 @@ private:
             FrameDesc src{nullptr, 0, 0, 0, 0};
             s.empty[img] = empty[i];
             if (!empty[i]) {
-                if (on_device) src = FrameDesc{frames[i], rows[i], cols[i], steps[i], 0};
+                if (on_device && src_dev[i] < 0) src = FrameDesc{frames[i], rows[i], cols[i], steps[i], 0};
+                else if (on_device) src = FrameDesc{s.d_stage + s.stage_used + off[i], rows[i], cols[i], steps[i], 0};
                 else src = FrameDesc{s.d_stage + s.stage_used + off[i], rows[i], cols[i], cols[i] * 3, 0};
             }
             s.h_frames[img] = src;
@@ -984,6 +1071,8 @@ private:
 
     // ------------------------------------------------------------------------------------------ state
     int device_ = 0;
+    bool check_residency_ = false, force_scatter_ = false;
+    long scattered_frames_ = 0;               // device frames that arrived from another device (peer copies issued)
     std::vector<float> ratios_;                // the network preset's anchor ratios (empty: a preset without anchors)
     int na_ = 2;                               // anchors per cell the preset decodes (head_a_: what the model's heads carry)
     std::unique_ptr<ParallelCopier> copier_;
@@ -994,6 +1083,8 @@ private:
     std::vector<void *> dev_allocs_, host_allocs_;
     const int strides_[3] = {32, 16, 8};
 
+    Plan plan_;                               // skeleton (shapes, names): what build_lane needs when a lane is built later
+    Lane *building_ = nullptr;
     std::vector<Lane> lanes_;
     int next_lane_ = 0, last_lane_ = 0, last_first_image_ = 0, pending_lane_ = -1;
     int cap_images_ = 0;                      // images per launch = max_batch * coalesce
@@ -1023,6 +1114,7 @@ void prepare_pack(const std::string &model_dir, const EngineOptions &opt, Plan *
     for (const char *c = __DATE__ " " __TIME__ " " __FILE__; *c; c++) { key.build ^= (unsigned char)*c; key.build *= 1099511628211ull; }
     key.precision = opt.precision;
     key.stem2 = std::is_same<T, half_t>::value ? stem2_variant() : 0;
+    if (const char *dc = getenv("RF_STEM2_DC")) { if (atoi(dc) == 0) key.stem2 |= 0x100; }     // probe knob: another packed image
     const std::string path = opt.plan_cache_path.empty() ? plan_cache_path(model_dir, opt.model_stem, opt.precision) : opt.plan_cache_path;
     *from_cache = false;
     if (opt.plan_cache) {

@@ -21,6 +21,7 @@ template <> struct DwWeightT<int8_t> { typedef float type; };
 // The launch helpers keep per-device state (CU count, LDS attribute / occupancy of each kernel instance); the engine tells
 // them which device the calling thread is bound to (engine.cpp DeviceGuard).
 void bind_launch_device(int device);
+constexpr int kMaxDevices = 64;      // device ordinals a process may use (per-device launch state is sized by it; engine / multi.cpp enforce it)
 
 // One input frame: CV_8UC3 BGR, row y at ptr + y*step (cv::Mat data/step; RetinaFace.cpp:594).
 struct FrameDesc {
@@ -69,7 +70,9 @@ struct Stem2Params {
     const half_t *w0; const float *b0;
     const float *dw0_w; const float *dw0_b; const half_t *pw0_w; const float *pw0_b;
     const uint32_t *dw1_mma; const float *dw1_b;   // conv3: taps as diagonal MFMA A fragments [5][64] dwords (pack.h), bias [16]
-    const half_t *pw1_w; const float *pw1_b;       // conv4: 32 x 16, MFMA-fragment packed (K padded to 32), bias [32]
+    const half_t *pw1_w; const float *pw1_b;       // conv4: 32 x 16 as hi | lo along K (k < 16: rn16(w), k >= 16: rn16(w - hi)), MFMA-fragment packed, bias [32]
+    const uint32_t *c2_floor, *c3_floor;           // DC-centred conv2 / conv3 tiles: -mu per channel as packed fp16 pairs, [8] dwords each (the
+                                                   // biases above are pre-adjusted on the host, weights.h)
     int n, net_h, net_w;
 };
 void launch_stem2(hipStream_t s, const Stem2Params &p);

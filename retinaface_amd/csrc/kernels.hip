@@ -9,6 +9,9 @@
 //
 // What each kernel replaces in the reference is cited at its definition.
 #include "kernels.h"
+
+#include <atomic>
+
 #include "pack.h"
 
 namespace rf {
@@ -105,7 +108,9 @@ static void set_max_lds(F func, size_t bytes) {
 // Per-device launch state.  Function attributes (dynamic-LDS limit) and occupancy are properties of (kernel, device): with more
 // than one engine in a process (rf_options.devices) each device sets them up on its first launch.  The engine binds the calling
 // thread's device with bind_launch_device() (engine.cpp DeviceGuard); unbound threads ask the runtime.
-constexpr int kMaxDevices = 32;
+// (kMaxDevices: kernels.h; the engine refuses ordinals beyond it, so no two devices ever share a slot.  The caches are atomics:
+// MultiEngine's per-device host threads -- and two engines on ONE device -- run these first launches concurrently; every
+// writer stores the same value.)
 static thread_local int t_launch_device = -1;
 void bind_launch_device(int device) { t_launch_device = device; }
 static int launch_device() {
@@ -120,15 +125,17 @@ typedef Unsupported LaunchUnsupported;
 
 // Persistent grid: as many workgroups as the chip keeps resident (CUs x RESIDENT), trimmed so every workgroup walks the
 // same number of tiles (no nearly-empty last round).  Launches with fewer tiles than that get one tile per workgroup.
-static int g_num_cus[kMaxDevices] = {};
+static std::atomic<int> g_num_cus[kMaxDevices] = {};
 static int num_cus() {
     const int dev = launch_device();
-    if (!g_num_cus[dev]) {
+    int cus = g_num_cus[dev].load(std::memory_order_relaxed);
+    if (!cus) {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return 256;
-        g_num_cus[dev] = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        g_num_cus[dev].store(cus, std::memory_order_relaxed);
     }
-    return g_num_cus[dev];
+    return cus;
 }
 // Below `min_rounds` x resident tiles the hardware dispatcher's dynamic one-tile-per-workgroup schedule is at least as
 // good as walking two tiles in sequence, so the grid stays one workgroup per tile.
@@ -149,10 +156,15 @@ template <typename F> static int resident_per_cu(F kern, size_t lds_bytes) {
     return nb;
 }
 // first launch of a kernel instance on the current device: raise its dynamic-LDS limit, query its residency
-template <typename F> static int kernel_residency(int (&cache)[kMaxDevices], F kern, size_t lds_bytes) {
+template <typename F> static int kernel_residency(std::atomic<int> (&cache)[kMaxDevices], F kern, size_t lds_bytes) {
     const int dev = launch_device();
-    if (!cache[dev]) { set_max_lds(kern, lds_bytes); cache[dev] = resident_per_cu(kern, lds_bytes); }
-    return cache[dev];
+    int r = cache[dev].load(std::memory_order_acquire);
+    if (!r) {
+        set_max_lds(kern, lds_bytes);
+        r = resident_per_cu(kern, lds_bytes);
+        cache[dev].store(r, std::memory_order_release);      // published only after the attribute is set
+    }
+    return r;
 }
 
 // =============================================================================================
@@ -397,6 +409,14 @@ __device__ __forceinline__ uint32_t pack_f16(float a, float b, bool relu) {
     s16x2_ h = __builtin_bit_cast(s16x2_, __builtin_convertvector(f, f16x2_));
     const s16x2_ z = {0, 0};
     if (relu) h = __builtin_elementwise_max(h, z);
+    return __builtin_bit_cast(uint32_t, h);
+}
+
+// The same with a per-channel floor instead of 0 (DC-centred storage, see stem2_kernel): floor2 = two packed fp16 values -mu.
+// max(rn(x), -mu) == rn(max(x, -mu)) because -mu is an fp16 number and rounding is monotonic.  One v_cvt_pk + one v_pk_max_f16.
+__device__ __forceinline__ uint32_t pack_f16_floor(float a, float b, uint32_t floor2) {
+    const f32x2_ f = {a, b};
+    const f16x2_ h = __builtin_elementwise_max(__builtin_convertvector(f, f16x2_), __builtin_bit_cast(f16x2_, floor2));
     return __builtin_bit_cast(uint32_t, h);
 }
 
@@ -742,7 +762,8 @@ struct Stem2Args {
     const half_t *w0; const float *b0;              // conv0 (as StemArgs)
     const float *dw0_w; const float *dw0_b; const half_t *pw0_w; const float *pw0_b;     // conv1 / conv2 (as StemArgs)
     const uint32_t *dw1_mma; const float *dw1_b;    // conv3 taps as diagonal MFMA A fragments [5][64] dwords (pack.h dw_mma_dword), bias [16]
-    const half_t *pw1_w; const float *pw1_b;        // conv4: 32 x 16 packed (K padded to 32), bias [32]
+    const half_t *pw1_w; const float *pw1_b;        // conv4: 32 x 16 as hi | lo along K (32 K slots, all used), bias [32]
+    const uint32_t *c2_floor, *c3_floor;            // DC-centred tiles: -mu of the conv2 / conv3 tile per channel, packed fp16 pairs [8] each
     int ho, wo, ho4, wo4, tiles_x, tiles_y, nblk;   // ho x wo = conv0 / conv2 map (net / 2), ho4 x wo4 = conv4 map (net / 4)
 };
 
@@ -940,12 +961,18 @@ __global__ __launch_bounds__((Stem2Cfg<TW_, F16P>::THREADS), (Stem2Cfg<TW_, F16P
         }
     }
     const f16x8 pw0_frag = ((const f16x8 *)a.pw0_w)[lane];            // phase 4's operands: requested before the barrier
-    const f32x4 pw0_bias = *(const f32x4 *)(a.pw0_b + kb * 4);
+    const f32x4 pw0_bias = *(const f32x4 *)(a.pw0_b + kb * 4);        // bias - mu2 (host)
+    const uint2 c2_floor = *(const uint2 *)(a.c2_floor + kb * 2);     // -mu2 of the lane's 4 channels
     RF_TRACE(4, 3);
     __syncthreads();
 
     // ---- phase 4: pointwise conv2 (8 -> 16) on MFMA, K slots [W_hi x_hi | W_hi x_lo | W_lo x_hi | 0]; the result tile is fp16
     //      (the rounding point the un-fused engine had in HBM).  Pixels outside the 224^2 map are conv3's zero padding.
+    //      DC-CENTRED STORAGE: this tile carried ~25 % of what was left of the fp16 engine's box-error variance, because its
+    //      values ride on a large per-channel DC level (the response to the frame's mean brightness) and fp16 rounds relative to the
+    //      magnitude.  The tile therefore holds relu(y) - mu2[c], mu2 = the layer's response to a flat mid-grey frame (an fp16
+    //      number per channel, weights.h): the MFMA's bias is b - mu2, ReLU becomes a max with -mu2, zero padding becomes -mu2,
+    //      and conv3 adds mu2 * sum(taps) back through ITS bias -- exact algebra, no extra instruction, rounding error / 4.6.
 #pragma unroll 1
     for (int t = wave; t < C::T2; t += NW) {
         const int i = t * 16 + (lane & 15);
@@ -959,14 +986,15 @@ __global__ __launch_bounds__((Stem2Cfg<TW_, F16P>::THREADS), (Stem2Cfg<TW_, F16P
             inside = inside && (unsigned)y2 < (unsigned)a.ho && (unsigned)x2 < (unsigned)a.wo;
         }
         uint2 h;
-        h.x = inside ? pack_f16(acc[0], acc[1], true) : 0u;
-        h.y = inside ? pack_f16(acc[2], acc[3], true) : 0u;
+        h.x = inside ? pack_f16_floor(acc[0], acc[1], c2_floor.x) : c2_floor.x;
+        h.y = inside ? pack_f16_floor(acc[2], acc[3], c2_floor.y) : c2_floor.y;
         *(uint2 *)(s_c2 + i * 16 + kb * 4) = h;
     }
     uint32_t dw1v[kDwMmaChunks];                             // phase 5's operands: requested before the barrier
 #pragma unroll
     for (int kc = 0; kc < kDwMmaChunks; kc++) dw1v[kc] = a.dw1_mma[kc * 64 + lane];
-    const f32x4 dbias = *(const f32x4 *)(a.dw1_b + kb * 4);
+    const f32x4 dbias = *(const f32x4 *)(a.dw1_b + kb * 4);           // bias + mu2 * sum(taps) - mu3 (host)
+    const uint2 c3_floor = *(const uint2 *)(a.c3_floor + kb * 2);     // the conv3 result is stored centred as well (conv4 is 1x1: its bias takes W mu3)
     RF_TRACE(4, 4);
     __syncthreads();
 
@@ -1001,8 +1029,8 @@ __global__ __launch_bounds__((Stem2Cfg<TW_, F16P>::THREADS), (Stem2Cfg<TW_, F16P
                 acc = M::mma(__builtin_bit_cast(M::Frag, wa), bf[kc], acc);
             }
             uint2 h;
-            h.x = pack_f16(acc[0], acc[1], true);
-            h.y = pack_f16(acc[2], acc[3], true);
+            h.x = pack_f16_floor(acc[0], acc[1], c3_floor.x);
+            h.y = pack_f16_floor(acc[2], acc[3], c3_floor.y);
             *(uint2 *)(s_a1 + p * LDA1 + kb * 4) = h;      // region A again: the conv1 result is dead since the barrier after phase 4
         }
     }
@@ -1011,11 +1039,12 @@ __global__ __launch_bounds__((Stem2Cfg<TW_, F16P>::THREADS), (Stem2Cfg<TW_, F16P
     RF_TRACE(4, 5);
     __syncthreads();
 
-    // ---- phase 6: pointwise conv4 (16 -> 32) on MFMA: 2 channel tiles x T4 pixel tiles, K = 16 of 32
+    // ---- phase 6: pointwise conv4 (16 -> 32) on MFMA: 2 channel tiles x T4 pixel tiles.  K = 16, and the MFMA has 32 slots: the
+    //      weights ride as an fp16 hi | lo pair along K (both halves read the same 16 inputs), so their rounding costs nothing
 #pragma unroll 1
     for (int pr = wave; pr < 2 * C::T4; pr += NW) {
         const int ct = pr & 1, pt = pr >> 1;
-        const M::Frag x = kb < 2 ? *(const M::Frag *)(s_a1 + (pt * 16 + (lane & 15)) * LDA1 + kb * 8) : M::zero();
+        const M::Frag x = *(const M::Frag *)(s_a1 + (pt * 16 + (lane & 15)) * LDA1 + (kb & 1) * 8);
         const f32x4 acc = M::mma(ct ? pw1_frag1 : pw1_frag0, x, ct ? pw1_bias1 : pw1_bias0);
         uint2 h;
         h.x = pack_f16(acc[0], acc[1], true);
@@ -1050,6 +1079,7 @@ void launch_stem2(hipStream_t s, const Stem2Params &p) {
     a.frames = p.frames; a.out = p.out; a.w0 = p.w0; a.b0 = p.b0;
     a.dw0_w = p.dw0_w; a.dw0_b = p.dw0_b; a.pw0_w = p.pw0_w; a.pw0_b = p.pw0_b;
     a.dw1_mma = p.dw1_mma; a.dw1_b = p.dw1_b; a.pw1_w = p.pw1_w; a.pw1_b = p.pw1_b;
+    a.c2_floor = p.c2_floor; a.c3_floor = p.c3_floor;
     a.ho = p.net_h / 2; a.wo = p.net_w / 2; a.ho4 = p.net_h / 4; a.wo4 = p.net_w / 4;
     const int v = stem2_variant();
     const int tw = v == 2 ? 16 : 8;
@@ -1471,7 +1501,7 @@ template <typename T, int CIN, int COUT, int STRIDE, bool HAS_DW, int TH, int TW
 static void dwpw_launch(hipStream_t s, const DwPwParams<T> *p, int tiles_x, int tiles_y) {
     typedef DwPwCfg<T, CIN, COUT, STRIDE, HAS_DW, TH, TW, PADROW> C;
     auto kern = dwpw_kernel<T, CIN, COUT, STRIDE, HAS_DW, TH, TW, LAT, PADROW>;
-    static int resident_cache[kMaxDevices] = {};
+    static std::atomic<int> resident_cache[kMaxDevices] = {};
     const int resident = kernel_residency(resident_cache, kern, C::LDS_BYTES);
     DwPwArgs<T> a{p->in, p->out, p->dw_w, p->dw_b, p->dw_mma, p->pw_w, p->pw_b, p->lat_w, p->lat_b, p->lat_out, p->pw_m, p->lat_m, p->dw_m,
                   p->hin, p->win, p->hout, p->wout, tiles_x, tiles_y, p->n * tiles_x * tiles_y};
@@ -1761,7 +1791,7 @@ void launch_dwpw2(hipStream_t s, const DwPw2Params &p) {
     a.hin = p.hin; a.win = p.win; a.hout = p.hin / 2; a.wout = p.win / 2;
     a.tiles_x = (a.wout + 7) / 8; a.tiles_y = (a.hout + 3) / 4;
     a.nblk = p.n * a.tiles_x * a.tiles_y;
-    static int resident_cache[kMaxDevices] = {};
+    static std::atomic<int> resident_cache[kMaxDevices] = {};
     const int resident = kernel_residency(resident_cache, dwpw2_kernel, 0);
     hipLaunchKernelGGL(dwpw2_kernel, dim3(persistent_grid(a.nblk, resident)), dim3(kThreads), 0, s, a);
 }
@@ -2097,7 +2127,7 @@ template <typename T, int CIN, int COUT, int TH, int TW, bool UPADD, bool ALLC, 
 static void conv3_launch(hipStream_t s, Conv3Args<T> &a, int nlv, int total_tiles) {
     typedef Conv3Cfg<T, CIN, COUT, TH, TW, ALLC, PADROW> C;
     auto kern = conv3x3_kernel<T, CIN, COUT, TH, TW, UPADD, ALLC, PADROW>;
-    static int resident_cache[kMaxDevices] = {};
+    static std::atomic<int> resident_cache[kMaxDevices] = {};
     const int resident = kernel_residency(resident_cache, kern, C::LDS_BYTES);
     // grid: persistent size for the whole launch, shared out to the levels in proportion to their tiles
     const int want = sizeof(T) <= 2 ? persistent_grid(total_tiles, resident) : total_tiles;
@@ -2503,9 +2533,9 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(NmsParams a) {
 
 void launch_nms(hipStream_t s, const NmsParams &p) {
     size_t lds = (size_t)p.cap * (8 + 16 + 4 + 1) + (size_t)p.max_det * 4 + 16;
-    static size_t attr_bytes[kMaxDevices] = {};
+    static std::atomic<size_t> attr_bytes[kMaxDevices] = {};
     const int dev = launch_device();
-    if (lds > attr_bytes[dev]) { set_max_lds(nms_kernel, lds); attr_bytes[dev] = lds; }
+    if (lds > attr_bytes[dev].load(std::memory_order_acquire)) { set_max_lds(nms_kernel, lds); attr_bytes[dev].store(lds, std::memory_order_release); }
     hipLaunchKernelGGL(nms_kernel, dim3(p.n), dim3(NMS_THREADS), lds, s, p);
 }
 

@@ -5,6 +5,9 @@
 // cache (trtnetbase.cpp:205-243 -> RFW1).
 #include "model.h"
 
+#include <unistd.h>
+
+#include <atomic>
 #include <cstdio>
 #include <cstring>
 #include <fstream>
@@ -538,7 +541,9 @@ bool read_file_if_exists(const std::string &path, std::string *bytes) {
 }
 
 void write_file_best_effort(const std::string &path, const std::string &bytes) {
-    const std::string tmp = path + ".tmp" + std::to_string((unsigned long)(uintptr_t)&bytes & 0xffffff);
+    // unique per writer: the ranks of `bench.py --gpus N` cold-start together and must not truncate each other's temporary file
+    static std::atomic<unsigned> counter{0};
+    const std::string tmp = path + ".tmp." + std::to_string((long)getpid()) + "." + std::to_string(counter.fetch_add(1));
     FILE *f = fopen(tmp.c_str(), "wb");
     if (!f) return;                                    // read-only model directory: run without a cache
     const bool ok = fwrite(bytes.data(), 1, bytes.size(), f) == bytes.size();

@@ -83,6 +83,8 @@ public:
         workers_.reserve(eng_.size());
         for (size_t g = 0; g < eng_.size(); g++) workers_.emplace_back(new Worker);
         lo_.assign(eng_.size() + 1, 0);
+        last_shard_ = lo_;
+        issued_.resize(eng_.size());
     }
     ~MultiEngine() override {
         workers_.clear();          // threads first: nothing may be running when the engines go
@@ -142,6 +144,9 @@ public:
         }
         last_n_ = n;
         last_from_wait_ = -1;
+        last_shard_ = lo_;                                   // what get_output / debug_activation locate images by: lo_ is scratch of the next call
+        for (int g = 0; g < G; g++)
+            if (lo_[g + 1] > lo_[g]) last_engine_ = g;
     }
 
     // the asynchronous API spreads whole enqueues round-robin over the devices (an enqueue is at most max_batch images: too
@@ -150,14 +155,22 @@ public:
                 float threshold) override {
         const int G = (int)eng_.size();
         const int g = next_;
+        const int t = eng_[g]->enqueue(fr, rows, cols, steps, n, on_device, threshold);     // throws before any state changes
         next_ = (next_ + 1) % G;
-        return g + G * eng_[g]->enqueue(fr, rows, cols, steps, n, on_device, threshold);
+        if ((int)issued_[g].size() <= t) issued_[g].resize(t + 1, 0);
+        issued_[g][t] = 1;
+        return g + G * t;
     }
     void wait(int ticket, rf_face *out, int cap_per_image, int *counts, bool *truncated) override {
         const int G = (int)eng_.size();
-        if (ticket < 0) throw ArgError("wait: invalid ticket");
+        // a ticket is only forwarded to the engine that issued it and has not been waited for yet: a stale or foreign number
+        // must not reach another engine's slot of the same index
+        if (ticket < 0 || ticket / G >= (int)issued_[ticket % G].size() || !issued_[ticket % G][ticket / G])
+            throw ArgError("wait: invalid ticket");
+        issued_[ticket % G][ticket / G] = 0;
         eng_[ticket % G]->wait(ticket / G, out, cap_per_image, counts, truncated);
         last_from_wait_ = ticket % G;
+        last_engine_ = ticket % G;
     }
     int num_slots() const override {
         int s = 0;
@@ -191,8 +204,9 @@ public:
         for (int i = 0; i < std::min(n, last_n_); i++) counts[i] = last_cand_[i];
         return last_n_;
     }
+    // the engine that served the most recent call (a sharded detect: the one whose slice held the call's last image)
     void last_timings(float *pre, float *infer, float *post, float *total) const override {
-        eng_[0]->last_timings(pre, infer, post, total);
+        eng_[last_engine_]->last_timings(pre, infer, post, total);
     }
     // per-launch accessors: image i of the last sharded call lives on the device whose slice holds it
     long get_output(const std::string &blob, int image, float *dst, size_t cap) override {
@@ -214,15 +228,16 @@ private:
     void locate(int image, int *g, int *local) const {
         if (last_from_wait_ >= 0) { *g = last_from_wait_; *local = image; return; }
         if (image < 0 || image >= last_n_) throw ArgError("image index out of range");
-        for (int k = 0; k + 1 < (int)lo_.size(); k++)
-            if (image >= lo_[k] && image < lo_[k + 1]) { *g = k; *local = image - lo_[k]; return; }
+        for (int k = 0; k + 1 < (int)last_shard_.size(); k++)
+            if (image >= last_shard_[k] && image < last_shard_[k + 1]) { *g = k; *local = image - last_shard_[k]; return; }
         throw ArgError("image index out of range");
     }
 
     std::vector<std::unique_ptr<Engine>> eng_;
     std::vector<std::unique_ptr<Worker>> workers_;
-    std::vector<int> lo_;
-    int next_ = 0, last_n_ = 0, last_from_wait_ = -1;
+    std::vector<int> lo_, last_shard_;
+    std::vector<std::vector<char>> issued_;              // per engine: its tickets that are outstanding
+    int next_ = 0, last_n_ = 0, last_from_wait_ = -1, last_engine_ = 0;
     std::vector<int> last_cand_;
     std::vector<std::vector<int32_t>> last_anchor_;
 };
@@ -237,7 +252,7 @@ std::unique_ptr<Engine> Engine::create(const std::string &model_dir, const std::
         eo.devices.clear();
         return create_single(model_dir, network, nms, eo);
     }
-    if (opt.devices.size() > 64) throw ArgError("at most 64 device entries");
+    if ((int)opt.devices.size() > kMaxDevices) throw ArgError("at most " + std::to_string(kMaxDevices) + " device entries");
     return std::unique_ptr<Engine>(new MultiEngine(model_dir, network, nms, opt));
 }
 

@@ -15,7 +15,7 @@
 #include <cstddef>
 #include <cstdint>
 
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
 #define RF_HD __host__ __device__
 #else
 #define RF_HD

@@ -78,7 +78,7 @@ template <typename T> constexpr int mma_kpl() { return sizeof(T) == 1 ? 16 : siz
 
 
 // ---------------------------------------------------------------------------------------------------- byte archive
-constexpr uint32_t kPlanCacheVersion = 3;      // bump when the packing / layout of anything below changes
+constexpr uint32_t kPlanCacheVersion = 5;      // bump when the packing / layout of anything below changes
 
 struct ArOut {
     std::string b;
@@ -132,6 +132,7 @@ struct WeightPack {
     size_t c0_w_ = 0, c0_b_ = 0, c0_hi_ = 0;
     DwW stem_dw_{0, 0}, stem2_dw_{0, 0};
     GemmW stem_pw_{0, 0}, stem2_pw_{0, 0};
+    size_t stem2_c2_b_ = 0, stem2_c2_floor_ = 0, stem2_c3_floor_ = 0;      // stem2's DC-centred tiles (pack())
     float aggr_a_lat_[2] = {1.f, 1.f}, aggr_a_up_[2] = {1.f, 1.f};
     std::map<std::string, std::vector<float>> act_scale_;    // int8: blob -> per-channel scales (debug accessors dequantise)
     std::vector<DwW> dw_w_;
@@ -360,9 +361,71 @@ struct WeightPack {
                     // other depthwise stage, see equalize_depthwise), conv4 as a standard packed 32 x 16 GEMM
                     FoldedConv dwq = plan.blocks[1].dw, pwq = plan.blocks[1].pw;
                     equalize_depthwise(dwq, pwq);
+                    // DC-centred LDS tiles (stem2_kernel phases 4-6).  mu = the layers' response to a flat mid-grey frame (every
+                    // pixel 128: the interior of every map is then one constant per channel), rounded to fp16 so that the shift
+                    // itself is exact.  Shifting a tensor by a per-channel constant is exact algebra as long as its consumer's bias
+                    // takes the constant back: conv3 (depthwise, taps t): + mu2 * sum(t); conv4 (1x1, W): + W mu3.  Both sums use
+                    // the weights AS THE KERNEL SEES THEM (fp16-rounded taps, hi + lo pointwise weights).  RF_STEM2_DC=0: mu = 0
+                    // (probe / test knob: the tiles are then plain ReLU outputs as in round 2).
+                    std::vector<float> mu2(16, 0.f), mu3(16, 0.f);
+                    const char *dc_env = getenv("RF_STEM2_DC");
+                    if (!dc_env || atoi(dc_env) != 0) {
+                        double y0[8], y1[8];
+                        for (int c = 0; c < 8; c++) {
+                            double sw = 0.0;
+                            for (int k = 0; k < 27; k++) sw += plan.conv0.w[(size_t)c * 27 + k];
+                            y0[c] = std::max(0.0, (double)plan.conv0.b[c] + 128.0 * sw);
+                            double st = 0.0;
+                            for (int t = 0; t < 9; t++) st += b0.dw.w[(size_t)c * 9 + t];
+                            y1[c] = std::max(0.0, (double)b0.dw.b[c] + y0[c] * st);
+                        }
+                        for (int o = 0; o < 16; o++) {
+                            double y2 = b0.pw.b[o];
+                            for (int c = 0; c < 8; c++) y2 += (double)b0.pw.w[(size_t)o * 8 + c] * y1[c];
+                            mu2[o] = (float)(half_t)(float)std::min(30000.0, std::max(0.0, y2));       // (far inside the fp16 range)
+                            double st = 0.0;
+                            for (int t = 0; t < 9; t++) st += dwq.w[(size_t)o * 9 + t];
+                            mu3[o] = (float)(half_t)(float)std::min(30000.0, std::max(0.0, (double)dwq.b[o] + (double)mu2[o] * st));
+                        }
+                    }
+                    auto packed_floor = [&](const std::vector<float> &mu) {
+                        std::vector<uint32_t> f(8);
+                        for (int i = 0; i < 8; i++) {
+                            half_t lo = (half_t)(mu[2 * i] == 0.f ? 0.f : -mu[2 * i]), hi = (half_t)(mu[2 * i + 1] == 0.f ? 0.f : -mu[2 * i + 1]);
+                            uint16_t bl, bh;
+                            std::memcpy(&bl, &lo, 2); std::memcpy(&bh, &hi, 2);
+                            f[i] = (uint32_t)bl | ((uint32_t)bh << 16);
+                        }
+                        return f;
+                    };
+                    {   // conv2: bias - mu2 (its own copy: the un-fused stem kernel shares stem_pw_ and stores plain values)
+                        std::vector<float> b2(b0.pw.b);
+                        for (int o = 0; o < 16; o++) b2[o] -= mu2[o];
+                        stem2_c2_b_ = arena_.put(b2);
+                        stem2_c2_floor_ = arena_.put(packed_floor(mu2));
+                        stem2_c3_floor_ = arena_.put(packed_floor(mu3));
+                    }
+                    for (int c = 0; c < 16; c++) {          // conv3: + mu2 * sum(fp16 taps) - mu3
+                        double st = 0.0;
+                        for (int t = 0; t < 9; t++) st += (double)(float)(half_t)dwq.w[(size_t)c * 9 + t];
+                        dwq.b[c] = (float)((double)dwq.b[c] + (double)mu2[c] * st - (double)mu3[c]);
+                    }
                     stem2_dw_ = put_dw(dwq);
-                    stem2_pw_.w = arena_.put(pack_gemm<half_t>(pwq.w, pwq.cout, 16, 32, 8));
-                    stem2_pw_.b = arena_.put(pwq.b);
+                    // conv4: K = 16 of the MFMA's 32 slots -> the weights ride as hi | lo along K; bias + (hi + lo) mu3
+                    std::vector<float> w2((size_t)pwq.cout * 32, 0.f), b4(pwq.b);
+                    for (int o = 0; o < pwq.cout; o++) {
+                        double corr = 0.0;
+                        for (int k = 0; k < 16; k++) {
+                            const float w = pwq.w[(size_t)o * 16 + k];
+                            const float hi = (float)(half_t)w, lo = (float)(half_t)(w - hi);
+                            w2[(size_t)o * 32 + k] = hi;
+                            w2[(size_t)o * 32 + 16 + k] = lo;
+                            corr += ((double)hi + (double)lo) * (double)mu3[k];
+                        }
+                        b4[o] = (float)((double)b4[o] + corr);
+                    }
+                    stem2_pw_.w = arena_.put(pack_gemm<half_t>(w2, pwq.cout, 32, 32, 8));
+                    stem2_pw_.b = arena_.put(b4);
                     first_block = 2;
                     dw_w_.push_back(DwW{0, 0});
                     pw_w_.push_back(GemmW{0, 0});
@@ -466,6 +529,7 @@ struct WeightPack {
     template <class Ar> void io(Ar &ar) {
         ar.pod(c0_w_); ar.pod(c0_b_); ar.pod(c0_hi_);
         ar.pod(stem_dw_); ar.pod(stem2_dw_); ar.pod(stem_pw_); ar.pod(stem2_pw_);
+        ar.pod(stem2_c2_b_); ar.pod(stem2_c2_floor_); ar.pod(stem2_c3_floor_);
         ar.pod(aggr_a_lat_); ar.pod(aggr_a_up_); ar.pod(head_a_);
         ar.vec(dw_w_); ar.vec(pw_w_);
         ar.pod(lat_w_); ar.pod(aggr_w_); ar.pod(ssh_w_);
@@ -479,7 +543,30 @@ struct WeightPack {
         }
         ar.vec(arena_.host());
     }
+
+    // every offset a launch dereferences must lie inside the image (a cache file whose checksum matches was written by this code,
+    // so this only ever fires on a logic error -- but it turns an out-of-bounds device read into a rebuild)
+    bool offsets_in_bounds() const {
+        const size_t n = arena_.bytes();
+        auto ok = [n](size_t off) { return off == kNone || off < n; };
+        auto okg = [&](const GemmW &g) { return ok(g.w) && ok(g.b) && ok(g.m); };
+        auto okd = [&](const DwW &d) { return ok(d.w) && ok(d.b) && ok(d.mma) && ok(d.m); };
+        bool good = ok(c0_w_) && ok(c0_b_) && ok(c0_hi_) && okd(stem_dw_) && okd(stem2_dw_) && okg(stem_pw_) && okg(stem2_pw_) &&
+                    ok(stem2_c2_b_) && ok(stem2_c2_floor_) && ok(stem2_c3_floor_);
+        for (const auto &d : dw_w_) good = good && okd(d);
+        for (const auto &g : pw_w_) good = good && okg(g);
+        for (const auto &g : lat_w_) good = good && okg(g);
+        for (const auto &g : aggr_w_) good = good && okg(g);
+        for (const auto &lv : ssh_w_) for (const auto &g : lv) good = good && okg(g);
+        return good && dw_w_.size() == pw_w_.size();
+    }
 };
+
+inline uint64_t fnv1a64(const char *p, size_t n) {
+    uint64_t h = 1469598103934665603ull;
+    for (size_t i = 0; i < n; i++) { h ^= (unsigned char)p[i]; h *= 1099511628211ull; }
+    return h;
+}
 
 // what a cache file is valid for
 struct PlanCacheKey {
@@ -498,8 +585,13 @@ template <typename T> std::string save_plan_cache(const PlanCacheKey &key, Plan 
     ar.pod(ver);
     PlanCacheKey k = key;
     ar.pod(k);
-    io_plan(ar, plan);
-    wp.io(ar);
+    ArOut body;
+    io_plan(body, plan);
+    wp.io(body);
+    uint64_t len = body.b.size(), sum = fnv1a64(body.b.data(), body.b.size());     // payload length + checksum: a torn or bit-rotted file is rebuilt
+    ar.pod(len);
+    ar.pod(sum);
+    ar.raw(body.b.data(), body.b.size());
     return ar.b;
 }
 // false = not a cache for this key (stale / other precision / other version): rebuild.  Throws IoError on a damaged file.
@@ -513,9 +605,15 @@ template <typename T> bool load_plan_cache(const std::string &bytes, const PlanC
     PlanCacheKey k;
     ar.pod(k);
     if (k.source_hash != key.source_hash || k.build != key.build || k.precision != key.precision || k.stem2 != key.stem2) return false;
+    uint64_t len = 0, sum = 0;
+    ar.pod(len);
+    ar.pod(sum);
+    if (len != bytes.size() - ar.p) throw IoError("plan cache: payload length mismatch (torn write?)");
+    if (fnv1a64(bytes.data() + ar.p, (size_t)len) != sum) throw IoError("plan cache: checksum mismatch");
     io_plan(ar, *plan);
     wp->io(ar);
     if (ar.p != bytes.size()) throw IoError("plan cache: trailing bytes");
+    if (!wp->offsets_in_bounds()) throw IoError("plan cache: weight offset outside the image");
     return true;
 }
 

@@ -653,6 +653,48 @@ def test_multi_device_handle_shards_by_image(rfa):
         rfa.RetinaFace(ASSETS, "net3", 0.4, precision=FP16, net_hw=(448, 448), model_stem="mnet25", devices=[0, 99])
 
 
+def test_device_frames_resident_elsewhere_are_scattered_to_the_slices_device(rfa):
+    """The batch split of a multi-GPU node (north_star: "batches shard across the GPUs ... batch split / gather"): a frame handed
+    to rf_detect_batch_device / rf_enqueue_batch_device that does not live on the engine's (slice's) device is copied to it with
+    one peer copy over xGMI on the lane's stream (engine.cpp submit(): hipPointerGetAttributes + hipMemcpyPeerAsync); pointers
+    the HIP runtime does not know are refused with RF_ERR_INVALID_ARG instead of faulting.  The one-GPU box runs that path with
+    RF_FORCE_SCATTER=1 (every device frame treated as foreign: the peer copy is device 0 -> device 0): dense frames, a strided
+    ROI at an unaligned address, single and [0, 0] multi handles, synchronous and asynchronous entry points -- results
+    identical to reading the frames in place."""
+    import torch
+    from retinaface_amd.frames import synth_frames
+    frames = synth_frames(448, 448, 12, config=17)
+    d = torch.from_numpy(np.stack(frames)).cuda()
+    ptrs = [d[i].data_ptr() for i in range(12)]
+    one = engine(rfa, "mnet25", FP16, (448, 448))
+    want = _key(one.detect_device(ptrs, [448] * 12, [448] * 12, 0.5))
+    assert sum(len(r) for r in want) > 0
+    # a strided ROI: 300 x 401 window of a wider device image, odd byte offset
+    wide = torch.zeros((448, 448 * 3 + 13), dtype=torch.uint8, device="cuda")
+    wide[:, 1:1 + 448 * 3] = d[0].reshape(448, -1)
+    roi_ptr, roi_step = wide.data_ptr() + 1 + 3 * 20 + 50 * wide.shape[1], wide.shape[1]
+    want_roi = _key(one.detect_device([roi_ptr], [300], [401], 0.5, steps=[roi_step]))
+    os.environ["RF_FORCE_SCATTER"] = "1"
+    try:
+        for devs in (None, [0, 0]):
+            det = rfa.RetinaFace(ASSETS, "net3", 0.4, precision=FP16, net_hw=(448, 448), model_stem="mnet25", devices=devs)
+            assert _key(det.detect_device(ptrs, [448] * 12, [448] * 12, 0.5)) == want          # chunked (max_batch 8) and, for [0, 0], sharded
+            assert _key(det.detect_device([roi_ptr], [300], [401], 0.5, steps=[roi_step])) == want_roi
+            t = [det.enqueue_device(ptrs[:8], [448] * 8, [448] * 8, 0.5) for _ in range(5)]
+            for x in t:
+                assert _key(det.wait(x, 8)) == want[:8]
+            # host memory passed as a device pointer: refused, and the handle stays usable
+            with pytest.raises(rfa._lib.RFError):
+                det.detect_device([frames[0].ctypes.data], [448], [448], 0.5)
+            assert _key(det.detect_device(ptrs[:3], [448] * 3, [448] * 3, 0.5)) == want[:3]
+            # pinned host memory is device-accessible: read in place, not an error
+            pinned = torch.from_numpy(frames[1]).pin_memory()
+            assert _key(det.detect_device([pinned.data_ptr()], [448], [448], 0.5)) == want[1:2]
+            det.close()
+    finally:
+        os.environ.pop("RF_FORCE_SCATTER", None)
+
+
 def test_device_frames_unaligned_pointer_odd_step_and_roi(rfa, oracles, base_frame):
     """Device-resident frames exactly as the stem's descriptor path sees them: a frame pointer that is not dword aligned, a row
     step that is not a multiple of 4, and an ROI of a larger device image (step > cols*3, last row ends before the allocation

@@ -244,6 +244,25 @@ def test_bench_self_launches_n_ranks_and_gathers_results():
     assert bad.returncode != 0 and "WORLD_SIZE=3" in (bad.stderr + bad.stdout)
 
 
+@pytest.mark.parametrize("gpus,gbatch", [(8, 256), (3, 10)])
+def test_bench_strong_mode_shards_one_global_batch(gpus, gbatch):
+    """BASELINE.json configs[4] as stated: ONE batch of 256 images per step split over 8 GPUs (`--global-batch 256 --gpus 8`),
+    "scaling": "strong".  Rank r takes shard_range(G, r, N) images of every step (ragged when N does not divide G: 10 over 3 =
+    4 + 4 + 2); every image's record must come back through the gather exactly once.  --dry: stub engine, gloo."""
+    import json
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--dry", "--global-batch", str(gbatch),
+                          "--steps", "12", "--warmup", "2"], capture_output=True, text=True, env=env, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    j = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+    assert j["n_gpus"] == gpus and j["scaling"] == "strong" and j["config"]["global_batch"] == gbatch
+    assert j["result_gather"]["records_gathered"] == j["result_gather"]["expected"] == gbatch * j["steps"]
+    assert abs(j["images_per_sec"] * j["timed_seconds"] - gbatch * j["steps"]) < 1e-3 * gbatch * j["steps"]
+    assert j["regions"]["n"] == 3 and j["regions"]["min"] <= j["value"] <= j["regions"]["max"]
+
+
 def test_rfw_reader_rejects_corrupt_files(built_lib, tmp_path):
     """Dims / counts inside a .rfw are checked against the bytes that are left before anything is sized by them."""
     import struct

@@ -20,6 +20,8 @@ def descriptor(mangled: str) -> str:
     if m:
         cin, cout, th, tw, up = m.groups()
         return f"conv3x3<{cin},{cout},{th}x{tw}{',up' if up == '1' else ''}>"
+    if "dwpw2_kernel" in mangled:
+        return "dwpw2<32,32,64>"
     for k in ("stem2", "stem", "conv0", "head", "nms", "resize_area", "resize_bilinear"):
         if k + "_kernel" in mangled:
             return k
