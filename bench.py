@@ -359,11 +359,24 @@ def main() -> int:
             det.detect_device(ptrs, rows, cols, args.threshold)
             lat.append(time.perf_counter() - t)
         extra["sync_call_ms"] = float(np.median(lat) * 1e3)
+        # the same call without the Python binding's per-call work (argument arrays and result objects built once): what a C / C++
+        # caller of the C ABI sees
+        import ctypes as C
+        from retinaface_amd._lib import rf_face
+        pa, ra, ca = (C.c_void_p * B)(*ptrs), (C.c_int * B)(*rows), (C.c_int * B)(*cols)
+        sa = (C.c_int * B)(*[3 * x for x in cols])
+        outb, cnt = (rf_face * (B * det.max_detections))(), (C.c_int * B)()
+        lat_c = []
+        for _ in range(200):
+            t = time.perf_counter()
+            det._lib.rf_detect_batch_device(det._h, pa, ra, ca, sa, B, C.c_float(args.threshold), outb, det.max_detections, cnt)
+            lat_c.append(time.perf_counter() - t)
+        extra["sync_call_ms_c_abi"] = float(np.median(lat_c[20:]) * 1e3)
         # the reference's metric point as the reference measures it: ONE synchronous detectBatchImages of B device-resident
         # frames at a time (RetinaFace.cpp:757 -> :920), nothing in flight besides it
         nf = sum(len(r) for r in det.detect_device(ptrs, rows, cols, args.threshold))
-        extra["sync_batch"] = {"batch": B, "ms_per_call": extra["sync_call_ms"], "images_per_sec": B / float(np.median(lat)),
-                               "faces_per_sec": nf / float(np.median(lat)),
+        extra["sync_batch"] = {"batch": B, "ms_per_call": extra["sync_call_ms_c_abi"], "ms_per_call_python_binding": extra["sync_call_ms"],
+                               "images_per_sec": B / (extra["sync_call_ms_c_abi"] * 1e-3), "faces_per_sec": nf / (extra["sync_call_ms_c_abi"] * 1e-3),
                                "note": "one synchronous rf_detect_batch_device call at a time (no pipelining, no coalescing); `value` is the pipelined rate"}
         if args.host_seconds > 0:
             extra["host_frames"] = host_frames(det, frames_np, args, slots, B, run, rank)
@@ -665,6 +678,7 @@ def baseline_config(args) -> str:
 
 _CPU_WORKER = r"""
 import os, sys, time, json
+os.sched_setaffinity(0, {cpus!r})          # one physical core per thread, disjoint between workers (set before OpenMP starts)
 sys.path.insert(0, {root!r})
 import numpy as np, torch
 torch.set_num_threads({threads})
@@ -689,12 +703,27 @@ def cpu_all_cores(args, threads: int, ncpu: int, seconds: float):
     """The same oracle as `nproc` independent processes x `threads` torch threads, started together: what the host's cores give
     when the reference's single-process loop is simply run several times (SURVEY.md 8d "core count stated")."""
     threads = min(threads, 8)                       # beyond ~8 threads per process oneDNN loses on these small convolutions
-    nproc = max(1, min(32, ncpu // (2 * threads)))  # one thread per physical core (2 hardware threads each)
-    src = _CPU_WORKER.format(root=ROOT, threads=threads, model=args.model, h=args.height, w=args.width, thr=args.threshold,
-                             seconds=seconds)
+    # one logical CPU per physical core (first hardware thread of every sibling set this process may run on), handed out in
+    # disjoint blocks of `threads`: round 2 left placement to the scheduler and 32 x 4 threads gave 2.5x one process -- the
+    # workers were migrating and sharing cores
+    allowed = sorted(os.sched_getaffinity(0))
+    cores, seen = [], set()
+    for c in allowed:
+        try:
+            sib = open(f"/sys/devices/system/cpu/cpu{c}/topology/thread_siblings_list").read().strip()
+        except OSError:
+            sib = str(c)
+        if sib not in seen:
+            seen.add(sib)
+            cores.append(c)
+    nproc = max(1, min(32, len(cores) // threads))
     env = dict(os.environ, OMP_NUM_THREADS=str(threads), HIP_VISIBLE_DEVICES="")
-    procs = [subprocess.Popen([sys.executable, "-c", src], stdin=subprocess.PIPE, stdout=subprocess.PIPE, text=True, env=env)
-             for _ in range(nproc)]
+    load_before = os.getloadavg()[0]
+    procs = []
+    for k in range(nproc):
+        src = _CPU_WORKER.format(root=ROOT, threads=threads, model=args.model, h=args.height, w=args.width, thr=args.threshold,
+                                 seconds=seconds, cpus=set(cores[k * threads:(k + 1) * threads]))
+        procs.append(subprocess.Popen([sys.executable, "-c", src], stdin=subprocess.PIPE, stdout=subprocess.PIPE, text=True, env=env))
     try:
         for p in procs:
             assert p.stdout.readline().strip() == "ready"
@@ -710,8 +739,10 @@ def cpu_all_cores(args, threads: int, ncpu: int, seconds: float):
                 pass
             p.wait(timeout=60)
     dt = max(r["dt"] for r in res)
-    return {"processes": nproc, "threads_per_process": threads, "cores": nproc * threads,
-            "images_per_sec": sum(r["n"] for r in res) / dt, "value": sum(r["f"] for r in res) / dt, "unit": "faces/s"}
+    return {"processes": nproc, "threads_per_process": threads, "cores": nproc * threads, "physical_cores_available": len(cores),
+            "pinned": "each worker to its own block of physical cores (sched_setaffinity)", "loadavg_1min_before": load_before,
+            "images_per_sec": sum(r["n"] for r in res) / dt, "value": sum(r["f"] for r in res) / dt, "unit": "faces/s",
+            "per_process_images_per_sec": [round(r["n"] / r["dt"], 2) for r in res]}
 
 
 def cpu_baseline(frames_np, args, det):

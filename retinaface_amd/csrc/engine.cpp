@@ -2,7 +2,9 @@
 #include "engine.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
+#include <cstdio>
 #include <cstring>
 #include <set>
 #include <thread>
@@ -21,6 +23,22 @@ namespace rf {
     } while (0)
 
 namespace {
+
+// RF_HOST_TRACE=1 (probe): where the HOST time of a call goes -- per-stage wall-clock sums, printed when the engine is destroyed
+struct HostTrace {
+    bool on = getenv("RF_HOST_TRACE") != nullptr;
+    double sum[8] = {};
+    long n[8] = {};
+    static double now() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+    void add(int k, double t0) { if (on) { sum[k] += now() - t0; n[k]++; } }
+    void report(const char *tag) const {
+        if (!on) return;
+        static const char *names[8] = {"detect() total", "submit: checks + table fill", "launch: table H2D enqueue", "launch: graph / kernel launches",
+                                       "launch: event record", "harvest: event synchronize", "harvest: copy records", "wait: copy out"};
+        for (int k = 0; k < 8; k++)
+            if (n[k]) fprintf(stderr, "[rf host trace %s] %-32s %9.2f us avg over %ld\n", tag, names[k], sum[k] / n[k], n[k]);
+    }
+};
 
 // The HIP current device is per host thread and defaults to 0: every entry point binds the calling thread to the engine's
 // device for the duration of the call and puts the caller's device back (rf_options.device may differ from it, and the
@@ -159,6 +177,7 @@ public:
 
     ~EngineImpl() override {
         DeviceGuard guard(device_);
+        trace_.report(sizeof(T) == 1 ? "int8" : sizeof(T) == 2 ? "fp16" : "fp32");
         for (auto &r : registered_) if (r.owned) (void)hipHostUnregister((void *)r.base);
         for (auto &l : lanes_) free_lane(l);
         for (void *p : dev_allocs_) (void)hipFree(p);
@@ -173,6 +192,8 @@ public:
         if (n < 0 || (n > 0 && (!frames || !rows || !cols || !counts))) throw ArgError("null argument");
         if (cap_per_image < 0 || (cap_per_image > 0 && !out)) throw ArgError("out is null");
         DeviceGuard guard(device_);
+        const double t_detect = trace_.on ? HostTrace::now() : 0.0;
+        struct AtExit { HostTrace &t; double t0; ~AtExit() { t.add(0, t0); } } at_exit{trace_, t_detect};
         *truncated = false;
         // every frame is checked before the first chunk is launched: a bad frame in a later chunk must not leave earlier
         // chunks in flight with nobody waiting for them
@@ -872,7 +893,11 @@ private:
     // copy a finished super-batch's results out of the lane's pinned block into its tickets, so the lane can be reused
     void harvest(Lane &L) {
         if (!L.busy) return;
+        double tt = trace_.on ? HostTrace::now() : 0.0;
         RF_HIP(hipEventSynchronize(L.done));
+        trace_.add(5, tt);
+        tt = trace_.on ? HostTrace::now() : 0.0;
+        struct AtExit { HostTrace &t; double t0; ~AtExit() { t.add(6, t0); } } at_exit{trace_, tt};
         const int mb = cap_images_;
         for (int id : L.tickets) {
             Ticket &t = tickets_[id];
@@ -907,7 +932,10 @@ private:
             for (int i = 0; i < n; i++)
                 s.h_frames[mb + i] = FrameDesc{s.d_canvas + (size_t)i * net_h_ * net_w_ * 3, net_h_, net_w_, net_w_ * 3, 0};
         }
+        double tt = trace_.on ? HostTrace::now() : 0.0;
         RF_HIP(hipMemcpyAsync(s.d_frames, s.h_frames, s.table_bytes, hipMemcpyHostToDevice, s.stream));
+        trace_.add(2, tt);
+        tt = trace_.on ? HostTrace::now() : 0.0;
         if (s.need_resize) {
             if (opt_.resize_bilinear) launch_resize_bilinear(s.stream, s.d_frames, s.d_canvas, n, net_h_, net_w_);
             else launch_resize_area(s.stream, s.d_frames, s.d_canvas, n, net_h_, net_w_);
@@ -926,8 +954,11 @@ private:
             s.warmed.insert(n);    // first run of a batch size is always eager: function attributes get set outside capture
         }
         RF_HIP(hipGetLastError());
+        trace_.add(3, tt);
+        tt = trace_.on ? HostTrace::now() : 0.0;
         if (eager_timed) RF_HIP(hipEventRecord(s.time_ev[3], s.stream));
         RF_HIP(hipEventRecord(s.done, s.stream));
+        trace_.add(4, tt);
         s.busy = true;
         for (int id : s.tickets) tickets_[id].state = Ticket::LAUNCHED;
     }
@@ -1071,6 +1102,7 @@ private:
 
     // ------------------------------------------------------------------------------------------ state
     int device_ = 0;
+    HostTrace trace_;
     bool check_residency_ = false, force_scatter_ = false;
     long scattered_frames_ = 0;               // device frames that arrived from another device (peer copies issued)
     std::vector<float> ratios_;                // the network preset's anchor ratios (empty: a preset without anchors)

@@ -135,12 +135,12 @@ def test_synthetic_batch8_against_golden(rfa, stem, prec):
             assert abs(ncand[i] - int(g[f"ncand{tag}_{i}"])) <= TOL[prec]["ncand"]
 
 
-@pytest.mark.parametrize("knob", ["RF_STEM2=0", "RF_STEM2=2", "RF_STEM2=3", "RF_DWPW2=0", "RF_CONV3=0"])
+@pytest.mark.parametrize("knob", ["RF_STEM2=0", "RF_STEM2=2", "RF_STEM2=3", "RF_DWPW2=0", "RF_CONV3=0", "RF_STEM2_DC=0"])
 def test_probe_knob_kernel_variants_stay_correct(rfa, knob):
     """The measured-and-rejected kernel variants DESIGN.md cites stay selectable (RF_* probe knobs, read once per process): each
     is held to the same fp16 parity bar as the default path, in a subprocess so that the knob is seen at library start-up.
     RF_STEM2=0: K_a' stem + separate dwpw<16,32,s2>; 2: 7x16 tiles, 8 waves; 3: fp16 patch; RF_DWPW2=0: blocks 2 and 3 as two
-    launches; RF_CONV3=0: 3x3 convs without the bank-row padding."""
+    launches; RF_CONV3=0: 3x3 convs without the bank-row padding; RF_STEM2_DC=0: stem2's LDS tiles without the DC centring."""
     code = (
         "import sys, json; sys.path.insert(0, %r)\n"
         "import retinaface_amd\n"
@@ -360,6 +360,42 @@ def test_int8_engine_is_bit_exact_against_the_integer_oracle(rfa, nets, oracles,
     res = big.detectBatchImages(pair, 0.5)
     for i in range(2):
         _assert_int8_image_bit_exact(big, q, i, (896, 1280), 0.5, res[i])
+
+
+def test_calibration_tool_end_to_end(rfa, nets, oracles, tmp_path):
+    """SURVEY 8f rank 3, the INT8 calibration-table generator, as a whole: tools/calibrate_int8.py (per-channel, amax rule, a small
+    built-in calibration set that shows only fixture faces 0 / 2 / 4) collects activations from the fp32 HIP engine and writes a
+    table in the reference's text format; the table goes into a model container, the int8 engine built from it must (a) be
+    BIT-exact against the integer oracle built from the same table and (b) find the fp32 oracle's faces on held-out frames
+    (faces 1 / 3 / 5) at the int8 bar.  (TensorRT's calibrator is closed source: the tool's thresholds themselves stay
+    "parity unpinned"; what is pinned is that a table it writes drives the int8 path correctly.)"""
+    from oracle.caffe_io import read_int8_table, read_rfw, write_rfw
+    from oracle.int8_forward import Int8Net
+    from retinaface_amd.frames import synth_frames
+    table = tmp_path / "mnet25.table.int8"
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "calibrate_int8.py"), "--model", "mnet25", "--per-channel", "--rule", "amax",
+                          "--frames", "12", "--config", "91", "--out", str(table)], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    scales = read_int8_table(str(table))
+    assert "mobilenet0_relu2_fwd" in scales and "mobilenet0_relu2_fwd#15" in scales and "_plus1#63" in scales and len(scales) > 1000
+    net = read_rfw(os.path.join(ASSETS, "mnet25.rfw"))
+    net.int8_scales = scales
+    write_rfw(net, str(tmp_path / "mnet25.rfw"))
+    det = rfa.RetinaFace(str(tmp_path), "net3", 0.4, precision=INT8, net_hw=(448, 448), model_stem="mnet25", max_batch=8, keep_outputs=True,
+                         use_graph=False, plan_cache=False)
+    q = Int8Net(net)
+    held = synth_frames(448, 448, 8, config=305, faces=[1, 3, 5])
+    res = det.detectBatchImages(held, 0.5)
+    for i in range(8):
+        _assert_int8_image_bit_exact(det, q, i, (448, 448), 0.5, res[i])
+    refs = []
+    for f in held:
+        o = oracles["mnet25"].detect(f, 0.5, 0.4, net_hw=(448, 448))
+        refs.append([(d.rect, d.score, d.anchor_index) for d in o.detections])
+    same, worst, agree, ds = _int8_stats(res, refs)
+    print(f"calibration tool, 12 frames: same face count {same}, worst IoU {worst:.3f}, anchor agreement {agree:.2f}, max |dscore| {ds:.3f}")
+    assert same and worst >= 0.85 and ds <= 0.05, (same, worst, agree, ds)
+    det.close()
 
 
 def test_int8_integer_blend_is_bit_identical_to_the_fp32_blend(rfa):
