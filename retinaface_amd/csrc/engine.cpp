@@ -707,6 +707,10 @@ private:
         struct Level3 { Conv3Params<T> p[3]; };
         Level3 lv_a, lv_b, lv_c;
         OpInfo op_a, op_b, op_c, op_h;
+        // fp16 / int8: conv_b and conv_c of the context module are ONE launch (ssh_tail_kernel); context_conv3_1 stays in LDS
+        bool fuse_tail = false;
+        if constexpr (sizeof(T) <= 2) fuse_tail = ssh_tail_variant() != 0;
+        struct Tail3 { SshTailParams<T> p[3]; } tl;
         struct HeadLevels { HeadParams<T> p[3]; } hl;
         int anchor_off = 0;
         for (int i = 0; i < 3; i++) {
@@ -715,7 +719,7 @@ private:
             std::string pre = "rf_c" + std::to_string(3 - i) + "_det_";
             T *cat = act(pre + "concat_relu", fh, fw, 64);
             T *ctx1 = act(pre + "context_conv1_relu", fh, fw, 16);
-            T *ctx31 = act(pre + "context_conv3_1_relu", fh, fw, 16);
+            T *ctx31 = fuse_tail ? nullptr : act(pre + "context_conv3_1_relu", fh, fw, 16);
             auto fill = [&](Conv3Params<T> &p, OpInfo &op, const FoldedConv &f, const GemmW &gw, const T *in, int cin, T *o0,
                             int ld0, int off0, int n0, T *o1, int ld1, int off1, int nlayers) {
                 p.in = in; p.in_ld = cin; p.in_off = 0; p.up = nullptr;
@@ -730,6 +734,12 @@ private:
             fill(lv_a.p[i], op_a, m.conv_a, ssh_w_[i][0], feat[i], 64, cat, 64, 0, 32, ctx1, 16, 0, 2);
             fill(lv_b.p[i], op_b, m.conv_b, ssh_w_[i][1], ctx1, 16, cat, 64, 32, 16, ctx31, 16, 0, 2);
             fill(lv_c.p[i], op_c, m.conv_c, ssh_w_[i][2], ctx31, 16, cat, 64, 48, 16, nullptr, 0, 0, 1);
+            if constexpr (sizeof(T) <= 2) {
+                SshTailParams<T> &tp = tl.p[i];
+                tp.in = ctx1; tp.cat = cat; tp.n = 0; tp.h = fh; tp.w_ = fw;
+                tp.wb = arena_.template ptr<T>(ssh_w_[i][1].w); tp.bb = arena_.template ptr<float>(ssh_w_[i][1].b); tp.mb = mult_ptr(ssh_w_[i][1]);
+                tp.wc = arena_.template ptr<T>(ssh_w_[i][2].w); tp.bc = arena_.template ptr<float>(ssh_w_[i][2].b); tp.mc = mult_ptr(ssh_w_[i][2]);
+            }
             HeadParams<T> &hp = hl.p[i];
             hp.in = cat; hp.w = arena_.template ptr<T>(ssh_w_[i][3].w); hp.b = arena_.template ptr<float>(ssh_w_[i][3].b);
             hp.m = mult_ptr(ssh_w_[i][3]);
@@ -759,8 +769,21 @@ private:
         op_c.kernel = "conv3x3<16,16,8x8>";
         op_h.kernel = "head";
         L.ops.push_back(op_a);
-        L.ops.push_back(op_b);
-        L.ops.push_back(op_c);
+        if (fuse_tail) {
+            if constexpr (sizeof(T) <= 2) {
+                OpInfo op_t;
+                op_t.name = op_b.name + " | " + op_c.name;
+                op_t.kernel = "ssh_tail<16,32,16>";
+                op_t.alg_elems_in = op_b.alg_elems_in + op_c.alg_elems_in;       // layer-wise accounting, fused or not
+                op_t.alg_elems_out = op_b.alg_elems_out + op_c.alg_elems_out;
+                op_t.macs = op_b.macs + op_c.macs;
+                op_t.launch = [tl](hipStream_t s, int n) { Tail3 q = tl; for (auto &p : q.p) p.n = n; launch_ssh_tail<T>(s, q.p, 3); };
+                L.ops.push_back(op_t);
+            }
+        } else {
+            L.ops.push_back(op_b);
+            L.ops.push_back(op_c);
+        }
         L.first_post = L.ops.size();
         op_h.name += " +softmax+decode";
         op_h.launch = [hl](hipStream_t s, int n) { HeadLevels q = hl; for (auto &p : q.p) p.n = n; launch_head<T>(s, q.p, 3); };

@@ -125,6 +125,19 @@ struct Conv3Params {
 // `levels`: 1..3 parameter sets of the same (cin, cout) covered by ONE launch (the FPN levels of the SSH module)
 template <typename T> void launch_conv3x3(hipStream_t s, const Conv3Params<T> *levels, int nlevels);
 
+// ---- K_c2 (fp16 / int8 engines): the tail of the SSH context module -- conv_b (16 -> 32: context_conv2 || context_conv3_1) and conv_c
+//      (16 -> 16: context_conv3_2 on context_conv3_1) -- in one launch; context_conv3_1 never leaves LDS; writes concat[32:64].
+template <typename T>
+struct SshTailParams {
+    const T *in;                                   // context_conv1 output [n][h][w][16]
+    const T *wb; const float *bb; const float *mb; // conv_b packed (k = 144), bias [32], int8 multipliers [32] or nullptr
+    const T *wc; const float *bc; const float *mc; // conv_c packed, bias [16], multipliers [16] or nullptr
+    T *cat;                                        // concat tensor [n][h][w][64]: channels 32..63 are written
+    int n, h, w_;
+};
+template <typename T> void launch_ssh_tail(hipStream_t s, const SshTailParams<T> *levels, int nlevels);   // 1..3 FPN levels per launch
+int ssh_tail_variant();     // probe knob RF_SSHTAIL: 0 = off (two conv3x3<16,*> launches)
+
 // ---- K_d: the three 1x1 heads of one stride as one 64->32 GEMM + 2-class softmax + anchor decode +
 //      bbox / landmark regression + clip + threshold compaction (RetinaFace.cpp:666-724, 378-432, 179-199).
 template <typename T>

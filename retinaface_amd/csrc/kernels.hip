@@ -2226,6 +2226,255 @@ template TileInfo conv3x3_tile_info<float>(int, int, int, int);
 template TileInfo conv3x3_tile_info<int8_t>(int, int, int, int);
 
 // =============================================================================================
+// K_c2  the tail of the SSH context module in ONE launch (fp16 / int8 engines):
+//       conv_b = context_conv2 (16 ch, -> concat[32:48]) || context_conv3_1 (16 ch, + ReLU)      3x3, 16 -> 32   (prototxt :1285-1380 etc.)
+//       conv_c = context_conv3_2 (16 ch, -> concat[48:64]) on context_conv3_1's output            3x3, 16 -> 16
+//   As two conv3x3<16,*> launches these were the only kernels of the path bound by scalar bookkeeping (SQ: SALU / VALU 1.7-2.4:
+//   ~95 SALU per 8x8 tile for the tile walk, three per-image descriptors and the level select, against ~30 VALU + 5 MFMA), and the
+//   16-channel context_conv3_1 map made an HBM round trip in between.  Here a workgroup computes conv_b on the 10 x 10 region its
+//   8 x 8 tile of conv_c needs (recompute 1.56x of a 144-MAC-per-output conv: nothing), keeps context_conv3_1 in LDS (zeros
+//   outside the map = conv_c's padding), and writes concat[32:64] as one 32-channel run per pixel.  Per tile: 1 staged halo
+//   (12 x 12 x 16 ch), 3 barriers, 14 + 4 (pixel tile, channel tile) GEMM units of KCH MFMAs, one store.  All three FPN levels in
+//   one grid, persistent + prefetching like K_c.
+// =============================================================================================
+template <typename T> struct SshTailCfg {
+    typedef Mma<T> M;
+    static constexpr int VEC = Vec<T>::N;
+    static constexpr int TH = 8, TW = 8, P = TH * TW;                  // conv_c outputs per tile
+    static constexpr int R1 = TW + 2, N1 = (TH + 2) * R1, PT1 = (N1 + 15) / 16;      // conv_b region 10 x 10 = 100 px -> 7 MFMA pixel tiles
+    static constexpr int HC = TW + 4, NH = (TH + 4) * HC;              // context_conv1 halo 12 x 12
+    static constexpr int LDI = lds_row<T>(16);                         // pixel pitch of the 16-channel tiles (32 bytes)
+    static constexpr int LDO = lds_row<T>(32);                         // out tile: 32 channels per pixel
+    static constexpr int KTOT = 9 * 16, KCH = (KTOT + M::K - 1) / M::K;
+    static constexpr int CPV = 16 / VEC;                               // 16-byte items per halo pixel
+    static constexpr int STAGE_ITEMS = NH * CPV, NPF = (STAGE_ITEMS + kThreads - 1) / kThreads;
+    static constexpr size_t IN_BYTES = sizeof(T) * (size_t)(NH * LDI), MID_BYTES = sizeof(T) * (size_t)(PT1 * 16 * LDI),
+                            OUT_BYTES = sizeof(T) * (size_t)(P * LDO);
+    static constexpr size_t LDS_BYTES = IN_BYTES + MID_BYTES + OUT_BYTES;
+    static_assert(IN_BYTES % 16 == 0 && MID_BYTES % 16 == 0, "LDS carve must stay 16-byte aligned");
+};
+
+template <typename T>
+struct SshTailLevel {
+    const T *in; const T *wb; const float *bb; const float *mb; const T *wc; const float *bc; const float *mc; T *cat;
+    int h, w_, tiles_x, tiles_y, ntiles, gb_begin, gsz;
+};
+template <typename T> struct SshTailArgs { SshTailLevel<T> lv[3]; };
+
+// 4 consecutive output channels of one pixel as packed storage bits (what store_acc writes): fp16 -> 8 bytes, int8 -> 4 bytes in .x
+template <typename T, typename ACC>
+__device__ __forceinline__ uint2 pack_acc(f32x4 mult, f32x4 bv, ACC acc) {
+    uint2 h = {0u, 0u};
+    if constexpr (sizeof(T) == 2) {
+        h.x = pack_f16((float)acc[0], (float)acc[1], true);
+        h.y = pack_f16((float)acc[2], (float)acc[3], true);
+    } else {
+        static_assert(sizeof(T) == 1, "fp16 / int8 engines only");
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+            h.x = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_rintf(__builtin_amdgcn_fmed3f(fmaf((float)acc[r], mult[r], bv[r]), 0.f, 127.f)), r, h.x);
+    }
+    return h;
+}
+template <typename T> __device__ __forceinline__ void store_packed4(T *dst, uint2 h) {
+    if constexpr (sizeof(T) == 2) *(uint2 *)dst = h;
+    else *(uint32_t *)dst = h.x;
+}
+
+template <typename T, int OCC>
+__global__ __launch_bounds__(kThreads, OCC) void ssh_tail_kernel(SshTailArgs<T> a) {
+    typedef SshTailCfg<T> C;
+    typedef typename Vec<T>::type V;
+    typedef Mma<T> M;
+    typedef typename M::Frag Frag;
+    constexpr int VEC = C::VEC, TH = C::TH, TW = C::TW, P = C::P, R1 = C::R1, N1 = C::N1, PT1 = C::PT1, HC = C::HC;
+    constexpr int LDI = C::LDI, LDO = C::LDO, KTOT = C::KTOT, KCH = C::KCH, CPV = C::CPV, NPF = C::NPF;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    T *s_in = (T *)smem;                                          // context_conv1 halo, 12 x 12 px
+    T *s_mid = (T *)(smem + C::IN_BYTES);                         // context_conv3_1 region, 10 x 10 px (zeros outside the map)
+    T *s_out = (T *)(smem + C::IN_BYTES + C::MID_BYTES);          // concat[32:64] of the 8 x 8 tile
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int gbid = xcd_remap(blockIdx.x, gridDim.x);
+    const int lvl = (gbid >= a.lv[1].gb_begin ? 1 : 0) + (gbid >= a.lv[2].gb_begin ? 1 : 0);
+    const SshTailLevel<T> &L = a.lv[lvl];
+    const int first = gbid - L.gb_begin, G = L.gsz, ntiles = L.ntiles;
+    const int lh = L.h, lw = L.w_;
+    const int kg = lane >> 4;
+
+    // ---- once per workgroup: the wave's weight fragments (conv_b: channel tile wave & 1; conv_c: its one tile), biases
+    const int ctb = wave & 1, ptb0 = wave >> 1;                   // conv_b units: channel tile ctb, pixel tiles ptb0 + 2 i
+    Frag wb[1][KCH], wc[1][KCH];
+    {
+        const Frag *sb = (const Frag *)L.wb + (size_t)ctb * KCH * 64 + lane, *sc = (const Frag *)L.wc + lane;
+#pragma unroll
+        for (int kc = 0; kc < KCH; kc++) { wb[0][kc] = sb[kc * 64]; wc[0][kc] = sc[kc * 64]; }
+    }
+    const f32x4 bias_b = *(const f32x4 *)(L.bb + acc_cout(ctb, lane, 0)), mult_b = load_mult(L.mb, acc_cout(ctb, lane, 0));
+    const f32x4 bias_c = *(const f32x4 *)(L.bc + acc_cout(0, lane, 0)), mult_c = load_mult(L.mc, acc_cout(0, lane, 0));
+
+    // per-lane constants: conv_b pixels (region index, clamped for the tail lanes of the last pixel tile), conv_c pixel
+    int pb1[4], ryx1[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int pt = ptb0 + 2 * i;
+        int p = pt * 16 + (lane & 15);
+        const bool real = pt < PT1 && p < N1;
+        p = real ? p : N1 - 1;
+        const int ry = p / R1, rx = p % R1;
+        pb1[i] = (ry * HC + rx) * LDI;
+        ryx1[i] = real ? (ry << 8 | rx) : -1;
+    }
+    const int p2 = wave * 16 + (lane & 15);                       // conv_c: pixel tile = wave
+    const int pb2 = ((p2 / TW) * R1 + p2 % TW) * LDI;
+
+    // ---- halo of a tile -> registers (unconditional buffer loads; rows by the range check, columns by a poisoned offset)
+    V pre[NPF];
+    int koff[NPF], kdx[NPF];
+#pragma unroll
+    for (int k = 0; k < NPF; k++) {
+        int i = tid + k * kThreads;
+        i = i < C::STAGE_ITEMS ? i : C::STAGE_ITEMS - 1;
+        const int pix = i / CPV, cv = i % CPV;
+        koff[k] = (((pix / HC) * lw + pix % HC) * 16 + cv * VEC) * (int)sizeof(T);
+        kdx[k] = pix % HC;
+    }
+    const unsigned in_img_bytes = (unsigned)(lh * lw * 16) * (unsigned)sizeof(T);
+    auto fetch = [&](int tx, int ty, int img) {
+        const auto rs = image_rsrc(L.in + (size_t)img * lh * lw * 16, in_img_bytes);
+        const int iy0 = ty * TH - 2, ix0 = tx * TW - 2;
+        const int sbase = (iy0 * lw + ix0) * 16 * (int)sizeof(T);
+#pragma unroll
+        for (int k = 0; k < NPF; k++) {
+            const unsigned off = (unsigned)(ix0 + kdx[k]) < (unsigned)lw ? (unsigned)(koff[k] + sbase) : kOobOffset;
+            pre[k] = buf_load16<V>(rs, off);
+        }
+    };
+    // ---- finished tile -> concat[32:64]: one 32-channel run per pixel
+    auto store_tile = [&](int img, int oy0, int ox0) {
+        constexpr int OPV = 32 / VEC;
+        const auto ro = image_rsrc(L.cat + (size_t)img * lh * lw * 64 + 32, (unsigned)(lh * lw * 64 - 32) * (unsigned)sizeof(T));
+        const int pbase = oy0 * lw + ox0;
+        for (int i = tid; i < P * OPV; i += kThreads) {
+            const int p = i / OPV, cv = i % OPV;
+            const int py = p / TW, px = p % TW;
+            const unsigned off = ox0 + px < lw ? (unsigned)(((pbase + py * lw + px) * 64 + cv * VEC) * (int)sizeof(T)) : kOobOffset;
+            buf_store16(ro, off, *(const V *)(s_out + p * LDO + cv * VEC));
+        }
+    };
+    const TileStep step(G, L.tiles_x, L.tiles_y);
+    TileCoord cur(first, L.tiles_x, L.tiles_y), nxt = cur;
+    step.advance(nxt);
+    if (first < ntiles) fetch(cur.tx, cur.ty, cur.img);
+    __builtin_amdgcn_s_waitcnt(0x0F70);       // vmcnt(0): the once-per-workgroup loads have landed before the tile loop
+
+    auto xf_tap = [&](int kc, int rowp) -> int {       // LDS element offset of this lane's K slice in chunk kc, or -1 past the 9 taps
+        const int kb = kc * M::K + kg * M::KPL;        // k = tap * 16 + c
+        const int tap = kb / 16, c = kb % 16;
+        return kb < KTOT ? (tap / 3) * rowp + (tap % 3) * LDI + c : -1;
+    };
+
+    int p_img = -1, p_oy0 = 0, p_ox0 = 0;
+    for (int t = first; t < ntiles; t += G) {
+        const int oy0 = cur.ty * TH, ox0 = cur.tx * TW, img = cur.img;
+#pragma unroll
+        for (int k = 0; k < NPF; k++) {
+            const int i = tid + k * kThreads;
+            if (i < C::STAGE_ITEMS) *(V *)(s_in + (i / CPV) * LDI + (i % CPV) * VEC) = pre[k];
+        }
+        if (t + G < ntiles) fetch(nxt.tx, nxt.ty, nxt.img);
+        cur = nxt;
+        step.advance(nxt);
+        if (p_img >= 0) store_tile(p_img, p_oy0, p_ox0);
+        p_img = img; p_oy0 = oy0; p_ox0 = ox0;
+        __syncthreads();
+
+        // ---- conv_b on the 10 x 10 region: this wave's channel tile x its (up to) 4 pixel tiles, two at a time (four accumulators
+        //      + their B-fragment queue pushed the kernel over the 128-VGPR budget of 4 workgroups per CU)
+#pragma unroll
+        for (int half = 0; half < 2; half++) {
+            typename M::Acc acc[1][2];
+#pragma unroll
+            for (int j = 0; j < 2; j++) acc[0][j] = acc_init<T>(bias_b);
+            gemm_stationary<T, 1, 2, KCH, 2>(acc, wb, [&](int j, int kc) -> Frag {
+                const int o = xf_tap(kc, HC * LDI);
+                return o >= 0 ? *(const Frag *)(s_in + pb1[2 * half + j] + o) : M::zero();
+            });
+#pragma unroll
+            for (int jj = 0; jj < 2; jj++) {
+                const int j = 2 * half + jj;
+                if (ryx1[j] < 0) continue;
+                const int ry = ryx1[j] >> 8, rx = ryx1[j] & 0xff;
+                const uint2 h = pack_acc<T>(mult_b, bias_b, acc[0][jj]);
+                if (ctb == 0) {
+                    // context_conv2 -> concat[32:48]: only the tile's own 8 x 8 pixels
+                    if ((unsigned)(ry - 1) < (unsigned)TH && (unsigned)(rx - 1) < (unsigned)TW)
+                        store_packed4<T>(s_out + ((ry - 1) * TW + rx - 1) * LDO + kg * 4, h);
+                } else {
+                    // context_conv3_1 on the whole region; outside the map it is conv_c's ZERO padding
+                    const int y = oy0 - 1 + ry, x = ox0 - 1 + rx;
+                    const bool inside = (unsigned)y < (unsigned)lh && (unsigned)x < (unsigned)lw;
+                    const uint2 z = {0u, 0u};
+                    store_packed4<T>(s_mid + (ry * R1 + rx) * LDI + kg * 4, inside ? h : z);
+                }
+            }
+        }
+        __syncthreads();
+
+        // ---- conv_c on the 8 x 8 tile: pixel tile = wave
+        {
+            typename M::Acc acc[1][1];
+            acc[0][0] = acc_init<T>(bias_c);
+            gemm_stationary<T, 1, 1, KCH, 2>(acc, wc, [&](int, int kc) -> Frag {
+                const int o = xf_tap(kc, R1 * LDI);
+                return o >= 0 ? *(const Frag *)(s_mid + pb2 + o) : M::zero();
+            });
+            store_packed4<T>(s_out + p2 * LDO + 16 + kg * 4, pack_acc<T>(mult_c, bias_c, acc[0][0]));
+        }
+        __syncthreads();
+    }
+    if (p_img >= 0) store_tile(p_img, p_oy0, p_ox0);
+}
+
+int ssh_tail_variant() {
+    static int v = -1;
+    if (v < 0) { const char *e = getenv("RF_SSHTAIL"); v = e ? atoi(e) : 1; }      // probe knob: 0 = two conv3x3<16,*> launches, 2 = 3 workgroups per CU
+    return v;
+}
+
+template <typename T> void launch_ssh_tail(hipStream_t s, const SshTailParams<T> *levels, int nlevels) {
+    typedef SshTailCfg<T> C;
+    if (nlevels < 1 || nlevels > 3) throw LaunchUnsupported("ssh tail: 1..3 levels per launch");
+    // RF_SSHTAIL=2 (probe knob): the 3-workgroups-per-CU build (155 VGPRs, no spill) instead of the 4-per-CU one (128 VGPRs)
+    const bool occ3 = ssh_tail_variant() == 2;
+    auto kern = occ3 ? ssh_tail_kernel<T, 3> : ssh_tail_kernel<T, 4>;
+    static std::atomic<int> resident_cache[2][kMaxDevices] = {};
+    const int resident = kernel_residency(resident_cache[occ3 ? 1 : 0], kern, C::LDS_BYTES);
+    SshTailArgs<T> a;
+    int total = 0;
+    for (int l = 0; l < 3; l++) {
+        const SshTailParams<T> &q = levels[l < nlevels ? l : nlevels - 1];
+        const int tiles_x = (q.w_ + C::TW - 1) / C::TW, tiles_y = (q.h + C::TH - 1) / C::TH;
+        a.lv[l] = SshTailLevel<T>{q.in, q.wb, q.bb, q.mb, q.wc, q.bc, q.mc, q.cat, q.h, q.w_, tiles_x, tiles_y, q.n * tiles_x * tiles_y, 0, 1};
+        if (l < nlevels) total += q.n * tiles_x * tiles_y;
+    }
+    if (total == 0) return;
+    const int want = persistent_grid(total, resident);
+    int grid = 0;
+    for (int l = 0; l < 3; l++) {
+        SshTailLevel<T> &L = a.lv[l];
+        if (l >= nlevels) { L.gb_begin = 0x7fffffff; L.gsz = 1; L.ntiles = 0; continue; }
+        long g = want == total ? L.ntiles : ((long)L.ntiles * want + total - 1) / total;
+        if (g < 1) g = 1;
+        if (g > L.ntiles) g = L.ntiles;
+        L.gb_begin = grid; L.gsz = (int)g; grid += (int)g;
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), C::LDS_BYTES, s, a);
+}
+template void launch_ssh_tail<half_t>(hipStream_t, const SshTailParams<half_t> *, int);
+template void launch_ssh_tail<int8_t>(hipStream_t, const SshTailParams<int8_t> *, int);
+
+// =============================================================================================
 // K_d  heads + softmax + decode + threshold compaction
 //   reference: 3 x 1x1 Convolution + Reshape/Softmax/Reshape on the GPU (prototxt :1434-1511), 9 D2H copies
 //   (trtretinafacenet.cpp:63-72) and the CPU loop RetinaFace.cpp:666-724 with bbox_pred (:378-398),

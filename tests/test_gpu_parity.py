@@ -76,6 +76,8 @@ def test_every_fused_op_against_the_oracle_blob(rfa, oracles, crop448, prec):
         names.remove("mobilenet0_relu0_fwd")
         names.remove("mobilenet0_relu2_fwd")
         names.remove("mobilenet0_relu6_fwd")      # conv5..conv8 are one launch too (dwpw2): relu6 stays in LDS, relu8 is its output
+        for c in (3, 2, 1):                       # the SSH tail is one launch (ssh_tail): context_conv3_1 stays in LDS; concat is checked
+            names.remove(f"rf_c{c}_det_context_conv3_1_relu")
     for n in names:
         a = det.debug_activation(n)
         r = blobs[n][0].transpose(1, 2, 0)
@@ -135,7 +137,7 @@ def test_synthetic_batch8_against_golden(rfa, stem, prec):
             assert abs(ncand[i] - int(g[f"ncand{tag}_{i}"])) <= TOL[prec]["ncand"]
 
 
-@pytest.mark.parametrize("knob", ["RF_STEM2=0", "RF_STEM2=2", "RF_STEM2=3", "RF_DWPW2=0", "RF_CONV3=0", "RF_STEM2_DC=0"])
+@pytest.mark.parametrize("knob", ["RF_STEM2=0", "RF_STEM2=2", "RF_STEM2=3", "RF_DWPW2=0", "RF_CONV3=0", "RF_STEM2_DC=0", "RF_SSHTAIL=0"])
 def test_probe_knob_kernel_variants_stay_correct(rfa, knob):
     """The measured-and-rejected kernel variants DESIGN.md cites stay selectable (RF_* probe knobs, read once per process): each
     is held to the same fp16 parity bar as the default path, in a subprocess so that the knob is seen at library start-up.
@@ -306,7 +308,7 @@ def _assert_int8_image_bit_exact(det, q, img, hw, thr, got):
             continue                     # depthwise intermediates / `_plus` tensors never leave the kernels
         assert a.shape == ref.shape and np.array_equal(a.astype(np.int8), ref), (n, img, int(np.abs(a - ref).max()), float((a != ref).mean()))
         checked += 1
-    assert checked >= 24, checked        # 12 block outputs (fewer where blocks are fused through LDS) + 5 FPN + 9 SSH tensors
+    assert checked >= 21, checked        # 12 block outputs (fewer where blocks are fused through LDS) + 5 FPN + 6..9 SSH tensors
     heads = acts["__heads__"]
     for s in HEAD_STRIDES:
         pn, bn, ln = head_names(s)
@@ -429,6 +431,8 @@ def test_int8_layers_stay_within_quantisation_noise(rfa, oracles, crop448):
         names += [f"rf_c{c}_det_context_conv1_relu", f"rf_c{c}_det_context_conv3_1_relu", f"rf_c{c}_det_concat_relu"]
     worst = {}
     for n in names:
+        if n.endswith("context_conv3_1_relu"):
+            continue                     # stays in LDS (ssh_tail); the concat tensor it feeds is checked
         a = det.debug_activation(n)
         r = blobs[n][0].transpose(1, 2, 0)
         scale = max(1.0, float(np.abs(r).max()))
