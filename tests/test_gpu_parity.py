@@ -1044,7 +1044,7 @@ def test_profile_accounting_matches_baseline_md(rfa):
     det = engine(rfa, "mnet25", FP16, (448, 448))
     frames = torch.zeros((8, 448, 448, 3), dtype=torch.uint8, device="cuda")
     prof = det.profile([frames[i].data_ptr() for i in range(8)], iters=2)
-    assert len(prof) == 2 + 9 + 2 + 3 + 1 + 1        # stem2 (conv0 + blocks 0, 1), dwpw2 (blocks 2, 3), 9 dw/pw blocks (3 with a fused lateral), 2 aggr, 3 SSH, heads, NMS
+    assert len(prof) == 2 + 9 + 2 + 2 + 1 + 1        # stem2 (conv0 + blocks 0, 1), dwpw2 (blocks 2, 3), 9 dw/pw blocks (3 with a fused lateral), 2 aggr, 2 SSH (conv_a, fused tail), heads, NMS
     assert prof[0]["kernel"] == "stem2"
     assert abs(sum(p["alg_bytes"] for p in prof) / 8 - 27615616) < 1
     assert abs(sum(p["macs"] for p in prof) / 8 - 481764864) / 481764864 < 2.5e-3     # + the 4-tap upsample MACs
