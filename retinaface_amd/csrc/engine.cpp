@@ -562,7 +562,7 @@ private:
                 T *out = act(b1.pw.out_blob, h4, w4, b1.pw.cout);
                 Stem2Params sp;
                 sp.frames = L.d_frames + mb; sp.out = out;
-                sp.w0 = arena_.template ptr<half_t>(c0_hi_); sp.b0 = arena_.template ptr<float>(c0_b_);
+                sp.w0 = arena_.template ptr<half_t>(c0_hi_); sp.b0 = arena_.template ptr<float>(WP::c0_b_mma_);
                 sp.dw0_w = arena_.template ptr<float>(stem_dw_.w); sp.dw0_b = arena_.template ptr<float>(stem_dw_.b);
                 sp.pw0_w = arena_.template ptr<half_t>(stem_pw_.w); sp.pw0_b = arena_.template ptr<float>(WP::stem2_c2_b_);
                 sp.c2_floor = arena_.template ptr<uint32_t>(WP::stem2_c2_floor_); sp.c3_floor = arena_.template ptr<uint32_t>(WP::stem2_c3_floor_);
@@ -612,7 +612,7 @@ private:
             T *out = act(blk.pw.out_blob, h, w, blk.pw.cout);
             StemParams<T> sp;
             sp.frames = L.d_frames + mb; sp.out = out;
-            sp.w0 = arena_.template ptr<half_t>(c0_hi_); sp.b0 = arena_.template ptr<float>(c0_b_);
+            sp.w0 = arena_.template ptr<half_t>(c0_hi_); sp.b0 = arena_.template ptr<float>(WP::c0_b_mma_);
             sp.dw_w = arena_.template ptr<float>(stem_dw_.w); sp.dw_b = arena_.template ptr<float>(stem_dw_.b);
             sp.pw_w = arena_.template ptr<half_t>(stem_pw_.w); sp.pw_b = arena_.template ptr<float>(stem_pw_.b);
             sp.pw_m = mult_ptr(stem_pw_);

@@ -510,14 +510,17 @@ struct StemArgs {
 
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 
-// 4 u8 in a dword -> 4 fp16, exact: (0x6400 | b) is the fp16 number 1024 + b
+// 4 u8 in a dword -> 4 fp16 holding 1024 + b, exact: (0x6400 | b) IS the fp16 number 1024 + b.  The offset is not subtracted
+// here (round 2 spent one v_pk_add_f16 per two bytes on it, 6 of the ~30 VALU instructions of a conv0 MFMA tile in kernels that
+// are VALU-issue bound): conv0 is linear, so it is folded into the bias on the host -- b0 - 1024 * sum(all 27 taps), using the
+// hi + lo fp16 weights the MFMA really multiplies by (weights.h c0_b_mma_).  That constant is right for zero-padding pixels too:
+// a padded byte is 0, arrives as 1024, and its 1024 * w is part of the sum that was taken off.  The X byte of a BGRX pixel
+// meets a zero weight.  The fp32 accumulator then carries ~1e4-magnitude partial sums (ulp 1e-3) instead of ~1e3: still two
+// orders below the fp16 rounding of the first tensor that is stored.
 __device__ __forceinline__ void u8x4_to_f16(uint32_t v, f16x8 &dst, int at) {
     union { uint32_t u; f16x2 h; } lo, hi;
     lo.u = __builtin_amdgcn_perm(0x64646464u, v, 0x04010400u);     // {b0, 0x64, b1, 0x64}
     hi.u = __builtin_amdgcn_perm(0x64646464u, v, 0x04030402u);     // {b2, 0x64, b3, 0x64}
-    const f16x2 k = {(half_t)1024, (half_t)1024};
-    lo.h -= k;
-    hi.h -= k;
     dst[at] = lo.h[0]; dst[at + 1] = lo.h[1]; dst[at + 2] = hi.h[0]; dst[at + 3] = hi.h[1];
 }
 

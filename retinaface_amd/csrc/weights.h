@@ -78,7 +78,7 @@ template <typename T> constexpr int mma_kpl() { return sizeof(T) == 1 ? 16 : siz
 
 
 // ---------------------------------------------------------------------------------------------------- byte archive
-constexpr uint32_t kPlanCacheVersion = 5;      // bump when the packing / layout of anything below changes
+constexpr uint32_t kPlanCacheVersion = 6;      // bump when the packing / layout of anything below changes
 
 struct ArOut {
     std::string b;
@@ -129,7 +129,7 @@ struct WeightPack {
     struct DwW { size_t w, b, mma = 0, m = kNone; };     // m: int8 depthwise-on-MFMA tap scales
 
     Arena arena_;
-    size_t c0_w_ = 0, c0_b_ = 0, c0_hi_ = 0;
+    size_t c0_w_ = 0, c0_b_ = 0, c0_hi_ = 0, c0_b_mma_ = 0;      // c0_b_mma_: conv0 bias of the MFMA stems (offset-folded, see pack())
     DwW stem_dw_{0, 0}, stem2_dw_{0, 0};
     GemmW stem_pw_{0, 0}, stem2_pw_{0, 0};
     size_t stem2_c2_b_ = 0, stem2_c2_floor_ = 0, stem2_c3_floor_ = 0;      // stem2's DC-centred tiles (pack())
@@ -325,6 +325,21 @@ struct WeightPack {
                         frag[((half * 2 + 1) * 64 + lane) * 8 + el] = (half_t)(w - (float)h);
                     }
             c0_hi_ = arena_.put(frag);
+            // the stems feed 1024 + pixel into those fragments (kernels.hip u8x4_to_f16): bias - 1024 * sum of the hi + lo weights
+            {
+                std::vector<float> bm(plan.conv0.b);
+                for (int row = 0; row < 8; row++) {
+                    double sw = 0.0;
+                    for (int tap = 0; tap < 9; tap++)
+                        for (int c = 0; c < 3; c++) {
+                            const float w = plan.conv0.w[(size_t)row * 27 + tap * 3 + c];
+                            const half_t h = (half_t)w;
+                            sw += (double)(float)h + (double)(float)(half_t)(w - (float)h);
+                        }
+                    bm[row] = (float)((double)plan.conv0.b[row] - 1024.0 * sw);
+                }
+                c0_b_mma_ = arena_.put(bm);
+            }
             // the stem computes its depthwise + pointwise block in fp16 whatever the storage type of its OUTPUT
             const auto &b0 = plan.blocks[0];
             std::vector<float> dw((size_t)9 * 8);                  // taps stay fp32 (see the stem kernel's header)
@@ -527,7 +542,7 @@ struct WeightPack {
 
     // ------------------------------------------------------------------------------------------ (de)serialisation
     template <class Ar> void io(Ar &ar) {
-        ar.pod(c0_w_); ar.pod(c0_b_); ar.pod(c0_hi_);
+        ar.pod(c0_w_); ar.pod(c0_b_); ar.pod(c0_hi_); ar.pod(c0_b_mma_);
         ar.pod(stem_dw_); ar.pod(stem2_dw_); ar.pod(stem_pw_); ar.pod(stem2_pw_);
         ar.pod(stem2_c2_b_); ar.pod(stem2_c2_floor_); ar.pod(stem2_c3_floor_);
         ar.pod(aggr_a_lat_); ar.pod(aggr_a_up_); ar.pod(head_a_);
@@ -551,7 +566,7 @@ struct WeightPack {
         auto ok = [n](size_t off) { return off == kNone || off < n; };
         auto okg = [&](const GemmW &g) { return ok(g.w) && ok(g.b) && ok(g.m); };
         auto okd = [&](const DwW &d) { return ok(d.w) && ok(d.b) && ok(d.mma) && ok(d.m); };
-        bool good = ok(c0_w_) && ok(c0_b_) && ok(c0_hi_) && okd(stem_dw_) && okd(stem2_dw_) && okg(stem_pw_) && okg(stem2_pw_) &&
+        bool good = ok(c0_w_) && ok(c0_b_) && ok(c0_hi_) && ok(c0_b_mma_) && okd(stem_dw_) && okd(stem2_dw_) && okg(stem_pw_) && okg(stem2_pw_) &&
                     ok(stem2_c2_b_) && ok(stem2_c2_floor_) && ok(stem2_c3_floor_);
         for (const auto &d : dw_w_) good = good && okd(d);
         for (const auto &g : pw_w_) good = good && okg(g);

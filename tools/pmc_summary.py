@@ -22,6 +22,8 @@ def descriptor(mangled: str) -> str:
         return f"conv3x3<{cin},{cout},{th}x{tw}{',up' if up == '1' else ''}>"
     if "dwpw2_kernel" in mangled:
         return "dwpw2<32,32,64>"
+    if "ssh_tail_kernel" in mangled:
+        return "ssh_tail<16,32,16>"
     for k in ("stem2", "stem", "conv0", "head", "nms", "resize_area", "resize_bilinear"):
         if k + "_kernel" in mangled:
             return k
