@@ -153,6 +153,7 @@ public:
         // device frames are checked for residency whenever another device exists they could live on (RF_FORCE_SCATTER: test knob,
         // treats every device frame as foreign so the scatter path runs on a one-GPU box)
         force_scatter_ = getenv("RF_FORCE_SCATTER") != nullptr;
+        if (const char *cs = getenv("RF_COPY_STREAMS")) copy_streams_ = atoi(cs) > 1 ? 2 : 1;
         check_residency_ = ndev > 1 || force_scatter_;
         DeviceGuard guard(device_);                  // the caller's current device is put back when construction ends
         try { arena_.upload(); } catch (const std::exception &e) { throw HipError(e.what()); }
@@ -412,6 +413,12 @@ private:
         bool built = false;
         std::vector<void *> dev_allocs, host_allocs;      // what build_lane allocated for this lane
         hipStream_t stream = nullptr;
+        // RF_COPY_STREAMS=2 (probe): host-frame uploads alternate between the lane's stream and a second one (a second SDMA
+        // engine); the launch waits for both
+        hipStream_t copy2 = nullptr;
+        hipEvent_t copy2_done = nullptr;
+        bool copy2_used = false;
+        unsigned uploads = 0;
         hipEvent_t time_ev[4] = {nullptr, nullptr, nullptr, nullptr};
         hipEvent_t done = nullptr;
         std::map<int, hipGraphExec_t> graphs;
@@ -477,6 +484,8 @@ private:
         for (auto &kv : l.graphs) (void)hipGraphExecDestroy(kv.second);
         for (hipEvent_t &e : l.time_ev) { if (e) (void)hipEventDestroy(e); e = nullptr; }
         if (l.done) (void)hipEventDestroy(l.done);
+        if (l.copy2_done) (void)hipEventDestroy(l.copy2_done);
+        if (l.copy2) { (void)hipStreamSynchronize(l.copy2); (void)hipStreamDestroy(l.copy2); }
         if (l.d_stage) (void)hipFree(l.d_stage);
         if (l.h_stage) (void)hipHostFree(l.h_stage);
         if (l.stream) (void)hipStreamDestroy(l.stream);
@@ -523,6 +532,10 @@ private:
         RF_HIP(hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking));
         for (auto &e : L.time_ev) RF_HIP(hipEventCreate(&e));
         RF_HIP(hipEventCreateWithFlags(&L.done, hipEventDisableTiming));
+        if (copy_streams_ > 1) {
+            RF_HIP(hipStreamCreateWithFlags(&L.copy2, hipStreamNonBlocking));
+            RF_HIP(hipEventCreateWithFlags(&L.copy2_done, hipEventDisableTiming));
+        }
 
         L.table_bytes = 2 * mb * sizeof(FrameDesc) + sizeof(RunParams);
         unsigned char *htab = halloc<unsigned char>(L.table_bytes);
@@ -955,6 +968,11 @@ private:
             for (int i = 0; i < n; i++)
                 s.h_frames[mb + i] = FrameDesc{s.d_canvas + (size_t)i * net_h_ * net_w_ * 3, net_h_, net_w_, net_w_ * 3, 0};
         }
+        if (s.copy2_used) {             // uploads that went through the second copy stream: the launch waits for them
+            RF_HIP(hipEventRecord(s.copy2_done, s.copy2));
+            RF_HIP(hipStreamWaitEvent(s.stream, s.copy2_done, 0));
+            s.copy2_used = false;
+        }
         double tt = trace_.on ? HostTrace::now() : 0.0;
         RF_HIP(hipMemcpyAsync(s.d_frames, s.h_frames, s.table_bytes, hipMemcpyHostToDevice, s.stream));
         trace_.add(2, tt);
@@ -1045,6 +1063,8 @@ private:
         try {
             if (stage_need) {
                 uint8_t *hbase = s.h_stage + s.stage_used, *dbase = s.d_stage + s.stage_used;
+                hipStream_t up = s.stream;
+                if (s.copy2 && !on_device && (s.uploads++ & 1)) { up = s.copy2; s.copy2_used = true; }
                 if (on_device) {
                     // the batch split of a multi-GPU node: frames resident on another device cross xGMI as one peer copy each
                     // (SDMA, on this lane's stream: it overlaps the compute of the super-batches in flight on the other lanes)
@@ -1062,14 +1082,14 @@ private:
                         const size_t fb = (size_t)rows[i] * cols[i] * 3;
                         if (steps[i] != cols[i] * 3) {
                             RF_HIP(hipMemcpy2DAsync(dbase + off[i], (size_t)cols[i] * 3, frames[i], (size_t)steps[i], (size_t)cols[i] * 3,
-                                                    (size_t)rows[i], hipMemcpyHostToDevice, s.stream));
+                                                    (size_t)rows[i], hipMemcpyHostToDevice, up));
                             continue;
                         }
                         size_t run = fb;
                         int j = i + 1;
                         while (j < n && !empty[j] && steps[j] == cols[j] * 3 && frames[j] == frames[i] + run && off[j] == off[i] + run)
                             run += (size_t)rows[j] * cols[j] * 3, j++;
-                        RF_HIP(hipMemcpyAsync(dbase + off[i], frames[i], run, hipMemcpyHostToDevice, s.stream));
+                        RF_HIP(hipMemcpyAsync(dbase + off[i], frames[i], run, hipMemcpyHostToDevice, up));
                         i = j - 1;
                     }
                 } else {
@@ -1078,7 +1098,7 @@ private:
                         if (!empty[i])
                             copy_jobs_.push_back(ParallelCopier::Job{hbase + off[i], frames[i], (size_t)cols[i] * 3, (size_t)rows[i], (size_t)steps[i]});
                     copier_->run(copy_jobs_);          // the caller's buffers are free again when this returns
-                    RF_HIP(hipMemcpyAsync(dbase, hbase, stage_need, hipMemcpyHostToDevice, s.stream));
+                    RF_HIP(hipMemcpyAsync(dbase, hbase, stage_need, hipMemcpyHostToDevice, up));
                 }
             }
         } catch (...) {
@@ -1127,6 +1147,7 @@ private:
     int device_ = 0;
     HostTrace trace_;
     bool check_residency_ = false, force_scatter_ = false;
+    int copy_streams_ = 1;
     long scattered_frames_ = 0;               // device frames that arrived from another device (peer copies issued)
     std::vector<float> ratios_;                // the network preset's anchor ratios (empty: a preset without anchors)
     int na_ = 2;                               // anchors per cell the preset decodes (head_a_: what the model's heads carry)
