@@ -153,7 +153,7 @@ public:
         // device frames are checked for residency whenever another device exists they could live on (RF_FORCE_SCATTER: test knob,
         // treats every device frame as foreign so the scatter path runs on a one-GPU box)
         force_scatter_ = getenv("RF_FORCE_SCATTER") != nullptr;
-        if (const char *cs = getenv("RF_COPY_STREAMS")) copy_streams_ = atoi(cs) > 1 ? 2 : 1;
+        if (const char *cs = getenv("RF_COPY_STREAMS")) copy_streams_ = atoi(cs) > 1 ? 2 : 1;       // probe knob (tools/probes/host_rate.py)
         check_residency_ = ndev > 1 || force_scatter_;
         DeviceGuard guard(device_);                  // the caller's current device is put back when construction ends
         try { arena_.upload(); } catch (const std::exception &e) { throw HipError(e.what()); }
@@ -413,8 +413,8 @@ private:
         bool built = false;
         std::vector<void *> dev_allocs, host_allocs;      // what build_lane allocated for this lane
         hipStream_t stream = nullptr;
-        // RF_COPY_STREAMS=2 (probe): host-frame uploads alternate between the lane's stream and a second one (a second SDMA
-        // engine); the launch waits for both
+        // host-frame uploads from the pinned staging block alternate between the lane's stream and a second one (a second SDMA
+        // engine); the launch waits for both.  RF_COPY_STREAMS=1 (probe knob) switches the second stream off
         hipStream_t copy2 = nullptr;
         hipEvent_t copy2_done = nullptr;
         bool copy2_used = false;
@@ -1064,7 +1064,9 @@ private:
             if (stage_need) {
                 uint8_t *hbase = s.h_stage + s.stage_used, *dbase = s.d_stage + s.stage_used;
                 hipStream_t up = s.stream;
-                if (s.copy2 && !on_device && (s.uploads++ & 1)) { up = s.copy2; s.copy2_used = true; }
+                // staged (pageable) frames: measured 69-74 k -> 76-81 k images/s at 448 x 448 with the second stream (48.6 GB/s = 0.9 of
+                // the box's pinned-copy rate); frames in rf_host_register'ed memory got SLOWER with it (75.6 k -> 69.4 k) and stay on one
+                if (s.copy2 && !on_device && !all_registered && (s.uploads++ & 1)) { up = s.copy2; s.copy2_used = true; }
                 if (on_device) {
                     // the batch split of a multi-GPU node: frames resident on another device cross xGMI as one peer copy each
                     // (SDMA, on this lane's stream: it overlaps the compute of the super-batches in flight on the other lanes)
@@ -1147,7 +1149,7 @@ private:
     int device_ = 0;
     HostTrace trace_;
     bool check_residency_ = false, force_scatter_ = false;
-    int copy_streams_ = 1;
+    int copy_streams_ = 2;
     long scattered_frames_ = 0;               // device frames that arrived from another device (peer copies issued)
     std::vector<float> ratios_;                // the network preset's anchor ratios (empty: a preset without anchors)
     int na_ = 2;                               // anchors per cell the preset decodes (head_a_: what the model's heads carry)
