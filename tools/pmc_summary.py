@@ -20,6 +20,15 @@ def descriptor(mangled: str) -> str:
     if m:
         cin, cout, th, tw, up = m.groups()
         return f"conv3x3<{cin},{cout},{th}x{tw}{',up' if up == '1' else ''}>"
+    # the same instances when the profiler reports them demangled ("void rf::dwpw_kernel<signed char, 128, 128, 1, true, 4, 8, false, true>(...)")
+    m = re.search(r"dwpw_kernel<[^,]+, (\d+), (\d+), (\d+), (?:true|false), (\d+), (\d+), (true|false)", mangled)
+    if m:
+        cin, cout, st, th, tw, lat = m.groups()
+        return f"dwpw<{cin},{cout},s{st}{',lat' if lat == 'true' else ''}>"
+    m = re.search(r"conv3x3_kernel<[^,]+, (\d+), (\d+), (\d+), (\d+), (true|false)", mangled)
+    if m:
+        cin, cout, th, tw, up = m.groups()
+        return f"conv3x3<{cin},{cout},{th}x{tw}{',up' if up == 'true' else ''}>"
     if "dwpw2_kernel" in mangled:
         return "dwpw2<32,32,64>"
     if "ssh_tail_kernel" in mangled:
