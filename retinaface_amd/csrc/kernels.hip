@@ -738,7 +738,7 @@ template void launch_stem<int8_t>(hipStream_t, const StemParams<int8_t> &);
 //   out) | 4 pointwise conv2 on MFMA -> fp16 tile (zero outside the map: it is conv3's padding) | 5 depthwise conv3 stride 2
 //   | 6 pointwise conv4 on MFMA | 7 coalesced NHWC store.  Numerics of phases 1-4 are exactly K_a' (same rounding points).
 // =============================================================================================
-template <int TW_, bool F16P> struct Stem2Cfg {     // F16P: the staged patch holds fp16 (converted once) instead of u8
+template <int TW_, bool F16P, int PADKB = 0> struct Stem2Cfg {     // F16P: the staged patch holds fp16 (converted once) instead of u8; PADKB: unused LDS (occupancy probe)
     static constexpr int TH = 7, TW = TW_, P4 = TH * TW;                // conv4 output tile
     static constexpr int R2H = 2 * TH + 1, R2W = 2 * TW + 1, N2 = R2H * R2W;     // conv2 pixels the tile needs
     static constexpr int R0H = R2H + 2, R0W = R2W + 2, N0 = R0H * R0W;           // conv0 / conv1-input pixels
@@ -752,7 +752,7 @@ template <int TW_, bool F16P> struct Stem2Cfg {     // F16P: the staged patch ho
     static constexpr int MAX3(int a, int b, int c) { return a > b ? (a > c ? a : c) : (b > c ? b : c); }
     static constexpr int REGION_A = MAX3(IN_BYTES, A_BYTES, A1_BYTES + OUT_BYTES);
     static constexpr int REGION_B = C0_BYTES > C2_BYTES ? C0_BYTES : C2_BYTES;
-    static constexpr int LDS_BYTES = REGION_A + REGION_B + 9 * 8 * 4;
+    static constexpr int LDS_BYTES = REGION_A + REGION_B + 9 * 8 * 4 + PADKB * 1024;
     // 7 x 8 tiles: 4 waves per workgroup; 7 x 16 tiles: the same work per thread with 8 waves (half the horizontal halo per output,
     // twice the LDS per workgroup, the same 32 waves per CU)
     static constexpr int THREADS = TW_ >= 16 ? 512 : 256;
@@ -770,9 +770,9 @@ struct Stem2Args {
     int ho, wo, ho4, wo4, tiles_x, tiles_y, nblk;   // ho x wo = conv0 / conv2 map (net / 2), ho4 x wo4 = conv4 map (net / 4)
 };
 
-template <int TW_, bool F16P>
-__global__ __launch_bounds__((Stem2Cfg<TW_, F16P>::THREADS), (Stem2Cfg<TW_, F16P>::OCC)) void stem2_kernel(Stem2Args a) {
-    typedef Stem2Cfg<TW_, F16P> C;
+template <int TW_, bool F16P, int PADKB = 0>
+__global__ __launch_bounds__((Stem2Cfg<TW_, F16P, PADKB>::THREADS), (Stem2Cfg<TW_, F16P, PADKB>::OCC)) void stem2_kernel(Stem2Args a) {
+    typedef Stem2Cfg<TW_, F16P, PADKB> C;
     constexpr int NT = C::THREADS, NW = NT / 64;         // threads / waves per workgroup
     typedef half_t T;
     typedef Mma<T> M;
@@ -1090,7 +1090,15 @@ void launch_stem2(hipStream_t s, const Stem2Params &p) {
     a.nblk = p.n * a.tiles_x * a.tiles_y;
     if (tw == 16) hipLaunchKernelGGL((stem2_kernel<16, false>), dim3(a.nblk), dim3(Stem2Cfg<16, false>::THREADS), 0, s, a);
     else if (v == 3) hipLaunchKernelGGL((stem2_kernel<8, true>), dim3(a.nblk), dim3(kThreads), 0, s, a);
-    else hipLaunchKernelGGL((stem2_kernel<8, false>), dim3(a.nblk), dim3(kThreads), 0, s, a);
+    else {
+        // RF_STEM2_PAD (probe knob): 3 / 7 KB of unused LDS per workgroup = 7 / 6 workgroups per CU instead of 8: stem2 alone gets slower
+        // (+3.5 % / +10 %), but at 8 it owns every wave slot of the chip and nothing of another lane can run beside it
+        static int pad = -1;
+        if (pad < 0) { const char *e = getenv("RF_STEM2_PAD"); pad = e ? atoi(e) : 0; }
+        if (pad == 3) hipLaunchKernelGGL((stem2_kernel<8, false, 3>), dim3(a.nblk), dim3(kThreads), 0, s, a);
+        else if (pad == 7) hipLaunchKernelGGL((stem2_kernel<8, false, 7>), dim3(a.nblk), dim3(kThreads), 0, s, a);
+        else hipLaunchKernelGGL((stem2_kernel<8, false>), dim3(a.nblk), dim3(kThreads), 0, s, a);
+    }
 }
 
 // =============================================================================================
