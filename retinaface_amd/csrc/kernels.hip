@@ -1606,7 +1606,7 @@ struct DwPw2Args {
     int hin, win, hout, wout, tiles_x, tiles_y, nblk;
 };
 
-__global__ __launch_bounds__(kThreads, 4) void dwpw2_kernel(DwPw2Args a) {
+__global__ __launch_bounds__(kThreads, 3) void dwpw2_kernel(DwPw2Args a) {
     typedef half_t T;
     typedef Mma<T> M;
     typedef M::Frag Frag;
@@ -1622,8 +1622,7 @@ __global__ __launch_bounds__(kThreads, 4) void dwpw2_kernel(DwPw2Args a) {
     constexpr int IN_BYTES = NH * LD * 2, A_BYTES = PTA * 16 * LD * 2, B_BYTES = P * LD * 2, OUT_BYTES = P * LDO * 2;
     constexpr int NPF = (NH * 4 + kThreads - 1) / kThreads;            // halo items (16 B) per thread: 4
     static_assert(PTA % 2 == 0 && PTA * 16 * LD * 2 <= IN_BYTES && B_BYTES + OUT_BYTES <= A_BYTES, "region reuse");
-    __shared__ __attribute__((aligned(16))) unsigned char s_raw[IN_BYTES + A_BYTES + 160 * 4];
-    float *s_bias = (float *)(s_raw + IN_BYTES + A_BYTES);      // the four bias vectors [dwa 32 | pwa 32 | dwb 32 | pwb 64]: read per phase instead of 16 VGPRs held over the loop
+    __shared__ __attribute__((aligned(16))) unsigned char s_raw[IN_BYTES + A_BYTES];
     T *s_in = (T *)s_raw;                              // halo                       (phases 1-2)
     T *s_mid = (T *)s_raw;                             // block-A output tile        (phases 3-4)
     T *s_a = (T *)(s_raw + IN_BYTES);                  // depthwise-A result         (phases 2-3)
@@ -1650,9 +1649,8 @@ __global__ __launch_bounds__(kThreads, 4) void dwpw2_kernel(DwPw2Args a) {
     }
     const Frag pwa = ((const Frag *)a.pwa_w)[g * 64 + lane];
     const Frag pwb = ((const Frag *)a.pwb_w)[wave * 64 + lane];
-    if (tid < 32) { s_bias[tid] = a.dwa_b[tid]; s_bias[32 + tid] = a.pwa_b[tid]; s_bias[64 + tid] = a.dwb_b[tid]; }
-    if (tid < 64) s_bias[96 + tid] = a.pwb_b[tid];             // visible after the first barrier of the tile loop
-    const int bo_g = acc_cout(g, lane, 0), bo_w = 96 + acc_cout(wave, lane, 0);
+    const f32x4 dwa_b = *(const f32x4 *)(a.dwa_b + acc_cout(g, lane, 0)), pwa_b = *(const f32x4 *)(a.pwa_b + acc_cout(g, lane, 0));
+    const f32x4 dwb_b = *(const f32x4 *)(a.dwb_b + acc_cout(g, lane, 0)), pwb_b = *(const f32x4 *)(a.pwb_b + acc_cout(wave, lane, 0));
     auto dw_frag = [&](uint32_t wd) -> Frag {          // diagonal depthwise A fragment from its one dword per lane
         typedef uint32_t u32x4_ __attribute__((ext_vector_type(4)));
         asm volatile("" : "+v"(wd));
@@ -1671,7 +1669,7 @@ __global__ __launch_bounds__(kThreads, 4) void dwpw2_kernel(DwPw2Args a) {
         pa_base[i] = ((pc / RW) * HW + pc % RW) * LD + g * 16 + (kb & 1) * 8;
     }
     // tap of chunk kc: 2 kc for lanes 0..31, 2 kc + 1 for lanes 32..63 (k = tap*16 + c): two compile-time offsets per chunk,
-    // picked by the lane half when used (a per-lane array would be 10 more registers held over the loop)
+    // picked by the lane half when used (this kernel runs at 3 workgroups per CU: the 128-VGPR budget of a 4th spills 37 registers)
     const bool hi = lane >= 32;
     auto tap_a = [&](int kc) -> int { const int t0 = 2 * kc, t1 = 2 * kc + 1; return hi ? (t1 < 9 ? ((t1 / 3) * HW + t1 % 3) * LD : -1) : ((t0 / 3) * HW + t0 % 3) * LD; };
     auto tap_b = [&](int kc) -> int { const int t0 = 2 * kc, t1 = 2 * kc + 1; return hi ? (t1 < 9 ? ((t1 / 3) * RW + t1 % 3) * LD : -1) : ((t0 / 3) * RW + t0 % 3) * LD; };
@@ -1720,44 +1718,35 @@ __global__ __launch_bounds__(kThreads, 4) void dwpw2_kernel(DwPw2Args a) {
         RF_TRACE(5, 1);
         __syncthreads();
 
-        // ---- phase 2: depthwise A (3x3, stride 1) on the 153-pixel region: the wave's 5 pixel tiles advance 3 + 2 at a time (round 3:
-        //      five accumulators + five B fragments at once, together with the four bias vectors held over the loop, were what kept
-        //      the kernel at 160 VGPRs = 3 workgroups per CU; with the split and the biases read from LDS per phase it is 128 = 4)
+        // ---- phase 2: depthwise A (3x3, stride 1) on the 153-pixel region: the wave's 5 pixel tiles advance together, so five
+        //      independent accumulators are in flight and each chunk's fragment is expanded once
+        {
+            M::Acc acc[UA];
 #pragma unroll
-        for (int part = 0; part < 2; part++) {
-            constexpr int U0[2] = {0, 3}, UN[2] = {3, 2};
-            M::Acc acc[3];
-            const f32x4 dwa_b = *(const f32x4 *)(s_bias + bo_g);
-#pragma unroll
-            for (int i = 0; i < 3; i++) acc[i] = dwa_b;                 // bias rides in the accumulator (acc_init)
+            for (int i = 0; i < UA; i++) acc[i] = dwa_b;                 // bias rides in the accumulator (acc_init)
 #pragma unroll
             for (int kc = 0; kc < kDwMmaChunks; kc++) {
-                Frag bf[3];
+                Frag bf[UA];
 #pragma unroll
-                for (int i = 0; i < 3; i++) if (i < UN[part]) bf[i] = tap_a(kc) >= 0 ? *(const Frag *)(s_in + pa_base[U0[part] + i] + tap_a(kc)) : M::zero();
+                for (int i = 0; i < UA; i++) bf[i] = tap_a(kc) >= 0 ? *(const Frag *)(s_in + pa_base[i] + tap_a(kc)) : M::zero();
                 const Frag af = dw_frag(dwa[kc]);
 #pragma unroll
-                for (int i = 0; i < 3; i++) if (i < UN[part]) acc[i] = M::mma(af, bf[i], acc[i]);
+                for (int i = 0; i < UA; i++) acc[i] = M::mma(af, bf[i], acc[i]);
             }
 #pragma unroll
-            for (int i = 0; i < 3; i++) if (i < UN[part]) store_acc<T, LD>(s_a, ones, dwa_b, acc[i], g, (wave >> 1) + 2 * (U0[part] + i), lane, true);
+            for (int i = 0; i < UA; i++) store_acc<T, LD>(s_a, ones, dwa_b, acc[i], g, (wave >> 1) + 2 * i, lane, true);
         }
         RF_TRACE(5, 2);
         __syncthreads();
 
         // ---- phase 3: pointwise A (CI -> CA, K = 32: one MFMA per pixel tile); outside the map the tile holds block B's zero padding
+        {
+            Frag bf[UA];
 #pragma unroll
-        for (int part = 0; part < 2; part++) {
-            constexpr int U0[2] = {0, 3}, UN[2] = {3, 2};
-            const f32x4 pwa_b = *(const f32x4 *)(s_bias + 32 + bo_g);
-            Frag bf[3];
+            for (int i = 0; i < UA; i++) bf[i] = *(const Frag *)(s_a + (((wave >> 1) + 2 * i) * 16 + (lane & 15)) * LD + kb * 8);
 #pragma unroll
-            for (int ii = 0; ii < 3; ii++) if (ii < UN[part]) bf[ii] = *(const Frag *)(s_a + (((wave >> 1) + 2 * (U0[part] + ii)) * 16 + (lane & 15)) * LD + kb * 8);
-#pragma unroll
-            for (int ii = 0; ii < 3; ii++) {
-                if (ii >= UN[part]) continue;
-                const int i = U0[part] + ii;
-                const M::Acc acc = M::mma(pwa, bf[ii], pwa_b);
+            for (int i = 0; i < UA; i++) {
+                const M::Acc acc = M::mma(pwa, bf[i], pwa_b);
                 const int y = 2 * oy0 - 1 + (pa_yx[i] >> 16), x = 2 * ox0 - 1 + (pa_yx[i] & 0xffff);
                 const bool inside = (unsigned)y < (unsigned)a.hin && (unsigned)x < (unsigned)a.win;
                 uint2 h;
@@ -1771,7 +1760,6 @@ __global__ __launch_bounds__(kThreads, 4) void dwpw2_kernel(DwPw2Args a) {
 
         // ---- phase 4: depthwise B (3x3, stride 2) on the 32 output pixels: one (group, pixel tile) unit per wave
         {
-            const f32x4 dwb_b = *(const f32x4 *)(s_bias + 64 + bo_g);
             M::Acc acc = dwb_b;
             Frag bf[kDwMmaChunks];
 #pragma unroll
@@ -1785,7 +1773,6 @@ __global__ __launch_bounds__(kThreads, 4) void dwpw2_kernel(DwPw2Args a) {
 
         // ---- phase 5: pointwise B (CA -> CB): wave = output-channel tile, both pixel tiles
         {
-            const f32x4 pwb_b = *(const f32x4 *)(s_bias + bo_w);
             Frag bf[2];
 #pragma unroll
             for (int pt = 0; pt < 2; pt++) bf[pt] = *(const Frag *)(s_b + (pt * 16 + (lane & 15)) * LD + kb * 8);
