@@ -521,7 +521,7 @@ def measure_counters(args, n_img, B, H, W):
             out = os.path.join(tmp, tag)
             cmd = ["rocprofv3", "--pmc"] + counters + ["-d", out, "-o", "pmc", "--", sys.executable,
                    os.path.join(ROOT, "tools", "probes", "pmc_probe.py"), str(n_img), args.precision, args.model, str(H), str(W), str(B)]
-            r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=150)
+            r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=90)
             found = [os.path.join(d, f) for d, _, fs in os.walk(out) for f in fs if f.endswith(".db")]
             if r.returncode != 0 or not found:
                 if tag == "SQ":
