@@ -1359,11 +1359,23 @@ __global__ __launch_bounds__(kThreads, (DwPwCfg<T, CIN, COUT, STRIDE, HAS_DW, TH
         cur = nxt;
         step.advance(nxt);
         RF_TRACE(2, 10);
-        if (p_img >= 0) store_tile(p_img, p_oy0, p_ox0);
-        p_img = img; p_oy0 = ty * TH; p_ox0 = tx * TW;
+        // Two barriers per tile instead of three where there is no fused lateral (round 3): the previous tile is stored AFTER this
+        // tile's first barrier, so the barrier that used to close a tile (epilogue -> s_out visible) is this one.  Hazards: s_in is
+        // rewritten by the next staging after every thread has passed the depthwise barrier; s_a by the next stencil after the next
+        // first barrier, which every thread reaches only after its GEMM has read s_a; s_out is read here (after the first barrier,
+        // which follows the epilogue that wrote it) and rewritten by this tile's epilogue after the depthwise barrier.  With a
+        // lateral the result tile of the lateral shares s_a with the stencil, so the store has to stay ahead of the barrier.
+        constexpr bool LATE_STORE = HAS_DW && !LAT && sizeof(T) <= 2;
+        if constexpr (!LATE_STORE) {
+            if (p_img >= 0) store_tile(p_img, p_oy0, p_ox0);
+        }
         RF_TRACE(2, 1);
         __syncthreads();
         RF_TRACE(2, 2);
+        if constexpr (LATE_STORE) {
+            if (p_img >= 0) store_tile(p_img, p_oy0, p_ox0);
+        }
+        p_img = img; p_oy0 = ty * TH; p_ox0 = tx * TW;
 
         if constexpr (DWMMA) {
             // ---- phase 2 (fp16 / int8): depthwise 3x3 as diagonal-weight implicit GEMM, D[c][pixel] per 16-channel group
@@ -1477,7 +1489,7 @@ __global__ __launch_bounds__(kThreads, (DwPwCfg<T, CIN, COUT, STRIDE, HAS_DW, TH
             for (int j = 0; j < WS::NJ; j++)
                 store_acc<T, LDO>(s_out, pw_mult[i], pw_bias[i], acc[i][j], wn + i * WS::WN, wp + j * WS::WP, lane, true);
         RF_TRACE(2, 5);
-        __syncthreads();
+        if constexpr (!LATE_STORE) __syncthreads();
         RF_TRACE(2, 6);
 
         if constexpr (LAT) {
@@ -1505,6 +1517,7 @@ __global__ __launch_bounds__(kThreads, (DwPwCfg<T, CIN, COUT, STRIDE, HAS_DW, TH
         }
         RF_TRACE(2, 7);
     }
+    if constexpr (HAS_DW && !LAT && sizeof(T) <= 2) __syncthreads();      // (LATE_STORE: the last tile's epilogue has no closing barrier)
     if (p_img >= 0) store_tile(p_img, p_oy0, p_ox0);
 }
 
@@ -1837,8 +1850,10 @@ template <typename T, int CIN, int COUT, int TH, int TW, bool ALLC = false, bool
     static constexpr size_t IN_BYTES = sizeof(T) * (size_t)(HR * ROWP);
     static constexpr size_t O_BYTES = sizeof(T) * (size_t)(P * LDO);
     // persistent + software pipelined like K_b: tile t+G is staged while tile t's result is still being stored, so the
-    // halo tile and the result tile are separate LDS regions (and the GEMM -> epilogue barrier disappears)
-    static constexpr size_t LDS_BYTES = IN_BYTES + O_BYTES;
+    // halo tile and the result tile are separate LDS regions (and the GEMM -> epilogue barrier disappears).  fp16 / int8
+    // engines (round 3): BOTH regions are double buffered, which leaves ONE barrier per tile (see the tile loop)
+    static constexpr bool DB = sizeof(T) <= 2;
+    static constexpr size_t LDS_BYTES = (DB ? 2 : 1) * (IN_BYTES + O_BYTES);
     static_assert(IN_BYTES % 16 == 0, "LDS carve must stay 16-byte aligned");
     static constexpr int NT = COUT / 16, PT = P / 16;
     static constexpr int KTOT = 9 * CIN;
@@ -1888,8 +1903,10 @@ __global__ __launch_bounds__(kThreads, (Conv3Cfg<T, CIN, COUT, TH, TW, ALLC, PAD
     constexpr int WN = C::WN, WP = C::WP, NI = C::NI, NJ = C::NJ;
     constexpr bool STAT = C::STAT;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    T *s_in = (T *)smem;
-    T *s_out = (T *)(smem + C::IN_BYTES);
+    constexpr bool DB = C::DB;
+    constexpr int IN_ELEMS = (int)(C::IN_BYTES / sizeof(T)), O_ELEMS = (int)(C::O_BYTES / sizeof(T));
+    T *s_in = (T *)smem;                                               // [2][IN_ELEMS] when double buffered
+    T *s_out = (T *)(smem + (DB ? 2 : 1) * C::IN_BYTES);               // [2][O_ELEMS]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -1973,7 +1990,7 @@ __global__ __launch_bounds__(kThreads, (Conv3Cfg<T, CIN, COUT, TH, TW, ALLC, PAD
     // ---- tile (img, oy0, ox0), finished in LDS, -> HBM (two destinations: the concat slice and the next conv's input)
     T *out0 = L.out0, *out1 = L.out1;
     const int n0 = L.n0, ld0 = L.ld0, off0 = L.off0, ld1 = L.ld1, off1 = L.off1;
-    auto store_tile = [&](int img, int oy0, int ox0) {
+    auto store_tile = [&](const T *s_res, int img, int oy0, int ox0) {
         constexpr int OPV = COUT / VEC;
         const auto r0 = image_rsrc(out0 + (size_t)img * lh * lw * ld0 + off0, (unsigned)(lh * lw * ld0 - off0) * (unsigned)sizeof(T));
         const auto r1 = image_rsrc(out1 + (size_t)img * lh * lw * ld1 + off1, (unsigned)(lh * lw * ld1 - off1) * (unsigned)sizeof(T));
@@ -1984,7 +2001,7 @@ __global__ __launch_bounds__(kThreads, (Conv3Cfg<T, CIN, COUT, TH, TW, ALLC, PAD
             const int c = cv * VEC;
             const int pix = pbase + py * lw + px;
             const bool okx = ox0 + px < lw;
-            const V v = *(const V *)(s_out + p * LDO + c);
+            const V v = *(const V *)(s_res + p * LDO + c);
             if (c < n0) buf_store16(r0, okx ? (unsigned)((pix * ld0 + c) * (int)sizeof(T)) : kOobOffset, v);
             else buf_store16(r1, okx ? (unsigned)((pix * ld1 + (c - n0)) * (int)sizeof(T)) : kOobOffset, v);
         }
@@ -2002,10 +2019,18 @@ __global__ __launch_bounds__(kThreads, (Conv3Cfg<T, CIN, COUT, TH, TW, ALLC, PAD
         pbase[j] = (p / TW) * ROWP + (p % TW) * LDI;
     }
 
-    // tile loop:  stage(t) | fetch(t+G) issued | store(t-1) | barrier | GEMM(t) | epilogue(t) -> s_out | barrier
+    // tile loop, fp32 engine:  stage(t) | fetch(t+G) issued | store(t-1) | barrier | GEMM(t) | epilogue(t) -> s_out | barrier
+    // fp16 / int8 (double buffered):  stage(t) -> s_in[b] | fetch(t+G) | BARRIER | store(t-1) <- s_out[b^1] | GEMM(t) <- s_in[b] |
+    //   epilogue(t) -> s_out[b] | b ^= 1.  One barrier per tile is enough: s_out[b^1] was written by epilogue(t-1) before the barrier
+    //   and is next written by epilogue(t+1), after the next barrier; s_in[b] is next written by stage(t+2), two barriers later, and
+    //   s_in[b^1] -- written by stage(t+1) right after this tile's GEMM -- was last read by GEMM(t-1), before this tile's barrier.
     int p_img = -1, p_oy0 = 0, p_ox0 = 0;
+    int buf = 0;
     for (int t = first; t < ntiles; t += G) {
         const int tx = cur.tx, ty = cur.ty, img = cur.img;
+        T *const s_in_b = s_in + (DB ? buf * IN_ELEMS : 0);
+        T *const s_out_b = s_out + (DB ? buf * O_ELEMS : 0);
+        const T *const s_out_p = s_out + (DB ? (buf ^ 1) * O_ELEMS : 0);
         RF_TRACE(3, 8);
 #pragma unroll
         for (int k = 0; k < NPF; k++) {
@@ -2086,7 +2111,7 @@ __global__ __launch_bounds__(kThreads, (Conv3Cfg<T, CIN, COUT, TH, TW, ALLC, PAD
 #pragma unroll
                     for (int e = 0; e < VEC; e++) v[e] = ok ? to_T<T>(fmaf((float)v[e], a_lat, sacc[e] * a_up)) : to_T<T>(0.f);
                 }
-                *(V *)(s_in + ((i / CPV) / HC) * ROWP + ((i / CPV) % HC) * LDI + (i % CPV) * VEC) = v;
+                *(V *)(s_in_b + ((i / CPV) / HC) * ROWP + ((i / CPV) % HC) * LDI + (i % CPV) * VEC) = v;
             }
         }
         RF_TRACE(3, 9);
@@ -2094,11 +2119,16 @@ __global__ __launch_bounds__(kThreads, (Conv3Cfg<T, CIN, COUT, TH, TW, ALLC, PAD
         cur = nxt;
         step.advance(nxt);
         RF_TRACE(3, 10);
-        if (p_img >= 0) store_tile(p_img, p_oy0, p_ox0);
-        p_img = img; p_oy0 = ty * TH; p_ox0 = tx * TW;
+        if constexpr (!DB) {
+            if (p_img >= 0) store_tile(s_out_p, p_img, p_oy0, p_ox0);
+        }
         RF_TRACE(3, 1);
         __syncthreads();
         RF_TRACE(3, 2);
+        if constexpr (DB) {
+            if (p_img >= 0) store_tile(s_out_p, p_img, p_oy0, p_ox0);
+        }
+        p_img = img; p_oy0 = ty * TH; p_ox0 = tx * TW;
 
         if (gemm_wave) {
             typename M::Acc acc[NI][NJ];
@@ -2110,7 +2140,7 @@ __global__ __launch_bounds__(kThreads, (Conv3Cfg<T, CIN, COUT, TH, TW, ALLC, PAD
                 const int kb = kc * M::K + (lane >> 4) * M::KPL;      // k = tap*CIN + c, KPL consecutive c of one tap
                 const int tap = kb / CIN, c = kb % CIN;
                 const int koff = (tap / 3) * ROWP + (tap % 3) * LDI + c;
-                return kb < KTOT ? *(const Frag *)(s_in + pbase[j] + koff) : M::zero();
+                return kb < KTOT ? *(const Frag *)(s_in_b + pbase[j] + koff) : M::zero();
             };
             if constexpr (STAT) {
                 gemm_stationary<T, NI, NJ, KCH>(acc, wst, xf);
@@ -2124,13 +2154,15 @@ __global__ __launch_bounds__(kThreads, (Conv3Cfg<T, CIN, COUT, TH, TW, ALLC, PAD
             for (int i = 0; i < NI; i++)
 #pragma unroll
                 for (int j = 0; j < NJ; j++)
-                    store_acc<T, LDO>(s_out, mult[i], bias[i], acc[i][j], wn + i * WN, wp + j * WP, lane, true);
+                    store_acc<T, LDO>(s_out_b, mult[i], bias[i], acc[i][j], wn + i * WN, wp + j * WP, lane, true);
         }
         RF_TRACE(3, 5);
-        __syncthreads();
+        if constexpr (!DB) __syncthreads();
+        else buf ^= 1;
         RF_TRACE(3, 6);
     }
-    if (p_img >= 0) store_tile(p_img, p_oy0, p_ox0);
+    if constexpr (DB) __syncthreads();                                 // the last tile's epilogue has no closing barrier
+    if (p_img >= 0) store_tile(s_out + (DB ? (buf ^ 1) * O_ELEMS : 0), p_img, p_oy0, p_ox0);
     RF_TRACE(3, 7);
 }
 
@@ -2245,7 +2277,7 @@ template TileInfo conv3x3_tile_info<int8_t>(int, int, int, int);
 //   16-channel context_conv3_1 map made an HBM round trip in between.  Here a workgroup computes conv_b on the 10 x 10 region its
 //   8 x 8 tile of conv_c needs (recompute 1.56x of a 144-MAC-per-output conv: nothing), keeps context_conv3_1 in LDS (zeros
 //   outside the map = conv_c's padding), and writes concat[32:64] as one 32-channel run per pixel.  Per tile: 1 staged halo
-//   (12 x 12 x 16 ch), 3 barriers, 14 + 4 (pixel tile, channel tile) GEMM units of KCH MFMAs, one store.  All three FPN levels in
+//   (12 x 12 x 16 ch), 2 barriers (out tile double buffered), 14 + 4 (pixel tile, channel tile) GEMM units of KCH MFMAs, one store.  All three FPN levels in
 //   one grid, persistent + prefetching like K_c.
 // =============================================================================================
 template <typename T> struct SshTailCfg {
@@ -2261,7 +2293,7 @@ template <typename T> struct SshTailCfg {
     static constexpr int STAGE_ITEMS = NH * CPV, NPF = (STAGE_ITEMS + kThreads - 1) / kThreads;
     static constexpr size_t IN_BYTES = sizeof(T) * (size_t)(NH * LDI), MID_BYTES = sizeof(T) * (size_t)(PT1 * 16 * LDI),
                             OUT_BYTES = sizeof(T) * (size_t)(P * LDO);
-    static constexpr size_t LDS_BYTES = IN_BYTES + MID_BYTES + OUT_BYTES;
+    static constexpr size_t LDS_BYTES = IN_BYTES + MID_BYTES + 2 * OUT_BYTES;      // the out tile is double buffered (2 barriers per tile)
     static_assert(IN_BYTES % 16 == 0 && MID_BYTES % 16 == 0, "LDS carve must stay 16-byte aligned");
 };
 
@@ -2362,7 +2394,7 @@ __global__ __launch_bounds__(kThreads, OCC) void ssh_tail_kernel(SshTailArgs<T> 
         }
     };
     // ---- finished tile -> concat[32:64]: one 32-channel run per pixel
-    auto store_tile = [&](int img, int oy0, int ox0) {
+    auto store_tile = [&](const T *s_res, int img, int oy0, int ox0) {
         constexpr int OPV = 32 / VEC;
         const auto ro = image_rsrc(L.cat + (size_t)img * lh * lw * 64 + 32, (unsigned)(lh * lw * 64 - 32) * (unsigned)sizeof(T));
         const int pbase = oy0 * lw + ox0;
@@ -2370,7 +2402,7 @@ __global__ __launch_bounds__(kThreads, OCC) void ssh_tail_kernel(SshTailArgs<T> 
             const int p = i / OPV, cv = i % OPV;
             const int py = p / TW, px = p % TW;
             const unsigned off = ox0 + px < lw ? (unsigned)(((pbase + py * lw + px) * 64 + cv * VEC) * (int)sizeof(T)) : kOobOffset;
-            buf_store16(ro, off, *(const V *)(s_out + p * LDO + cv * VEC));
+            buf_store16(ro, off, *(const V *)(s_res + p * LDO + cv * VEC));
         }
     };
     const TileStep step(G, L.tiles_x, L.tiles_y);
@@ -2385,9 +2417,16 @@ __global__ __launch_bounds__(kThreads, OCC) void ssh_tail_kernel(SshTailArgs<T> 
         return kb < KTOT ? (tap / 3) * rowp + (tap % 3) * LDI + c : -1;
     };
 
+    // Two barriers per tile: the out tile is double buffered and the previous tile is stored after this tile's first barrier (s_out[b ^ 1] was
+    // completed by conv_c(t-1) before that barrier and is next written after the next tile's first barrier; s_in is rewritten by the next
+    // staging after conv_b's readers have passed the second barrier; s_mid by conv_b(t+1) after the next first barrier, which follows
+    // conv_c(t)'s reads).
     int p_img = -1, p_oy0 = 0, p_ox0 = 0;
+    int buf = 0;
+    constexpr int O_ELEMS = (int)(C::OUT_BYTES / sizeof(T));
     for (int t = first; t < ntiles; t += G) {
         const int oy0 = cur.ty * TH, ox0 = cur.tx * TW, img = cur.img;
+        T *const s_out_b = s_out + buf * O_ELEMS;
 #pragma unroll
         for (int k = 0; k < NPF; k++) {
             const int i = tid + k * kThreads;
@@ -2396,9 +2435,9 @@ __global__ __launch_bounds__(kThreads, OCC) void ssh_tail_kernel(SshTailArgs<T> 
         if (t + G < ntiles) fetch(nxt.tx, nxt.ty, nxt.img);
         cur = nxt;
         step.advance(nxt);
-        if (p_img >= 0) store_tile(p_img, p_oy0, p_ox0);
-        p_img = img; p_oy0 = oy0; p_ox0 = ox0;
         __syncthreads();
+        if (p_img >= 0) store_tile(s_out + (buf ^ 1) * O_ELEMS, p_img, p_oy0, p_ox0);
+        p_img = img; p_oy0 = oy0; p_ox0 = ox0;
 
         // ---- conv_b on the 10 x 10 region: this wave's channel tile x its (up to) 4 pixel tiles, two at a time (four accumulators
         //      + their B-fragment queue pushed the kernel over the 128-VGPR budget of 4 workgroups per CU)
@@ -2420,7 +2459,7 @@ __global__ __launch_bounds__(kThreads, OCC) void ssh_tail_kernel(SshTailArgs<T> 
                 if (ctb == 0) {
                     // context_conv2 -> concat[32:48]: only the tile's own 8 x 8 pixels
                     if ((unsigned)(ry - 1) < (unsigned)TH && (unsigned)(rx - 1) < (unsigned)TW)
-                        store_packed4<T>(s_out + ((ry - 1) * TW + rx - 1) * LDO + kg * 4, h);
+                        store_packed4<T>(s_out_b + ((ry - 1) * TW + rx - 1) * LDO + kg * 4, h);
                 } else {
                     // context_conv3_1 on the whole region; outside the map it is conv_c's ZERO padding
                     const int y = oy0 - 1 + ry, x = ox0 - 1 + rx;
@@ -2440,11 +2479,12 @@ __global__ __launch_bounds__(kThreads, OCC) void ssh_tail_kernel(SshTailArgs<T> 
                 const int o = xf_tap(kc, R1 * LDI);
                 return o >= 0 ? *(const Frag *)(s_mid + pb2 + o) : M::zero();
             });
-            store_packed4<T>(s_out + p2 * LDO + 16 + kg * 4, pack_acc<T>(mult_c, bias_c, acc[0][0]));
+            store_packed4<T>(s_out_b + p2 * LDO + 16 + kg * 4, pack_acc<T>(mult_c, bias_c, acc[0][0]));
         }
-        __syncthreads();
+        buf ^= 1;
     }
-    if (p_img >= 0) store_tile(p_img, p_oy0, p_ox0);
+    __syncthreads();                                               // the last tile's conv_c has no closing barrier
+    if (p_img >= 0) store_tile(s_out + (buf ^ 1) * O_ELEMS, p_img, p_oy0, p_ox0);
 }
 
 int ssh_tail_variant() {
