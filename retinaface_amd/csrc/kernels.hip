@@ -1850,9 +1850,12 @@ template <typename T, int CIN, int COUT, int TH, int TW, bool ALLC = false, bool
     static constexpr size_t IN_BYTES = sizeof(T) * (size_t)(HR * ROWP);
     static constexpr size_t O_BYTES = sizeof(T) * (size_t)(P * LDO);
     // persistent + software pipelined like K_b: tile t+G is staged while tile t's result is still being stored, so the
-    // halo tile and the result tile are separate LDS regions (and the GEMM -> epilogue barrier disappears).  fp16 / int8
-    // engines (round 3): BOTH regions are double buffered, which leaves ONE barrier per tile (see the tile loop)
-    static constexpr bool DB = sizeof(T) <= 2;
+    // halo tile and the result tile are separate LDS regions (and the GEMM -> epilogue barrier disappears).  DB: BOTH regions
+    // double buffered, which leaves ONE barrier per tile (see the tile loop).  Built and measured in round 3, correct (the whole
+    // -m gpu suite) and OFF: c1 87.4 -> 86.7 us, c2 29.7 -> 29.3, the SSH 64 -> 48 conv 103.6 -> 105.8 (fp16, A/B inside one call,
+    // tools/gpu/r3_call13.sh; int8 unchanged) for twice the LDS -- these tile loops do not wait at their barriers, they wait for
+    // the dependent LDS -> MFMA -> LDS chain inside each wave.
+    static constexpr bool DB = false;
     static constexpr size_t LDS_BYTES = (DB ? 2 : 1) * (IN_BYTES + O_BYTES);
     static_assert(IN_BYTES % 16 == 0, "LDS carve must stay 16-byte aligned");
     static constexpr int NT = COUT / 16, PT = P / 16;
