@@ -1365,7 +1365,9 @@ __global__ __launch_bounds__(kThreads, (DwPwCfg<T, CIN, COUT, STRIDE, HAS_DW, TH
         // first barrier, which every thread reaches only after its GEMM has read s_a; s_out is read here (after the first barrier,
         // which follows the epilogue that wrote it) and rewritten by this tile's epilogue after the depthwise barrier.  With a
         // lateral the result tile of the lateral shares s_a with the stencil, so the store has to stay ahead of the barrier.
-        constexpr bool LATE_STORE = HAS_DW && !LAT && sizeof(T) <= 2;
+        // int8 only: per kernel it is 1.5-2 % in both precisions, but the fp16 three-lane pipeline measured 289.5 -> 287.6 k images/s with
+        // it (int8: 363.2 -> 366.1 k; tools/gpu/r3_call14.sh, two interleaved repetitions each)
+        constexpr bool LATE_STORE = HAS_DW && !LAT && sizeof(T) == 1;
         if constexpr (!LATE_STORE) {
             if (p_img >= 0) store_tile(p_img, p_oy0, p_ox0);
         }
@@ -1517,7 +1519,7 @@ __global__ __launch_bounds__(kThreads, (DwPwCfg<T, CIN, COUT, STRIDE, HAS_DW, TH
         }
         RF_TRACE(2, 7);
     }
-    if constexpr (HAS_DW && !LAT && sizeof(T) <= 2) __syncthreads();      // (LATE_STORE: the last tile's epilogue has no closing barrier)
+    if constexpr (HAS_DW && !LAT && sizeof(T) == 1) __syncthreads();      // (LATE_STORE: the last tile's epilogue has no closing barrier)
     if (p_img >= 0) store_tile(p_img, p_oy0, p_ox0);
 }
 
