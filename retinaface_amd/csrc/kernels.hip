@@ -392,6 +392,11 @@ __device__ __forceinline__ void gemm_stationary(typename Mma<T>::Acc (&acc)[NI][
     }
 }
 
+// int8 ReLU epilogue: v_cvt_pk_u8_f32 IS clamp(rint(x), 0, 255) -- round to nearest even, ties included, saturating (measured on gfx950:
+// tools/probes/cvt_pk_u8.cpp, all 256 ties + neighbours + out-of-range values; and the whole bit-exact int8 suite passes on a build
+// without the separate v_rndne_f32 that rounds 1 and 2 spent per value).  Only the upper clamp at 127 is left to the VALU.
+#define RF_RNDNE(x) (x)
+
 // ReLU on the bit pattern: a signed integer max with 0 is max(x, +0) for every float (negative floats, -0 included, have the sign
 // bit set = negative integers).  One v_max_i32 / v_pk_max_i16; fmaxf() costs two instructions wherever the compiler cannot prove
 // its operand canonical (MFMA results), and these kernels are VALU-issue bound.
@@ -451,12 +456,12 @@ __device__ __forceinline__ void store_acc(T *s_out, f32x4 mult, f32x4 bv, ACC ac
         for (int r = 0; r < 4; r++) v[r] = fmaf((float)acc[r], mult[r], bv[r]);
         uint32_t packed = 0;
         if (relu) {
-            // ReLU'd quanta are 0..127: clamp with one v_med3, round to nearest even (as rintf), then v_cvt_pk_u8_f32 converts the
-            // now integral value and drops it into its byte -- 3 instructions per value instead of ~7 (clamp pair, convert, mask,
-            // shift, or); the int8 epilogues were a third of these kernels' VALU work
+            // ReLU'd quanta are 0..127: clamp with one v_med3, then v_cvt_pk_u8_f32 rounds to nearest even (as rintf) and drops the value
+            // into its byte -- 2 instructions per value after the fma instead of ~7 (clamp pair, round, convert, mask, shift, or); the
+            // int8 epilogues were a third of these kernels' VALU work
 #pragma unroll
             for (int r = 0; r < 4; r++)
-                packed = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_rintf(__builtin_amdgcn_fmed3f(v[r], 0.f, 127.f)), r, packed);
+                packed = __builtin_amdgcn_cvt_pk_u8_f32(RF_RNDNE(__builtin_amdgcn_fmed3f(v[r], 0.f, 127.f)), r, packed);
         } else {
 #pragma unroll
             for (int r = 0; r < 4; r++) packed |= ((uint32_t)(uint8_t)to_T<int8_t>(v[r])) << (8 * r);
@@ -2320,7 +2325,7 @@ __device__ __forceinline__ uint2 pack_acc(f32x4 mult, f32x4 bv, ACC acc) {
         static_assert(sizeof(T) == 1, "fp16 / int8 engines only");
 #pragma unroll
         for (int r = 0; r < 4; r++)
-            h.x = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_rintf(__builtin_amdgcn_fmed3f(fmaf((float)acc[r], mult[r], bv[r]), 0.f, 127.f)), r, h.x);
+            h.x = __builtin_amdgcn_cvt_pk_u8_f32(RF_RNDNE(__builtin_amdgcn_fmed3f(fmaf((float)acc[r], mult[r], bv[r]), 0.f, 127.f)), r, h.x);
     }
     return h;
 }
