@@ -110,3 +110,49 @@ def test_int8_oracle_tracks_the_fp32_oracle(nets, oracles, stem):
             same_anchor += best.anchor_index == r.anchor_index
             faces += 1
     assert faces >= 4 and min(ious) >= 0.85 and same_anchor / faces >= 0.5, (min(ious), same_anchor, faces)
+
+
+def test_per_channel_table_with_equal_channels_equals_the_per_tensor_table(nets):
+    """The per-channel extension of the table format (`blob#c` lines) must reduce to the TensorRT per-tensor semantics when every
+    channel carries the tensor's scale -- except for the FPN adds, where per-channel tables give the three tensors of an add one
+    common scale (the largest) and blend in integers: with equal scales for all three the two blends are the same function, so the
+    whole network must agree activation for activation."""
+    import copy
+    net = copy.deepcopy(nets["mnet-deconv-0517"])
+    base = dict(net.int8_scales)
+    # force the three tensors of each add to one per-tensor scale, so that the per-tensor engine's ratios are exactly 1
+    for group in (("rf_c3_lateral_relu", "rf_c2_lateral_relu", "_plus0"), ("rf_c2_aggr_relu", "rf_c1_red_conv_relu", "_plus1")):
+        m = max(base[g] for g in group)
+        for g in group:
+            base[g] = m
+    net.int8_scales = dict(base)
+    per_tensor = i8.Int8Net(net)
+    assert not per_tensor.per_channel and per_tensor.a_lat == [1.0, 1.0] and per_tensor.a_up == [1.0, 1.0]
+    chans = {"_plus0": 64, "_plus1": 64}
+    for i in range(13):
+        c = i8.Int8Net.BLOCK_COUT[i]
+        chans[f"mobilenet0_relu{2 * i + 2}_fwd"] = c
+        chans[f"mobilenet0_relu{2 * i + 1}_fwd"] = 8 if i == 0 else i8.Int8Net.BLOCK_COUT[i - 1]
+    for n in ("rf_c3_lateral_relu", "rf_c2_lateral_relu", "rf_c1_red_conv_relu", "rf_c2_aggr_relu", "rf_c1_aggr_relu"):
+        chans[n] = 64
+    for c in (3, 2, 1):
+        chans[f"rf_c{c}_det_concat_relu"] = 64
+        chans[f"rf_c{c}_det_context_conv1_relu"] = 16
+        chans[f"rf_c{c}_det_context_conv3_1_relu"] = 16
+    wide = dict(base)
+    for n, c in chans.items():
+        for k in range(c):
+            wide[f"{n}#{k}"] = base[n]
+    net2 = copy.deepcopy(net)
+    net2.int8_scales = wide
+    per_channel = i8.Int8Net(net2)
+    assert per_channel.per_channel
+    rng = np.random.default_rng(23)
+    x = rng.integers(0, 128, (32, 48, 16)).astype(np.int8)
+    a = per_tensor.forward_from("mobilenet0_relu2_fwd", x)
+    b = per_channel.forward_from("mobilenet0_relu2_fwd", x)
+    for k in a:
+        if k == "__heads__":
+            assert all(np.array_equal(a[k][h], b[k][h]) for h in a[k])
+        else:
+            assert np.array_equal(a[k], b[k]), k
