@@ -695,16 +695,23 @@ __global__ __launch_bounds__(kThreads, (StemCfg<TO>::OCC)) void stem_kernel(Stem
     // ---- phase 4: pointwise 8 -> 16 (conv2) on MFMA, K padded to 32
     f32x4 acc[1][4];
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
-        if constexpr (sizeof(TO) == 1) acc[0][j] = vzero<f32x4, 4>();       // int8 output: bias added after the requantising multiply
-        else acc[0][j] = pw_bias;
-    }
+    for (int j = 0; j < 4; j++) acc[0][j] = pw_bias;      // (int8 output: weights and bias are already divided by the output scale, weights.h)
     // K slots of the one MFMA: [W_hi x_hi | W_hi x_lo | W_lo x_hi | 0]
     pipe.run(acc, [&](int j, int) -> M::Frag {
         return kb < 3 ? *(const M::Frag *)(s_a + acc_pixel(wave + j * 4, lane) * LDA + (kb & 1) * 8) : M::zero();
     });
 #pragma unroll
-    for (int j = 0; j < 4; j++) store_acc<TO, LDO>(s_out, pw_mult, pw_bias, acc[0][j], 0, wave + j * 4, lane, true);
+    for (int j = 0; j < 4; j++) {
+        if constexpr (sizeof(TO) == 1) {
+            // the accumulator is the value in output quanta: clamp, round to nearest even + pack (v_cvt_pk_u8_f32), 2 instructions per value
+            uint32_t packed = 0;
+#pragma unroll
+            for (int r = 0; r < 4; r++) packed = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_amdgcn_fmed3f(acc[0][j][r], 0.f, 127.f), r, packed);
+            *(uint32_t *)(s_out + acc_pixel(wave + j * 4, lane) * LDO + acc_cout(0, lane, 0)) = packed;
+        } else {
+            store_acc<TO, LDO>(s_out, pw_mult, pw_bias, acc[0][j], 0, wave + j * 4, lane, true);
+        }
+    }
     __syncthreads();
     typedef typename Vec<TO>::type VO;
     constexpr int OPV = 16 / Vec<TO>::N;                                  // 16-byte chunks per output pixel

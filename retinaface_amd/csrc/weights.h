@@ -78,7 +78,7 @@ template <typename T> constexpr int mma_kpl() { return sizeof(T) == 1 ? 16 : siz
 
 
 // ---------------------------------------------------------------------------------------------------- byte archive
-constexpr uint32_t kPlanCacheVersion = 6;      // bump when the packing / layout of anything below changes
+constexpr uint32_t kPlanCacheVersion = 7;      // bump when the packing / layout of anything below changes
 
 struct ArOut {
     std::string b;
@@ -347,23 +347,25 @@ struct WeightPack {
                 for (int t = 0; t < 9; t++) dw[(size_t)t * 8 + ch] = b0.dw.w[(size_t)ch * 9 + t];
             stem_dw_ = DwW{arena_.put(dw), arena_.put(b0.dw.b)};
             // pointwise 16 x 8: one A fragment whose K slots are [w_hi | w_hi | w_lo | 0] (pack.h stem_pw_slot)
+            // int8 engine: the stem's output is in quanta of its calibrated scale.  The 1 / scale is folded into the (hi + lo) weights and
+            // the bias here, so the kernel's accumulator IS the value to round: no multiply in the epilogue (round 3; it was fma(acc, 1 / s, b / s))
+            Sc stem_os(b0.pw.cout, 1.f);
+            if constexpr (kInt8) stem_os = scales_of(plan, b0.pw.out_blob, b0.pw.cout);
             std::vector<half_t> pwf((size_t)64 * 8, (half_t)0);
             for (int lane = 0; lane < 64; lane++) {
                 int row = 0, use_lo = 0;
                 if (!stem_pw_slot(lane, &row, &use_lo)) continue;
                 for (int e = 0; e < 8; e++) {
-                    const float w = b0.pw.w[(size_t)row * 8 + e];
+                    const float w = kInt8 ? b0.pw.w[(size_t)row * 8 + e] / stem_os[row] : b0.pw.w[(size_t)row * 8 + e];
                     const half_t hi = (half_t)w;
                     pwf[(size_t)lane * 8 + e] = use_lo ? (half_t)(w - (float)hi) : hi;
                 }
             }
             stem_pw_.w = arena_.put(pwf);
             if constexpr (kInt8) {
-                const Sc os = scales_of(plan, b0.pw.out_blob, b0.pw.cout);
-                std::vector<float> b(b0.pw.b), m(b0.pw.cout);
-                for (int o = 0; o < b0.pw.cout; o++) { m[o] = 1.f / os[o]; b[o] /= os[o]; }
+                std::vector<float> b(b0.pw.b);
+                for (int o = 0; o < b0.pw.cout; o++) b[o] /= stem_os[o];
                 stem_pw_.b = arena_.put(b);
-                stem_pw_.m = arena_.put(m);
             } else {
                 stem_pw_.b = arena_.put(b0.pw.b);
             }
