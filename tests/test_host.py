@@ -486,3 +486,24 @@ def test_plan_cache_round_trip_and_invalidation(built_lib, tmp_path):
     assert probe(1) == 0 and probe(1) == 1
     # nowhere to write: still works, never a hit
     assert probe(1, "/proc/definitely/not/writable.rfplan") == 0 and probe(1, "/proc/definitely/not/writable.rfplan") == 0
+
+
+def test_bench_physical_fractions_pick_the_binding_resource():
+    """bench.py's `roofline` reports what the hardware did, not only the layer-wise credit: HBM bytes / time / 8 TB/s, VALU / LDS / MFMA busy
+    cycles / (GPU-active cycles x SIMDs), `bound` = the largest.  Round 2's stem2 numbers (VALU-issue bound at 0.17 of the HBM peak) and an
+    HBM-bound kernel, from counter values of the shape rocprofv3 returns (SQ_ACTIVE_INST_* in quad-cycles, GRBM_GUI_ACTIVE already / 8)."""
+    sys.path.insert(0, ROOT)
+    import bench
+    gpu_cycles = 640_000.0                                   # ~0.267 ms at 2.4 GHz
+    stem2 = dict(kernel="stem2", grid=1, launches_per_pass=1, hbm_bytes=360e6, valu_quad=0.80 * gpu_cycles * 1024 / 4,
+                 lds_quad=0.21 * gpu_cycles * 1024 / 4, mfma_cycles=0.18 * gpu_cycles * 1024, gpu_cycles=gpu_cycles)
+    r = bench.physical_fractions([stem2], 0.267, 1024)
+    assert r["bound"] == "valu_issue" and abs(r["bound_frac"] - 0.80) < 1e-9 and abs(r["hbm_frac_measured"] - 360e6 / 0.267e-3 / 8e12) < 1e-9
+    assert abs(r["mfma_busy"] - 0.18) < 1e-9 and abs(r["lds_active"] - 0.21) < 1e-9
+    copy = dict(kernel="dwpw", grid=1, launches_per_pass=4, hbm_bytes=155e6, valu_quad=0.05 * 60_000 * 1024 / 4, lds_quad=0.0,
+                mfma_cycles=0.08 * 60_000 * 1024, gpu_cycles=60_000.0)
+    r = bench.physical_fractions([copy], 4 * 0.0257, 1024)
+    assert r["bound"] == "hbm" and abs(r["hbm_frac_measured"] - 4 * 155e6 / (4 * 0.0257e-3) / 8e12) < 1e-9
+    # without the SQ pass only the traffic is known
+    r = bench.physical_fractions([dict(stem2, valu_quad=None, lds_quad=None, mfma_cycles=None)], 0.267, 1024)
+    assert r["bound"] == "hbm" and "valu_active" not in r
