@@ -369,7 +369,7 @@ struct GemmPipe {
 // GEMM with the weight fragments resident in registers: acc[i][j] += w[i][kc] x xf(j, kc).  The activation (B) fragments are
 // read from LDS DEPTH-1 K-chunks ahead of the MFMAs that use them -- written out explicitly, because the compiler keeps
 // source order here and would otherwise expose one LDS round trip (~100+ cycles) per K-chunk against 16 cycles per MFMA.
-template <typename T, int NI, int NJ, int KCH, int DEPTH = (NJ >= 4 ? 2 : 3), typename XF>
+template <typename T, int NI, int NJ, int KCH, int DEPTH = (NJ >= 4 ? 2 : 3), bool PIN = false, typename XF>
 __device__ __forceinline__ void gemm_stationary(typename Mma<T>::Acc (&acc)[NI][NJ], const typename Mma<T>::Frag (&w)[NI][KCH], XF &&xf) {
     typedef Mma<T> M;
     typename M::Frag x[DEPTH][NJ];
@@ -385,10 +385,18 @@ __device__ __forceinline__ void gemm_stationary(typename Mma<T>::Acc (&acc)[NI][
 #pragma unroll
             for (int j = 0; j < NJ; j++) x[(kc + DEPTH - 1) % DEPTH][j] = xf(j, kc + DEPTH - 1);
         }
+        // Pin the software pipeline (round 4): left to itself hipcc's scheduler sinks every B-fragment read to just before the MFMA that
+        // consumes it (one register set, `ds_read; s_waitcnt lgkmcnt(0); v_mfma` per MFMA: the ISA of round 3's 3x3 convs exposed one LDS
+        // round trip per one or two MFMAs).  Nothing may cross these two fences, so the reads of chunk kc + DEPTH - 1 are in flight while the
+        // MFMAs of chunk kc issue.  PIN is a per-call-site choice, measured (tools/gpu/r4_call3.sh): the long K loops of the 64-channel 3x3
+        // convs gain 10 %, the 5-chunk loops of ssh_tail and the fused laterals lose (44 -> 50 us, +1.4 us): their reads are better left
+        // where the compiler puts them.
+        if constexpr (PIN) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int i = 0; i < NI; i++)
 #pragma unroll
             for (int j = 0; j < NJ; j++) acc[i][j] = M::mma(w[i][kc], x[kc % DEPTH][j], acc[i][j]);
+        if constexpr (PIN) __builtin_amdgcn_sched_barrier(0);
     }
 }
 
@@ -2160,7 +2168,7 @@ __global__ __launch_bounds__(kThreads, (Conv3Cfg<T, CIN, COUT, TH, TW, ALLC, PAD
                 return kb < KTOT ? *(const Frag *)(s_in_b + pbase[j] + koff) : M::zero();
             };
             if constexpr (STAT) {
-                gemm_stationary<T, NI, NJ, KCH>(acc, wst, xf);
+                gemm_stationary<T, NI, NJ, KCH, (NJ >= 4 ? 2 : 3), (KCH >= 9)>(acc, wst, xf);
             } else {
                 GemmPipe<T, NI, NJ, KCH, WN, C::GFRAGS> pipe;
                 pipe.init(L.w, wn, lane);
@@ -2183,9 +2191,236 @@ __global__ __launch_bounds__(kThreads, (Conv3Cfg<T, CIN, COUT, TH, TW, ALLC, PAD
     RF_TRACE(3, 7);
 }
 
+// =============================================================================================
+// K_c'  the merged SSH conv (3x3, 64 -> 48, all three FPN levels) WAVE-SPECIALISED (round 4).
+//   48 output channels = three MFMA channel tiles: three waves of the workgroup own one each (18 stationary A fragments) and the
+//   fourth had nothing to multiply.  In K_c all four waves walked every tile in lock step -- stage the halo, request the next one,
+//   store the previous result, barrier, GEMM (3 of 4 waves), epilogue, barrier -- and the phase timeline (tools/probes/phase_trace.py,
+//   profiles/r04_phase_timelines.txt) showed the GEMM to be only half of a tile's 3.9 us: 1.2 us went to the three memory phases that
+//   precede it and 0.4 us to the two barriers.  Here the roles are split:
+//     wave 3  (producer)   per tile: stores the PREVIOUS tile's result (s_out[b^1] -> HBM) and brings in the NEXT halo tile by
+//                          LDS-DMA (`buffer_load_dwordx4 ... lds`: HBM -> s_in[b^1], no VGPRs, no ds_write pass; zero padding by
+//                          the descriptor's range check, out-of-range lanes land as zeros: tools/probes/lds_dma.cpp)
+//     waves 0-2 (consumers) per tile: GEMM on s_in[b] + epilogue into s_out[b]; they execute no global memory instruction in the loop
+//   and everybody meets at ONE barrier per tile.  The halo image in LDS is lane-linear per DMA instruction (1 KiB = 64 slots of
+//   16 B), so the padded layout of K_c (pixel pitch 32 mod 64 bytes, row pitch a multiple of 256 bytes: conflict-free B fragments)
+//   is kept by giving the pad chunks slots of their own that load nothing.
+// =============================================================================================
+typedef __attribute__((address_space(3))) void *lds_void_ptr;
+// One LDS-DMA wave-instruction: lane l fetches 16 bytes at buffer offset off[l] and the hardware writes them to lds_base + 16 * l (the
+// destination is wave-uniform base + lane-linear; out-of-range offsets land as zeros).  A plain (non-template) device function: inside a
+// template the host pass, which does not know the builtin, silently drops the whole kernel instantiation.
+__device__ __forceinline__ void lds_dma16(__amdgpu_buffer_rsrc_t rs, void *lds_base, unsigned off) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_ptr)lds_base, 16, (int)off, 0, 0, 0);
+}
+
+template <typename T, int NBUF> struct Conv3WsCfg {
+    typedef Conv3Cfg<T, 64, 48, 8, 8, false, true> B;                  // tile geometry, LDS pitches, wave split (ODD: 3 GEMM waves)
+    static constexpr int VEC = B::VEC;
+    static constexpr int CPP = B::LDI / VEC;                           // 16-byte chunks per halo pixel, padding included
+    static constexpr int CPR = B::ROWP / VEC;                          // chunks per halo row, padding included
+    static constexpr int DPP = 64 / VEC;                               // data chunks per pixel
+    static constexpr int SLOTS = B::HR * CPR;
+    static constexpr int PIECES = (SLOTS + 63) / 64;                   // DMA wave-instructions per halo tile
+    static constexpr int NSTORE = B::P * (48 / VEC) / 64;              // store wave-instructions per result tile (producer wave)
+    static constexpr size_t IN_BYTES = (size_t)PIECES * 1024;          // whole KiB: the last piece may overhang the image
+    static constexpr size_t O_BYTES = B::O_BYTES;
+    static constexpr size_t LDS_BYTES = NBUF * IN_BYTES + 2 * O_BYTES; // NBUF halo tiles (prefetch distance NBUF - 1), result tile double buffered
+    static_assert(B::LDI % VEC == 0 && B::ROWP % VEC == 0 && B::ODD && B::STAT, "layout assumptions of the warp-specialised conv");
+    static_assert(IN_BYTES >= B::IN_BYTES && O_BYTES % 16 == 0 && (NBUF == 2 || NBUF == 3), "LDS carve");
+    static_assert(NSTORE + PIECES < 64, "counted vmcnt");
+};
+
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+// workgroup barrier that does NOT drain the vector-memory counter (__syncthreads() does when an LDS-DMA is in flight): LDS traffic of this
+// wave is complete, then s_barrier.  Whoever needs a DMA to have landed waits for it explicitly (counted vmcnt) before calling this.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+template <typename T, int DEPTH, int NBUF>
+__global__ __launch_bounds__(kThreads, (NBUF == 2 || sizeof(T) == 1 ? 3 : 2)) void conv3x3_ws_kernel(Conv3Args<T> a) {
+    typedef Conv3WsCfg<T, NBUF> W;
+    typedef typename W::B C;
+    typedef typename Vec<T>::type V;
+    typedef Mma<T> M;
+    typedef typename M::Frag Frag;
+    constexpr int CIN = 64, COUT = 48, TH = 8, TW = 8;
+    constexpr int VEC = C::VEC, P = C::P, HC = C::HC, LDI = C::LDI, LDO = C::LDO, ROWP = C::ROWP;
+    constexpr int KTOT = C::KTOT, KCH = C::KCH, NJ = C::NJ;
+    constexpr int DIST = NBUF - 1;                                     // the producer runs DIST tiles ahead of the consumers
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int IN_ELEMS = (int)(W::IN_BYTES / sizeof(T)), O_ELEMS = (int)(W::O_BYTES / sizeof(T));
+    T *s_in = (T *)smem;                                               // [NBUF][IN_ELEMS]
+    T *s_out = (T *)(smem + NBUF * W::IN_BYTES);                       // [2][O_ELEMS]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);         // scalar: the role branch below is a scalar branch
+    const int gbid = xcd_remap(blockIdx.x, gridDim.x);
+    const int lvl = (gbid >= a.lv[1].gb_begin ? 1 : 0) + (gbid >= a.lv[2].gb_begin ? 1 : 0);
+    const Conv3Level<T> &L = a.lv[lvl];
+    const int first = gbid - L.gb_begin, G = L.gsz, ntiles = L.ntiles;
+    const int lh = L.h, lw = L.w_;
+    const int n_my = first < ntiles ? (ntiles - 1 - first) / G + 1 : 0;            // tiles this workgroup walks
+    T *out0 = L.out0, *out1 = L.out1;
+    const int ld0 = L.ld0, off0 = L.off0, ld1 = L.ld1, off1 = L.off1;      // (n0 == 32: checked by the launcher)
+    // finished tile (img, oy0, ox0) in LDS -> HBM by threads t0, t0 + nthr, ...: channels [0, 32) -> the concat slice, [32, 48) -> context_conv1's
+    // own tensor.  Two loops, one per destination: a loop that picked the descriptor per lane would be serialised by the compiler into a
+    // "waterfall" over the distinct descriptors
+    auto store_tile = [&](const T *s_res, int img, int oy0, int ox0, int t0, int nthr) {
+        constexpr int N0 = 32, V0 = N0 / VEC, V1 = (COUT - N0) / VEC;
+        const auto r0 = image_rsrc(out0 + (size_t)img * lh * lw * ld0 + off0, (unsigned)(lh * lw * ld0 - off0) * (unsigned)sizeof(T));
+        const auto r1 = image_rsrc(out1 + (size_t)img * lh * lw * ld1 + off1, (unsigned)(lh * lw * ld1 - off1) * (unsigned)sizeof(T));
+        const int pbase = oy0 * lw + ox0;
+        for (int i = t0; i < P * V0; i += nthr) {
+            const int p = i / V0, c = (i % V0) * VEC;
+            const int py = p / TW, px = p % TW;
+            const int pix = pbase + py * lw + px;
+            buf_store16(r0, ox0 + px < lw ? (unsigned)((pix * ld0 + c) * (int)sizeof(T)) : kOobOffset, *(const V *)(s_res + p * LDO + c));
+        }
+        for (int i = t0; i < P * V1; i += nthr) {
+            const int p = i / V1, c = (i % V1) * VEC;
+            const int py = p / TW, px = p % TW;
+            const int pix = pbase + py * lw + px;
+            buf_store16(r1, ox0 + px < lw ? (unsigned)((pix * ld1 + c) * (int)sizeof(T)) : kOobOffset, *(const V *)(s_res + p * LDO + N0 + c));
+        }
+    };
+
+    if (wave == 3) {
+        // ================================================= producer
+        // slot s of the halo image -> (halo row, halo column, chunk); pad slots and slots past the last row load nothing (they are
+        // given an out-of-range offset: the DMA writes zeros there, inside this buffer's whole-KiB region)
+        int kpack[W::PIECES];                                          // byte offset inside the image | halo column << 27 (31 = no pixel)
+        const int in_ld = L.in_ld;
+#pragma unroll
+        for (int i = 0; i < W::PIECES; i++) {
+            const int s = i * 64 + lane;
+            const int row = s / W::CPR, rem = s % W::CPR;
+            const int px = rem / W::CPP, ch = rem % W::CPP;
+            const bool real = row < C::HR && px < HC && ch < W::DPP;
+            kpack[i] = real ? ((((row * lw + px) * in_ld + ch * VEC) * (int)sizeof(T)) | (px << 27)) : (int)(31u << 27);
+        }
+        const unsigned in_img_bytes = (unsigned)(lh * lw * in_ld - L.in_off) * (unsigned)sizeof(T);
+        const T *in = L.in + L.in_off;
+        auto dma = [&](int tx, int ty, int img, T *dst) {
+            const auto rs = image_rsrc(in + (size_t)img * lh * lw * in_ld, in_img_bytes);
+            const int iy0 = ty * TH - 1, ix0 = tx * TW - 1;
+            const int sbase = (iy0 * lw + ix0) * in_ld * (int)sizeof(T);
+#pragma unroll
+            for (int i = 0; i < W::PIECES; i++) {
+                const int dx = (int)((unsigned)kpack[i] >> 27);
+                const unsigned off = (dx != 31 && (unsigned)(ix0 + dx) < (unsigned)lw) ? (unsigned)((kpack[i] & 0x07ffffff) + sbase) : kOobOffset;
+                lds_dma16(rs, (unsigned char *)dst + i * 1024, off);
+            }
+        };
+        const TileStep step(G, L.tiles_x, L.tiles_y);
+        TileCoord cur(first, L.tiles_x, L.tiles_y), pf = cur;         // cur: the tile the consumers multiply; pf: the next tile to fetch
+        // prologue: the first DIST tiles are requested; tile 0 has landed when at most the younger request is outstanding
+#pragma unroll
+        for (int d = 0; d < DIST; d++)
+            if (d < n_my) { dma(pf.tx, pf.ty, pf.img, s_in + d * IN_ELEMS); step.advance(pf); }
+        if (DIST == 2 && n_my >= 2) wait_vmcnt<W::PIECES>();
+        else wait_vmcnt<0>();
+        lds_barrier();
+        int p_img = 0, p_oy0 = 0, p_ox0 = 0;
+        for (int k = 0; k < n_my; k++) {
+            const bool st = k > 0, ld = k + DIST < n_my;
+            if (st) store_tile(s_out + ((k - 1) & 1) * O_ELEMS, p_img, p_oy0, p_ox0, lane, 64);
+            if (ld) { dma(pf.tx, pf.ty, pf.img, s_in + ((k + DIST) % NBUF) * IN_ELEMS); step.advance(pf); }
+            p_img = cur.img; p_oy0 = cur.ty * TH; p_ox0 = cur.tx * TW;
+            step.advance(cur);
+            // tile k + 1 must have landed before the barrier.  DIST == 1: it is the request just made.  DIST == 2: it was requested one
+            // interval ago; everything issued in THIS interval (NSTORE stores, PIECES loads) may stay in flight (the counter is in order)
+            if (DIST == 1) wait_vmcnt<0>();
+            else if (st && ld) wait_vmcnt<W::NSTORE + W::PIECES>();
+            else if (ld) wait_vmcnt<W::PIECES>();
+            else if (st) wait_vmcnt<W::NSTORE>();
+            else wait_vmcnt<0>();
+            lds_barrier();
+        }
+        if (n_my > 0) store_tile(s_out + ((n_my - 1) & 1) * O_ELEMS, p_img, p_oy0, p_ox0, lane, 64);
+    } else {
+        // ================================================= consumers: wave = output-channel tile
+        const int wn = wave;
+        Frag wst[1][KCH];
+        {
+            const Frag *wsrc = (const Frag *)L.w + (size_t)wn * KCH * 64 + lane;
+#pragma unroll
+            for (int kc = 0; kc < KCH; kc++) wst[0][kc] = wsrc[kc * 64];
+        }
+        const f32x4 bias = *(const f32x4 *)(L.b + acc_cout(wn, lane, 0));
+        const f32x4 mult = load_mult(L.m, acc_cout(wn, lane, 0));
+        int pbase[NJ];
+#pragma unroll
+        for (int j = 0; j < NJ; j++) {
+            const int p = acc_pixel(j, lane);
+            pbase[j] = (p / TW) * ROWP + (p % TW) * LDI;
+        }
+        __builtin_amdgcn_s_waitcnt(0x0F70);                            // weights are in registers: no global access below this line
+        lds_barrier();
+        for (int k = 0; k < n_my; k++) {
+            const T *s_in_b = s_in + (k % NBUF) * IN_ELEMS;
+            T *s_out_b = s_out + (k & 1) * O_ELEMS;
+            typename M::Acc acc[1][NJ];
+#pragma unroll
+            for (int j = 0; j < NJ; j++) acc[0][j] = acc_init<T>(bias);
+            gemm_stationary<T, 1, NJ, KCH, DEPTH, true>(acc, wst, [&](int j, int kc) -> Frag {
+                const int kb = kc * M::K + (lane >> 4) * M::KPL;       // k = tap*CIN + c, KPL consecutive c of one tap
+                const int tap = kb / CIN, c = kb % CIN;
+                const int koff = (tap / 3) * ROWP + (tap % 3) * LDI + c;
+                return kb < KTOT ? *(const Frag *)(s_in_b + pbase[j] + koff) : M::zero();
+            });
+#pragma unroll
+            for (int j = 0; j < NJ; j++) store_acc<T, LDO>(s_out_b, mult, bias, acc[0][j], wn, j, lane, true);
+            lds_barrier();
+        }
+    }
+}
+
+static int conv3_ws_variant() {
+    static int v = -1;
+    if (v < 0) { const char *e = getenv("RF_CONV3WS"); v = e ? atoi(e) : 1; }        // probe knob: 0 = K_c for the merged SSH conv as well; 22 / 23 / 32 / 33: see conv3_ws_launch
+    return v;
+}
+
+template <typename T, int DEPTH, int NBUF>
+static void conv3_ws_launch_v(hipStream_t s, Conv3Args<T> &a, int nlv, int total_tiles) {
+    typedef Conv3WsCfg<T, NBUF> W;
+    auto kern = conv3x3_ws_kernel<T, DEPTH, NBUF>;
+    static std::atomic<int> resident_cache[kMaxDevices] = {};
+    const int resident = kernel_residency(resident_cache, kern, W::LDS_BYTES);
+    const int want = persistent_grid(total_tiles, resident);
+    int grid = 0;
+    for (int l = 0; l < 3; l++) {
+        Conv3Level<T> &L = a.lv[l];
+        if (l >= nlv) { L.gb_begin = 0x7fffffff; L.gsz = 1; L.ntiles = 0; continue; }
+        long g = want == total_tiles ? L.ntiles : ((long)L.ntiles * want + total_tiles - 1) / total_tiles;
+        if (g < 1) g = 1;
+        if (g > L.ntiles) g = L.ntiles;
+        L.gb_begin = grid;
+        L.gsz = (int)g;
+        grid += (int)g;
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), W::LDS_BYTES, s, a);
+}
+// RF_CONV3WS = 10 * halo buffers + B-fragment prefetch depth (probe knob): 22, 23, 32, 33; 1 = the default
+template <typename T>
+static void conv3_ws_launch(hipStream_t s, Conv3Args<T> &a, int nlv, int total_tiles) {
+    switch (conv3_ws_variant()) {
+        case 22: conv3_ws_launch_v<T, 2, 2>(s, a, nlv, total_tiles); break;
+        case 23: conv3_ws_launch_v<T, 3, 2>(s, a, nlv, total_tiles); break;
+        case 32: conv3_ws_launch_v<T, 2, 3>(s, a, nlv, total_tiles); break;
+        case 33: conv3_ws_launch_v<T, 3, 3>(s, a, nlv, total_tiles); break;
+        default: conv3_ws_launch_v<T, 2, 2>(s, a, nlv, total_tiles); break;
+    }
+}
+
 template <typename T, int CIN, int COUT, int TH, int TW, bool UPADD, bool ALLC, bool PADROW>
 static void conv3_launch(hipStream_t s, Conv3Args<T> &a, int nlv, int total_tiles) {
     typedef Conv3Cfg<T, CIN, COUT, TH, TW, ALLC, PADROW> C;
+    if constexpr (sizeof(T) <= 2 && CIN == 64 && COUT == 48 && TH == 8 && TW == 8 && !UPADD && !ALLC && PADROW) {
+        bool split32 = true;
+        for (int l = 0; l < nlv; l++) split32 = split32 && a.lv[l].n0 == 32 && a.lv[l].out1 != nullptr;
+        if (conv3_ws_variant() && split32) { conv3_ws_launch<T>(s, a, nlv, total_tiles); return; }
+    }
     auto kern = conv3x3_kernel<T, CIN, COUT, TH, TW, UPADD, ALLC, PADROW>;
     static std::atomic<int> resident_cache[kMaxDevices] = {};
     const int resident = kernel_residency(resident_cache, kern, C::LDS_BYTES);
