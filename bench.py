@@ -26,6 +26,17 @@ Prints ONE JSON line (rank 0): metric faces/sec (BASELINE.json), images/sec and 
 `roofline` for the dominant kernel (HIP-event timed inside this process, algorithmic bytes per SURVEY.md 8d) and `cpu_baseline`
 (the CPU oracle = restatement of the reference's Caffe path, timed on the host cores on a bounded sample of the same frames;
 N = 1, rank 0 only).  --dry runs the launcher / sharding / gather / JSON plumbing with a stub engine on gloo (CPU tests).
+
+The default invocation (N = 1, the metric point) also times the OTHER BASELINE.json configurations in the same run and reports them
+in `configs`: [2] mnet-deconv-0517 int8 batch 32, [3] mnet25 fp16 1280x896 batch 1, [4]'s per-GPU shape mnet25 int8 batch 32 -- a
+timed region of >= --extra-seconds each with images/s, faces/s, dtype, the dominant kernel and (one extra set of counter passes,
+collected while the CPU baseline runs) its binding resource.  With N > 1 a short STRONG-scaling leg of configs[4] as stated (one
+global batch of 256 int8 images per step split over the ranks) follows the weak-scaling measurement (`configs4_strong`), and
+`result_gather` says which backend carried the gather, the communicator size seen through an RCCL collective and the RCCL version.
+
+`roofline.frac` is the PHYSICAL fraction of the dominant kernel's binding resource (HBM bytes moved, VALU / MFMA / LDS issue cycles,
+measured by rocprofv3 --pmc in this run): always <= 1.  The layer-wise algorithmic-bytes figure of SURVEY.md 8d, which counts bytes
+a fused kernel never moves and therefore exceeds 1, stays beside it as `frac_layerwise_credit` / `hbm_layerwise`.
 """
 from __future__ import annotations
 
@@ -79,6 +90,9 @@ def parse_args(argv=None):
                     help="STRONG scaling: a step is ONE batch of this many images split over the ranks by shard_range (BASELINE.json "
                          "configs[4]: --global-batch 256 --gpus 8 --precision int8); 0 = weak scaling, --batch images per rank")
     ap.add_argument("--regions", type=int, default=3, help="timed regions; `value` is the median one, min / max are reported beside it")
+    ap.add_argument("--extra-seconds", type=float, default=0.4,
+                    help="timed region of each additional BASELINE.json config the default invocation also measures (`configs`); 0 = skip")
+    ap.add_argument("--no-extra-configs", action="store_true", help="measure only the configuration named by the flags")
     ap.add_argument("--master-port", type=int, default=0)
     return ap.parse_args(argv)
 
@@ -133,6 +147,83 @@ class StubEngine:
         pass
 
 
+class Runner:
+    """One engine configuration on this rank: keeps the engine's pipeline full (up to `slots` batches in flight, every step's results
+    collected) and, with N > 1, all-gathers the fixed-size result records of every global super-batch (retinaface_amd/shard.py) --
+    one gather stays in flight while the next block fills."""
+
+    def __init__(self, det, B, B_pad, slots, per_launch, world, cdev, dry, thr):
+        import numpy as np
+        import torch
+        from retinaface_amd import shard
+        self.np, self.torch, self.shard = np, torch, shard
+        self.det, self.B, self.B_pad, self.slots, self.per_launch = det, B, B_pad, slots, per_launch
+        self.world, self.cdev, self.dry, self.thr = world, cdev, dry, thr
+        self.rec_w = 1 + GATHER_CAP * shard.RECORD_FLOATS
+        self.gs = {"buf": np.zeros((per_launch * B_pad, self.rec_w), np.float32), "fill": 0, "handle": None, "out": None, "block": None,
+                   "gathers": 0, "images": torch.zeros((), dtype=torch.int64, device=cdev)}
+
+    def record_step(self, counts, n):
+        """Append this step's per-image records (count + first GATHER_CAP faces) to the rank's block; all_gather it when the
+        block holds one super-batch."""
+        gs, det = self.gs, self.det
+        faces = det.last_faces if self.dry else det.last_wait_faces()
+        blk = gs["buf"][gs["fill"]:gs["fill"] + n]
+        blk[:, 0] = counts
+        blk[:, 1:].reshape(n, GATHER_CAP, self.shard.RECORD_FLOATS)[:, :, :15] = faces[:n, :GATHER_CAP]
+        gs["buf"][gs["fill"] + n:gs["fill"] + self.B_pad, 0] = -1.0            # strong mode, ragged split: this rank's slice is shorter
+        gs["fill"] += self.B_pad
+        if gs["fill"] == gs["buf"].shape[0]:
+            self.flush_gather()
+
+    def finish_gather(self):
+        gs = self.gs
+        if gs["handle"] is not None:
+            gs["handle"].wait()                 # RCCL: orders the current stream behind the collective, the host does not block
+            gs["images"] += (gs["out"][:, 0] >= 0).sum()          # consume the gathered block (records of every rank), on device
+            gs["handle"] = None
+
+    def flush_gather(self, final=False):
+        import torch.distributed as dist
+        gs, torch = self.gs, self.torch
+        self.finish_gather()
+        if gs["fill"]:
+            block = torch.from_numpy(gs["buf"][:gs["fill"]].copy())
+            if gs["fill"] < gs["buf"].shape[0]:                       # ragged tail: pad to the fixed block size
+                pad = torch.full((gs["buf"].shape[0] - gs["fill"], self.rec_w), -1.0)
+                block = torch.cat([block, pad])
+            gs["block"] = block.to(self.cdev, non_blocking=True)
+            gs["out"] = torch.empty((self.world * block.shape[0], self.rec_w), dtype=torch.float32, device=self.cdev)
+            gs["handle"] = dist.all_gather_into_tensor(gs["out"], gs["block"], async_op=True)
+            gs["gathers"] += 1
+            gs["fill"] = 0
+        if final:
+            self.finish_gather()
+
+    def run(self, steps: int, ring, gather: bool, enqueue=None) -> int:
+        """Keep the engine's pipeline full: up to `slots` batches in flight, the results of every step are collected."""
+        det, B = self.det, self.B
+        enqueue = enqueue or det.enqueue_prepared
+        faces = 0
+        inflight = []
+        nring = len(ring)
+        for s in range(steps):
+            if len(inflight) == self.slots:
+                c = det.wait_counts(inflight.pop(0), B)
+                faces += sum(c)
+                if gather:
+                    self.record_step(c, B)
+            inflight.append(enqueue(ring[s % nring], self.thr))
+        while inflight:
+            c = det.wait_counts(inflight.pop(0), B)
+            faces += sum(c)
+            if gather:
+                self.record_step(c, B)
+        if gather:
+            self.flush_gather(final=True)
+        return faces
+
+
 def main() -> int:
     args = parse_args()
     env_world = os.environ.get("WORLD_SIZE")
@@ -170,6 +261,22 @@ def main() -> int:
         dist.init_process_group(backend)
 
     from retinaface_amd import shard
+
+    # who takes part in the collectives, as seen THROUGH a collective of the backend that carries the result gather
+    comm = {"backend": backend, "ranks_in_communicator": 1, "ranks": [[0, 0 if args.dry else local_rank]]}
+    if world > 1:
+        me = torch.tensor([[rank, -1 if args.dry else torch.cuda.current_device()]], dtype=torch.int64, device=cdev)
+        everyone = torch.empty((world, 2), dtype=torch.int64, device=cdev)
+        dist.all_gather_into_tensor(everyone, me)
+        comm["ranks"] = [[int(a), int(b)] for a, b in everyone.cpu().tolist()]
+        comm["ranks_in_communicator"] = len({r for r, _ in comm["ranks"]})
+        comm["distinct_devices"] = len({d for _, d in comm["ranks"]})
+    if backend == "nccl":
+        try:
+            comm["rccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception:  # noqa: BLE001
+            comm["rccl_version"] = None
+        comm["rccl_ranks"] = comm["ranks_in_communicator"]
 
     B, H, W = args.batch, args.height, args.width
     strong = args.global_batch > 0
@@ -215,68 +322,8 @@ def main() -> int:
         if not args.dry:
             torch.cuda.synchronize()
 
-    # ---- result gather of the sharded call (N > 1): one all_gather of fixed-size records per global super-batch
-    rec_w = 1 + GATHER_CAP * shard.RECORD_FLOATS
-    gather_state = {"buf": np.zeros((per_launch * B_pad, rec_w), np.float32), "fill": 0, "handle": None, "out": None, "block": None,
-                    "gathers": 0, "images": torch.zeros((), dtype=torch.int64, device=cdev)}
-
-    def record_step(counts, n):
-        """Append this step's per-image records (count + first GATHER_CAP faces) to the rank's block; all_gather it when the
-        block holds one super-batch.  One gather stays in flight while the next block fills."""
-        gs = gather_state
-        faces = det.last_faces if args.dry else det.last_wait_faces()
-        blk = gs["buf"][gs["fill"]:gs["fill"] + n]
-        blk[:, 0] = counts
-        blk[:, 1:].reshape(n, GATHER_CAP, shard.RECORD_FLOATS)[:, :, :15] = faces[:n, :GATHER_CAP]
-        gs["buf"][gs["fill"] + n:gs["fill"] + B_pad, 0] = -1.0            # strong mode, ragged split: this rank's slice is shorter
-        gs["fill"] += B_pad
-        if gs["fill"] == gs["buf"].shape[0]:
-            flush_gather()
-
-    def finish_gather():
-        gs = gather_state
-        if gs["handle"] is not None:
-            gs["handle"].wait()                 # RCCL: orders the current stream behind the collective, the host does not block
-            gs["images"] += (gs["out"][:, 0] >= 0).sum()          # consume the gathered block (records of every rank), on device
-            gs["handle"] = None
-
-    def flush_gather(final=False):
-        gs = gather_state
-        finish_gather()
-        if gs["fill"]:
-            block = torch.from_numpy(gs["buf"][:gs["fill"]].copy())
-            if gs["fill"] < gs["buf"].shape[0]:                       # ragged tail: pad to the fixed block size
-                pad = torch.full((gs["buf"].shape[0] - gs["fill"], rec_w), -1.0)
-                block = torch.cat([block, pad])
-            gs["block"] = block.to(cdev, non_blocking=True)
-            gs["out"] = torch.empty((world * block.shape[0], rec_w), dtype=torch.float32, device=cdev)
-            gs["handle"] = dist.all_gather_into_tensor(gs["out"], gs["block"], async_op=True)
-            gs["gathers"] += 1
-            gs["fill"] = 0
-        if final:
-            finish_gather()
-
-    def run(steps: int, ring, gather: bool, enqueue=None) -> int:
-        """Keep the engine's pipeline full: up to `slots` batches in flight, the results of every step are collected."""
-        enqueue = enqueue or det.enqueue_prepared
-        faces = 0
-        inflight = []
-        nring = len(ring)
-        for s in range(steps):
-            if len(inflight) == slots:
-                c = det.wait_counts(inflight.pop(0), B)
-                faces += sum(c)
-                if gather:
-                    record_step(c, B)
-            inflight.append(enqueue(ring[s % nring], thr))
-        while inflight:
-            c = det.wait_counts(inflight.pop(0), B)
-            faces += sum(c)
-            if gather:
-                record_step(c, B)
-        if gather:
-            flush_gather(final=True)
-        return faces
+    R = Runner(det, B, B_pad, slots, per_launch, world, cdev, args.dry, thr)
+    run, flush_gather, gather_state = R.run, R.flush_gather, R.gs
 
     do_gather = world > 1
     t0 = time.perf_counter()
@@ -332,6 +379,12 @@ def main() -> int:
     med = order[len(order) // 2]
     dt, faces = regions[med]
     region_rates = [regions_all[i][1] / regions_all[i][0] for i in range(len(regions_all))]
+
+    # N > 1, weak-scaling invocation (what the driver's SCALE run types): a short STRONG-scaling leg of BASELINE.json configs[4] as stated
+    # follows -- ONE global batch of 256 int8 images per step, rank r runs shard_range(256, r, N) of it, records gathered in the region
+    strong_leg = None
+    if world > 1 and not strong and not args.timed_only and not args.no_extra_configs and args.extra_seconds > 0:
+        strong_leg = strong_config4(args, world, rank, dev, cdev, barrier, frames if not args.dry else None, thr)
 
     extra = {}
     if not args.dry and not args.timed_only:
@@ -415,9 +468,13 @@ def main() -> int:
         if world > 1:
             out["result_gather"] = {"collective": "all_gather_into_tensor (RCCL)" if backend == "nccl" else
                                     ("all_gather_into_tensor (gloo, dry)" if args.dry else "all_gather_into_tensor (gloo: ranks share a GPU, RCCL refuses that)"),
+                                    "backend": comm["backend"], "rccl_ranks": comm.get("rccl_ranks"), "rccl_version": comm.get("rccl_version"),
+                                    "ranks_in_communicator": comm["ranks_in_communicator"], "rank_device": comm["ranks"],
                                     "gathers_in_timed_region": gather_state["gathers"],
-                                    "bytes_per_rank_per_gather": int(per_launch * B_pad * rec_w * 4),
+                                    "bytes_per_rank_per_gather": int(per_launch * B_pad * R.rec_w * 4),
                                     "records_gathered": int(gather_state["images"].item()), "expected": images_total}
+        if strong_leg is not None:
+            out["configs4_strong"] = strong_leg
         if args.dry:
             out["dry"] = True
         elif args.timed_only:
@@ -425,8 +482,20 @@ def main() -> int:
         else:
             out.update(extra)
             out.update(device_side_report(args, det, frames, B, H, W, per_launch, prec, images_total, world, dt_max))
+            pmc_thread = None
+            if (world == 1 and not args.no_extra_configs and args.extra_seconds > 0 and
+                    baseline_config(args).startswith("BASELINE.json configs[1]")):
+                out["configs"] = [dict(id=1, workload=out["config"]["workload"], images_per_sec=out["images_per_sec"], faces_per_sec=out["value"],
+                                       ms_per_step=out["ms_per_step"], dtype=out["dtype"], dominant_kernel=out["roofline"]["kernel_instance"],
+                                       dominant_kernel_ms=out["roofline"]["kernel_ms"], bound=out["roofline"]["bound"],
+                                       bound_frac=out["roofline"]["bound_frac"], hbm_frac_measured=out["roofline"]["hbm_frac_measured"],
+                                       note="the metric point: this line's `value`")]
+                out["configs"] += [measure_extra_config(c, args, frames, dev) for c in EXTRA_CONFIGS]
+                pmc_thread = start_extra_counters(args, out["configs"][1:])       # runs beside the CPU baseline (the GPU is idle then)
             if world == 1 and not args.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline(frames_np[:B], args, det)
+            if pmc_thread is not None:
+                finish_extra_counters(pmc_thread, out["configs"][1:], torch.cuda.get_device_properties(0).multi_processor_count)
         assert out["n_gpus"] == args.gpus
         print(json.dumps(out), flush=True)
     det.close()
@@ -493,16 +562,186 @@ def host_frames(det, frames_np, args, slots, B, run, rank):
     return res
 
 
+# The other BASELINE.json configurations the default invocation also measures (`configs` in the JSON)
+EXTRA_CONFIGS = [
+    {"id": 2, "model": "mnet-deconv-0517", "precision": "int8", "height": 448, "width": 448, "batch": 32},
+    {"id": 3, "model": "mnet25", "precision": "fp16", "height": 896, "width": 1280, "batch": 1},
+    {"id": 4, "model": "mnet25", "precision": "int8", "height": 448, "width": 448, "batch": 32,
+     "note": "per-GPU shape of configs[4] (256 images = 32 per GPU x 8 GPUs); the 8-GPU job itself: `--gpus 8` (configs4_strong)"},
+]
+
+
+def measure_extra_config(cfg, args, frames_main, dev):
+    """One additional BASELINE.json configuration in the same process: its own engine, a ring of distinct HBM-resident frames, a timed
+    region of >= --extra-seconds with the pipeline kept full, and the per-kernel HIP-event profile at the launch size (dominant kernel)."""
+    import numpy as np
+    import torch
+    import retinaface_amd
+    from retinaface_amd.frames import synth_frames
+    H, W, B = cfg["height"], cfg["width"], cfg["batch"]
+    prec = {"fp16": retinaface_amd.PRECISION_FP16, "fp32": retinaface_amd.PRECISION_FP32, "int8": 2}[cfg["precision"]]
+    cargs = argparse.Namespace(model=cfg["model"], precision=cfg["precision"], height=H, width=W, batch=B, global_batch=0)
+    if (H, W) == (args.height, args.width):
+        frames, how = frames_main, "the metric point's ring"
+    else:
+        # frame synthesis is the slow part (0.15 s per 1280x896 frame): 24 seeded frames x 4 circular shifts = 96 distinct frames
+        base = synth_frames(H, W, 24, config=cfg["id"])
+        frames = torch.from_numpy(np.stack([np.roll(f, sh, axis=1) for sh in (0, W // 4, W // 2, 3 * W // 4) for f in base])).to(dev)
+        how = "24 seeded frames x 4 circular shifts"
+    det = retinaface_amd.RetinaFace(os.path.join(ROOT, "assets"), "net3", 0.4, precision=prec, net_hw=(H, W), max_batch=B,
+                                    model_stem=cfg["model"])
+    slots = det.num_slots()
+    per_launch = max(slots // 3, 1)
+    nb = max(frames.shape[0] // B, 1)
+    ring = [det.prepare_device_batch([frames[(k * B + i) % frames.shape[0]].data_ptr() for i in range(B)], [H] * B, [W] * B) for k in range(nb)]
+    R = Runner(det, B, B, slots, per_launch, 1, torch.device("cpu"), False, float(args.threshold))
+    R.run(2 * slots, ring, False)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    R.run(slots, ring, False)
+    torch.cuda.synchronize()
+    est = (time.perf_counter() - t0) / slots
+    steps = -(-int(np.ceil(args.extra_seconds / max(est, 1e-7))) // slots) * slots
+    for _ in range(2):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        faces = R.run(steps, ring, False)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if dt >= 0.7 * args.extra_seconds:
+            break
+        steps = -(-int(np.ceil(steps * 1.2 * args.extra_seconds / max(dt, 1e-6))) // slots) * slots
+    det.close()
+    eager = retinaface_amd.RetinaFace(os.path.join(ROOT, "assets"), "net3", 0.4, precision=prec, net_hw=(H, W), max_batch=B,
+                                      model_stem=cfg["model"], use_graph=False, lanes=1)
+    n_prof = B * per_launch
+    prof = eager.profile([frames[i % frames.shape[0]].data_ptr() for i in range(n_prof)], iters=10)
+    eager.close()
+    dom = max(prof, key=lambda p: p["ms"])
+    kernel_ms = sum(p["ms"] for p in prof)
+    res = {"id": cfg["id"], "workload": f"{cfg['model']} {cfg['precision']} HIP, {W}x{H}, batch {B} per GPU ({baseline_config(cargs)})",
+           "images_per_sec": steps * B / dt, "faces_per_sec": faces / dt, "ms_per_step": dt / steps * 1e3, "steps": steps, "timed_seconds": dt,
+           "dtype": {"fp16": "f16", "fp32": "f32", "int8": "i8"}[cfg["precision"]],
+           "input": f"{frames.shape[0]} distinct HBM-resident frames ({frames.shape[0] * H * W * 3 / 1e6:.0f} MB; {how})",
+           "images_per_launch": n_prof, "kernels_ms_per_launch_sequence": kernel_ms, "launches": len(prof),
+           "dominant_kernel": dom["kernel"], "dominant_kernel_layers": dom["name"], "dominant_kernel_ms": dom["ms"],
+           "dominant_kernel_share_of_gpu_time": dom["ms"] / kernel_ms,
+           "frac_layerwise_credit": dom["alg_bytes"] / (dom["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+           "bound": None, "bound_frac": None, "hbm_frac_measured": None,
+           "_pmc": {"n": n_prof, "precision": cfg["precision"], "model": cfg["model"], "H": H, "W": W, "B": B},
+           "_kernels": {p["kernel"]: p["ms"] for p in prof}}
+    if "note" in cfg:
+        res["note"] = cfg["note"]
+    return res
+
+
+def start_extra_counters(args, entries):
+    """The additional configurations' hardware counters: ONE set of three rocprofv3 --pmc passes whose probe process runs the fp16
+    1280x896 configuration and the int8 448x448 configuration one after the other (the two int8 configs launch the same kernel
+    instances on the same shapes: one measurement serves both).  Started in a thread: the passes use the GPU while the CPU baseline
+    (which follows) uses the host cores."""
+    import threading
+    seen, cfgs = set(), []
+    for e in entries:
+        key = (e["_pmc"]["precision"], e["_pmc"]["H"], e["_pmc"]["W"])
+        if key not in seen:
+            seen.add(key)
+            cfgs.append(e["_pmc"])
+    holder = {"result": None, "cfgs": cfgs}
+    th = threading.Thread(target=lambda: holder.__setitem__("result", measure_counters(args, cfgs)), daemon=True)
+    th.start()
+    holder["thread"] = th
+    return holder
+
+
+def finish_extra_counters(holder, entries, n_cu):
+    holder["thread"].join(timeout=400)
+    counters = holder["result"]
+    for e in entries:
+        pm, kern = e.pop("_pmc"), e.pop("_kernels")
+        if not counters:
+            e["counters"] = "no counter pass (rocprofv3 unavailable or failed)"
+            continue
+        mine = [c for c in counters if c["dtype"] == pm["precision"] and c["kernel"] == e["dominant_kernel"]]
+        if not mine:
+            continue
+        m = max(mine, key=lambda c: c["hbm_bytes"])
+        phys = physical_fractions([dict(m, launches_per_pass=1)], e["dominant_kernel_ms"], 4 * n_cu)
+        e.update({"bound": phys["bound"], "bound_frac": phys["bound_frac"], "hbm_frac_measured": phys["hbm_frac_measured"],
+                  "valu_active": phys.get("valu_active"), "mfma_busy": phys.get("mfma_busy"), "lds_active": phys.get("lds_active"),
+                  "hbm_bytes_dominant_kernel": phys["hbm_bytes"],
+                  "counters": "rocprofv3 --pmc passes of this run (collected while the CPU baseline ran)" +
+                              ("; int8 kernel instances and shapes are the same for both int8 configs: one measurement" if pm["precision"] == "int8" else "")})
+        path = [c for c in counters if c["dtype"] in (pm["precision"], "") and c["kernel"] in kern]
+        if path and all(c.get("gpu_cycles") for c in path):
+            whole = physical_fractions(path, e["kernels_ms_per_launch_sequence"], 4 * n_cu)
+            e["whole_path"] = {"hbm_bytes_per_image_measured": whole["hbm_bytes"] / e["images_per_launch"], "bound": whole["bound"],
+                               "hbm_frac_measured_in_kernels": whole["hbm_frac_measured"], "valu_active": whole.get("valu_active"),
+                               "mfma_busy": whole.get("mfma_busy")}
+
+
+def strong_config4(args, world, rank, dev, cdev, barrier, frames, thr, G=256):
+    """BASELINE.json configs[4] as stated, on this job's N ranks: a step is ONE batch of G = 256 mnet25 int8 448x448 images, rank r runs
+    shard_range(G, r, N) of it, every image's record comes back through the all_gather inside the timed region.  Every rank calls this."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from retinaface_amd import shard
+    lo, hi = shard.shard_range(G, rank, world)
+    Bs, B_pad = hi - lo, -(-G // world)
+    H = W = 448
+    if args.dry:
+        det = StubEngine(B_pad, 0, 0)
+        ring = [1000 * rank + k * max(Bs, 1) for k in range(4)]
+    else:
+        import retinaface_amd
+        from retinaface_amd.frames import synth_frames
+        if frames is None or tuple(frames.shape[1:3]) != (H, W):
+            frames = torch.from_numpy(np.stack(synth_frames(H, W, 4 * B_pad, config=41 + rank))).to(dev)
+        det = retinaface_amd.RetinaFace(os.path.join(ROOT, "assets"), "net3", 0.4, precision=2, net_hw=(H, W), max_batch=B_pad, model_stem="mnet25")
+        nb = max(frames.shape[0] // max(Bs, 1), 1)
+        ring = [det.prepare_device_batch([frames[(k * Bs + i) % frames.shape[0]].data_ptr() for i in range(Bs)], [H] * Bs, [W] * Bs)
+                for k in range(nb)]
+    slots = det.num_slots()
+    per_launch = max(slots // 3, 1)
+    R = Runner(det, Bs, B_pad, slots, per_launch, world, cdev, args.dry, thr)
+    t0 = time.perf_counter()
+    R.run(slots, ring, True)
+    est = (time.perf_counter() - t0) / slots
+    steps = slots if args.dry else -(-int(np.ceil(args.extra_seconds / max(est, 1e-7))) // slots) * slots
+    st = torch.tensor([steps], dtype=torch.int64, device=cdev)
+    dist.all_reduce(st, op=dist.ReduceOp.MAX)
+    steps = int(st.item())
+    R.gs["gathers"] = 0
+    R.gs["images"].zero_()
+    barrier()
+    t0 = time.perf_counter()
+    faces = R.run(steps, ring, True)
+    barrier()
+    dt = time.perf_counter() - t0
+    tt = torch.tensor([dt, float(faces)], dtype=torch.float64, device=cdev)
+    tmax, tsum = tt.clone(), tt.clone()
+    dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+    det.close()
+    return {"workload": f"mnet25 int8 HIP, 448x448, global batch {G} split over {world} GPU(s) by shard_range (BASELINE.json configs[4] as stated)",
+            "scaling": "strong", "global_batch": G, "images_per_rank": B_pad, "steps": steps, "timed_seconds": float(tmax[0]),
+            "images_per_sec": steps * G / float(tmax[0]), "faces_per_sec": float(tsum[1]) / float(tmax[0]),
+            "ms_per_step": float(tmax[0]) / steps * 1e3, "dtype": "i8",
+            "result_gather": {"gathers_in_timed_region": R.gs["gathers"], "records_gathered": int(R.gs["images"].item()), "expected": steps * G}}
+
+
 SQ_COUNTERS = "SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE"
 
 
-def measure_counters(args, n_img, B, H, W):
+def measure_counters(args, cfgs):
     """Hardware counters per kernel instance, measured NOW: three rocprofv3 --pmc passes (FETCH_SIZE | WRITE_SIZE | the SQ set: they
-    do not fit one pass) over tools/probes/pmc_probe.py = eager launches of the same engine configuration at the same launch size.
-    Corrections as MI355X_MICROARCH.md prescribes (FETCH_SIZE x 2; SQ_ACTIVE_INST_* count quad-cycles, SQ_VALU_MFMA_BUSY_CYCLES
-    cycles, GRBM_GUI_ACTIVE is summed over the 8 XCDs).  Counter passes carry no trace flag.  Returns a list of
-    {kernel, grid, launches_per_pass, hbm_bytes, valu_quad, lds_quad, mfma_cycles, gpu_cycles} (one entry per kernel symbol and
-    grid), or None when rocprofv3 is not there / fails (the caller then joins the newest committed summary under profiles/)."""
+    do not fit one pass) over tools/probes/pmc_probe.py = eager launches of the same engine configuration(s) at the same launch size.
+    `cfgs` = [{n, precision, model, H, W, B}, ...]; several configurations share one process per pass, their kernels are told apart by
+    element type (`dtype` of every entry) and grid.  Corrections as MI355X_MICROARCH.md prescribes (FETCH_SIZE x 2; SQ_ACTIVE_INST_* count
+    quad-cycles, SQ_VALU_MFMA_BUSY_CYCLES cycles, GRBM_GUI_ACTIVE is summed over the 8 XCDs).  Counter passes carry no trace flag.  Returns
+    a list of {kernel, dtype, grid, launches_per_pass, hbm_bytes, valu_quad, lds_quad, mfma_cycles, gpu_cycles} (one entry per kernel
+    symbol and grid), or None when rocprofv3 is not there / fails (the caller then joins the newest committed summary under profiles/)."""
     import shutil
     import subprocess
     import tempfile
@@ -520,8 +759,8 @@ def measure_counters(args, n_img, B, H, W):
         for tag, counters in (("FETCH_SIZE", ["FETCH_SIZE"]), ("WRITE_SIZE", ["WRITE_SIZE"]), ("SQ", SQ_COUNTERS.split())):
             out = os.path.join(tmp, tag)
             cmd = ["rocprofv3", "--pmc"] + counters + ["-d", out, "-o", "pmc", "--", sys.executable,
-                   os.path.join(ROOT, "tools", "probes", "pmc_probe.py"), str(n_img), args.precision, args.model, str(H), str(W), str(B)]
-            r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=90)
+                   os.path.join(ROOT, "tools", "probes", "pmc_probe.py"), "--multi", json.dumps(cfgs)]
+            r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=60 + 40 * len(cfgs))
             found = [os.path.join(d, f) for d, _, fs in os.walk(out) for f in fs if f.endswith(".db")]
             if r.returncode != 0 or not found:
                 if tag == "SQ":
@@ -531,16 +770,18 @@ def measure_counters(args, n_img, B, H, W):
         f, w = pmc_summary.per_kernel(dbs["FETCH_SIZE"], "FETCH_SIZE"), pmc_summary.per_kernel(dbs["WRITE_SIZE"], "WRITE_SIZE")
         sq = {c: pmc_summary.per_kernel(dbs["SQ"], c) for c in SQ_COUNTERS.split()} if "SQ" in dbs else {}
         keys = [k for k in set(f) | set(w) if k[0].startswith("_ZN2rf") or "rf::" in k[0]]
-        base = min((f[k][0] for k in keys if k in f and f[k][0]), default=1)
         res = []
-        for k in keys:
-            g = lambda c: sq.get(c, {}).get(k, (0, None))[1]       # noqa: E731
-            res.append({"kernel": pmc_summary.descriptor(k[0]), "grid": k[1],
-                        "launches_per_pass": max(1, round(f.get(k, (base, 0))[0] / base)),
-                        "hbm_bytes": 2 * f.get(k, (0, 0.0))[1] * 1024.0 + w.get(k, (0, 0.0))[1] * 1024.0,
-                        "valu_quad": g("SQ_ACTIVE_INST_VALU"), "lds_quad": g("SQ_ACTIVE_INST_LDS"),
-                        "mfma_cycles": g("SQ_VALU_MFMA_BUSY_CYCLES"),
-                        "gpu_cycles": (g("GRBM_GUI_ACTIVE") / 8.0) if g("GRBM_GUI_ACTIVE") else None})
+        for dt in sorted({pmc_summary.dtype_of(k[0]) for k in keys}):
+            mine = [k for k in keys if pmc_summary.dtype_of(k[0]) == dt]
+            base = min((f[k][0] for k in mine if k in f and f[k][0]), default=1)       # launches of a once-per-pass kernel of this type
+            for k in mine:
+                g = lambda c: sq.get(c, {}).get(k, (0, None))[1]       # noqa: E731
+                res.append({"kernel": pmc_summary.descriptor(k[0]), "dtype": dt, "grid": k[1],
+                            "launches_per_pass": max(1, round(f.get(k, (base, 0))[0] / base)),
+                            "hbm_bytes": 2 * f.get(k, (0, 0.0))[1] * 1024.0 + w.get(k, (0, 0.0))[1] * 1024.0,
+                            "valu_quad": g("SQ_ACTIVE_INST_VALU"), "lds_quad": g("SQ_ACTIVE_INST_LDS"),
+                            "mfma_cycles": g("SQ_VALU_MFMA_BUSY_CYCLES"),
+                            "gpu_cycles": (g("GRBM_GUI_ACTIVE") / 8.0) if g("GRBM_GUI_ACTIVE") else None})
         shutil.rmtree(tmp, ignore_errors=True)
         return res or None
     except Exception:  # noqa: BLE001
@@ -594,8 +835,12 @@ def device_side_report(args, det, frames, B, H, W, per_launch, prec, images_tota
     # Hardware counters (HBM bytes = FETCH_SIZE x 2 + WRITE_SIZE; VALU / LDS / MFMA busy) of the same launches, measured now in
     # three separate rocprofv3 --pmc passes (PMC collection cannot run inside this process); when rocprofv3 is not usable the
     # newest committed traffic summary for this (frame, precision) is joined instead and the SQ fractions stay null.
-    counters = measure_counters(args, n_prof, B, H, W) if world == 1 else None      # N > 1: the other ranks are waiting at the barrier
+    counters = measure_counters(args, [{"n": n_prof, "precision": args.precision, "model": args.model, "H": H, "W": W, "B": B}]) \
+        if world == 1 else None      # N > 1: the other ranks are waiting at the barrier
+    if counters:
+        counters = [e for e in counters if e["dtype"] in (args.precision, "")]
     dom_phys = path_phys = None
+    mine = []
     traffic = traffic_src = None
     if counters:
         mine = [e for e in counters if e["kernel"] == dom["kernel"]]
@@ -622,14 +867,39 @@ def device_side_report(args, det, frames, B, H, W, per_launch, prec, images_tota
             break
     images_per_sec_gpu = images_total / world / dt_max
     layerwise = dom["alg_bytes"] / (dom["ms"] * 1e-3) / 1e9
+    # `frac` = the PHYSICAL fraction of the binding resource of the dominant kernel (always <= 1): HBM bytes moved / time / 8 TB/s, or
+    # busy issue cycles of the VALU / matrix / LDS pipes / (GPU-active cycles x SIMDs), whichever is largest (`bound`).  `achieved`,
+    # `peak`, `unit` describe that same resource.  The contract's layer-wise figure (ALGORITHMIC bytes of SURVEY.md 8d / the kernel's
+    # HIP-event duration, against the HBM peak) counts bytes a fused kernel never moves, so it can exceed 1: it is fusion credit and
+    # stays in `frac_layerwise_credit` / `hbm_layerwise`.
+    bound = (dom_phys or {}).get("bound")
+    clock_ghz = None
+    if dom_phys and mine and mine[0].get("gpu_cycles"):
+        clock_ghz = mine[0]["gpu_cycles"] / (dom["ms"] * 1e-3) / 1e9          # effective shader clock during the counter pass
+    if bound == "hbm":
+        res_achieved, res_peak, res_unit = dom_phys["hbm_GBs_measured"], HBM_PEAK_GBS, "GB/s"
+    elif bound == "mfma":
+        res_achieved, res_peak, res_unit = dom_phys["mfma_busy"] * MFMA_PEAK_TFLOPS[args.precision], MFMA_PEAK_TFLOPS[args.precision], \
+            "TFLOP/s (matrix-pipe busy fraction x dense peak)"
+    elif bound in ("valu_issue", "lds_issue"):
+        res_achieved, res_peak, res_unit = dom_phys["bound_frac"], 1.0, \
+            ("VALU" if bound == "valu_issue" else "LDS") + " issue cycles / (GPU-active cycles x SIMDs)"
+    else:                                                                   # no counter pass: only the layer-wise figure is known
+        res_achieved, res_peak, res_unit = layerwise, HBM_PEAK_GBS, "GB/s (layer-wise algorithmic bytes: no counter pass in this run)"
     roofline = {
-        # contract fields: ALGORITHMIC (layer-wise) bytes of the dominant kernel / its HIP-event duration, against the
-        # HBM peak.  For a fused kernel that figure counts bytes fusion never moves, so it can exceed 1: it is fusion credit, kept
-        # as `frac_layerwise_credit`; what the hardware actually did is in `physical` (dominant kernel) and `whole_path`.
-        "bound": (dom_phys or {}).get("bound", "unmeasured (no counter pass)"),
+        "bound": bound or "unmeasured (no counter pass)",
         "kernel": dom["name"], "kernel_instance": dom["kernel"],
-        "achieved": layerwise, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": layerwise / HBM_PEAK_GBS,
+        "achieved": res_achieved, "peak": res_peak, "unit": res_unit,
+        "frac": (dom_phys["bound_frac"] if dom_phys else min(1.0, layerwise / HBM_PEAK_GBS)),
+        "frac_is": "physical fraction of the binding resource (rocprofv3 --pmc passes of this run)" if dom_phys else
+                   "layer-wise credit capped at 1 (no counter pass)",
         "frac_layerwise_credit": layerwise / HBM_PEAK_GBS,
+        "hbm_layerwise": {"achieved": layerwise, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": layerwise / HBM_PEAK_GBS,
+                          "note": "SURVEY.md 8d layer-wise algorithmic bytes / kernel duration: > 1 = bytes fusion never moves"},
+        "effective_clock_GHz_in_counter_pass": clock_ghz,
+        "kernel_ms_method": "HIP events around back-to-back repeats of the launch on the engine's stream (rf_profile); the pipeline's "
+                            "rocprofv3 kernel trace averages ~5 % longer for the same kernel (cold caches between different kernels): "
+                            "profiles/r03_bench_b8_448_fp16_kernel_trace_lanes1.txt",
         "traffic": traffic, "traffic_source": traffic_src,
         "traffic_GBs": (traffic / (dom["ms"] * 1e-3) / 1e9) if traffic else None,
         "hbm_frac_measured": (traffic / (dom["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,

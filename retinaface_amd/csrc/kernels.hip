@@ -2401,15 +2401,17 @@ static void conv3_ws_launch_v(hipStream_t s, Conv3Args<T> &a, int nlv, int total
     }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), W::LDS_BYTES, s, a);
 }
-// RF_CONV3WS = 10 * halo buffers + B-fragment prefetch depth (probe knob): 22, 23, 32, 33; 1 = the default
+// RF_CONV3WS = 10 * halo buffers + B-fragment prefetch depth (probe knob): 22, 23, 32, 33; 1 = the default = 32.  Measured per 256 images
+// (tools/gpu/r4_call5.sh, 4 repetitions each, profiles/r04_ws_conv_ab.txt): fp16 lock-step 87-90 us (100-104 before its pipeline was pinned),
+// two halo buffers 75-85 (bimodal: the interval is then one memory round trip), THREE 56-58 at either depth; int8 37.2 lock-step, 39-41 /
+// 44 warp-specialised (its GEMM is too short to hide one producer wave's issue work): int8 stays on K_c.
 template <typename T>
 static void conv3_ws_launch(hipStream_t s, Conv3Args<T> &a, int nlv, int total_tiles) {
     switch (conv3_ws_variant()) {
         case 22: conv3_ws_launch_v<T, 2, 2>(s, a, nlv, total_tiles); break;
         case 23: conv3_ws_launch_v<T, 3, 2>(s, a, nlv, total_tiles); break;
-        case 32: conv3_ws_launch_v<T, 2, 3>(s, a, nlv, total_tiles); break;
         case 33: conv3_ws_launch_v<T, 3, 3>(s, a, nlv, total_tiles); break;
-        default: conv3_ws_launch_v<T, 2, 2>(s, a, nlv, total_tiles); break;
+        default: conv3_ws_launch_v<T, 2, 3>(s, a, nlv, total_tiles); break;
     }
 }
 
@@ -2419,7 +2421,8 @@ static void conv3_launch(hipStream_t s, Conv3Args<T> &a, int nlv, int total_tile
     if constexpr (sizeof(T) <= 2 && CIN == 64 && COUT == 48 && TH == 8 && TW == 8 && !UPADD && !ALLC && PADROW) {
         bool split32 = true;
         for (int l = 0; l < nlv; l++) split32 = split32 && a.lv[l].n0 == 32 && a.lv[l].out1 != nullptr;
-        if (conv3_ws_variant() && split32) { conv3_ws_launch<T>(s, a, nlv, total_tiles); return; }
+        const bool want = conv3_ws_variant() > 1 || (conv3_ws_variant() == 1 && sizeof(T) == 2);       // default: fp16 only (see conv3_ws_launch)
+        if (want && split32) { conv3_ws_launch<T>(s, a, nlv, total_tiles); return; }
     }
     auto kern = conv3x3_kernel<T, CIN, COUT, TH, TW, UPADD, ALLC, PADROW>;
     static std::atomic<int> resident_cache[kMaxDevices] = {};

@@ -4,9 +4,13 @@ size-independent properties (batch-composition invariance, determinism, graph ==
 
 Tolerances (stated once, used everywhere):
   fp32 engine : anchor indices identical, candidate counts identical, box IoU >= 1 - 1e-5, |score| <= 1e-5
-  fp16 engine : anchor indices identical, box IoU >= 1 - 1e-3 (north_star's bound), |score| <= 2e-3, landmarks within
-                0.15 px, candidate count within +-4 of the oracle (threshold margin band: an fp16 logit can move a
-                borderline candidate across `conf <= thr`).  Round 1 needed 2e-3 on ~50 px faces; the per-tensor error
+  fp16 engine : anchor indices identical AND in the oracle's order, box IoU >= 1 - 1e-3 (north_star's bound), |score| <= 2e-3,
+                landmarks within 0.15 px.  Candidate count: within the number of anchors whose oracle probability lies inside the
+                score-noise band |p - thr| <= 2e-3 (only those can cross `conf <= thr`; 0..2 on the golden frames, minted into
+                tests/golden/threshold_bands.npz by tools/make_golden.py --bands; computed live where the oracle runs) -- round 4,
+                a flat +-4 before.  Per-layer activations: within 2x what plain fp16 storage is PREDICTED to cost at that tensor
+                (tools/fp16_error_budget.py predicted_layer_errors: the fused-op sequence replayed on the CPU with fp16 rounding at
+                every storage point), a flat 3 % of the range before.  Round 1 needed 2e-3 on ~50 px faces; the per-tensor error
                 budget (tools/fp16_error_budget.py) showed 73 % of the box-error variance came from three tensors that
                 never leave the stem kernel's LDS (conv0 output, first depthwise output and its taps, on raw 0..255
                 pixels); they are fp32-grade now and the whole engine sits at <= ~7e-4.
@@ -29,7 +33,37 @@ from oracle.retinaface_post import iou_plus1, preprocess_trt_identity
 pytestmark = pytest.mark.gpu
 
 FP32, FP16 = 0, 1
-TOL = {FP32: dict(iou=1e-5, score=1e-5, lm=2e-3, ncand=0), FP16: dict(iou=1e-3, score=2e-3, lm=0.15, ncand=4)}
+TOL = {FP32: dict(iou=1e-5, score=1e-5, lm=2e-3), FP16: dict(iou=1e-3, score=2e-3, lm=0.15)}
+SCORE_NOISE = TOL[FP16]["score"]          # an fp16 score is within this of the oracle's: the width of the threshold band
+LAYER_ERR_FACTOR = 2.0                    # fp16 per-layer bar = this x the error-budget tool's prediction for plain fp16 storage
+
+
+def ncand_band(prec, key=None, heads=None, thr=0.5):
+    """How far the engine's candidate count may be from the oracle's: the number of anchors whose oracle foreground probability is
+    within the fp16 score noise of the threshold (fp32 engine: none).  `key` looks the count up in the minted golden, `heads` (the
+    oracle's 9 blobs) computes it."""
+    if prec == FP32:
+        return 0
+    if heads is not None:
+        n = 0
+        for s_ in HEAD_STRIDES:
+            p = heads[head_names(s_)[0]]
+            n += int((np.abs(p[:, p.shape[1] // 2:] - np.float32(thr)) <= SCORE_NOISE).sum())
+        return n
+    g = golden("threshold_bands.npz")
+    assert abs(float(g["score_noise"]) - SCORE_NOISE) < 1e-9
+    return int(g[key])
+
+
+def same_order_where_the_oracle_is_decisive(got_idx, ref_idx, ref_scores, prec):
+    """The engine's detections, sorted by its own scores, must follow the oracle's order wherever two oracle scores differ by more
+    than twice the score noise (closer pairs may legitimately swap)."""
+    noise = SCORE_NOISE if prec == FP16 else TOL[FP32]["score"]
+    pos = {a: i for i, a in enumerate(got_idx)}
+    for i in range(len(ref_idx)):
+        for j in range(i + 1, len(ref_idx)):
+            if ref_scores[i] - ref_scores[j] > 2 * noise:
+                assert pos[ref_idx[i]] < pos[ref_idx[j]], (ref_idx[i], ref_idx[j], ref_scores[i], ref_scores[j])
 
 
 @pytest.fixture(scope="module")
@@ -70,7 +104,14 @@ def test_every_fused_op_against_the_oracle_blob(rfa, oracles, crop448, prec):
     names += ["rf_c3_lateral_relu", "rf_c2_lateral_relu", "rf_c2_aggr_relu", "rf_c1_red_conv_relu", "rf_c1_aggr_relu"]
     for c in (3, 2, 1):
         names += [f"rf_c{c}_det_context_conv1_relu", f"rf_c{c}_det_context_conv3_1_relu", f"rf_c{c}_det_concat_relu"]
-    rel_max, rel_mean = (1e-4, 1e-5) if prec == FP32 else (3e-2, 2e-3)
+    rel_max, rel_mean = (1e-4, 1e-5) if prec == FP32 else (None, 2e-3)
+    pred = {}
+    if prec == FP16:
+        import importlib.util
+        spec = importlib.util.spec_from_file_location("fp16_error_budget", os.path.join(ROOT, "tools", "fp16_error_budget.py"))
+        feb = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(feb)
+        pred = feb.predicted_layer_errors("mnet-deconv-0517", crop448)
     if prec == FP16:
         # the fp16 engine runs conv0 .. conv4 as one launch (stem2): relu0 / relu2 never exist in HBM; relu4 is its output
         names.remove("mobilenet0_relu0_fwd")
@@ -84,7 +125,14 @@ def test_every_fused_op_against_the_oracle_blob(rfa, oracles, crop448, prec):
         assert a.shape == r.shape, n
         scale = max(1.0, float(np.abs(r).max()))
         d = np.abs(a - r)
-        assert d.max() <= rel_max * scale and d.mean() <= rel_mean * scale, (n, float(d.max()), float(d.mean()), scale)
+        if prec == FP16:
+            # the bar is the PREDICTED cost of plain fp16 storage at this tensor (the engine is fp32-grade at several points of the
+            # stem, DC-centred and tap-equalised elsewhere: it should sit at or below the prediction), not a flat fraction of the range
+            bar = LAYER_ERR_FACTOR * pred[n][0]
+            print(f"fp16 layer {n:36s} max err {d.max():.3e}  predicted {pred[n][0]:.3e}  ratio {d.max() / pred[n][0]:.2f}  range {scale:.2f}")
+            assert d.max() <= bar and d.mean() <= rel_mean * scale, (n, float(d.max()), bar, float(d.mean()), scale)
+        else:
+            assert d.max() <= rel_max * scale and d.mean() <= rel_mean * scale, (n, float(d.max()), float(d.mean()), scale)
 
 
 @pytest.mark.parametrize("prec", [FP32, FP16])
@@ -99,7 +147,7 @@ def test_head_blobs_against_golden(rfa, crop448, stem, prec):
         for n in head_names(s):
             assert np.abs(det.get_output(n) - g[n]).max() <= atol, n
     compare(got, g["det"], g["det_idx"], prec)
-    assert abs(det.last_candidate_counts(1)[0] - len(g["cand_idx"])) <= TOL[prec]["ncand"]
+    assert abs(det.last_candidate_counts(1)[0] - len(g["cand_idx"])) <= ncand_band(prec, f"{stem}/crop448/05")
 
 
 @pytest.mark.parametrize("prec", [FP32, FP16])
@@ -111,10 +159,10 @@ def test_reference_fixture_image_1280x896(rfa, base_frame, stem, prec):
     got = det.detect(base_frame, 0.5)
     assert len(got) == 6
     compare(got, g["det"], g["det_idx"], prec)
-    assert abs(det.last_candidate_counts(1)[0] - len(g["cand_idx"])) <= TOL[prec]["ncand"]
+    assert abs(det.last_candidate_counts(1)[0] - len(g["cand_idx"])) <= ncand_band(prec, f"{stem}/fixture/05")
     got9 = det.detect(base_frame, 0.9)                   # main.cpp:43 uses 0.9
     compare(got9, g["det09"], g["det09_idx"], prec)
-    assert abs(det.last_candidate_counts(1)[0] - int(g["ncand09"])) <= TOL[prec]["ncand"]
+    assert abs(det.last_candidate_counts(1)[0] - int(g["ncand09"])) <= ncand_band(prec, f"{stem}/fixture/09")
     # the unpadded 886-row frame is placed top-left on the zero canvas: same result as the padded one
     got_u = det.detect(np.ascontiguousarray(base_frame[:886]), 0.5)
     assert [d.anchor_index for d in got_u] == [d.anchor_index for d in got]
@@ -134,7 +182,7 @@ def test_synthetic_batch8_against_golden(rfa, stem, prec):
         ncand = det.last_candidate_counts(8)
         for i in range(8):
             compare(res[i], g[f"det{tag}_{i}"], g[f"idx{tag}_{i}"], prec)
-            assert abs(ncand[i] - int(g[f"ncand{tag}_{i}"])) <= TOL[prec]["ncand"]
+            assert abs(ncand[i] - int(g[f"ncand{tag}_{i}"])) <= ncand_band(prec, f"{stem}/synth448_{i}/{tag}"), (stem, tag, i, ncand[i])
 
 
 @pytest.mark.parametrize("knob", ["RF_STEM2=0", "RF_STEM2=2", "RF_STEM2=3", "RF_DWPW2=0", "RF_CONV3=0", "RF_STEM2_DC=0", "RF_SSHTAIL=0", "RF_CONV3WS=0"])
@@ -455,7 +503,7 @@ def test_fp16_contract_over_200_frames_both_models_both_sizes(rfa, oracles):
     every frame, worst 1 - IoU <= 9e-4 (the bound is 1e-3; the margin is asserted, not hoped for), candidate counts within the
     threshold band.  The distribution is printed so a kernel change is judged by its margin."""
     from retinaface_amd.frames import synth_frames
-    worst_all, rows = [], []
+    worst_all, rows, bands = [], [], []
     for stem in STEMS:
         for hw, plan in (((448, 448), ((32, 400), (8, 401), (8, 402), (8, 403), (8, 404))), ((896, 1280), ((32, 410), (8, 411)))):
             for nb, cfg in plan:
@@ -466,9 +514,14 @@ def test_fp16_contract_over_200_frames_both_models_both_sizes(rfa, oracles):
                 for i, f in enumerate(frames):
                     ref = oracles[stem].detect(f, 0.5, 0.4, net_hw=hw)
                     by_anchor = {d.anchor_index: d for d in got[i]}
-                    # faces are matched by global anchor index (two faces whose scores differ by less than the fp16 score noise may swap places)
+                    # faces are matched by global anchor index; the ORDER must be the oracle's wherever its scores differ by more than
+                    # twice the fp16 score noise (closer pairs may swap places)
                     assert sorted(by_anchor) == sorted(d.anchor_index for d in ref.detections) and len(by_anchor) == len(got[i]), (stem, hw, cfg, i)
-                    assert abs(ncand[i] - len(ref.candidates)) <= TOL[FP16]["ncand"], (stem, hw, cfg, i, ncand[i], len(ref.candidates))
+                    same_order_where_the_oracle_is_decisive([d.anchor_index for d in got[i]], [d.anchor_index for d in ref.detections],
+                                                            [d.score for d in ref.detections], FP16)
+                    band = ncand_band(FP16, heads=ref.heads, thr=0.5)
+                    bands.append(band)
+                    assert abs(ncand[i] - len(ref.candidates)) <= band, (stem, hw, cfg, i, ncand[i], len(ref.candidates), band)
                     w = max([1 - iou_plus1(by_anchor[r.anchor_index].rect, r.rect) for r in ref.detections], default=0.0)
                     worst_all.append(w)
                     rows.append((w, f"{stem} {hw[1]}x{hw[0]} b{nb} cfg{cfg} #{i}"))
@@ -476,6 +529,8 @@ def test_fp16_contract_over_200_frames_both_models_both_sizes(rfa, oracles):
     rows.sort(key=lambda r: -r[0])
     print(f"fp16 contract: {len(ws)} frames, worst 1-IoU {ws.max():.3e}, mean {ws.mean():.3e}, p99 {np.quantile(ws, 0.99):.3e}; worst: "
           + "; ".join(f"{w:.2e} {n}" for w, n in rows[:4]))
+    print(f"fp16 contract: candidate-count bands (anchors within {SCORE_NOISE} of the threshold): max {max(bands)}, mean {np.mean(bands):.2f}, "
+          f"{sum(b == 0 for b in bands)} of {len(bands)} frames with an empty band (count must then be identical)")
     assert len(ws) >= 200 and ws.max() <= 9e-4, rows[:6]
 
 

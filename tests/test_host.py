@@ -237,6 +237,12 @@ def test_bench_self_launches_n_ranks_and_gathers_results():
     assert j["n_gpus"] == 2 and j["steps"] >= 100 and j["scaling"] == "weak" and j["metric"] == "faces/sec"
     g = j["result_gather"]
     assert g["records_gathered"] == g["expected"] == 2 * 8 * j["steps"] and g["gathers_in_timed_region"] >= 1
+    # who took part, as seen through a collective of the gather's backend (on the GPUs: RCCL, with `rccl_ranks` == N and its version)
+    assert g["backend"] == "gloo" and g["ranks_in_communicator"] == 2 and sorted(r for r, _ in g["rank_device"]) == [0, 1]
+    # the weak-scaling invocation is followed by a strong-scaling leg of BASELINE.json configs[4] as stated (256 int8 images per step over N)
+    s4 = j["configs4_strong"]
+    assert s4["scaling"] == "strong" and s4["global_batch"] == 256 and s4["images_per_rank"] == 128 and s4["dtype"] == "i8"
+    assert s4["result_gather"]["records_gathered"] == s4["result_gather"]["expected"] == 256 * s4["steps"]
     # under an external launcher the rank count must agree with --gpus
     env2 = dict(env, WORLD_SIZE="3", RANK="0", LOCAL_RANK="0")
     bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry"], capture_output=True, text=True,

@@ -76,7 +76,12 @@ class Sim:
     def act(self, y, name, narrow):
         if name not in self.points:
             self.points.append(name)
-        return h16(y) if f"a:{name}" in narrow else y
+        y = h16(y) if f"a:{name}" in narrow else y
+        if self.keep is not None:
+            self.keep[name] = y
+        return y
+
+    keep = None        # set to a dict to record every storage point's tensor of the next forward (predicted_layer_errors)
 
     def forward(self, frame_bgr: np.ndarray, narrow) -> dict:
         x = torch.from_numpy(frame_bgr[:, :, ::-1].copy()).permute(2, 0, 1)[None].float()     # RGB planar, raw 0..255
@@ -123,6 +128,49 @@ class Sim:
         acts = [f"a:{p}" for p in self.points]
         wts = [f"w:{n}" for n in self.W if n != "conv0"]
         return acts, wts
+
+
+# storage point of the simulation -> the reference blob the engine's debug accessor serves (engine.cpp act() names)
+def blob_of_point(p: str):
+    if p == "conv0":
+        return "mobilenet0_relu0_fwd", None
+    if p.startswith("pw"):
+        return f"mobilenet0_relu{2 * int(p[2:]) + 2}_fwd", None
+    if p.startswith("lateral"):
+        return ["rf_c3_lateral_relu", "rf_c2_lateral_relu", "rf_c1_red_conv_relu"][int(p[7:])], None
+    if p.startswith("aggr"):
+        return ["rf_c2_aggr_relu", "rf_c1_aggr_relu"][int(p[4:])], None
+    if p.startswith("ssh") and p.endswith(".a"):
+        return f"rf_c{3 - int(p[3])}_det_context_conv1_relu", slice(32, 48)
+    return None, None
+
+
+def predicted_layer_errors(stem: str, frame_bgr: np.ndarray) -> dict:
+    """What plain fp16 storage (every activation and weight point narrow, fp32 accumulation) costs at every tensor the engine can
+    show: {blob name: (max |fp16 run - fp32 run|, max |fp32 run|)} from two forwards of the simulated fused-op sequence.  The -m gpu
+    per-layer test holds the real engine to a small multiple of these instead of a flat fraction of the range."""
+    sim = Sim(stem)
+    acts, wts = sim.all_points(frame_bgr)
+    runs = []
+    for narrow in (set(), set(acts) | set(wts)):
+        sim.keep = {}
+        sim.forward(frame_bgr, narrow)
+        runs.append(sim.keep)
+    sim.keep = None
+    out = {}
+    for p, wide in runs[0].items():
+        blob, sl = blob_of_point(p)
+        if blob is None:
+            continue
+        a, b = wide[0], runs[1][p][0]
+        if sl is not None:
+            a, b = a[sl], b[sl]
+        out[blob] = (float((a - b).abs().max()), float(a.abs().max()))
+    for i in range(3):       # the concat tensor: det_conv1 | context_conv2 | context_conv3_2 slices, all ReLU'd
+        parts = [[r[f"ssh{i}.a"][0][:32], r[f"ssh{i}.b"][0][:16], r[f"ssh{i}.c"][0]] for r in runs]
+        a, b = torch.cat(parts[0]), torch.cat(parts[1])
+        out[f"rf_c{3 - i}_det_concat_relu"] = (float((a - b).abs().max()), float(a.abs().max()))
+    return out
 
 
 def detect(sim, frame, narrow, thr=0.5):

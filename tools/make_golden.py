@@ -75,5 +75,41 @@ def main():
         print(stem, "synth448:", [len(d[f'det05_{i}']) for i in range(8)])
 
 
+SCORE_NOISE = 2e-3      # fp16 engine: bound on |score - oracle score| asserted by tests/test_gpu_parity.py (TOL[FP16]["score"])
+
+
+def band(heads, thr, noise=SCORE_NOISE):
+    """Anchors whose foreground probability lies within `noise` of the threshold: the only ones an engine whose scores are within
+    `noise` of the oracle's can move across `conf > thr` (RetinaFace.cpp:693).  The foreground maps are the second half of each
+    cls_prob blob."""
+    n = 0
+    for s in HEAD_STRIDES:
+        p = heads[head_names(s)[0]]
+        a = p.shape[1] // 2
+        n += int((np.abs(p[:, a:] - np.float32(thr)) <= noise).sum())
+    return n
+
+
+def bands():
+    """tests/golden/threshold_bands.npz: for every golden frame and threshold, how many anchors sit inside the fp16 score-noise band
+    around the threshold -- the tolerance the fp16 candidate-count assertions use instead of a flat +-4 (round 4)."""
+    frame = padded_base_frame()
+    crop = np.ascontiguousarray(frame[30:478, 440:888])
+    synth = synth_frames(448, 448, 8, config=1)
+    d = {"score_noise": np.float32(SCORE_NOISE)}
+    for stem in ("mnet-deconv-0517", "mnet25"):
+        det = OracleDetector(read_rfw(os.path.join(ROOT, "assets", stem + ".rfw")))
+        for thr, tag in ((0.5, "05"), (0.9, "09")):
+            d[f"{stem}/fixture/{tag}"] = np.int32(band(det.detect(frame, thr, 0.4).heads, thr))
+            d[f"{stem}/crop448/{tag}"] = np.int32(band(det.detect(crop, thr, 0.4, net_hw=(448, 448)).heads, thr))
+            for i, f in enumerate(synth):
+                d[f"{stem}/synth448_{i}/{tag}"] = np.int32(band(det.detect(f, thr, 0.4, net_hw=(448, 448)).heads, thr))
+    np.savez_compressed(os.path.join(OUT, "threshold_bands.npz"), **d)
+    print({k: int(v) for k, v in d.items() if k != "score_noise"})
+
+
 if __name__ == "__main__":
-    main()
+    if "--bands" in sys.argv:
+        bands()
+    else:
+        main()

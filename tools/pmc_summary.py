@@ -29,6 +29,8 @@ def descriptor(mangled: str) -> str:
     if m:
         cin, cout, th, tw, up = m.groups()
         return f"conv3x3<{cin},{cout},{th}x{tw}{',up' if up == 'true' else ''}>"
+    if "conv3x3_ws_kernel" in mangled:       # the warp-specialised instance of the merged SSH conv (same op name as the lock-step one)
+        return "conv3x3<64,48,8x8>"
     if "dwpw2_kernel" in mangled:
         return "dwpw2<32,32,64>"
     if "ssh_tail_kernel" in mangled:
@@ -37,6 +39,20 @@ def descriptor(mangled: str) -> str:
         if k + "_kernel" in mangled:
             return k
     return mangled
+
+
+def dtype_of(symbol: str) -> str:
+    """Element type a kernel instance was built for, from its (mangled or demangled) symbol: 'fp16' | 'int8' | 'fp32' | '' (untyped:
+    nms, resize)."""
+    if "DF16_" in symbol or "_Float16" in symbol:
+        return "fp16"
+    if re.search(r"_kernelIa|<signed char", symbol):
+        return "int8"
+    if re.search(r"_kernelIf|<float", symbol):
+        return "fp32"
+    if "stem2_kernel" in symbol or "dwpw2_kernel" in symbol:
+        return "fp16"
+    return ""
 
 
 def per_kernel(db_path, counter):
