@@ -156,6 +156,8 @@ public:
         if (const char *cs = getenv("RF_COPY_STREAMS")) copy_streams_ = atoi(cs) > 1 ? 2 : 1;       // probe knob (tools/probes/host_rate.py)
         check_residency_ = ndev > 1 || force_scatter_;
         DeviceGuard guard(device_);                  // the caller's current device is put back when construction ends
+        if (sizeof(T) == 1 && cvt_pk_u8_selfcheck() != 0)
+            throw Unsupported("int8: v_cvt_pk_u8_f32 on this device does not round to nearest even / saturate as the requantising epilogues assume");
         try { arena_.upload(); } catch (const std::exception &e) { throw HipError(e.what()); }
         // Lanes are built on first use: a caller that only makes synchronous calls of <= max_batch images keeps re-using lane 0 and
         // never pays for the other lanes' activation buffers (~13 MB per 448 x 448 image in fp16 x the super-batch size).  Lane 0
@@ -170,6 +172,17 @@ public:
                 opt_.coalesce = std::max(1, opt_.coalesce / 2);
                 cap_images_ = opt_.max_batch * opt_.coalesce;
             }
+        }
+        // RF_PREBUILD_LANES=1: build every lane now (allocation, first eager run and graph capture happen at create time instead of
+        // in the middle of the asynchronous steady state: one latency spike per lane less for latency-sensitive callers).  A lane
+        // that does not fit is dropped, as on first use.  num_slots() may therefore be smaller than lanes x coalesce: callers read it
+        // after rf_create, and again if an enqueue ever fails with RF_ERR_HIP.
+        if (const char *pb = getenv("RF_PREBUILD_LANES")) {
+            if (atoi(pb) != 0)
+                for (int l = 1; l < (int)lanes_.size(); l++) {
+                    try { ensure_lane(l); }
+                    catch (const HipError &) { lanes_.resize(l); break; }
+                }
         }
         const int hw = (int)std::thread::hardware_concurrency();
         const int helpers = opt_.copy_threads > 0 ? opt_.copy_threads - 1 : std::max(0, std::min(8, hw / 4) - 1);
@@ -218,7 +231,7 @@ public:
                 int m = std::min(opt_.max_batch, n - base);
                 std::vector<int> st(m);
                 for (int i = 0; i < m; i++) st[i] = steps ? steps[base + i] : cols[base + i] * 3;
-                if ((int)inflight.size() == (int)lanes_.size() || (timed && !inflight.empty())) collect();
+                if ((int)inflight.size() >= (int)lanes_.size() || (timed && !inflight.empty())) collect();      // (>=: pick_lane() may have dropped lanes that did not fit)
                 int ticket = submit(frames + base, rows + base, cols + base, st.data(), m, on_device, threshold, true);
                 inflight.emplace_back(ticket, base);
             }
@@ -413,6 +426,7 @@ private:
         bool built = false;
         std::vector<void *> dev_allocs, host_allocs;      // what build_lane allocated for this lane
         hipStream_t stream = nullptr;
+        unsigned long long launch_seq = 0;    // order of this lane's last launch among all launches of the engine (pick_lane)
         // host-frame uploads from the pinned staging block alternate between the lane's stream and a second one (a second SDMA
         // engine); the launch waits for both.  RF_COPY_STREAMS=1 (probe knob) switches the second stream off
         hipStream_t copy2 = nullptr;
@@ -519,7 +533,12 @@ private:
                 try { ensure_lane(l); return l; }
                 catch (const HipError &) { if (l == 0) throw; lanes_.resize(l); next_lane_ %= l; break; }      // lanes l.. were never built: drop them
             }
-        return next_lane_ % (int)lanes_.size();
+        // every lane is busy: the one launched longest ago (its results are harvested first; next_lane_ is not it once idle lanes
+        // have been preferred out of order)
+        int oldest = 0;
+        for (int l = 1; l < (int)lanes_.size(); l++)
+            if (lanes_[l].launch_seq < lanes_[oldest].launch_seq) oldest = l;
+        return oldest;
     }
 
     static constexpr bool kInt8 = sizeof(T) == 1;
@@ -826,14 +845,15 @@ private:
 
     // Staging capacity of a lane: room for a full super-batch of net-sized frames, or for what one enqueue needs if that is more
     // (sized by the frames actually staged, not by cap_images x the largest frame ever seen).
-    void ensure_stage(Lane &L, size_t need) {
-        if (need <= L.stage_cap) return;
-        const size_t want = std::max(need, (size_t)cap_images_ * align256((size_t)net_h_ * net_w_ * 3));
+    void ensure_stage(Lane &L, size_t need, bool device_only = false) {
+        if (need <= L.stage_cap && (device_only || L.h_stage)) return;
+        const size_t want = std::max(std::max(need, L.stage_cap), (size_t)cap_images_ * align256((size_t)net_h_ * net_w_ * 3));
         RF_HIP(hipStreamSynchronize(L.stream));
         if (L.d_stage) RF_HIP(hipFree(L.d_stage));
         if (L.h_stage) RF_HIP(hipHostFree(L.h_stage));
         L.d_stage = nullptr; L.h_stage = nullptr; L.stage_cap = 0;
-        RF_HIP(hipHostMalloc((void **)&L.h_stage, want, hipHostMallocDefault));
+        // frames scattered from other GPUs (peer copies) never touch host memory: no pinned mirror for a handle that only stages those
+        if (!device_only) RF_HIP(hipHostMalloc((void **)&L.h_stage, want, hipHostMallocDefault));
         RF_HIP(hipMalloc((void **)&L.d_stage, want));
         L.stage_cap = want;
     }
@@ -842,7 +862,13 @@ private:
     // engine's kernels (its own device's memory, or pinned / managed host memory); >= 0: the ordinal of ANOTHER device of the
     // node -- the frame is then scattered to this device over xGMI before the launch (submit()).  Anything the runtime does not
     // know as device-accessible memory is refused here instead of faulting inside a kernel.
-    int foreign_device_of(const uint8_t *p) const {
+    // The answer is cached per 2 MiB page of the address space (device allocations are at least that coarse; a camera ring or a
+    // frame tensor is looked up once, not once per frame per call): the cache is dropped whenever it has grown past a few thousand
+    // pages, and a pointer the runtime rejects is never cached (the caller may register / allocate it later).
+    int foreign_device_of(const uint8_t *p) {
+        const uintptr_t page = (uintptr_t)p >> 21;
+        auto hit = residency_.find(page);
+        if (hit != residency_.end()) return hit->second;
         hipPointerAttribute_t attr;
         memset(&attr, 0, sizeof(attr));
         if (hipPointerGetAttributes(&attr, p) != hipSuccess) {
@@ -850,9 +876,16 @@ private:
             throw ArgError("device frame pointer is not known to the HIP runtime (host memory passed to a *_device entry point?)");
         }
         if (attr.type == hipMemoryTypeUnregistered) throw ArgError("device frame pointer is unregistered host memory");
-        if (attr.type == hipMemoryTypeHost || attr.type == hipMemoryTypeManaged) return -1;
-        if (attr.device == device_) return force_scatter_ ? device_ : -1;
-        return attr.device;
+        int where;
+        if (attr.type == hipMemoryTypeHost || attr.type == hipMemoryTypeManaged) where = -1;
+        else if (attr.device == device_) where = force_scatter_ ? device_ : -1;
+        else where = attr.device;
+        // host / managed memory can be unpinned and re-used under the same address: only device allocations are remembered
+        if (attr.type != hipMemoryTypeHost && attr.type != hipMemoryTypeManaged) {
+            if (residency_.size() > 4096) residency_.clear();
+            residency_[page] = where;
+        }
+        return where;
     }
 
     bool is_registered(const uint8_t *p, size_t bytes) const {
@@ -1001,6 +1034,7 @@ private:
         RF_HIP(hipEventRecord(s.done, s.stream));
         trace_.add(4, tt);
         s.busy = true;
+        s.launch_seq = ++launch_counter_;
         for (int id : s.tickets) tickets_[id].state = Ticket::LAUNCHED;
     }
 
@@ -1037,7 +1071,8 @@ private:
         if (pending_lane_ >= 0) {
             Lane &p = lanes_[pending_lane_];
             if (p.n_images + n > mb || p.threshold != threshold || eager_timed || p.timed ||
-                (stage_need && p.stage_used + stage_need > p.stage_cap))
+                (stage_need && p.stage_used + stage_need > p.stage_cap) ||
+                (stage_need && !on_device && !p.h_stage))             // the open lane only has a device-side staging block (peer copies so far)
                 launch_pending();
         }
         const int id = alloc_ticket();
@@ -1045,7 +1080,7 @@ private:
             const int lane = pick_lane();
             Lane &s = lanes_[lane];
             harvest(s);                       // waits for the previous super-batch on this lane, if any
-            if (stage_need) ensure_stage(s, stage_need);
+            if (stage_need) ensure_stage(s, stage_need, on_device);
             next_lane_ = (lane + 1) % (int)lanes_.size();
             s.n_images = 0;
             s.stage_used = 0;
@@ -1165,6 +1200,8 @@ private:
     Lane *building_ = nullptr;
     std::vector<Lane> lanes_;
     int next_lane_ = 0, last_lane_ = 0, last_first_image_ = 0, pending_lane_ = -1;
+    unsigned long long launch_counter_ = 0;
+    std::unordered_map<uintptr_t, int> residency_;      // 2 MiB page of a device allocation -> where it lives (foreign_device_of)
     int cap_images_ = 0;                      // images per launch = max_batch * coalesce
     std::vector<Ticket> tickets_;
     int next_ticket_ = 0;

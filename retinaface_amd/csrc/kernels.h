@@ -21,6 +21,8 @@ template <> struct DwWeightT<int8_t> { typedef float type; };
 // The launch helpers keep per-device state (CU count, LDS attribute / occupancy of each kernel instance); the engine tells
 // them which device the calling thread is bound to (engine.cpp DeviceGuard).
 void bind_launch_device(int device);
+// int8 engines: 0 when v_cvt_pk_u8_f32 on the bound device rounds to nearest even and saturates (what the requantising epilogues rely on)
+int cvt_pk_u8_selfcheck();
 constexpr int kMaxDevices = 64;      // device ordinals a process may use (per-device launch state is sized by it; engine / multi.cpp enforce it)
 
 // One input frame: CV_8UC3 BGR, row y at ptr + y*step (cv::Mat data/step; RetinaFace.cpp:594).

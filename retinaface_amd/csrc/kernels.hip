@@ -283,6 +283,20 @@ template <typename V, typename R> __device__ __forceinline__ void buf_store16(R 
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rsrc, (int)off, 0, 0);
 }
 
+// ---- LDS-DMA and the synchronisation primitives of the warp-specialised kernels (round 4)
+typedef __attribute__((address_space(3))) void *lds_void_ptr;
+// One LDS-DMA wave-instruction: lane l fetches 16 bytes at buffer offset off[l] and the hardware writes them to lds_base + 16 * l (the
+// destination is wave-uniform base + lane-linear; out-of-range offsets land as zeros).  A plain (non-template) device function: inside a
+// template the host pass, which does not know the builtin, silently drops the whole kernel instantiation.
+__device__ __forceinline__ void lds_dma16(__amdgpu_buffer_rsrc_t rs, void *lds_base, unsigned off) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_ptr)lds_base, 16, (int)off, 0, 0, 0);
+}
+
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+// workgroup barrier that does NOT drain the vector-memory counter (__syncthreads() does when an LDS-DMA is in flight): LDS traffic of this
+// wave is complete, then s_barrier.  Whoever needs a DMA to have landed waits for it explicitly (counted vmcnt) before calling this.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // =============================================================================================
 // GEMM core shared by K_b / K_c / K_d:  acc[i][j] += W-fragment(ct_i, kc) x X-fragment(pt_j, kc)
 // 4 waves split the output-channel tiles first (WN), the pixel tiles second (WP).
@@ -404,6 +418,11 @@ __device__ __forceinline__ void gemm_stationary(typename Mma<T>::Acc (&acc)[NI][
 // tools/probes/cvt_pk_u8.cpp, all 256 ties + neighbours + out-of-range values; and the whole bit-exact int8 suite passes on a build
 // without the separate v_rndne_f32 that rounds 1 and 2 spent per value).  Only the upper clamp at 127 is left to the VALU.
 #define RF_RNDNE(x) (x)
+// The claim is about ONE instruction on ONE architecture under the default rounding mode: this file is built for nothing else (and the
+// engine re-checks it on the device it runs on: cvt_pk_u8_selfcheck(), called once per device from rf_create).
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "kernels.hip relies on gfx950 semantics (v_cvt_pk_u8_f32 rounding, LDS-DMA, MFMA shapes): build with --offload-arch=gfx950"
+#endif
 
 // ReLU on the bit pattern: a signed integer max with 0 is max(x, +0) for every float (negative floats, -0 included, have the sign
 // bit set = negative integers).  One v_max_i32 / v_pk_max_i16; fmaxf() costs two instructions wherever the compiler cannot prove
@@ -1543,6 +1562,320 @@ __global__ __launch_bounds__(kThreads, (DwPwCfg<T, CIN, COUT, STRIDE, HAS_DW, TH
     if (p_img >= 0) store_tile(p_img, p_oy0, p_ox0);
 }
 
+// =============================================================================================
+// K_b'  depthwise + pointwise (+ lateral) block WAVE-SPECIALISED (round 4): K_b's phases with the memory side taken off the four
+//   GEMM waves.  A fifth wave (the producer) owns every global-memory instruction of the tile loop: it stores the previous tile's
+//   result(s) from LDS and brings the halo of the tile DIST = NBUF - 1 steps ahead into one of NBUF LDS buffers by LDS-DMA
+//   (buffer_load ... lds: no VGPRs, no ds_write pass, zero padding by the descriptor's range check); the consumers run
+//   depthwise (diagonal MFMA) -> barrier -> pointwise GEMM -> [barrier -> lateral GEMM] -> barrier on LDS only.  The producer joins the
+//   consumers' barriers (s_barrier is workgroup wide) but waits only for the halo the NEXT interval needs, with a counted vmcnt: its own
+//   stores and the younger DMA stay in flight across the barrier.  Same tile geometry, LDS pitches, weight packing and arithmetic as
+//   K_b: the results are bit-identical (the int8 instance is held to the integer oracle like K_b's).
+//   What it took off the critical path in the merged SSH conv (K_c'): 104 -> 56 us.
+// =============================================================================================
+template <typename T, int CIN, int COUT, int STRIDE, int TH, int TW, bool LAT, int NBUF, bool PADROW> struct DwPwWsCfg {
+    typedef DwPwCfg<T, CIN, COUT, STRIDE, true, TH, TW, PADROW> B;
+    static constexpr int VEC = B::VEC, P = B::P;
+    static constexpr int CPP = B::LDIN / VEC;                          // 16-byte chunks per halo pixel, padding included
+    static constexpr int CPR = B::ROWP / VEC;                          // chunks per halo row, padding included
+    static constexpr int DPP = CIN / VEC;                              // data chunks per pixel
+    static constexpr int SLOTS = B::HR * CPR;
+    static constexpr int PIECES = (SLOTS + 63) / 64;                   // DMA wave-instructions per halo tile
+    static constexpr int LDL = 64 + VEC;
+    static constexpr int NSTORE = P * (COUT / VEC) / 64 + (LAT ? P * (64 / VEC) / 64 : 0);      // store wave-instructions per tile
+    static constexpr size_t IN_BYTES = (size_t)PIECES * 1024;
+    static constexpr size_t A_BYTES = B::A_BYTES, O_BYTES = B::O_BYTES;
+    static constexpr size_t L_BYTES = LAT ? sizeof(T) * (size_t)(P * LDL) : 0;
+    static constexpr size_t LDS_BYTES = NBUF * IN_BYTES + A_BYTES + O_BYTES + L_BYTES;
+    static constexpr int THREADS = 320;                                // 4 consumer waves + the producer
+    static constexpr int WG_CAP = LAT ? 2 : 3;                         // (the lateral's second GEMM needs ~140 VGPRs: 3 workgroups of 5 waves would spill)
+    static constexpr int WG_PER_CU = (int)(160 * 1024 / LDS_BYTES) > WG_CAP ? WG_CAP : (int)(160 * 1024 / LDS_BYTES);
+    static constexpr int WAVES_PER_EU = (WG_PER_CU * 5 + 3) / 4;       // what __launch_bounds__ needs for WG_PER_CU resident workgroups
+    static_assert(B::DWMMA && B::STAT && sizeof(T) <= 2, "only the shapes whose depthwise stage runs on MFMA with stationary pointwise weights");
+    static_assert(B::LDIN % VEC == 0 && B::ROWP % VEC == 0 && IN_BYTES >= B::IN_BYTES, "halo layout in whole 16-byte slots");
+    static_assert((P * (COUT / VEC)) % 64 == 0 && (!LAT || (P * (64 / VEC)) % 64 == 0), "whole store instructions per tile");
+    static_assert(NBUF == 2 || NBUF == 3, "prefetch distance 1 or 2");
+    static_assert(!LAT || (COUT + Mma<T>::K - 1) / Mma<T>::K <= 8, "lateral weights stationary");
+};
+
+template <typename T, int CIN, int COUT, int STRIDE, int TH, int TW, bool LAT, int NBUF, bool PADROW>
+__global__ __launch_bounds__(320, (DwPwWsCfg<T, CIN, COUT, STRIDE, TH, TW, LAT, NBUF, PADROW>::WAVES_PER_EU))
+void dwpw_ws_kernel(DwPwArgs<T> a) {
+    typedef DwPwWsCfg<T, CIN, COUT, STRIDE, TH, TW, LAT, NBUF, PADROW> W;
+    typedef typename W::B C;
+    typedef typename Vec<T>::type V;
+    typedef Mma<T> M;
+    typedef typename M::Frag Frag;
+    typedef typename C::WS WS;
+    constexpr int VEC = C::VEC, P = C::P, HC = C::HC, LDA = C::LDA, LDO = C::LDO, LDIN = C::LDIN, ROWP = C::ROWP;
+    constexpr int PT = C::PT, KCH = C::KCH, LDL = W::LDL;
+    constexpr int DIST = NBUF - 1;
+    constexpr bool I8 = sizeof(T) == 1;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int IN_ELEMS = (int)(W::IN_BYTES / sizeof(T));
+    T *s_in = (T *)smem;                                                           // [NBUF][IN_ELEMS]
+    T *s_a = (T *)(smem + NBUF * W::IN_BYTES);                                     // depthwise result
+    T *s_out = (T *)(smem + NBUF * W::IN_BYTES + W::A_BYTES);                      // block output tile
+    T *s_lat = (T *)(smem + NBUF * W::IN_BYTES + W::A_BYTES + W::O_BYTES);         // lateral output tile (LAT)
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int G = gridDim.x;
+    const int first = xcd_remap(blockIdx.x, G);
+    const int n_my = first < a.nblk ? (a.nblk - 1 - first) / G + 1 : 0;
+
+    if (wave == 4) {
+        // ================================================= producer
+        int kpack[W::PIECES];                                          // byte offset inside the image | halo column << 26 (63 = no pixel)
+#pragma unroll
+        for (int i = 0; i < W::PIECES; i++) {
+            const int s = i * 64 + lane;
+            const int row = s / W::CPR, rem = s % W::CPR;
+            const int px = rem / W::CPP, ch = rem % W::CPP;
+            const bool real = row < C::HR && px < HC && ch < W::DPP;
+            kpack[i] = real ? ((((row * a.win + px) * CIN + ch * VEC) * (int)sizeof(T)) | (px << 26)) : (int)(63u << 26);
+        }
+        const unsigned in_img_bytes = (unsigned)(a.hin * a.win * CIN) * (unsigned)sizeof(T);
+        const unsigned out_img_bytes = (unsigned)(a.hout * a.wout * COUT) * (unsigned)sizeof(T);
+        auto dma = [&](int tx, int ty, int img, T *dst) {
+            const auto rs = image_rsrc(a.in + (size_t)img * a.hin * a.win * CIN, in_img_bytes);
+            const int iy0 = ty * TH * STRIDE - 1, ix0 = tx * TW * STRIDE - 1;
+            const int sbase = (iy0 * a.win + ix0) * CIN * (int)sizeof(T);
+#pragma unroll
+            for (int i = 0; i < W::PIECES; i++) {
+                const int dx = (int)((unsigned)kpack[i] >> 26);
+                const unsigned off = (dx != 63 && (unsigned)(ix0 + dx) < (unsigned)a.win) ? (unsigned)((kpack[i] & 0x03ffffff) + sbase) : kOobOffset;
+                lds_dma16(rs, (unsigned char *)dst + i * 1024, off);
+            }
+        };
+        auto store_tile = [&](int img, int oy0, int ox0) {
+            constexpr int OPV = COUT / VEC;
+            const auto ro = image_rsrc(a.out + (size_t)img * a.hout * a.wout * COUT, out_img_bytes);
+            const int obase = (oy0 * a.wout + ox0) * COUT * (int)sizeof(T);
+#pragma unroll
+            for (int i = lane; i < P * OPV; i += 64) {
+                const int p = i / OPV, cv = i % OPV;
+                const int py = p / TW, px = p % TW;
+                const unsigned off = ox0 + px < a.wout ? (unsigned)(((py * a.wout + px) * COUT + cv * VEC) * (int)sizeof(T) + obase) : kOobOffset;
+                buf_store16(ro, off, *(const V *)(s_out + p * LDO + cv * VEC));
+            }
+            if constexpr (LAT) {
+                constexpr int LPV = 64 / VEC;
+                const auto rl = image_rsrc(a.lat_out + (size_t)img * a.hout * a.wout * 64, (unsigned)(a.hout * a.wout * 64) * (unsigned)sizeof(T));
+                const int lbase = (oy0 * a.wout + ox0) * 64 * (int)sizeof(T);
+#pragma unroll
+                for (int i = lane; i < P * LPV; i += 64) {
+                    const int p = i / LPV, cv = i % LPV;
+                    const int py = p / TW, px = p % TW;
+                    const unsigned off = ox0 + px < a.wout ? (unsigned)(((py * a.wout + px) * 64 + cv * VEC) * (int)sizeof(T) + lbase) : kOobOffset;
+                    buf_store16(rl, off, *(const V *)(s_lat + p * LDL + cv * VEC));
+                }
+            }
+        };
+        const TileStep step(G, a.tiles_x, a.tiles_y);
+        TileCoord cur(first, a.tiles_x, a.tiles_y), pf = cur;         // cur: the tile the consumers work on; pf: the next tile to fetch
+#pragma unroll
+        for (int d = 0; d < DIST; d++)
+            if (d < n_my) { dma(pf.tx, pf.ty, pf.img, s_in + d * IN_ELEMS); step.advance(pf); }
+        if (DIST == 2 && n_my >= 2) wait_vmcnt<W::PIECES>();
+        else wait_vmcnt<0>();
+        lds_barrier();
+        int p_img = 0, p_oy0 = 0, p_ox0 = 0;
+        for (int k = 0; k < n_my; k++) {
+            const bool st = k > 0, ld = k + DIST < n_my;
+            // the previous tile's result(s): s_out / s_lat are rewritten by this interval's pointwise / lateral phase, i.e. after the
+            // barrier below, which this wave passes only with its LDS reads complete
+            if (st) store_tile(p_img, p_oy0, p_ox0);
+            if (ld) { dma(pf.tx, pf.ty, pf.img, s_in + ((k + DIST) % NBUF) * IN_ELEMS); step.advance(pf); }
+            p_img = cur.img; p_oy0 = cur.ty * TH; p_ox0 = cur.tx * TW;
+            step.advance(cur);
+            lds_barrier();                                             // (depthwise -> pointwise)
+            if constexpr (LAT) lds_barrier();                          // (pointwise -> lateral)
+            // tile k + 1 must have landed before the closing barrier; what was issued in THIS interval may stay in flight (DIST == 2)
+            if (DIST == 1) wait_vmcnt<0>();
+            else if (st && ld) wait_vmcnt<(W::NSTORE + W::PIECES < 63 ? W::NSTORE + W::PIECES : 63)>();
+            else if (ld) wait_vmcnt<W::PIECES>();
+            else if (st) wait_vmcnt<W::NSTORE>();
+            else wait_vmcnt<0>();
+            lds_barrier();
+        }
+        if (n_my > 0) store_tile(p_img, p_oy0, p_ox0);                // (the consumers' last writes precede the closing barrier)
+        return;
+    }
+
+    // ================================================= consumers (waves 0-3): once per workgroup, weights and per-lane constants as in K_b
+    const int wn = wave % WS::WN, wp = wave / WS::WN;
+    Frag wst[WS::NI][KCH];
+    {
+        const Frag *wsrc = (const Frag *)a.pw_w + (size_t)wn * KCH * 64 + lane;
+#pragma unroll
+        for (int i = 0; i < WS::NI; i++)
+#pragma unroll
+            for (int kc = 0; kc < KCH; kc++) wst[i][kc] = wsrc[((i * WS::WN) * KCH + kc) * 64];
+    }
+    f32x4 pw_bias[WS::NI], pw_mult[WS::NI];
+#pragma unroll
+    for (int i = 0; i < WS::NI; i++) {
+        pw_bias[i] = *(const f32x4 *)(a.pw_b + acc_cout(wn + i * WS::WN, lane, 0));
+        pw_mult[i] = load_mult(a.pw_m, acc_cout(wn + i * WS::WN, lane, 0));
+    }
+    constexpr int LKCH = (COUT + M::K - 1) / M::K;
+    Frag lst[1][LAT ? LKCH : 1];
+    f32x4 lat_bias = vzero<f32x4, 4>(), lat_mult = vzero<f32x4, 4>();
+    if constexpr (LAT) {
+        const Frag *lsrc = (const Frag *)a.lat_w + (size_t)wave * LKCH * 64 + lane;
+#pragma unroll
+        for (int kc = 0; kc < LKCH; kc++) lst[0][kc] = lsrc[kc * 64];
+        lat_bias = *(const f32x4 *)(a.lat_b + acc_cout(wave, lane, 0));
+        lat_mult = load_mult(a.lat_m, acc_cout(wave, lane, 0));
+    }
+    constexpr int NG = CIN / 16, DKCH = I8 ? kDwMmaChunksI8 : kDwMmaChunks;
+    constexpr int DPARTS = I8 ? 2 : 1;
+    constexpr int GW = NG >= 4 ? NG / 4 : 1;
+    constexpr int PW = (NG * PT / 4) / GW;
+    uint32_t dwv[GW][DKCH][DPARTS];
+    f32x4 dwb4[GW], dwm4[GW];
+    int dpix[PW], dtap[DKCH];
+    const int dsel = I8 ? dw_mma_dword_index_i8(lane) : dw_mma_dword_index(lane);
+#pragma unroll
+    for (int gi = 0; gi < GW; gi++) {
+        const int g = NG >= 4 ? wave + 4 * gi : wave % NG;
+#pragma unroll
+        for (int kc = 0; kc < DKCH; kc++)
+#pragma unroll
+            for (int hl = 0; hl < DPARTS; hl++) dwv[gi][kc][hl] = a.dw_mma[((g * DKCH + kc) * DPARTS + hl) * 64 + lane];
+        dwb4[gi] = *(const f32x4 *)(a.dw_b + acc_cout(g, lane, 0));
+        dwm4[gi] = load_mult(I8 ? a.dw_m : nullptr, acc_cout(g, lane, 0));
+    }
+#pragma unroll
+    for (int pi = 0; pi < PW; pi++) {
+        const int pt = NG >= 4 ? pi : wave / NG + pi * (4 / NG);
+        const int p = acc_pixel(pt, lane);
+        dpix[pi] = (p / TW) * STRIDE * ROWP + (p % TW) * STRIDE * LDIN + (I8 ? 0 : ((lane >> 4) & 1) * 8);
+    }
+#pragma unroll
+    for (int kc = 0; kc < DKCH; kc++) {
+        const int tap = I8 ? kc * 4 + (lane >> 4) : kc * 2 + (lane >> 5);
+        dtap[kc] = tap < 9 ? (tap / 3) * ROWP + (tap % 3) * LDIN : -1;
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);                                // everything above is in registers: no global access below this line
+    lds_barrier();                                                     // (the producer's prologue: tile 0 has landed)
+
+    for (int k = 0; k < n_my; k++) {
+        const T *s_in_b = s_in + (k % NBUF) * IN_ELEMS;
+        // ---- depthwise 3x3 as diagonal-weight implicit GEMM (K_b phase 2)
+#pragma unroll
+        for (int gi = 0; gi < GW; gi++) {
+            const int g = NG >= 4 ? wave + 4 * gi : wave % NG;
+            typename M::Acc dacc[DPARTS][PW];
+#pragma unroll
+            for (int hl = 0; hl < DPARTS; hl++)
+#pragma unroll
+                for (int pi = 0; pi < PW; pi++) dacc[hl][pi] = acc_init<T>(dwb4[gi]);
+            constexpr int NB = DKCH * PW, DDEPTH = NB < 4 ? NB : 4;
+            Frag bq[DDEPTH];
+            auto bload = [&](int idx) -> Frag {
+                const int kc = idx / PW, pi = idx % PW;
+                return dtap[kc] >= 0 ? *(const Frag *)(s_in_b + dpix[pi] + dtap[kc] + g * 16) : M::zero();
+            };
+#pragma unroll
+            for (int d = 0; d < DDEPTH - 1; d++) bq[d] = bload(d);
+#pragma unroll
+            for (int kc = 0; kc < DKCH; kc++) {
+                typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+                Frag af[DPARTS];
+#pragma unroll
+                for (int hl = 0; hl < DPARTS; hl++) {
+                    u32x4 wa;
+                    uint32_t wd = dwv[gi][kc][hl];
+                    asm volatile("" : "+v"(wd));
+#pragma unroll
+                    for (int d = 0; d < 4; d++) wa[d] = dsel == d ? wd : 0u;
+                    af[hl] = __builtin_bit_cast(Frag, wa);
+                }
+#pragma unroll
+                for (int pi = 0; pi < PW; pi++) {
+                    const int idx = kc * PW + pi;
+                    if (idx + DDEPTH - 1 < NB) bq[(idx + DDEPTH - 1) % DDEPTH] = bload(idx + DDEPTH - 1);
+#pragma unroll
+                    for (int hl = 0; hl < DPARTS; hl++) dacc[hl][pi] = M::mma(af[hl], bq[idx % DDEPTH], dacc[hl][pi]);
+                }
+            }
+#pragma unroll
+            for (int pi = 0; pi < PW; pi++) {
+                const int pt = NG >= 4 ? pi : wave / NG + pi * (4 / NG);
+                if constexpr (I8) {
+                    typename M::Acc tot;
+#pragma unroll
+                    for (int r = 0; r < 4; r++) tot[r] = dacc[0][pi][r] * 128 + dacc[DPARTS - 1][pi][r];
+                    store_acc<T, LDA>(s_a, dwm4[gi], dwb4[gi], tot, g, pt, lane, true);
+                } else {
+                    store_acc<T, LDA>(s_a, dwm4[gi], dwb4[gi], dacc[0][pi], g, pt, lane, true);
+                }
+            }
+        }
+        lds_barrier();
+        // ---- pointwise GEMM + epilogue (K_b phases 3-4)
+        {
+            typename M::Acc acc[WS::NI][WS::NJ];
+#pragma unroll
+            for (int i = 0; i < WS::NI; i++)
+#pragma unroll
+                for (int j = 0; j < WS::NJ; j++) acc[i][j] = acc_init<T>(pw_bias[i]);
+            gemm_stationary<T, WS::NI, WS::NJ, KCH>(acc, wst, [&](int j, int kc) -> Frag {
+                const int kb = kc * M::K + (lane >> 4) * M::KPL;
+                const int p = acc_pixel(wp + j * WS::WP, lane);
+                return kb < CIN ? *(const Frag *)(s_a + p * LDA + kb) : M::zero();
+            });
+#pragma unroll
+            for (int i = 0; i < WS::NI; i++)
+#pragma unroll
+                for (int j = 0; j < WS::NJ; j++)
+                    store_acc<T, LDO>(s_out, pw_mult[i], pw_bias[i], acc[i][j], wn + i * WS::WN, wp + j * WS::WP, lane, true);
+        }
+        if constexpr (LAT) {
+            lds_barrier();
+            // ---- fused lateral on the LDS-resident output tile (K_b phase 5): wave = output-channel tile, all pixel tiles
+            typename M::Acc acc2[1][PT];
+#pragma unroll
+            for (int j = 0; j < PT; j++) acc2[0][j] = acc_init<T>(lat_bias);
+            gemm_stationary<T, 1, PT, LKCH>(acc2, lst, [&](int j, int kc) -> Frag {
+                const int kb = kc * M::K + (lane >> 4) * M::KPL;
+                return *(const Frag *)(s_out + acc_pixel(j, lane) * LDO + kb);
+            });
+#pragma unroll
+            for (int j = 0; j < PT; j++) store_acc<T, LDL>(s_lat, lat_mult, lat_bias, acc2[0][j], wave, j, lane, true);
+        }
+        lds_barrier();
+    }
+}
+
+// probe knob RF_DWPWWS: 0 = off (K_b everywhere); 2 / 3 = halo buffers of the warp-specialised blocks
+static int dwpw_ws_variant() {
+    static int v = -1;
+    if (v < 0) { const char *e = getenv("RF_DWPWWS"); v = e ? atoi(e) : 0; }
+    return v;
+}
+
+template <typename T, int CIN, int COUT, int STRIDE, int TH, int TW, bool LAT, int NBUF, bool PADROW>
+static void dwpw_ws_launch(hipStream_t s, const DwPwParams<T> *p, int tiles_x, int tiles_y) {
+    typedef DwPwWsCfg<T, CIN, COUT, STRIDE, TH, TW, LAT, NBUF, PADROW> W;
+    auto kern = dwpw_ws_kernel<T, CIN, COUT, STRIDE, TH, TW, LAT, NBUF, PADROW>;
+    static std::atomic<int> resident_cache[kMaxDevices] = {};
+    const int dev = launch_device();
+    int resident = resident_cache[dev].load(std::memory_order_acquire);
+    if (!resident) {
+        set_max_lds(kern, W::LDS_BYTES);
+        int nb = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)kern, W::THREADS, W::LDS_BYTES) != hipSuccess || nb < 1) nb = 1;
+        resident = nb;
+        resident_cache[dev].store(resident, std::memory_order_release);
+    }
+    DwPwArgs<T> a{p->in, p->out, p->dw_w, p->dw_b, p->dw_mma, p->pw_w, p->pw_b, p->lat_w, p->lat_b, p->lat_out, p->pw_m, p->lat_m, p->dw_m,
+                  p->hin, p->win, p->hout, p->wout, tiles_x, tiles_y, p->n * tiles_x * tiles_y};
+    hipLaunchKernelGGL(kern, dim3(persistent_grid(a.nblk, resident)), dim3(W::THREADS), W::LDS_BYTES, s, a);
+}
+
 template <typename T, int CIN, int COUT, int STRIDE, bool HAS_DW, int TH, int TW, bool LAT, bool PADROW>
 static void dwpw_launch(hipStream_t s, const DwPwParams<T> *p, int tiles_x, int tiles_y) {
     typedef DwPwCfg<T, CIN, COUT, STRIDE, HAS_DW, TH, TW, PADROW> C;
@@ -1570,6 +1903,20 @@ static TileInfo dwpw_dispatch(hipStream_t s, const DwPwParams<T> *p, int hout, i
     int tiles_x = (wout + TW - 1) / TW, tiles_y = (hout + TH - 1) / TH;
     TileInfo ti{TH, TW, C::LDS_BYTES, tiles_x * tiles_y};
     if (!p) return ti;
+    // warp-specialised instances (K_b'): the stride-1 blocks with 64 / 128 channels, with or without the fused lateral
+    if constexpr (sizeof(T) <= 2 && HAS_DW && STRIDE == 1 && CIN == COUT && (CIN == 64 || CIN == 128) && C::DWMMA && C::STAT) {
+        const int v = dwpw_ws_variant();
+        if (v == 2 || v == 3) {
+            if (p->lat_out) {
+                if (v == 2) dwpw_ws_launch<T, CIN, COUT, STRIDE, TH, TW, true, 2, PADROW>(s, p, tiles_x, tiles_y);
+                else dwpw_ws_launch<T, CIN, COUT, STRIDE, TH, TW, true, 3, PADROW>(s, p, tiles_x, tiles_y);
+            } else {
+                if (v == 2) dwpw_ws_launch<T, CIN, COUT, STRIDE, TH, TW, false, 2, PADROW>(s, p, tiles_x, tiles_y);
+                else dwpw_ws_launch<T, CIN, COUT, STRIDE, TH, TW, false, 3, PADROW>(s, p, tiles_x, tiles_y);
+            }
+            return ti;
+        }
+    }
     if (p->lat_out) {
         // laterals tap the outputs of blocks 4 (64ch), 10 (128ch) and 12 (256ch)
         if constexpr (HAS_DW && STRIDE == 1 && CIN == COUT && COUT >= 64) dwpw_launch<T, CIN, COUT, STRIDE, HAS_DW, TH, TW, true, PADROW>(s, p, tiles_x, tiles_y);
@@ -2206,14 +2553,6 @@ __global__ __launch_bounds__(kThreads, (Conv3Cfg<T, CIN, COUT, TH, TW, ALLC, PAD
 //   16 B), so the padded layout of K_c (pixel pitch 32 mod 64 bytes, row pitch a multiple of 256 bytes: conflict-free B fragments)
 //   is kept by giving the pad chunks slots of their own that load nothing.
 // =============================================================================================
-typedef __attribute__((address_space(3))) void *lds_void_ptr;
-// One LDS-DMA wave-instruction: lane l fetches 16 bytes at buffer offset off[l] and the hardware writes them to lds_base + 16 * l (the
-// destination is wave-uniform base + lane-linear; out-of-range offsets land as zeros).  A plain (non-template) device function: inside a
-// template the host pass, which does not know the builtin, silently drops the whole kernel instantiation.
-__device__ __forceinline__ void lds_dma16(__amdgpu_buffer_rsrc_t rs, void *lds_base, unsigned off) {
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void_ptr)lds_base, 16, (int)off, 0, 0, 0);
-}
-
 template <typename T, int NBUF> struct Conv3WsCfg {
     typedef Conv3Cfg<T, 64, 48, 8, 8, false, true> B;                  // tile geometry, LDS pitches, wave split (ODD: 3 GEMM waves)
     static constexpr int VEC = B::VEC;
@@ -2230,11 +2569,6 @@ template <typename T, int NBUF> struct Conv3WsCfg {
     static_assert(IN_BYTES >= B::IN_BYTES && O_BYTES % 16 == 0 && (NBUF == 2 || NBUF == 3), "LDS carve");
     static_assert(NSTORE + PIECES < 64, "counted vmcnt");
 };
-
-template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
-// workgroup barrier that does NOT drain the vector-memory counter (__syncthreads() does when an LDS-DMA is in flight): LDS traffic of this
-// wave is complete, then s_barrier.  Whoever needs a DMA to have landed waits for it explicitly (counted vmcnt) before calling this.
-__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 template <typename T, int DEPTH, int NBUF>
 __global__ __launch_bounds__(kThreads, (NBUF == 2 || sizeof(T) == 1 ? 3 : 2)) void conv3x3_ws_kernel(Conv3Args<T> a) {
@@ -3204,6 +3538,39 @@ __global__ __launch_bounds__(kThreads) void resize_bilinear_kernel(const FrameDe
 void launch_resize_bilinear(hipStream_t s, const FrameDesc *src, uint8_t *dst, int n, int net_h, int net_w) {
     dim3 grid((net_w + 31) / 32, (net_h + 7) / 8, n);
     hipLaunchKernelGGL(resize_bilinear_kernel, grid, dim3(kThreads), 0, s, src, dst, net_h, net_w);
+}
+
+// One-off check per device that v_cvt_pk_u8_f32 is clamp(rint(x), 0, 255) with ties to even (the int8 epilogues have no separate
+// rounding instruction): 64 ties, their neighbours and out-of-range values.  Returns the number of mismatches (0 = as assumed).
+__global__ void cvt_pk_u8_probe_kernel(int *bad) {
+    const int i = threadIdx.x;
+    const float tie = (float)i + 0.5f;                           // positive: the neighbouring floats are the bit patterns +- 1
+    const float vals[4] = {tie, __builtin_bit_cast(float, __builtin_bit_cast(int, tie) - 1), __builtin_bit_cast(float, __builtin_bit_cast(int, tie) + 1),
+                           (float)i * 5.f - 30.f};
+    int wrong = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const unsigned got = __builtin_amdgcn_cvt_pk_u8_f32(vals[k], 0, 0u);
+        const float want = fminf(fmaxf(rintf(vals[k]), 0.f), 255.f);
+        wrong += got != (unsigned)want;
+    }
+    if (wrong) atomicAdd(bad, wrong);
+}
+int cvt_pk_u8_selfcheck() {
+    static std::atomic<int> result[kMaxDevices] = {};          // 0 = not run, 1 = ok, 2 = mismatch
+    const int dev = launch_device();
+    int r = result[dev].load(std::memory_order_acquire);
+    if (!r) {
+        int *d = nullptr, h = -1;
+        if (hipMalloc((void **)&d, sizeof(int)) != hipSuccess) return -1;
+        (void)hipMemset(d, 0, sizeof(int));
+        hipLaunchKernelGGL(cvt_pk_u8_probe_kernel, dim3(1), dim3(64), 0, 0, d);
+        if (hipMemcpy(&h, d, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) h = -1;
+        (void)hipFree(d);
+        r = h == 0 ? 1 : 2;
+        result[dev].store(r, std::memory_order_release);
+    }
+    return r == 1 ? 0 : 1;
 }
 
 #ifdef RF_KERNEL_TRACE

@@ -167,8 +167,10 @@ public:
         // must not reach another engine's slot of the same index
         if (ticket < 0 || ticket / G >= (int)issued_[ticket % G].size() || !issued_[ticket % G][ticket / G])
             throw ArgError("wait: invalid ticket");
-        issued_[ticket % G][ticket / G] = 0;
+        // the engine rejects a caller mistake (cap_per_image > 0 without an output array ...) WITHOUT consuming the ticket: it stays
+        // issued here too, so the caller can wait again with good arguments (clearing it first leaked the slot: ADVICE r3)
         eng_[ticket % G]->wait(ticket / G, out, cap_per_image, counts, truncated);
+        issued_[ticket % G][ticket / G] = 0;
         last_from_wait_ = ticket % G;
         last_engine_ = ticket % G;
     }

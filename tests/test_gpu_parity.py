@@ -8,7 +8,7 @@ Tolerances (stated once, used everywhere):
                 landmarks within 0.15 px.  Candidate count: within the number of anchors whose oracle probability lies inside the
                 score-noise band |p - thr| <= 2e-3 (only those can cross `conf <= thr`; 0..2 on the golden frames, minted into
                 tests/golden/threshold_bands.npz by tools/make_golden.py --bands; computed live where the oracle runs) -- round 4,
-                a flat +-4 before.  Per-layer activations: within 2x what plain fp16 storage is PREDICTED to cost at that tensor
+                a flat +-4 before.  Per-layer activations: within what plain fp16 storage is PREDICTED to cost at that tensor
                 (tools/fp16_error_budget.py predicted_layer_errors: the fused-op sequence replayed on the CPU with fp16 rounding at
                 every storage point), a flat 3 % of the range before.  Round 1 needed 2e-3 on ~50 px faces; the per-tensor error
                 budget (tools/fp16_error_budget.py) showed 73 % of the box-error variance came from three tensors that
@@ -35,7 +35,7 @@ pytestmark = pytest.mark.gpu
 FP32, FP16 = 0, 1
 TOL = {FP32: dict(iou=1e-5, score=1e-5, lm=2e-3), FP16: dict(iou=1e-3, score=2e-3, lm=0.15)}
 SCORE_NOISE = TOL[FP16]["score"]          # an fp16 score is within this of the oracle's: the width of the threshold band
-LAYER_ERR_FACTOR = 2.0                    # fp16 per-layer bar = this x the error-budget tool's prediction for plain fp16 storage
+LAYER_ERR_FACTOR = 1.0                    # fp16 per-layer bar = the error-budget tool's prediction for plain fp16 storage (measured: 0.14-0.37 of it)
 
 
 def ncand_band(prec, key=None, heads=None, thr=0.5):
@@ -793,6 +793,53 @@ def test_device_frames_resident_elsewhere_are_scattered_to_the_slices_device(rfa
             det.close()
     finally:
         os.environ.pop("RF_FORCE_SCATTER", None)
+
+
+def test_configs4_rehearsal_eight_engines_share_the_one_gpu(rfa):
+    """BASELINE.json configs[4] (mnet25 int8, 448 x 448, batch 256 sharded over 8 GPUs) through the LIBRARY on the one-GPU box: a handle
+    over devices [0] * 8 -- eight engines, eight host threads, contiguous slices of 32 -- takes ONE rf_detect_batch_device call of 256
+    device-resident frames with RF_FORCE_SCATTER=1 (every frame is treated as living on another GPU: each engine pulls its 32 frames
+    with peer copies on its lane's stream before it launches).  Same detections, anchors and candidate counts as the single engine
+    (which chunks the 256 into super-batches itself).  What this cannot show is a second physical device: see SCALE_rNN.json."""
+    import torch
+    from retinaface_amd.frames import synth_frames
+    frames = synth_frames(448, 448, 64, config=19)
+    d = torch.from_numpy(np.stack(frames)).cuda()
+    ptrs = [d[i % 64].data_ptr() for i in range(256)]
+    one = engine(rfa, "mnet25", INT8, (448, 448), max_batch=32)
+    want = _key(one.detect_device(ptrs, [448] * 256, [448] * 256, 0.5))
+    want_nc = one.last_candidate_counts(256)
+    assert sum(len(r) for r in want) >= 256
+    os.environ["RF_FORCE_SCATTER"] = "1"
+    try:
+        multi = rfa.RetinaFace(ASSETS, "net3", 0.4, precision=INT8, net_hw=(448, 448), model_stem="mnet25", max_batch=32, devices=[0] * 8)
+        assert multi.num_devices() == 8
+        for rep in range(2):                                   # the second call reuses the eight lanes' staging blocks
+            assert _key(multi.detect_device(ptrs, [448] * 256, [448] * 256, 0.5)) == want
+            assert multi.last_candidate_counts(256) == want_nc
+        # ragged: 250 images = 7 slices of 32 + one of 26
+        assert _key(multi.detect_device(ptrs[:250], [448] * 250, [448] * 250, 0.5)) == want[:250]
+        multi.close()
+    finally:
+        os.environ.pop("RF_FORCE_SCATTER", None)
+
+
+def test_bench_strong_mode_with_real_engines_two_ranks_on_the_one_gpu(rfa):
+    """bench.py's strong-scaling path (one global batch per step split by shard_range, the result gather inside the timed region) with
+    REAL engines: two ranks share the one GPU (--oversubscribe: RCCL refuses two ranks on a device, so the records travel over gloo --
+    everything else, launcher included, is what `--gpus 8 --global-batch 256` runs on the 8-GPU node)."""
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--oversubscribe", "--global-batch", "64", "--precision",
+                          "int8", "--steps", "20", "--warmup", "5", "--min-seconds", "0.3", "--regions", "1", "--no-cpu-baseline", "--host-seconds", "0",
+                          "--no-pmc", "--profile-iters", "5", "--ring-mb", "80"], capture_output=True, text=True, env=env, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    j = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert j["n_gpus"] == 2 and j["scaling"] == "strong" and j["config"]["global_batch"] == 64 and j["dtype"] == "i8"
+    g = j["result_gather"]
+    assert g["records_gathered"] == g["expected"] == 64 * j["steps"] and g["ranks_in_communicator"] == 2 and g["backend"] == "gloo"
+    assert j["value"] > 0 and abs(j["images_per_sec"] * j["timed_seconds"] - 64 * j["steps"]) < 1e-3 * 64 * j["steps"]
 
 
 def test_device_frames_unaligned_pointer_odd_step_and_roi(rfa, oracles, base_frame):
