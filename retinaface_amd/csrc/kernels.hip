@@ -95,9 +95,15 @@ __device__ unsigned g_trace_key = 0;      // 0 = any launch of that kernel famil
             (g_trace_key == 0 || rf_trace_key == g_trace_key))                                                \
             g_trace[blockIdx.x * kTraceSlots + (slot)] = __builtin_amdgcn_s_memtime();                         \
     } while (0)
+#define RF_TRACE_T(kid, slot, thread)                                                                        \
+    do {                                                                                                     \
+        if (g_trace_kernel == (kid) && threadIdx.x == (thread) && blockIdx.x < kTraceBlocks)                   \
+            g_trace[blockIdx.x * kTraceSlots + (slot)] = __builtin_amdgcn_s_memtime();                         \
+    } while (0)
 #else
 #define RF_TRACE_KEY(expr) do { } while (0)
 #define RF_TRACE(kid, slot) do { } while (0)
+#define RF_TRACE_T(kid, slot, thread) do { } while (0)
 #endif
 
 template <typename F>
@@ -1686,10 +1692,10 @@ void dwpw_ws_kernel(DwPwArgs<T> a) {
             // the previous tile's result(s): s_out / s_lat are rewritten by this interval's pointwise / lateral phase, i.e. after the
             // barrier below, which this wave passes only with its LDS reads complete
             if (st) store_tile(p_img, p_oy0, p_ox0);
-            if (ld) { dma(pf.tx, pf.ty, pf.img, s_in + ((k + DIST) % NBUF) * IN_ELEMS); step.advance(pf); }
+            lds_barrier();                                             // (depthwise -> pointwise)
+            if (ld) { dma(pf.tx, pf.ty, pf.img, s_in + ((k + DIST) % NBUF) * IN_ELEMS); step.advance(pf); }      // (issued under the pointwise phase)
             p_img = cur.img; p_oy0 = cur.ty * TH; p_ox0 = cur.tx * TW;
             step.advance(cur);
-            lds_barrier();                                             // (depthwise -> pointwise)
             if constexpr (LAT) lds_barrier();                          // (pointwise -> lateral)
             // tile k + 1 must have landed before the closing barrier; what was issued in THIS interval may stay in flight (DIST == 2)
             if (DIST == 1) wait_vmcnt<0>();
@@ -1986,8 +1992,10 @@ struct DwPw2Args {
     const uint32_t *dwa_mma; const float *dwa_b; const half_t *pwa_w; const float *pwa_b;
     const uint32_t *dwb_mma; const float *dwb_b; const half_t *pwb_w; const float *pwb_b;
     int hin, win, hout, wout, tiles_x, tiles_y, nblk;
+    int ring;                                           // 1 = depthwise A as one ring pipeline (round 4), 0 = chunk by chunk (probe knob RF_DWPW2_RING)
 };
 
+template <bool RINGP>
 __global__ __launch_bounds__(kThreads, 3) void dwpw2_kernel(DwPw2Args a) {
     typedef half_t T;
     typedef Mma<T> M;
@@ -2106,14 +2114,38 @@ __global__ __launch_bounds__(kThreads, 3) void dwpw2_kernel(DwPw2Args a) {
             M::Acc acc[UA];
 #pragma unroll
             for (int i = 0; i < UA; i++) acc[i] = dwa_b;                 // bias rides in the accumulator (acc_init)
+            if constexpr (RINGP) {
+                // round 4: the 25 (chunk, pixel tile) steps as ONE software pipeline -- B fragments run RING - 1 reads ahead of their
+                // MFMAs across chunk boundaries (round 3 read a chunk's five fragments, multiplied, and only then read the next chunk's:
+                // one exposed LDS round trip per chunk)
+                constexpr int NB = kDwMmaChunks * UA, RING = 4;
+                Frag bq[RING];
+                auto bload = [&](int idx) -> Frag {
+                    const int kc = idx / UA, i = idx % UA;
+                    return tap_a(kc) >= 0 ? *(const Frag *)(s_in + pa_base[i] + tap_a(kc)) : M::zero();
+                };
 #pragma unroll
-            for (int kc = 0; kc < kDwMmaChunks; kc++) {
-                Frag bf[UA];
+                for (int d = 0; d < RING - 1; d++) bq[d] = bload(d);
 #pragma unroll
-                for (int i = 0; i < UA; i++) bf[i] = tap_a(kc) >= 0 ? *(const Frag *)(s_in + pa_base[i] + tap_a(kc)) : M::zero();
-                const Frag af = dw_frag(dwa[kc]);
+                for (int kc = 0; kc < kDwMmaChunks; kc++) {
+                    const Frag af = dw_frag(dwa[kc]);
 #pragma unroll
-                for (int i = 0; i < UA; i++) acc[i] = M::mma(af, bf[i], acc[i]);
+                    for (int i = 0; i < UA; i++) {
+                        const int idx = kc * UA + i;
+                        if (idx + RING - 1 < NB) bq[(idx + RING - 1) % RING] = bload(idx + RING - 1);
+                        acc[i] = M::mma(af, bq[idx % RING], acc[i]);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int kc = 0; kc < kDwMmaChunks; kc++) {
+                    Frag bf[UA];
+#pragma unroll
+                    for (int i = 0; i < UA; i++) bf[i] = tap_a(kc) >= 0 ? *(const Frag *)(s_in + pa_base[i] + tap_a(kc)) : M::zero();
+                    const Frag af = dw_frag(dwa[kc]);
+#pragma unroll
+                    for (int i = 0; i < UA; i++) acc[i] = M::mma(af, bf[i], acc[i]);
+                }
             }
 #pragma unroll
             for (int i = 0; i < UA; i++) store_acc<T, LD>(s_a, ones, dwa_b, acc[i], g, (wave >> 1) + 2 * i, lane, true);
@@ -2184,15 +2216,110 @@ void launch_dwpw2(hipStream_t s, const DwPw2Params &p) {
     a.hin = p.hin; a.win = p.win; a.hout = p.hin / 2; a.wout = p.win / 2;
     a.tiles_x = (a.wout + 7) / 8; a.tiles_y = (a.hout + 3) / 4;
     a.nblk = p.n * a.tiles_x * a.tiles_y;
+    static int ring = -1;
+    if (ring < 0) { const char *e = getenv("RF_DWPW2_RING"); ring = e ? atoi(e) : 0; }      // measured and rejected: 107 -> 232 us (the ring costs 8 more registers than the 168-VGPR budget of 3 workgroups per CU has: spills)
+    a.ring = ring;
     static std::atomic<int> resident_cache[kMaxDevices] = {};
-    const int resident = kernel_residency(resident_cache, dwpw2_kernel, 0);
-    hipLaunchKernelGGL(dwpw2_kernel, dim3(persistent_grid(a.nblk, resident)), dim3(kThreads), 0, s, a);
+    if (ring) {
+        const int resident = kernel_residency(resident_cache, dwpw2_kernel<true>, 0);
+        hipLaunchKernelGGL(dwpw2_kernel<true>, dim3(persistent_grid(a.nblk, resident)), dim3(kThreads), 0, s, a);
+    } else {
+        static std::atomic<int> resident_cache0[kMaxDevices] = {};
+        const int resident = kernel_residency(resident_cache0, dwpw2_kernel<false>, 0);
+        hipLaunchKernelGGL(dwpw2_kernel<false>, dim3(persistent_grid(a.nblk, resident)), dim3(kThreads), 0, s, a);
+    }
 }
 
 int dwpw2_variant() {
     static int v = -1;
     if (v < 0) { const char *e = getenv("RF_DWPW2"); v = e ? atoi(e) : 1; }      // probe knob: 0 = two separate K_b launches
     return v;
+}
+
+// Input of the FPN aggregation convs: lateral + bilinear x2 upsample of the coarser level (Deconvolution k4 s2 p1 g64 + Crop + Eltwise SUM,
+// prototxt :1553-1592 / :1948-1987, closed form SURVEY.md App. B.6), one 16-byte item: `lat` = the lateral's channels, u0..u3 = the four
+// coarse-map taps (weights 9/16, 3/16, 3/16, 1/16: (my, mx), (my, mx2), (my2, mx), (my2, mx2)), ok = the pixel lies inside the map (outside,
+// the value is the conv's zero padding).  One function for the lock-step kernel (K_c, operands from HBM) and the warp-specialised one
+// (K_c'', operands from LDS): the arithmetic is the same instruction for instruction.
+template <typename T>
+__device__ __forceinline__ typename Vec<T>::type upadd_blend(typename Vec<T>::type v, typename Vec<T>::type t0, typename Vec<T>::type t1,
+                                                            typename Vec<T>::type t2, typename Vec<T>::type t3, bool ok, bool int_blend,
+                                                            float a_lat, float a_up) {
+    typedef typename Vec<T>::type V;
+    constexpr int VEC = Vec<T>::N;
+    if constexpr (sizeof(T) == 2) {
+        // fp16 engine: the blend in packed fp16 (v_pk_fma_f16, two channels per instruction).  The tap weights 9/16,
+        // 3/16, 3/16, 1/16 are exact in fp16; the sum is rounded after every step instead of once (the `plus` tensors
+        // carry 0.2 % of the fp16 engine's box-error variance, tools/fp16_error_budget.py) -- and the blend, which was
+        // ~40 % of this kernel's VALU instructions in fp32 (8 x (mul + 3 fma_mix + fma + select) + 4 converts per
+        // 16-byte item), is 4 x (mul + 3 fma + add + select)
+        typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+        const h2 w0 = {(half_t)0.5625f, (half_t)0.5625f}, w1 = {(half_t)0.1875f, (half_t)0.1875f}, w3 = {(half_t)0.0625f, (half_t)0.0625f};
+        uint4 r;
+        uint32_t *rp = (uint32_t *)&r;
+        const uint4 lat4 = __builtin_bit_cast(uint4, v), u0 = __builtin_bit_cast(uint4, t0), u1 = __builtin_bit_cast(uint4, t1),
+                    u2 = __builtin_bit_cast(uint4, t2), u3 = __builtin_bit_cast(uint4, t3);
+        const uint32_t *lp = (const uint32_t *)&lat4, *p0 = (const uint32_t *)&u0, *p1 = (const uint32_t *)&u1, *p2 = (const uint32_t *)&u2, *p3 = (const uint32_t *)&u3;
+#pragma unroll
+        for (int d = 0; d < 4; d++) {
+            h2 acc = __builtin_bit_cast(h2, p0[d]) * w0;
+            acc = __builtin_elementwise_fma(__builtin_bit_cast(h2, p1[d]), w1, acc);
+            acc = __builtin_elementwise_fma(__builtin_bit_cast(h2, p2[d]), w1, acc);
+            acc = __builtin_elementwise_fma(__builtin_bit_cast(h2, p3[d]), w3, acc);
+            acc = acc + __builtin_bit_cast(h2, lp[d]);
+            rp[d] = ok ? __builtin_bit_cast(uint32_t, acc) : 0u;
+        }
+        return __builtin_bit_cast(V, r);
+    } else if (sizeof(T) == 1 && int_blend) {
+        // int8 engine with per-channel scales (the three tensors of the add share one scale per channel, weights.h): the
+        // blend in packed 16-bit integer arithmetic on the byte lanes -- q = min(rne(lat + (9a + 3b + 3c + d) / 16), 127),
+        // every operand a ReLU output in 0..127, so the sum fits 11 bits.  Bit-identical to the fp32 path below (all its
+        // intermediate values are exact, its rounding is rintf's round-half-even) at ~8 instead of ~20 instructions per channel.
+        typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+        const uint4 lat4 = __builtin_bit_cast(uint4, v), u0 = __builtin_bit_cast(uint4, t0), u1 = __builtin_bit_cast(uint4, t1),
+                    u2 = __builtin_bit_cast(uint4, t2), u3 = __builtin_bit_cast(uint4, t3);
+        const uint32_t *lp = (const uint32_t *)&lat4, *p0 = (const uint32_t *)&u0, *p1 = (const uint32_t *)&u1, *p2 = (const uint32_t *)&u2, *p3 = (const uint32_t *)&u3;
+        uint4 r;
+        uint32_t *rp = (uint32_t *)&r;
+        const u16x2 c9 = {9, 9}, c3 = {3, 3}, c7 = {7, 7}, c1 = {1, 1}, c127 = {127, 127};
+#pragma unroll
+        for (int d = 0; d < 4; d++) {
+            uint32_t res[2];
+#pragma unroll
+            for (int par = 0; par < 2; par++) {                       // even / odd bytes of the dword as two 16-bit lanes
+                const uint32_t sel = par ? 0x0c030c01u : 0x0c020c00u;
+                auto lanes = [&](uint32_t x) -> u16x2 { return __builtin_bit_cast(u16x2, __builtin_amdgcn_perm(0u, x, sel)); };
+                u16x2 sum = lanes(p2[d]) * c3 + lanes(p3[d]);
+                sum = lanes(p1[d]) * c3 + sum;
+                sum = lanes(p0[d]) * c9 + sum;
+                const u16x2 lat2 = lanes(lp[d]);
+                const u16x2 odd = ((sum >> 4) + lat2) & c1;            // round half to even -- of lat + sum / 16, so the parity is the total's
+                sum = (sum + c7 + odd) >> 4;
+                sum = __builtin_elementwise_min((u16x2)(sum + lat2), c127);
+                res[par] = __builtin_bit_cast(uint32_t, sum);
+            }
+            const uint32_t packed = __builtin_amdgcn_perm(res[1], res[0], 0x06020400u);
+            rp[d] = ok ? packed : 0u;
+        }
+        return __builtin_bit_cast(V, r);
+    } else {
+        // the tap weights live in registers (not literals) so that each MAC is one v_fma_mix_f32 on the fp16 tap
+        // instead of a convert + fmac pair: this staging blend is ~half of the kernel's VALU instructions
+        float wq[4] = {0.5625f, 0.1875f, 0.1875f, 0.0625f};
+#pragma unroll
+        for (int q = 0; q < 4; q++) asm volatile("" : "+s"(wq[q]));
+        const V up[4] = {t0, t1, t2, t3};
+        float sacc[VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; e++) sacc[e] = wq[0] * (float)up[0][e];
+#pragma unroll
+        for (int q = 1; q < 4; q++)
+#pragma unroll
+            for (int e = 0; e < VEC; e++) sacc[e] = fmaf(wq[q], (float)up[q][e], sacc[e]);
+#pragma unroll
+        for (int e = 0; e < VEC; e++) v[e] = ok ? to_T<T>(fmaf((float)v[e], a_lat, sacc[e] * a_up)) : to_T<T>(0.f);
+        return v;
+    }
 }
 
 // =============================================================================================
@@ -2409,80 +2536,7 @@ __global__ __launch_bounds__(kThreads, (Conv3Cfg<T, CIN, COUT, TH, TW, ALLC, PAD
             const int i = tid + k * kThreads;
             if (i < C::STAGE_ITEMS) {
                 V v = pre[k];
-                if constexpr (UPADD && sizeof(T) == 2) {
-                    // fp16 engine: the blend in packed fp16 (v_pk_fma_f16, two channels per instruction).  The tap weights 9/16,
-                    // 3/16, 3/16, 1/16 are exact in fp16; the sum is rounded after every step instead of once (the `plus` tensors
-                    // carry 0.2 % of the fp16 engine's box-error variance, tools/fp16_error_budget.py) -- and the blend, which was
-                    // ~40 % of this kernel's VALU instructions in fp32 (8 x (mul + 3 fma_mix + fma + select) + 4 converts per
-                    // 16-byte item), is 4 x (mul + 3 fma + add + select)
-                    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
-                    const h2 w0 = {(half_t)0.5625f, (half_t)0.5625f}, w1 = {(half_t)0.1875f, (half_t)0.1875f}, w3 = {(half_t)0.0625f, (half_t)0.0625f};
-                    const bool ok = (pre_ok >> k) & 1u;
-                    uint4 r;
-                    uint32_t *rp = (uint32_t *)&r;
-                    const uint4 lat4 = __builtin_bit_cast(uint4, v), u0 = __builtin_bit_cast(uint4, upv[k][0]), u1 = __builtin_bit_cast(uint4, upv[k][1]),
-                                u2 = __builtin_bit_cast(uint4, upv[k][2]), u3 = __builtin_bit_cast(uint4, upv[k][3]);
-                    const uint32_t *lp = (const uint32_t *)&lat4, *p0 = (const uint32_t *)&u0, *p1 = (const uint32_t *)&u1, *p2 = (const uint32_t *)&u2, *p3 = (const uint32_t *)&u3;
-#pragma unroll
-                    for (int d = 0; d < 4; d++) {
-                        h2 acc = __builtin_bit_cast(h2, p0[d]) * w0;
-                        acc = __builtin_elementwise_fma(__builtin_bit_cast(h2, p1[d]), w1, acc);
-                        acc = __builtin_elementwise_fma(__builtin_bit_cast(h2, p2[d]), w1, acc);
-                        acc = __builtin_elementwise_fma(__builtin_bit_cast(h2, p3[d]), w3, acc);
-                        acc = acc + __builtin_bit_cast(h2, lp[d]);
-                        rp[d] = ok ? __builtin_bit_cast(uint32_t, acc) : 0u;
-                    }
-                    v = __builtin_bit_cast(V, r);
-                } else if (UPADD && sizeof(T) == 1 && int_blend) {
-                    // int8 engine with per-channel scales (the three tensors of the add share one scale per channel, weights.h): the
-                    // blend in packed 16-bit integer arithmetic on the byte lanes -- q = min(rne(lat + (9a + 3b + 3c + d) / 16), 127),
-                    // every operand a ReLU output in 0..127, so the sum fits 11 bits.  Bit-identical to the fp32 path below (all its
-                    // intermediate values are exact, its rounding is rintf's round-half-even) at ~8 instead of ~20 instructions per channel.
-                    typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
-                    const bool ok = (pre_ok >> k) & 1u;
-                    const uint4 lat4 = __builtin_bit_cast(uint4, v), u0 = __builtin_bit_cast(uint4, upv[k][0]), u1 = __builtin_bit_cast(uint4, upv[k][1]),
-                                u2 = __builtin_bit_cast(uint4, upv[k][2]), u3 = __builtin_bit_cast(uint4, upv[k][3]);
-                    const uint32_t *lp = (const uint32_t *)&lat4, *p0 = (const uint32_t *)&u0, *p1 = (const uint32_t *)&u1, *p2 = (const uint32_t *)&u2, *p3 = (const uint32_t *)&u3;
-                    uint4 r;
-                    uint32_t *rp = (uint32_t *)&r;
-                    const u16x2 c9 = {9, 9}, c3 = {3, 3}, c7 = {7, 7}, c1 = {1, 1}, c127 = {127, 127};
-#pragma unroll
-                    for (int d = 0; d < 4; d++) {
-                        uint32_t res[2];
-#pragma unroll
-                        for (int par = 0; par < 2; par++) {                       // even / odd bytes of the dword as two 16-bit lanes
-                            const uint32_t sel = par ? 0x0c030c01u : 0x0c020c00u;
-                            auto lanes = [&](uint32_t x) -> u16x2 { return __builtin_bit_cast(u16x2, __builtin_amdgcn_perm(0u, x, sel)); };
-                            u16x2 sum = lanes(p2[d]) * c3 + lanes(p3[d]);
-                            sum = lanes(p1[d]) * c3 + sum;
-                            sum = lanes(p0[d]) * c9 + sum;
-                            const u16x2 lat2 = lanes(lp[d]);
-                            const u16x2 odd = ((sum >> 4) + lat2) & c1;            // round half to even -- of lat + sum / 16, so the parity is the total's
-                            sum = (sum + c7 + odd) >> 4;
-                            sum = __builtin_elementwise_min((u16x2)(sum + lat2), c127);
-                            res[par] = __builtin_bit_cast(uint32_t, sum);
-                        }
-                        const uint32_t packed = __builtin_amdgcn_perm(res[1], res[0], 0x06020400u);
-                        rp[d] = ok ? packed : 0u;
-                    }
-                    v = __builtin_bit_cast(V, r);
-                } else if constexpr (UPADD) {
-                    // the tap weights live in registers (not literals) so that each MAC is one v_fma_mix_f32 on the fp16 tap
-                    // instead of a convert + fmac pair: this staging blend is ~half of the kernel's VALU instructions
-                    float wq[4] = {0.5625f, 0.1875f, 0.1875f, 0.0625f};
-#pragma unroll
-                    for (int q = 0; q < 4; q++) asm volatile("" : "+s"(wq[q]));
-                    float sacc[VEC];
-#pragma unroll
-                    for (int e = 0; e < VEC; e++) sacc[e] = wq[0] * (float)upv[k][0][e];
-#pragma unroll
-                    for (int q = 1; q < 4; q++)
-#pragma unroll
-                        for (int e = 0; e < VEC; e++) sacc[e] = fmaf(wq[q], (float)upv[k][q][e], sacc[e]);
-                    const bool ok = (pre_ok >> k) & 1u;
-#pragma unroll
-                    for (int e = 0; e < VEC; e++) v[e] = ok ? to_T<T>(fmaf((float)v[e], a_lat, sacc[e] * a_up)) : to_T<T>(0.f);
-                }
+                if constexpr (UPADD) v = upadd_blend<T>(v, upv[k][0], upv[k][1], upv[k][2], upv[k][3], (pre_ok >> k) & 1u, int_blend, a_lat, a_up);
                 *(V *)(s_in_b + ((i / CPV) / HC) * ROWP + ((i / CPV) % HC) * LDI + (i % CPV) * VEC) = v;
             }
         }
@@ -2709,6 +2763,422 @@ __global__ __launch_bounds__(kThreads, (NBUF == 2 || sizeof(T) == 1 ? 3 : 2)) vo
     }
 }
 
+// =============================================================================================
+// K_c''  the FPN aggregation convs (rf_c2_aggr / rf_c1_aggr: 3x3, 64 -> 64, input = lateral + bilinear x2 upsample of the coarser level)
+//   WAVE-SPECIALISED like K_c' (round 4).  In K_c the fused upsample + add made the staging phase the longest of the tile: every thread
+//   fetched its lateral item AND four coarse-map taps into registers (20 VGPRs per item: why the tile was 4 x 8), blended and wrote LDS,
+//   all in lock step with the GEMM.  Here the producer wave brings BOTH operands into LDS by LDS-DMA -- the 10 x 10 lateral halo in K_c's
+//   padded layout and the 8 x 8 coarse-map patch the tile's 2x upsample reads -- DIST tiles ahead; the four GEMM waves blend LDS -> LDS in
+//   place (same arithmetic: upadd_blend), barrier, multiply (8 x 8 tiles: 72 MFMAs per wave and tile, pinned B-fragment pipeline), write
+//   the result over the coarse patch's space, barrier.  One LDS ring of NBUF x [halo | coarse patch / result tile].
+// =============================================================================================
+template <typename T, int NBUF> struct Conv3UpWsCfg {
+    typedef Conv3Cfg<T, 64, 64, 8, 8, false, true> B;                  // 8 x 8 tile geometry and LDS pitches of the halo; wave = channel tile
+    static constexpr int VEC = B::VEC, P = B::P;
+    static constexpr int CPP = B::LDI / VEC, CPR = B::ROWP / VEC, DPP = 64 / VEC;
+    static constexpr int SLOTS = B::HR * CPR, PIECES = (SLOTS + 63) / 64;
+    static constexpr int CH = 8 / 2 + 4, CW = 8 / 2 + 4;               // coarse-map patch of an 8 x 8 tile: rows oy0/2 - 2 .. oy0/2 + 5
+    static constexpr int CSLOTS = CH * CW * DPP, CPIECES = (CSLOTS + 63) / 64;
+    static constexpr int LDO = 64 + VEC;                               // result tile pitch (elements)
+    static constexpr int NSTORE = P * (64 / VEC) / 64;
+    static constexpr size_t L_BYTES = (size_t)SLOTS * 16;              // exact: the last DMA piece is masked past the last slot
+    static constexpr size_t C_BYTES = (size_t)CSLOTS * 16, O_BYTES = sizeof(T) * (size_t)(P * LDO);
+    static constexpr size_t X_BYTES = C_BYTES > O_BYTES ? C_BYTES : O_BYTES;       // coarse patch, then (after the blend) the result tile
+    static constexpr size_t BUF_BYTES = L_BYTES + X_BYTES;
+    static constexpr size_t LDS_BYTES = NBUF * BUF_BYTES;
+    static constexpr int THREADS = 320;
+    static constexpr int WG_CAP = sizeof(T) == 2 ? 2 : 3;              // fp16: 18 stationary A fragments + the blend's operands need ~165 VGPRs
+    static constexpr int WG_PER_CU = (int)(160 * 1024 / LDS_BYTES) > WG_CAP ? WG_CAP : (int)(160 * 1024 / LDS_BYTES);
+    static constexpr int WAVES_PER_EU = (WG_PER_CU * 5 + 3) / 4;
+    static constexpr int NBL = (B::HR * B::HC * DPP + 255) / 256;      // blend items per consumer thread
+    static_assert(B::NI == 1 && B::NJ == 4 && B::WN == 4 && B::STAT && !B::ODD, "wave = output-channel tile, all four pixel tiles");
+    static_assert(L_BYTES % 16 == 0 && X_BYTES % 16 == 0 && CSLOTS % 64 == 0 && PIECES + CPIECES + NSTORE < 63, "LDS carve / counted vmcnt");
+};
+
+template <typename T, int DEPTH, int NBUF>
+__global__ __launch_bounds__(320, (Conv3UpWsCfg<T, NBUF>::WAVES_PER_EU)) void conv3x3_up_ws_kernel(Conv3Args<T> a) {
+    typedef Conv3UpWsCfg<T, NBUF> W;
+    typedef typename W::B C;
+    typedef typename Vec<T>::type V;
+    typedef Mma<T> M;
+    typedef typename M::Frag Frag;
+    constexpr int CIN = 64, TH = 8, TW = 8;
+    constexpr int VEC = C::VEC, P = C::P, HC = C::HC, HR = C::HR, LDI = C::LDI, ROWP = C::ROWP, LDO = W::LDO;
+    constexpr int KTOT = C::KTOT, KCH = C::KCH, NJ = C::NJ, DPP = W::DPP, CW = W::CW;
+    constexpr int DIST = NBUF - 1;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const Conv3Level<T> &L = a.lv[0];                                  // one level per launch (the aggregation convs are separate layers)
+    const int G = gridDim.x;
+    const int first = xcd_remap(blockIdx.x, G), ntiles = L.ntiles;
+    const int lh = L.h, lw = L.w_, hh = lh >> 1, wh = lw >> 1;
+    const int n_my = first < ntiles ? (ntiles - 1 - first) / G + 1 : 0;
+    const TileStep step(G, L.tiles_x, L.tiles_y);
+    auto halo_of = [&](int b) -> T * { return (T *)(smem + (size_t)b * W::BUF_BYTES); };
+    auto aux_of = [&](int b) -> T * { return (T *)(smem + (size_t)b * W::BUF_BYTES + W::L_BYTES); };
+
+    if (wave == 4) {
+        // ================================================= producer
+        int kl[W::PIECES], kc[W::CPIECES];                             // byte offset inside the image | column << 26 (63 = not a pixel)
+        const int in_ld = L.in_ld;
+#pragma unroll
+        for (int i = 0; i < W::PIECES; i++) {
+            const int s = i * 64 + lane;
+            const int row = s / W::CPR, rem = s % W::CPR;
+            const int px = rem / W::CPP, ch = rem % W::CPP;
+            const bool real = row < HR && px < HC && ch < DPP;
+            kl[i] = real ? ((((row * lw + px) * in_ld + ch * VEC) * (int)sizeof(T)) | (px << 26)) : (int)(63u << 26);
+        }
+#pragma unroll
+        for (int i = 0; i < W::CPIECES; i++) {
+            const int s = i * 64 + lane;
+            const int cpix = s / DPP, ch = s % DPP;
+            const int cy = cpix / CW, cx = cpix % CW;
+            kc[i] = (((cy * wh + cx) * CIN + ch * VEC) * (int)sizeof(T)) | (cx << 26);
+        }
+        const unsigned lat_bytes = (unsigned)(lh * lw * in_ld - L.in_off) * (unsigned)sizeof(T);
+        const unsigned up_bytes = (unsigned)(hh * wh * CIN) * (unsigned)sizeof(T);
+        const T *in = L.in + L.in_off;
+        auto dma = [&](int tx, int ty, int img, int b) {
+            const auto rs = image_rsrc(in + (size_t)img * lh * lw * in_ld, lat_bytes);
+            const auto ru = image_rsrc(L.up + (size_t)img * hh * wh * CIN, up_bytes);
+            const int iy0 = ty * TH - 1, ix0 = tx * TW - 1;
+            const int sbase = (iy0 * lw + ix0) * in_ld * (int)sizeof(T);
+            unsigned char *hd = (unsigned char *)halo_of(b), *cd = (unsigned char *)aux_of(b);
+#pragma unroll
+            for (int i = 0; i < W::PIECES; i++) {
+                const int dx = (int)((unsigned)kl[i] >> 26);
+                const unsigned off = (dx != 63 && (unsigned)(ix0 + dx) < (unsigned)lw) ? (unsigned)((kl[i] & 0x03ffffff) + sbase) : kOobOffset;
+                if (i * 64 + lane < W::SLOTS) lds_dma16(rs, hd + i * 1024, off);        // (only the last piece is partial)
+            }
+            const int cy0 = ty * (TH / 2) - 2, cx0 = tx * (TW / 2) - 2;
+            const int cbase = (cy0 * wh + cx0) * CIN * (int)sizeof(T);
+#pragma unroll
+            for (int i = 0; i < W::CPIECES; i++) {
+                const int cx = (int)((unsigned)kc[i] >> 26);
+                const unsigned off = (unsigned)(cx0 + cx) < (unsigned)wh ? (unsigned)((kc[i] & 0x03ffffff) + cbase) : kOobOffset;
+                lds_dma16(ru, cd + i * 1024, off);
+            }
+        };
+        T *out0 = L.out0;
+        const int ld0 = L.ld0, off0 = L.off0;
+        auto store_tile = [&](int b, int img, int oy0, int ox0) {
+            constexpr int OPV = 64 / VEC;
+            const T *s_res = aux_of(b);
+            const auto r0 = image_rsrc(out0 + (size_t)img * lh * lw * ld0 + off0, (unsigned)(lh * lw * ld0 - off0) * (unsigned)sizeof(T));
+            const int pbase = oy0 * lw + ox0;
+#pragma unroll
+            for (int i = lane; i < P * OPV; i += 64) {
+                const int p = i / OPV, c = (i % OPV) * VEC;
+                const int py = p / TW, px = p % TW;
+                buf_store16(r0, ox0 + px < lw ? (unsigned)(((pbase + py * lw + px) * ld0 + c) * (int)sizeof(T)) : kOobOffset, *(const V *)(s_res + p * LDO + c));
+            }
+        };
+        TileCoord cur(first, L.tiles_x, L.tiles_y), pf = cur;
+#pragma unroll
+        for (int d = 0; d < DIST; d++)
+            if (d < n_my) { dma(pf.tx, pf.ty, pf.img, d); step.advance(pf); }
+        if (DIST == 2 && n_my >= 2) wait_vmcnt<W::PIECES + W::CPIECES>();
+        else wait_vmcnt<0>();
+        lds_barrier();
+        int p_img = 0, p_oy0 = 0, p_ox0 = 0;
+        for (int k = 0; k < n_my; k++) {
+            const bool st = k > 0, ld = k + DIST < n_my;
+            RF_TRACE_T(6, 5, 256);
+            // the previous result sits in the aux space of buffer (k - 1) % NBUF == (k + DIST) % NBUF: it is read out (LDS reads complete
+            // before the stores that carry the data are issued) BEFORE the coarse patch of tile k + DIST is requested into the same space
+            lds_barrier();
+            RF_TRACE_T(6, 6, 256);                                             // (blend -> GEMM): joined FIRST -- this wave's issue work (~300 instructions)
+                                                                       // then overlaps the consumers' GEMM instead of holding up their short blend pass
+            if (st) store_tile((k - 1) % NBUF, p_img, p_oy0, p_ox0);
+            RF_TRACE_T(6, 7, 256);
+            if (ld) { dma(pf.tx, pf.ty, pf.img, (k + DIST) % NBUF); step.advance(pf); }
+            RF_TRACE_T(6, 8, 256);
+            p_img = cur.img; p_oy0 = cur.ty * TH; p_ox0 = cur.tx * TW;
+            step.advance(cur);
+            if (DIST == 1) wait_vmcnt<0>();
+            else if (st && ld) wait_vmcnt<W::NSTORE + W::PIECES + W::CPIECES>();
+            else if (ld) wait_vmcnt<W::PIECES + W::CPIECES>();
+            else if (st) wait_vmcnt<W::NSTORE>();
+            else wait_vmcnt<0>();
+            RF_TRACE_T(6, 9, 256);
+            lds_barrier();
+            RF_TRACE_T(6, 10, 256);
+        }
+        if (n_my > 0) store_tile((n_my - 1) % NBUF, p_img, p_oy0, p_ox0);
+        return;
+    }
+
+    // ================================================= consumers: wave = output-channel tile
+    const int wn = wave;
+    Frag wst[1][KCH];
+    {
+        const Frag *wsrc = (const Frag *)L.w + (size_t)wn * KCH * 64 + lane;
+#pragma unroll
+        for (int kc2 = 0; kc2 < KCH; kc2++) wst[0][kc2] = wsrc[kc2 * 64];
+    }
+    const f32x4 bias = *(const f32x4 *)(L.b + acc_cout(wn, lane, 0));
+    const f32x4 mult = load_mult(L.m, acc_cout(wn, lane, 0));
+    const float a_lat = L.a_lat, a_up = L.a_up;
+    const bool int_blend = L.int_blend != 0;
+    int pbase[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; j++) {
+        const int p = acc_pixel(j, lane);
+        pbase[j] = (p / TW) * ROWP + (p % TW) * LDI;
+    }
+    // blend items of this thread: halo pixel (dy, dx), 16-byte chunk cv -> element offsets of the lateral item and of the coarse patch's
+    // tap (my, mx); the other three taps are one row / one column further in the direction the pixel's parity picks (tile origins are
+    // multiples of 8: the parities are thread constants)
+    int b_lat[W::NBL], b_c0[W::NBL], b_step[W::NBL], b_yx[W::NBL];
+#pragma unroll
+    for (int m = 0; m < W::NBL; m++) {
+        int i = tid + m * 256;
+        const bool real = i < HR * HC * DPP;
+        i = real ? i : 0;
+        const int pix = i / DPP, cv = i % DPP;
+        const int dy = pix / HC, dx = pix % HC;
+        const int ly = 2 + ((dy - 1) >> 1), lx = 2 + ((dx - 1) >> 1);
+        const int sy = ((dy - 1) & 1) ? 1 : -1, sx = ((dx - 1) & 1) ? 1 : -1;
+        b_lat[m] = dy * ROWP + dx * LDI + cv * VEC;
+        b_c0[m] = (ly * CW + lx) * CIN + cv * VEC;
+        b_step[m] = (sy * CW * CIN) * 65536 + (sx * CIN + 32768);      // row step in the high half, column step (+32768) in the low half
+        b_yx[m] = real ? (dy << 8 | dx) : -1;
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);                                // weights are in registers: no global access below this line
+    lds_barrier();
+    TileCoord cur(first, L.tiles_x, L.tiles_y);
+    for (int k = 0; k < n_my; k++) {
+        const int b = k % NBUF;
+        T *s_in_b = halo_of(b);
+        T *s_x = aux_of(b);
+        const int iy0 = cur.ty * TH - 1, ix0 = cur.tx * TW - 1;
+        step.advance(cur);
+        RF_TRACE_T(6, 0, 0);
+        // ---- blend: lateral + upsample(coarse) -> the halo tile, in place (K_c's staging arithmetic, operands from LDS)
+#pragma unroll
+        for (int m = 0; m < W::NBL; m++) {
+            if (b_yx[m] < 0) continue;
+            const int rs_ = b_step[m] >> 16, cs_ = (b_step[m] & 0xffff) - 32768;
+            const V lat = *(const V *)(s_in_b + b_lat[m]);
+            const V u0 = *(const V *)(s_x + b_c0[m]), u1 = *(const V *)(s_x + b_c0[m] + cs_);
+            const V u2 = *(const V *)(s_x + b_c0[m] + rs_), u3 = *(const V *)(s_x + b_c0[m] + rs_ + cs_);
+            const bool ok = (unsigned)(iy0 + (b_yx[m] >> 8)) < (unsigned)lh && (unsigned)(ix0 + (b_yx[m] & 0xff)) < (unsigned)lw;
+            *(V *)(s_in_b + b_lat[m]) = upadd_blend<T>(lat, u0, u1, u2, u3, ok, int_blend, a_lat, a_up);
+        }
+        RF_TRACE_T(6, 1, 0);
+        lds_barrier();
+        RF_TRACE_T(6, 2, 0);
+        // ---- GEMM on the blended halo tile, result over the (dead) coarse patch
+        typename M::Acc acc[1][NJ];
+#pragma unroll
+        for (int j = 0; j < NJ; j++) acc[0][j] = acc_init<T>(bias);
+        gemm_stationary<T, 1, NJ, KCH, DEPTH, true>(acc, wst, [&](int j, int kc2) -> Frag {
+            const int kb = kc2 * M::K + (lane >> 4) * M::KPL;
+            const int tap = kb / CIN, c = kb % CIN;
+            const int koff = (tap / 3) * ROWP + (tap % 3) * LDI + c;
+            return kb < KTOT ? *(const Frag *)(s_in_b + pbase[j] + koff) : M::zero();
+        });
+#pragma unroll
+        for (int j = 0; j < NJ; j++) store_acc<T, LDO>(s_x, mult, bias, acc[0][j], wn, j, lane, true);
+        RF_TRACE_T(6, 3, 0);
+        lds_barrier();
+        RF_TRACE_T(6, 4, 0);
+    }
+}
+
+// =============================================================================================
+// K_c3  the aggregation convs with LDS-DMA staging and NO dedicated producer wave (round 4, after the phase stamps of K_c'': a five-wave
+//   workgroup at ~165 VGPRs is admitted only once per CU -- the 3-waves-per-SIMD register limit needs both workgroups' fifth waves on
+//   different SIMDs -- and its single producer wave spent 0.7 us per tile reading the result tile back from LDS store by store).
+//   Same LDS ring, same blend, same GEMM as K_c''; every one of the four waves (= output-channel tiles) issues a quarter of the
+//   tile's memory traffic itself: its share of the previous result's stores at the top of the interval, its share of the DMA for
+//   the tile DIST steps ahead right after the blend barrier -- i.e. under its own GEMM -- and waits (counted vmcnt) only for the share
+//   of the NEXT tile's halo it requested one interval earlier.
+// =============================================================================================
+template <typename T, int DEPTH, int NBUF>
+__global__ __launch_bounds__(kThreads, 2) void conv3x3_up_dma_kernel(Conv3Args<T> a) {
+    typedef Conv3UpWsCfg<T, NBUF> W;
+    typedef typename W::B C;
+    typedef typename Vec<T>::type V;
+    typedef Mma<T> M;
+    typedef typename M::Frag Frag;
+    constexpr int CIN = 64, TH = 8, TW = 8;
+    constexpr int VEC = C::VEC, P = C::P, HC = C::HC, HR = C::HR, LDI = C::LDI, ROWP = C::ROWP, LDO = W::LDO;
+    constexpr int KTOT = C::KTOT, KCH = C::KCH, NJ = C::NJ, DPP = W::DPP, CW = W::CW;
+    constexpr int DIST = NBUF - 1;
+    constexpr int LPW = (W::PIECES + 3) / 4, CPW = (W::CPIECES + 3) / 4;          // DMA pieces per wave: halo, coarse patch
+    constexpr int LMIN = W::PIECES / 4, CMIN = W::CPIECES / 4;                     // ... the fewest any wave issues
+    constexpr int SPW = P * (64 / VEC) / kThreads;                                 // store instructions per wave and tile
+    static_assert(P * (64 / VEC) % kThreads == 0 && SPW + LPW + CPW < 63, "whole store instructions per wave");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const Conv3Level<T> &L = a.lv[0];
+    const int G = gridDim.x;
+    const int first = xcd_remap(blockIdx.x, G), ntiles = L.ntiles;
+    const int lh = L.h, lw = L.w_, hh = lh >> 1, wh = lw >> 1;
+    const int n_my = first < ntiles ? (ntiles - 1 - first) / G + 1 : 0;
+    const TileStep step(G, L.tiles_x, L.tiles_y);
+    auto halo_of = [&](int b) -> T * { return (T *)(smem + (size_t)b * W::BUF_BYTES); };
+    auto aux_of = [&](int b) -> T * { return (T *)(smem + (size_t)b * W::BUF_BYTES + W::L_BYTES); };
+
+    // ---- this wave's share of the DMA: halo pieces wave, wave + 4, ...; coarse-patch pieces likewise
+    int kl[LPW], kc[CPW];                                              // byte offset inside the image | column << 26 (63 = not a pixel / no piece)
+    const int in_ld = L.in_ld;
+#pragma unroll
+    for (int j = 0; j < LPW; j++) {
+        const int s = (wave + 4 * j) * 64 + lane;
+        const int row = s / W::CPR, rem = s % W::CPR;
+        const int px = rem / W::CPP, ch = rem % W::CPP;
+        const bool real = row < HR && px < HC && ch < DPP;
+        kl[j] = real ? ((((row * lw + px) * in_ld + ch * VEC) * (int)sizeof(T)) | (px << 26)) : (int)(63u << 26);
+    }
+#pragma unroll
+    for (int j = 0; j < CPW; j++) {
+        const int s = (wave + 4 * j) * 64 + lane;
+        const int cpix = s / DPP, ch = s % DPP;
+        const int cy = cpix / CW, cx = cpix % CW;
+        kc[j] = (((cy * wh + cx) * CIN + ch * VEC) * (int)sizeof(T)) | (cx << 26);
+    }
+    const unsigned lat_bytes = (unsigned)(lh * lw * in_ld - L.in_off) * (unsigned)sizeof(T);
+    const unsigned up_bytes = (unsigned)(hh * wh * CIN) * (unsigned)sizeof(T);
+    const T *in = L.in + L.in_off;
+    auto dma = [&](int tx, int ty, int img, int b) {
+        const auto rs = image_rsrc(in + (size_t)img * lh * lw * in_ld, lat_bytes);
+        const auto ru = image_rsrc(L.up + (size_t)img * hh * wh * CIN, up_bytes);
+        const int iy0 = ty * TH - 1, ix0 = tx * TW - 1;
+        const int sbase = (iy0 * lw + ix0) * in_ld * (int)sizeof(T);
+        unsigned char *hd = (unsigned char *)halo_of(b), *cd = (unsigned char *)aux_of(b);
+#pragma unroll
+        for (int j = 0; j < LPW; j++) {
+            const int piece = wave + 4 * j;                            // (scalar)
+            const int dx = (int)((unsigned)kl[j] >> 26);
+            const unsigned off = (dx != 63 && (unsigned)(ix0 + dx) < (unsigned)lw) ? (unsigned)((kl[j] & 0x03ffffff) + sbase) : kOobOffset;
+            if (piece < W::PIECES && piece * 64 + lane < W::SLOTS) lds_dma16(rs, hd + piece * 1024, off);
+        }
+        const int cy0 = ty * (TH / 2) - 2, cx0 = tx * (TW / 2) - 2;
+        const int cbase = (cy0 * wh + cx0) * CIN * (int)sizeof(T);
+#pragma unroll
+        for (int j = 0; j < CPW; j++) {
+            const int piece = wave + 4 * j;
+            const int cx = (int)((unsigned)kc[j] >> 26);
+            const unsigned off = (unsigned)(cx0 + cx) < (unsigned)wh ? (unsigned)((kc[j] & 0x03ffffff) + cbase) : kOobOffset;
+            if (piece < W::CPIECES) lds_dma16(ru, cd + piece * 1024, off);
+        }
+    };
+    T *out0 = L.out0;
+    const int ld0 = L.ld0, off0 = L.off0;
+    auto store_tile = [&](int b, int img, int oy0, int ox0) {          // all 256 threads: SPW items each
+        constexpr int OPV = 64 / VEC;
+        const T *s_res = aux_of(b);
+        const auto r0 = image_rsrc(out0 + (size_t)img * lh * lw * ld0 + off0, (unsigned)(lh * lw * ld0 - off0) * (unsigned)sizeof(T));
+        const int pbase = oy0 * lw + ox0;
+        V v[SPW];
+#pragma unroll
+        for (int m = 0; m < SPW; m++) { const int i = tid + m * kThreads; v[m] = *(const V *)(s_res + (i / OPV) * LDO + (i % OPV) * VEC); }
+#pragma unroll
+        for (int m = 0; m < SPW; m++) {
+            const int i = tid + m * kThreads;
+            const int p = i / OPV, c = (i % OPV) * VEC;
+            const int py = p / TW, px = p % TW;
+            buf_store16(r0, ox0 + px < lw ? (unsigned)(((pbase + py * lw + px) * ld0 + c) * (int)sizeof(T)) : kOobOffset, v[m]);
+        }
+    };
+
+    // ---- weights (wave = output-channel tile), per-lane constants of the GEMM and the blend
+    const int wn = wave;
+    Frag wst[1][KCH];
+    {
+        const Frag *wsrc = (const Frag *)L.w + (size_t)wn * KCH * 64 + lane;
+#pragma unroll
+        for (int kc2 = 0; kc2 < KCH; kc2++) wst[0][kc2] = wsrc[kc2 * 64];
+    }
+    const f32x4 bias = *(const f32x4 *)(L.b + acc_cout(wn, lane, 0));
+    const f32x4 mult = load_mult(L.m, acc_cout(wn, lane, 0));
+    const float a_lat = L.a_lat, a_up = L.a_up;
+    const bool int_blend = L.int_blend != 0;
+    int pbase[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; j++) {
+        const int p = acc_pixel(j, lane);
+        pbase[j] = (p / TW) * ROWP + (p % TW) * LDI;
+    }
+    int b_lat[W::NBL], b_c0[W::NBL], b_step[W::NBL], b_yx[W::NBL];
+#pragma unroll
+    for (int m = 0; m < W::NBL; m++) {
+        int i = tid + m * 256;
+        const bool real = i < HR * HC * DPP;
+        i = real ? i : 0;
+        const int pix = i / DPP, cv = i % DPP;
+        const int dy = pix / HC, dx = pix % HC;
+        const int ly = 2 + ((dy - 1) >> 1), lx = 2 + ((dx - 1) >> 1);
+        const int sy = ((dy - 1) & 1) ? 1 : -1, sx = ((dx - 1) & 1) ? 1 : -1;
+        b_lat[m] = dy * ROWP + dx * LDI + cv * VEC;
+        b_c0[m] = (ly * CW + lx) * CIN + cv * VEC;
+        b_step[m] = (sy * CW * CIN) * 65536 + (sx * CIN + 32768);
+        b_yx[m] = real ? (dy << 8 | dx) : -1;
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);                                // weights are in registers: the counted waits below see only this wave's DMA and stores
+
+    TileCoord cur(first, L.tiles_x, L.tiles_y), pf = cur;
+#pragma unroll
+    for (int d = 0; d < DIST; d++)
+        if (d < n_my) { dma(pf.tx, pf.ty, pf.img, d); step.advance(pf); }
+    if (DIST == 2 && n_my >= 2) wait_vmcnt<LMIN + CMIN>();            // tile 0's share has landed (at most the younger request is outstanding)
+    else wait_vmcnt<0>();
+    lds_barrier();
+    int p_img = 0, p_oy0 = 0, p_ox0 = 0;
+    for (int k = 0; k < n_my; k++) {
+        const int b = k % NBUF;
+        const bool st = k > 0, ld = k + DIST < n_my;
+        T *s_in_b = halo_of(b);
+        T *s_x = aux_of(b);
+        const int iy0 = cur.ty * TH - 1, ix0 = cur.tx * TW - 1;
+        // ---- the previous result leaves (its space is the coarse patch of tile k + DIST, requested after the barrier below)
+        if (st) store_tile((k - 1) % NBUF, p_img, p_oy0, p_ox0);
+        p_img = cur.img; p_oy0 = cur.ty * TH; p_ox0 = cur.tx * TW;
+        step.advance(cur);
+        // ---- blend: lateral + upsample(coarse) -> the halo tile, in place
+#pragma unroll
+        for (int m = 0; m < W::NBL; m++) {
+            if (b_yx[m] < 0) continue;
+            const int rs_ = b_step[m] >> 16, cs_ = (b_step[m] & 0xffff) - 32768;
+            const V lat = *(const V *)(s_in_b + b_lat[m]);
+            const V u0 = *(const V *)(s_x + b_c0[m]), u1 = *(const V *)(s_x + b_c0[m] + cs_);
+            const V u2 = *(const V *)(s_x + b_c0[m] + rs_), u3 = *(const V *)(s_x + b_c0[m] + rs_ + cs_);
+            const bool ok = (unsigned)(iy0 + (b_yx[m] >> 8)) < (unsigned)lh && (unsigned)(ix0 + (b_yx[m] & 0xff)) < (unsigned)lw;
+            *(V *)(s_in_b + b_lat[m]) = upadd_blend<T>(lat, u0, u1, u2, u3, ok, int_blend, a_lat, a_up);
+        }
+        lds_barrier();
+        // ---- this wave's share of the halo + coarse patch of tile k + DIST: in flight under the GEMM
+        if (ld) { dma(pf.tx, pf.ty, pf.img, (k + DIST) % NBUF); step.advance(pf); }
+        typename M::Acc acc[1][NJ];
+#pragma unroll
+        for (int j = 0; j < NJ; j++) acc[0][j] = acc_init<T>(bias);
+        gemm_stationary<T, 1, NJ, KCH, DEPTH, true>(acc, wst, [&](int j, int kc2) -> Frag {
+            const int kb = kc2 * M::K + (lane >> 4) * M::KPL;
+            const int tap = kb / CIN, c = kb % CIN;
+            const int koff = (tap / 3) * ROWP + (tap % 3) * LDI + c;
+            return kb < KTOT ? *(const Frag *)(s_in_b + pbase[j] + koff) : M::zero();
+        });
+#pragma unroll
+        for (int j = 0; j < NJ; j++) store_acc<T, LDO>(s_x, mult, bias, acc[0][j], wn, j, lane, true);
+        // tile k + 1's share must have landed before the barrier.  DIST == 1: it is the request just made.  DIST == 2: it was made one
+        // interval ago; this interval's stores (SPW) and requests (>= LMIN + CMIN) may stay in flight
+        if (DIST == 1) wait_vmcnt<0>();
+        else if (st && ld) wait_vmcnt<SPW + LMIN + CMIN>();
+        else if (ld) wait_vmcnt<LMIN + CMIN>();
+        else if (st) wait_vmcnt<SPW>();
+        else wait_vmcnt<0>();
+        lds_barrier();
+    }
+    if (n_my > 0) store_tile((n_my - 1) % NBUF, p_img, p_oy0, p_ox0);
+}
+
 static int conv3_ws_variant() {
     static int v = -1;
     if (v < 0) { const char *e = getenv("RF_CONV3WS"); v = e ? atoi(e) : 1; }        // probe knob: 0 = K_c for the merged SSH conv as well; 22 / 23 / 32 / 33: see conv3_ws_launch
@@ -2808,9 +3278,55 @@ static int conv3_variant() {
     return v;
 }
 
+// probe knob RF_CONV3UPWS: 0 = K_c for the aggregation convs; 2 / 3 = halo buffers of the warp-specialised kernel (K_c'')
+static int conv3_up_ws_variant() {
+    static int v = -1;
+    if (v < 0) { const char *e = getenv("RF_CONV3UPWS"); v = e ? atoi(e) : 0; }
+    return v;
+}
+
+template <typename T, int DEPTH, int NBUF, bool PRODUCER_WAVE>
+static void conv3_up_ws_launch(hipStream_t s, const Conv3Params<T> &q) {
+    typedef Conv3UpWsCfg<T, NBUF> W;
+    auto kern = PRODUCER_WAVE ? conv3x3_up_ws_kernel<T, DEPTH, NBUF> : conv3x3_up_dma_kernel<T, DEPTH, NBUF>;
+    constexpr int THREADS = PRODUCER_WAVE ? W::THREADS : kThreads;
+    static std::atomic<int> resident_cache[kMaxDevices] = {};
+    const int dev = launch_device();
+    int resident = resident_cache[dev].load(std::memory_order_acquire);
+    if (!resident) {
+        set_max_lds(kern, W::LDS_BYTES);
+        int nb = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)kern, THREADS, W::LDS_BYTES) != hipSuccess || nb < 1) nb = 1;
+        resident = nb;
+        resident_cache[dev].store(resident, std::memory_order_release);
+    }
+    const int tiles_x = (q.w_ + 7) / 8, tiles_y = (q.h + 7) / 8;
+    Conv3Args<T> a;
+    for (int l = 0; l < 3; l++)
+        a.lv[l] = Conv3Level<T>{q.in, q.up, q.w, q.b, q.m, q.out0, q.out1, q.in_ld, q.in_off, q.ld0, q.off0, q.n0, q.ld1, q.off1,
+                                q.h, q.w_, tiles_x, tiles_y, q.n * tiles_x * tiles_y, 0, 1, q.a_lat, q.a_up,
+                                (sizeof(T) == 1 && q.a_lat == 1.f && q.a_up == 1.f && !getenv("RF_BLEND_FP32")) ? 1 : 0};
+    const int total = q.n * tiles_x * tiles_y;
+    if (total == 0) return;
+    a.lv[0].gsz = persistent_grid(total, resident);
+    hipLaunchKernelGGL(kern, dim3(a.lv[0].gsz), dim3(THREADS), W::LDS_BYTES, s, a);
+}
+
 template <typename T>
 static TileInfo conv3_select(hipStream_t s, const Conv3Params<T> *p, int nlv, int cin, int cout, int h, int w) {
     if constexpr (sizeof(T) <= 2) {
+        // the aggregation convs (fused upsample + add), warp-specialised: maps whose sides are even (tile origins must be: the upsample's
+        // parities are thread constants) and a single output tensor
+        if (p && nlv == 1 && p[0].up && cin == 64 && cout == 64 && conv3_up_ws_variant() >= 2 && p[0].h % 2 == 0 && p[0].w_ % 2 == 0 &&
+            p[0].n0 == 64 && p[0].in_ld == 64) {
+            switch (conv3_up_ws_variant()) {                           // 2 / 3: producer wave, 2 / 3 ring buffers; 12 / 13: every wave its own share
+                case 2: conv3_up_ws_launch<T, 2, 2, true>(s, p[0]); break;
+                case 3: conv3_up_ws_launch<T, 2, 3, true>(s, p[0]); break;
+                case 12: conv3_up_ws_launch<T, 2, 2, false>(s, p[0]); break;
+                default: conv3_up_ws_launch<T, 2, 3, false>(s, p[0]); break;
+            }
+            return TileInfo{8, 8, Conv3UpWsCfg<T, 3>::LDS_BYTES, ((w + 7) / 8) * ((h + 7) / 8)};
+        }
         // fp16 / int8: every wave owns all output channels of its pixels (Conv3Cfg ALLC), 8x8 tiles
         const int v = conv3_variant();
         if (v >= 1) {

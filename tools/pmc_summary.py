@@ -29,6 +29,8 @@ def descriptor(mangled: str) -> str:
     if m:
         cin, cout, th, tw, up = m.groups()
         return f"conv3x3<{cin},{cout},{th}x{tw}{',up' if up == 'true' else ''}>"
+    if "conv3x3_up_ws_kernel" in mangled or "conv3x3_up_dma_kernel" in mangled:    # the warp-specialised aggregation conv keeps the op name of the lock-step instance
+        return "conv3x3<64,64,4x8,up>"
     if "conv3x3_ws_kernel" in mangled:       # the warp-specialised instance of the merged SSH conv (same op name as the lock-step one)
         return "conv3x3<64,48,8x8>"
     if "dwpw2_kernel" in mangled:
