@@ -1954,6 +1954,13 @@ static TileInfo dwpw_select(hipStream_t s, const DwPwParams<T> *p, int cin, int 
     }
     RF_DWPW(128, 128, 1, true, 4, 8)
     RF_DWPW(128, 256, 2, true, 4, 8)
+    if constexpr (sizeof(T) <= 2) {
+        static int v256 = -1;
+        // 8x8 tiles: the streamed 256 x 256 weight matrix is read once per 64 pixels instead of 32.  Measured (tools/gpu/r4_call13.sh): int8 26.4 -> 24.4 us,
+        // fp16 35.5 -> 35.6 (its 64 accumulator registers on top of the fragment stream: 2-14 spills with the lateral): int8 only.  RF_TILE256 = 0 / 1 forces.
+        if (v256 < 0) { const char *e = getenv("RF_TILE256"); v256 = e ? atoi(e) : 2; }
+        if (v256 == 1 || (v256 == 2 && sizeof(T) == 1)) { RF_DWPW(256, 256, 1, true, 8, 8) }
+    }
     RF_DWPW(256, 256, 1, true, 4, 8)
     RF_DWPW(256, 64, 1, false, 4, 8)
     RF_DWPW(128, 64, 1, false, 4, 8)
@@ -2624,8 +2631,8 @@ template <typename T, int NBUF> struct Conv3WsCfg {
     static_assert(NSTORE + PIECES < 64, "counted vmcnt");
 };
 
-template <typename T, int DEPTH, int NBUF>
-__global__ __launch_bounds__(kThreads, (NBUF == 2 || sizeof(T) == 1 ? 3 : 2)) void conv3x3_ws_kernel(Conv3Args<T> a) {
+template <typename T, int DEPTH, int NBUF, int SPLIT = 0>
+__global__ __launch_bounds__(kThreads, (SPLIT ? 2 : (NBUF == 2 || sizeof(T) == 1 ? 3 : 2))) void conv3x3_ws_kernel(Conv3Args<T> a) {
     typedef Conv3WsCfg<T, NBUF> W;
     typedef typename W::B C;
     typedef typename Vec<T>::type V;
@@ -2725,8 +2732,52 @@ __global__ __launch_bounds__(kThreads, (NBUF == 2 || sizeof(T) == 1 ? 3 : 2)) vo
             lds_barrier();
         }
         if (n_my > 0) store_tile(s_out + ((n_my - 1) & 1) * O_ELEMS, p_img, p_oy0, p_ox0, lane, 64);
+    } else if (SPLIT && wave < 2) {
+        // ================================================= consumers 0 / 1 (SPLIT): output-channel tiles 0 and 1, pixel tiles 2 wave, 2 wave + 1.
+        // With the plain split (wave = channel tile) every B fragment is read from LDS by all three GEMM waves: 216 KB per tile for
+        // 72 MFMAs each, and LDS bandwidth is as loaded as the matrix pipe.  Here channels [0, 32) belong to two waves that split the
+        // PIXELS (each reads half of the fragments, uses each twice) and channels [32, 48) to the third: 144 KB, the same 72 MFMAs each.
+        Frag wst[2][KCH];
+        {
+            const Frag *wsrc = (const Frag *)L.w + lane;
+#pragma unroll
+            for (int i = 0; i < 2; i++)
+#pragma unroll
+                for (int kc = 0; kc < KCH; kc++) wst[i][kc] = wsrc[(i * KCH + kc) * 64];
+        }
+        f32x4 bias[2], mult[2];
+#pragma unroll
+        for (int i = 0; i < 2; i++) { bias[i] = *(const f32x4 *)(L.b + acc_cout(i, lane, 0)); mult[i] = load_mult(L.m, acc_cout(i, lane, 0)); }
+        int pbase[2];
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const int p = acc_pixel(2 * wave + j, lane);
+            pbase[j] = (p / TW) * ROWP + (p % TW) * LDI;
+        }
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+        lds_barrier();
+        for (int k = 0; k < n_my; k++) {
+            const T *s_in_b = s_in + (k % NBUF) * IN_ELEMS;
+            T *s_out_b = s_out + (k & 1) * O_ELEMS;
+            typename M::Acc acc[2][2];
+#pragma unroll
+            for (int i = 0; i < 2; i++)
+#pragma unroll
+                for (int j = 0; j < 2; j++) acc[i][j] = acc_init<T>(bias[i]);
+            gemm_stationary<T, 2, 2, KCH, (DEPTH > 2 ? DEPTH : 3), true>(acc, wst, [&](int j, int kc) -> Frag {
+                const int kb = kc * M::K + (lane >> 4) * M::KPL;
+                const int tap = kb / CIN, c = kb % CIN;
+                const int koff = (tap / 3) * ROWP + (tap % 3) * LDI + c;
+                return kb < KTOT ? *(const Frag *)(s_in_b + pbase[j] + koff) : M::zero();
+            });
+#pragma unroll
+            for (int i = 0; i < 2; i++)
+#pragma unroll
+                for (int j = 0; j < 2; j++) store_acc<T, LDO>(s_out_b, mult[i], bias[i], acc[i][j], i, 2 * wave + j, lane, true);
+            lds_barrier();
+        }
     } else {
-        // ================================================= consumers: wave = output-channel tile
+        // ================================================= consumers: wave = output-channel tile (SPLIT: only wave 2 = tile 2), all pixel tiles
         const int wn = wave;
         Frag wst[1][KCH];
         {
@@ -3185,10 +3236,10 @@ static int conv3_ws_variant() {
     return v;
 }
 
-template <typename T, int DEPTH, int NBUF>
+template <typename T, int DEPTH, int NBUF, int SPLIT = 0>
 static void conv3_ws_launch_v(hipStream_t s, Conv3Args<T> &a, int nlv, int total_tiles) {
     typedef Conv3WsCfg<T, NBUF> W;
-    auto kern = conv3x3_ws_kernel<T, DEPTH, NBUF>;
+    auto kern = conv3x3_ws_kernel<T, DEPTH, NBUF, SPLIT>;
     static std::atomic<int> resident_cache[kMaxDevices] = {};
     const int resident = kernel_residency(resident_cache, kern, W::LDS_BYTES);
     const int want = persistent_grid(total_tiles, resident);
@@ -3215,7 +3266,10 @@ static void conv3_ws_launch(hipStream_t s, Conv3Args<T> &a, int nlv, int total_t
         case 22: conv3_ws_launch_v<T, 2, 2>(s, a, nlv, total_tiles); break;
         case 23: conv3_ws_launch_v<T, 3, 2>(s, a, nlv, total_tiles); break;
         case 33: conv3_ws_launch_v<T, 3, 3>(s, a, nlv, total_tiles); break;
-        default: conv3_ws_launch_v<T, 2, 3>(s, a, nlv, total_tiles); break;
+        case 132: conv3_ws_launch_v<T, 2, 3, 1>(s, a, nlv, total_tiles); break;      // 1xx: the 2 + 2 + 1 role split of the GEMM waves
+        case 122: conv3_ws_launch_v<T, 2, 2, 1>(s, a, nlv, total_tiles); break;
+        case 32: conv3_ws_launch_v<T, 2, 3>(s, a, nlv, total_tiles); break;
+        default: conv3_ws_launch_v<T, 2, 3, 1>(s, a, nlv, total_tiles); break;       // = 132: three halo buffers, 2 + 2 + 1 roles (57.1 -> 54.5 us over 32, tools/gpu/r4_call14.sh)
     }
 }
 
