@@ -1943,9 +1943,15 @@ static TileInfo dwpw_select(hipStream_t s, const DwPwParams<T> *p, int cin, int 
     RF_DWPW(16, 32, 2, true, 8, 8)
     RF_DWPW(32, 32, 1, true, 8, 8)
     RF_DWPW(32, 64, 2, true, 4, 8)
+    if constexpr (sizeof(T) <= 2) {
+        static int v64 = -1;
+        if (v64 < 0) { const char *e = getenv("RF_TILE64"); v64 = e ? atoi(e) : 0; }          // probe knob (tools/probes)
+        if (v64 == 1) { RF_DWPW(64, 64, 1, true, 8, 8) }
+        if (v64 == 2) { RF_DWPW(64, 64, 1, true, 8, 16) }
+    }
     RF_DWPW(64, 64, 1, true, 4, 8)
     RF_DWPW(64, 128, 2, true, 4, 8)
-    if constexpr (sizeof(T) == 2) {
+    if constexpr (sizeof(T) <= 2) {
         static int v128 = -1;
         if (v128 < 0) { const char *e = getenv("RF_TILE128"); v128 = e ? atoi(e) : 0; }        // probe knob (tools/probes)
         if (v128 == 1) { RF_DWPW(128, 128, 1, true, 8, 8) }
@@ -3335,7 +3341,7 @@ static int conv3_variant() {
 // probe knob RF_CONV3UPWS: 0 = K_c for the aggregation convs; 2 / 3 = halo buffers of the warp-specialised kernel (K_c'')
 static int conv3_up_ws_variant() {
     static int v = -1;
-    if (v < 0) { const char *e = getenv("RF_CONV3UPWS"); v = e ? atoi(e) : 0; }
+    if (v < 0) { const char *e = getenv("RF_CONV3UPWS"); v = e ? atoi(e) : 1; }       // 1 = auto (see conv3_select)
     return v;
 }
 
@@ -3371,9 +3377,13 @@ static TileInfo conv3_select(hipStream_t s, const Conv3Params<T> *p, int nlv, in
     if constexpr (sizeof(T) <= 2) {
         // the aggregation convs (fused upsample + add), warp-specialised: maps whose sides are even (tile origins must be: the upsample's
         // parities are thread constants) and a single output tensor
-        if (p && nlv == 1 && p[0].up && cin == 64 && cout == 64 && conv3_up_ws_variant() >= 2 && p[0].h % 2 == 0 && p[0].w_ % 2 == 0 &&
+        // Default (RF_CONV3UPWS unset = 1): fp16 maps of >= 48 x 48 pixels take the variant where every wave issues its own share of the
+        // LDS-DMA (two ring buffers): rf_c1_aggr 77.8 -> 73.6 us per 256 images; the 28 x 28 map of rf_c2_aggr and the int8 engine measured
+        // equal or slower and stay on K_c (tools/gpu/r4_call12.sh, profiles/r04_rejected_ws_variants.txt).
+        const int upv = conv3_up_ws_variant() == 1 ? ((sizeof(T) == 2 && p && (long)p[0].h * p[0].w_ >= 48 * 48) ? 12 : 0) : conv3_up_ws_variant();
+        if (p && nlv == 1 && p[0].up && cin == 64 && cout == 64 && upv >= 2 && p[0].h % 2 == 0 && p[0].w_ % 2 == 0 &&
             p[0].n0 == 64 && p[0].in_ld == 64) {
-            switch (conv3_up_ws_variant()) {                           // 2 / 3: producer wave, 2 / 3 ring buffers; 12 / 13: every wave its own share
+            switch (upv) {                                             // 2 / 3: producer wave, 2 / 3 ring buffers; 12 / 13: every wave its own share
                 case 2: conv3_up_ws_launch<T, 2, 2, true>(s, p[0]); break;
                 case 3: conv3_up_ws_launch<T, 2, 3, true>(s, p[0]); break;
                 case 12: conv3_up_ws_launch<T, 2, 2, false>(s, p[0]); break;
