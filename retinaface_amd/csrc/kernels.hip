@@ -1209,7 +1209,7 @@ template <typename T, int CIN, int COUT, int STRIDE, bool HAS_DW, int TH, int TW
     // registers it wants (weights stationary + deep accumulators).
     static constexpr int LDS_OCC = (int)(160 * 1024 / LDS_BYTES) > 8 ? 8 : (int)(160 * 1024 / LDS_BYTES);
     static constexpr bool BIG_MAP = CIN <= 64 && HAS_DW && sizeof(T) <= 2;
-    static constexpr int OCC_CAP = sizeof(T) == 1 ? (CIN >= 64 ? 3 : 4) : (CIN >= 64 ? 4 : 5);   // 170 / 128 / 102 VGPRs: the largest budgets that compile without spills
+    static constexpr int OCC_CAP = sizeof(T) == 1 ? (P > 128 ? 2 : (CIN >= 64 || P > 64 ? 3 : 4)) : (CIN >= 64 ? 4 : 5);   // 170 / 128 / 102 VGPRs: the largest budgets that compile without spills
     static constexpr int OCC = BIG_MAP ? (LDS_OCC < 1 ? 1 : (LDS_OCC > OCC_CAP ? OCC_CAP : LDS_OCC)) : 1;
     static constexpr int GFRAGS = 12;                      // streamed case only
     // (capping the 128-channel blocks at 128 VGPRs for a 4th workgroup per CU spills 33 registers: 18 -> 37 us, measured)
@@ -1940,6 +1940,24 @@ static TileInfo dwpw_select(hipStream_t s, const DwPwParams<T> *p, int cin, int 
 #define RF_DWPW(CI, CO, ST, DW, TH_, TW_) \
     if (cin == CI && cout == CO && stride == ST && has_dw == DW) return dwpw_dispatch<T, CI, CO, ST, DW, TH_, TW_>(s, p, hout, wout);
     if constexpr (sizeof(T) > 1) { RF_DWPW(8, 16, 1, true, 8, 32) }      // int8: this block lives in the stem
+    if constexpr (sizeof(T) == 1) {
+        // Tile shapes of the int8 engine's big-map blocks (fp16 runs them inside stem2 / dwpw2).  These kernels spend their time in the requantising
+        // epilogue (VALU-active 0.5-0.64 of the chip), which is per element, so the tile shape moves little; measured one by one inside one call
+        // (tools/gpu/r4_call18.sh, us per 256 images, all bit-identical): 16->32 s2 8x8 56.2 | 8x16 53.5 | 16x16 57.2;  32->32 8x8 68.6 | 8x16 67.1 |
+        // 16x16 69.6;  32->64 s2 4x8 32.7 | 8x8 30.5 | 8x16 34.4;  64->128 s2 4x8 18.6 | 8x8 22.1.  Defaults = the best of each; 0 = round-3 shapes.
+        static int va = -1, vb = -1, vc = -1, vd = -1;
+        if (va < 0) { const char *e = getenv("RF_TILE_A"); va = e ? atoi(e) : 1; }
+        if (vb < 0) { const char *e = getenv("RF_TILE_B"); vb = e ? atoi(e) : 1; }
+        if (vc < 0) { const char *e = getenv("RF_TILE_C"); vc = e ? atoi(e) : 1; }
+        if (vd < 0) { const char *e = getenv("RF_TILE_D"); vd = e ? atoi(e) : 0; }
+        if (va == 1) { RF_DWPW(16, 32, 2, true, 8, 16) }
+        if (va == 2) { RF_DWPW(16, 32, 2, true, 16, 16) }
+        if (vb == 1) { RF_DWPW(32, 32, 1, true, 8, 16) }
+        if (vb == 2) { RF_DWPW(32, 32, 1, true, 16, 16) }
+        if (vc == 1) { RF_DWPW(32, 64, 2, true, 8, 8) }
+        if (vc == 2) { RF_DWPW(32, 64, 2, true, 8, 16) }
+        if (vd == 1) { RF_DWPW(64, 128, 2, true, 8, 8) }
+    }
     RF_DWPW(16, 32, 2, true, 8, 8)
     RF_DWPW(32, 32, 1, true, 8, 8)
     RF_DWPW(32, 64, 2, true, 4, 8)
@@ -1953,7 +1971,9 @@ static TileInfo dwpw_select(hipStream_t s, const DwPwParams<T> *p, int cin, int 
     RF_DWPW(64, 128, 2, true, 4, 8)
     if constexpr (sizeof(T) <= 2) {
         static int v128 = -1;
-        if (v128 < 0) { const char *e = getenv("RF_TILE128"); v128 = e ? atoi(e) : 0; }        // probe knob (tools/probes)
+        // 4x16 tiles for the int8 engine's 128-channel blocks: 26.0 -> 24.9 us each (tools/gpu/r4_call16.sh, r4_call18.sh); fp16: 27.7 -> 28.3, stays 4x8.
+        // RF_TILE128 = 0 / 1 / 2 / 3 forces 4x8 / 8x8 / 4x16 / 8x16 (probe knob)
+        if (v128 < 0) { const char *e = getenv("RF_TILE128"); v128 = e ? atoi(e) : (sizeof(T) == 1 ? 2 : 0); }
         if (v128 == 1) { RF_DWPW(128, 128, 1, true, 8, 8) }
         if (v128 == 2) { RF_DWPW(128, 128, 1, true, 4, 16) }
         if (v128 == 3) { RF_DWPW(128, 128, 1, true, 8, 16) }

@@ -18,7 +18,7 @@ def main():
     a = ap.parse_args()
     src = os.path.join(ROOT, "retinaface_amd", "csrc", "kernels.hip")
     cmd = ["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-x", "hip", "-I" + os.path.join(ROOT, "include"),
-           "-I" + os.path.dirname(src), "--cuda-device-only", "-S", src, "-o", a.asm, "-Rpass-analysis=kernel-resource-usage"]
+           "-I" + os.path.dirname(src), "--cuda-device-only", "-mllvm", "--amdgpu-mfma-vgpr-form", "-S", src, "-o", a.asm, "-Rpass-analysis=kernel-resource-usage"]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode:
         sys.exit(r.stderr[-3000:])
