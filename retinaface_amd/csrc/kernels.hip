@@ -1579,24 +1579,31 @@ __global__ __launch_bounds__(kThreads, (DwPwCfg<T, CIN, COUT, STRIDE, HAS_DW, TH
 //   K_b: the results are bit-identical (the int8 instance is held to the integer oracle like K_b's).
 //   What it took off the critical path in the merged SSH conv (K_c'): 104 -> 56 us.
 // =============================================================================================
-template <typename T, int CIN, int COUT, int STRIDE, int TH, int TW, bool LAT, int NBUF, bool PADROW> struct DwPwWsCfg {
+template <typename T, int CIN, int COUT, int STRIDE, int TH, int TW, bool LAT, int NBUF, bool PADROW, bool PROD = true> struct DwPwWsCfg {
     typedef DwPwCfg<T, CIN, COUT, STRIDE, true, TH, TW, PADROW> B;
     static constexpr int VEC = B::VEC, P = B::P;
     static constexpr int CPP = B::LDIN / VEC;                          // 16-byte chunks per halo pixel, padding included
     static constexpr int CPR = B::ROWP / VEC;                          // chunks per halo row, padding included
     static constexpr int DPP = CIN / VEC;                              // data chunks per pixel
     static constexpr int SLOTS = B::HR * CPR;
-    static constexpr int PIECES = (SLOTS + 63) / 64;                   // DMA wave-instructions per halo tile
+    // PROD: a fifth wave owns the memory side.  !PROD (K_b''): no producer wave -- each of the four waves issues a quarter of the halo DMA and of the
+    // stores (a 320-thread workgroup at this register budget is resident once per CU; 256-thread ones pack)
+    static constexpr int NW = PROD ? 1 : 4;                            // waves that share the memory side
+    static constexpr int PIECES = ((SLOTS + 63) / 64 + NW - 1) / NW * NW;      // DMA wave-instructions per halo tile (whole pieces per wave)
+    static constexpr int PPW = PIECES / NW;
     static constexpr int LDL = 64 + VEC;
-    static constexpr int NSTORE = P * (COUT / VEC) / 64 + (LAT ? P * (64 / VEC) / 64 : 0);      // store wave-instructions per tile
+    static constexpr int NST_OUT = P * (COUT / VEC) / 64, NST_LAT = LAT ? P * (64 / VEC) / 64 : 0;
+    static constexpr int NSTORE = NST_OUT + NST_LAT;                   // store wave-instructions per tile
+    static constexpr int NSTW = NSTORE / NW;
+    static constexpr bool SPLIT_OK = NST_OUT % NW == 0 && NST_LAT % NW == 0;      // the same number of vmcnt events in every wave
     static constexpr size_t IN_BYTES = (size_t)PIECES * 1024;
     static constexpr size_t A_BYTES = B::A_BYTES, O_BYTES = B::O_BYTES;
     static constexpr size_t L_BYTES = LAT ? sizeof(T) * (size_t)(P * LDL) : 0;
     static constexpr size_t LDS_BYTES = NBUF * IN_BYTES + A_BYTES + O_BYTES + L_BYTES;
-    static constexpr int THREADS = 320;                                // 4 consumer waves + the producer
+    static constexpr int THREADS = PROD ? 320 : 256;                   // 4 GEMM waves (+ the producer)
     static constexpr int WG_CAP = LAT ? 2 : 3;                         // (the lateral's second GEMM needs ~140 VGPRs: 3 workgroups of 5 waves would spill)
     static constexpr int WG_PER_CU = (int)(160 * 1024 / LDS_BYTES) > WG_CAP ? WG_CAP : (int)(160 * 1024 / LDS_BYTES);
-    static constexpr int WAVES_PER_EU = (WG_PER_CU * 5 + 3) / 4;       // what __launch_bounds__ needs for WG_PER_CU resident workgroups
+    static constexpr int WAVES_PER_EU = PROD ? (WG_PER_CU * 5 + 3) / 4 : WG_PER_CU;      // what __launch_bounds__ needs for WG_PER_CU resident workgroups
     static_assert(B::DWMMA && B::STAT && sizeof(T) <= 2, "only the shapes whose depthwise stage runs on MFMA with stationary pointwise weights");
     static_assert(B::LDIN % VEC == 0 && B::ROWP % VEC == 0 && IN_BYTES >= B::IN_BYTES, "halo layout in whole 16-byte slots");
     static_assert((P * (COUT / VEC)) % 64 == 0 && (!LAT || (P * (64 / VEC)) % 64 == 0), "whole store instructions per tile");
@@ -1604,10 +1611,10 @@ template <typename T, int CIN, int COUT, int STRIDE, int TH, int TW, bool LAT, i
     static_assert(!LAT || (COUT + Mma<T>::K - 1) / Mma<T>::K <= 8, "lateral weights stationary");
 };
 
-template <typename T, int CIN, int COUT, int STRIDE, int TH, int TW, bool LAT, int NBUF, bool PADROW>
-__global__ __launch_bounds__(320, (DwPwWsCfg<T, CIN, COUT, STRIDE, TH, TW, LAT, NBUF, PADROW>::WAVES_PER_EU))
+template <typename T, int CIN, int COUT, int STRIDE, int TH, int TW, bool LAT, int NBUF, bool PADROW, bool PROD = true>
+__global__ __launch_bounds__((DwPwWsCfg<T, CIN, COUT, STRIDE, TH, TW, LAT, NBUF, PADROW, PROD>::THREADS), (DwPwWsCfg<T, CIN, COUT, STRIDE, TH, TW, LAT, NBUF, PADROW, PROD>::WAVES_PER_EU))
 void dwpw_ws_kernel(DwPwArgs<T> a) {
-    typedef DwPwWsCfg<T, CIN, COUT, STRIDE, TH, TW, LAT, NBUF, PADROW> W;
+    typedef DwPwWsCfg<T, CIN, COUT, STRIDE, TH, TW, LAT, NBUF, PADROW, PROD> W;
     typedef typename W::B C;
     typedef typename Vec<T>::type V;
     typedef Mma<T> M;
@@ -1615,7 +1622,7 @@ void dwpw_ws_kernel(DwPwArgs<T> a) {
     typedef typename C::WS WS;
     constexpr int VEC = C::VEC, P = C::P, HC = C::HC, LDA = C::LDA, LDO = C::LDO, LDIN = C::LDIN, ROWP = C::ROWP;
     constexpr int PT = C::PT, KCH = C::KCH, LDL = W::LDL;
-    constexpr int DIST = NBUF - 1;
+    constexpr int DIST = NBUF - 1, NW = W::NW, PPW = W::PPW;
     constexpr bool I8 = sizeof(T) == 1;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int IN_ELEMS = (int)(W::IN_BYTES / sizeof(T));
@@ -1630,63 +1637,77 @@ void dwpw_ws_kernel(DwPwArgs<T> a) {
     const int first = xcd_remap(blockIdx.x, G);
     const int n_my = first < a.nblk ? (a.nblk - 1 - first) / G + 1 : 0;
 
-    if (wave == 4) {
-        // ================================================= producer
-        int kpack[W::PIECES];                                          // byte offset inside the image | halo column << 26 (63 = no pixel)
+    // ---- the memory side: the producer wave's (PROD) or this wave's quarter (!PROD) of the halo DMA and of the stores
+    const int mw = PROD ? 0 : wave;                                    // index among the NW waves that share it
+    int kpack[PPW];                                                    // byte offset inside the image | halo column << 26 (63 = no pixel)
 #pragma unroll
-        for (int i = 0; i < W::PIECES; i++) {
-            const int s = i * 64 + lane;
-            const int row = s / W::CPR, rem = s % W::CPR;
-            const int px = rem / W::CPP, ch = rem % W::CPP;
-            const bool real = row < C::HR && px < HC && ch < W::DPP;
-            kpack[i] = real ? ((((row * a.win + px) * CIN + ch * VEC) * (int)sizeof(T)) | (px << 26)) : (int)(63u << 26);
+    for (int i = 0; i < PPW; i++) {
+        const int s = (mw * PPW + i) * 64 + lane;
+        const int row = s / W::CPR, rem = s % W::CPR;
+        const int px = rem / W::CPP, ch = rem % W::CPP;
+        const bool real = row < C::HR && px < HC && ch < W::DPP;
+        kpack[i] = real ? ((((row * a.win + px) * CIN + ch * VEC) * (int)sizeof(T)) | (px << 26)) : (int)(63u << 26);
+    }
+    const unsigned in_img_bytes = (unsigned)(a.hin * a.win * CIN) * (unsigned)sizeof(T);
+    const unsigned out_img_bytes = (unsigned)(a.hout * a.wout * COUT) * (unsigned)sizeof(T);
+    auto dma = [&](int tx, int ty, int img, T *dst) {
+        const auto rs = image_rsrc(a.in + (size_t)img * a.hin * a.win * CIN, in_img_bytes);
+        const int iy0 = ty * TH * STRIDE - 1, ix0 = tx * TW * STRIDE - 1;
+        const int sbase = (iy0 * a.win + ix0) * CIN * (int)sizeof(T);
+#pragma unroll
+        for (int i = 0; i < PPW; i++) {
+            const int dx = (int)((unsigned)kpack[i] >> 26);
+            const unsigned off = (dx != 63 && (unsigned)(ix0 + dx) < (unsigned)a.win) ? (unsigned)((kpack[i] & 0x03ffffff) + sbase) : kOobOffset;
+            lds_dma16(rs, (unsigned char *)dst + (mw * PPW + i) * 1024, off);
         }
-        const unsigned in_img_bytes = (unsigned)(a.hin * a.win * CIN) * (unsigned)sizeof(T);
-        const unsigned out_img_bytes = (unsigned)(a.hout * a.wout * COUT) * (unsigned)sizeof(T);
-        auto dma = [&](int tx, int ty, int img, T *dst) {
-            const auto rs = image_rsrc(a.in + (size_t)img * a.hin * a.win * CIN, in_img_bytes);
-            const int iy0 = ty * TH * STRIDE - 1, ix0 = tx * TW * STRIDE - 1;
-            const int sbase = (iy0 * a.win + ix0) * CIN * (int)sizeof(T);
+    };
+    auto store_tile = [&](int img, int oy0, int ox0) {
+        constexpr int OPV = COUT / VEC;
+        const auto ro = image_rsrc(a.out + (size_t)img * a.hout * a.wout * COUT, out_img_bytes);
+        const int obase = (oy0 * a.wout + ox0) * COUT * (int)sizeof(T);
 #pragma unroll
-            for (int i = 0; i < W::PIECES; i++) {
-                const int dx = (int)((unsigned)kpack[i] >> 26);
-                const unsigned off = (dx != 63 && (unsigned)(ix0 + dx) < (unsigned)a.win) ? (unsigned)((kpack[i] & 0x03ffffff) + sbase) : kOobOffset;
-                lds_dma16(rs, (unsigned char *)dst + i * 1024, off);
-            }
-        };
-        auto store_tile = [&](int img, int oy0, int ox0) {
-            constexpr int OPV = COUT / VEC;
-            const auto ro = image_rsrc(a.out + (size_t)img * a.hout * a.wout * COUT, out_img_bytes);
-            const int obase = (oy0 * a.wout + ox0) * COUT * (int)sizeof(T);
+        for (int j = 0; j < W::NST_OUT / NW; j++) {
+            const int i = lane + 64 * (mw + NW * j);
+            const int p = i / OPV, cv = i % OPV;
+            const int py = p / TW, px = p % TW;
+            const unsigned off = ox0 + px < a.wout ? (unsigned)(((py * a.wout + px) * COUT + cv * VEC) * (int)sizeof(T) + obase) : kOobOffset;
+            buf_store16(ro, off, *(const V *)(s_out + p * LDO + cv * VEC));
+        }
+        if constexpr (LAT) {
+            constexpr int LPV = 64 / VEC;
+            const auto rl = image_rsrc(a.lat_out + (size_t)img * a.hout * a.wout * 64, (unsigned)(a.hout * a.wout * 64) * (unsigned)sizeof(T));
+            const int lbase = (oy0 * a.wout + ox0) * 64 * (int)sizeof(T);
 #pragma unroll
-            for (int i = lane; i < P * OPV; i += 64) {
-                const int p = i / OPV, cv = i % OPV;
+            for (int j = 0; j < W::NST_LAT / NW; j++) {
+                const int i = lane + 64 * (mw + NW * j);
+                const int p = i / LPV, cv = i % LPV;
                 const int py = p / TW, px = p % TW;
-                const unsigned off = ox0 + px < a.wout ? (unsigned)(((py * a.wout + px) * COUT + cv * VEC) * (int)sizeof(T) + obase) : kOobOffset;
-                buf_store16(ro, off, *(const V *)(s_out + p * LDO + cv * VEC));
+                const unsigned off = ox0 + px < a.wout ? (unsigned)(((py * a.wout + px) * 64 + cv * VEC) * (int)sizeof(T) + lbase) : kOobOffset;
+                buf_store16(rl, off, *(const V *)(s_lat + p * LDL + cv * VEC));
             }
-            if constexpr (LAT) {
-                constexpr int LPV = 64 / VEC;
-                const auto rl = image_rsrc(a.lat_out + (size_t)img * a.hout * a.wout * 64, (unsigned)(a.hout * a.wout * 64) * (unsigned)sizeof(T));
-                const int lbase = (oy0 * a.wout + ox0) * 64 * (int)sizeof(T);
-#pragma unroll
-                for (int i = lane; i < P * LPV; i += 64) {
-                    const int p = i / LPV, cv = i % LPV;
-                    const int py = p / TW, px = p % TW;
-                    const unsigned off = ox0 + px < a.wout ? (unsigned)(((py * a.wout + px) * 64 + cv * VEC) * (int)sizeof(T) + lbase) : kOobOffset;
-                    buf_store16(rl, off, *(const V *)(s_lat + p * LDL + cv * VEC));
-                }
-            }
-        };
-        const TileStep step(G, a.tiles_x, a.tiles_y);
-        TileCoord cur(first, a.tiles_x, a.tiles_y), pf = cur;         // cur: the tile the consumers work on; pf: the next tile to fetch
+        }
+    };
+    const TileStep step(G, a.tiles_x, a.tiles_y);
+    TileCoord cur(first, a.tiles_x, a.tiles_y), pf = cur;             // cur: the tile being computed; pf: the next tile to fetch
+    int p_img = 0, p_oy0 = 0, p_ox0 = 0;                               // the tile whose result is still in LDS
+    // what may stay in flight when tile k + 1 has to have landed: this interval's own stores and DMA (vmcnt is in order)
+    auto wait_next_halo = [&](bool st, bool ld) {
+        if (DIST == 1) wait_vmcnt<0>();
+        else if (st && ld) wait_vmcnt<(W::NSTW + PPW < 63 ? W::NSTW + PPW : 63)>();
+        else if (ld) wait_vmcnt<PPW>();
+        else if (st) wait_vmcnt<W::NSTW>();
+        else wait_vmcnt<0>();
+    };
+
+    if constexpr (PROD) {
+      if (wave == 4) {
+        // ================================================= producer
 #pragma unroll
         for (int d = 0; d < DIST; d++)
             if (d < n_my) { dma(pf.tx, pf.ty, pf.img, s_in + d * IN_ELEMS); step.advance(pf); }
-        if (DIST == 2 && n_my >= 2) wait_vmcnt<W::PIECES>();
+        if (DIST == 2 && n_my >= 2) wait_vmcnt<PPW>();
         else wait_vmcnt<0>();
         lds_barrier();
-        int p_img = 0, p_oy0 = 0, p_ox0 = 0;
         for (int k = 0; k < n_my; k++) {
             const bool st = k > 0, ld = k + DIST < n_my;
             // the previous tile's result(s): s_out / s_lat are rewritten by this interval's pointwise / lateral phase, i.e. after the
@@ -1698,15 +1719,17 @@ void dwpw_ws_kernel(DwPwArgs<T> a) {
             step.advance(cur);
             if constexpr (LAT) lds_barrier();                          // (pointwise -> lateral)
             // tile k + 1 must have landed before the closing barrier; what was issued in THIS interval may stay in flight (DIST == 2)
-            if (DIST == 1) wait_vmcnt<0>();
-            else if (st && ld) wait_vmcnt<(W::NSTORE + W::PIECES < 63 ? W::NSTORE + W::PIECES : 63)>();
-            else if (ld) wait_vmcnt<W::PIECES>();
-            else if (st) wait_vmcnt<W::NSTORE>();
-            else wait_vmcnt<0>();
+            wait_next_halo(st, ld);
             lds_barrier();
         }
         if (n_my > 0) store_tile(p_img, p_oy0, p_ox0);                // (the consumers' last writes precede the closing barrier)
         return;
+      }
+    } else {
+        // K_b'': every wave brings in its quarter of the first DIST halos; the wait below (weights + these) and the barrier publish them
+#pragma unroll
+        for (int d = 0; d < DIST; d++)
+            if (d < n_my) { dma(pf.tx, pf.ty, pf.img, s_in + d * IN_ELEMS); step.advance(pf); }
     }
 
     // ================================================= consumers (waves 0-3): once per workgroup, weights and per-lane constants as in K_b
@@ -1769,6 +1792,15 @@ void dwpw_ws_kernel(DwPwArgs<T> a) {
 
     for (int k = 0; k < n_my; k++) {
         const T *s_in_b = s_in + (k % NBUF) * IN_ELEMS;
+        const bool st = k > 0, ld = k + DIST < n_my;
+        if constexpr (!PROD) {
+            // this wave's quarter of the previous tile's stores (s_out / s_lat are rewritten after the next barrier, which the wave passes only
+            // with these LDS reads complete) and of the halo DIST tiles ahead (its buffer was last read before the previous interval's first barrier)
+            if (st) store_tile(p_img, p_oy0, p_ox0);
+            if (ld) { dma(pf.tx, pf.ty, pf.img, s_in + ((k + DIST) % NBUF) * IN_ELEMS); step.advance(pf); }
+            p_img = cur.img; p_oy0 = cur.ty * TH; p_ox0 = cur.tx * TW;
+            step.advance(cur);
+        }
         // ---- depthwise 3x3 as diagonal-weight implicit GEMM (K_b phase 2)
 #pragma unroll
         for (int gi = 0; gi < GW; gi++) {
@@ -1852,8 +1884,10 @@ void dwpw_ws_kernel(DwPwArgs<T> a) {
 #pragma unroll
             for (int j = 0; j < PT; j++) store_acc<T, LDL>(s_lat, lat_mult, lat_bias, acc2[0][j], wave, j, lane, true);
         }
+        if constexpr (!PROD) wait_next_halo(st, ld);                   // this wave's quarter of tile k + 1; the barrier publishes all four
         lds_barrier();
     }
+    if constexpr (!PROD) { if (n_my > 0) store_tile(p_img, p_oy0, p_ox0); }
 }
 
 // probe knob RF_DWPWWS: 0 = off (K_b everywhere); 2 / 3 = halo buffers of the warp-specialised blocks
@@ -1863,10 +1897,10 @@ static int dwpw_ws_variant() {
     return v;
 }
 
-template <typename T, int CIN, int COUT, int STRIDE, int TH, int TW, bool LAT, int NBUF, bool PADROW>
+template <typename T, int CIN, int COUT, int STRIDE, int TH, int TW, bool LAT, int NBUF, bool PADROW, bool PROD = true>
 static void dwpw_ws_launch(hipStream_t s, const DwPwParams<T> *p, int tiles_x, int tiles_y) {
-    typedef DwPwWsCfg<T, CIN, COUT, STRIDE, TH, TW, LAT, NBUF, PADROW> W;
-    auto kern = dwpw_ws_kernel<T, CIN, COUT, STRIDE, TH, TW, LAT, NBUF, PADROW>;
+    typedef DwPwWsCfg<T, CIN, COUT, STRIDE, TH, TW, LAT, NBUF, PADROW, PROD> W;
+    auto kern = dwpw_ws_kernel<T, CIN, COUT, STRIDE, TH, TW, LAT, NBUF, PADROW, PROD>;
     static std::atomic<int> resident_cache[kMaxDevices] = {};
     const int dev = launch_device();
     int resident = resident_cache[dev].load(std::memory_order_acquire);
@@ -1912,6 +1946,22 @@ static TileInfo dwpw_dispatch(hipStream_t s, const DwPwParams<T> *p, int hout, i
     // warp-specialised instances (K_b'): the stride-1 blocks with 64 / 128 channels, with or without the fused lateral
     if constexpr (sizeof(T) <= 2 && HAS_DW && STRIDE == 1 && CIN == COUT && (CIN == 64 || CIN == 128) && C::DWMMA && C::STAT) {
         const int v = dwpw_ws_variant();
+        if (v == 12 || v == 13) {           // K_b'': the memory side spread over the four GEMM waves (no producer wave)
+            if constexpr (DwPwWsCfg<T, CIN, COUT, STRIDE, TH, TW, true, 2, PADROW, false>::SPLIT_OK) {
+                if (p->lat_out) {
+                    if (v == 12) dwpw_ws_launch<T, CIN, COUT, STRIDE, TH, TW, true, 2, PADROW, false>(s, p, tiles_x, tiles_y);
+                    else dwpw_ws_launch<T, CIN, COUT, STRIDE, TH, TW, true, 3, PADROW, false>(s, p, tiles_x, tiles_y);
+                    return ti;
+                }
+            }
+            if constexpr (DwPwWsCfg<T, CIN, COUT, STRIDE, TH, TW, false, 2, PADROW, false>::SPLIT_OK) {
+                if (!p->lat_out) {
+                    if (v == 12) dwpw_ws_launch<T, CIN, COUT, STRIDE, TH, TW, false, 2, PADROW, false>(s, p, tiles_x, tiles_y);
+                    else dwpw_ws_launch<T, CIN, COUT, STRIDE, TH, TW, false, 3, PADROW, false>(s, p, tiles_x, tiles_y);
+                    return ti;
+                }
+            }
+        }
         if (v == 2 || v == 3) {
             if (p->lat_out) {
                 if (v == 2) dwpw_ws_launch<T, CIN, COUT, STRIDE, TH, TW, true, 2, PADROW>(s, p, tiles_x, tiles_y);
@@ -2028,7 +2078,7 @@ struct DwPw2Args {
     int ring;                                           // 1 = depthwise A as one ring pipeline (round 4), 0 = chunk by chunk (probe knob RF_DWPW2_RING)
 };
 
-template <bool RINGP>
+template <bool RINGP, bool HPAD = true, bool LAY2 = true>
 __global__ __launch_bounds__(kThreads, 3) void dwpw2_kernel(DwPw2Args a) {
     typedef half_t T;
     typedef Mma<T> M;
@@ -2041,10 +2091,22 @@ __global__ __launch_bounds__(kThreads, 3) void dwpw2_kernel(DwPw2Args a) {
     constexpr int PTA = (NR + 15) / 16;                                // 10 MFMA pixel tiles of block A
     constexpr int UA = PTA / 2;                                        // units (pixel tiles) of block A per wave: 5
     constexpr int LD = lds_row<T>(32);                                 // 48 halfs = 96 B per pixel: conflict-free B-fragment pitch
-    constexpr int LDO = lds_row<T>(CB);                                // 80
-    constexpr int IN_BYTES = NH * LD * 2, A_BYTES = PTA * 16 * LD * 2, B_BYTES = P * LD * 2, OUT_BYTES = P * LDO * 2;
+    // LAY2 (round 4, from the same counters): every 8-byte epilogue write of 16 pixels at a 96-byte pitch is a 4-way bank conflict (24 banks per pixel:
+    // four distinct bank positions), and block B's stride-2 depthwise fragments collide 2-way on the contiguous block-A tile.  The depthwise-A tile
+    // therefore sits at 80 bytes per pixel (writes 2-way, the pointwise reads 2-way instead of free: 5 x 8 + 5 x 8 instead of 5 x 16 + 5 x 4 LDS cycles per
+    // wave), the block-A tile at 80 bytes per pixel in rows of 88 slots (writes 2-way, block B's stride-2 reads conflict-free) and the output tile at
+    // 144 bytes per pixel (writes 2-way).
+    constexpr int LDO = LAY2 ? 72 : lds_row<T>(CB);                    // 72 / 80
+    constexpr int LDSA = LAY2 ? 40 : LD;                               // depthwise-A result: pixel pitch
+    constexpr int LDM = LAY2 ? 40 : LD, MROW = LAY2 ? 88 * 8 : RW * LD;      // block-A tile: pixel pitch, row pitch (halfs)
+    // Halo rows are padded by 4 slots of 16 B (HROW = 118 slots = 6 mod 16): a depthwise-A pixel tile is 16 consecutive pixels of the 17-wide region, so
+    // nearly every tile wraps from one halo row to the next; with the plain 19-pixel pitch (114 slots = 2 mod 16) the wrap shifted the second part of
+    // the tile by 12 slots and its ds_read_b128 lane groups collided 2-way (SQ_LDS_BANK_CONFLICT 0.42 of this kernel's cycles, LDS busy 0.75:
+    // tools/gpu/r4_call22.sh); 118 makes the wrap look like 17 contiguous pixels to the bank function (6 slots per pixel).
+    constexpr int HROW = HW * LD + (HPAD ? 32 : 0);                    // halfs per halo row
+    constexpr int IN_BYTES = HH * HROW * 2, A_BYTES = PTA * 16 * LDSA * 2, B_BYTES = P * LD * 2, OUT_BYTES = P * LDO * 2;
     constexpr int NPF = (NH * 4 + kThreads - 1) / kThreads;            // halo items (16 B) per thread: 4
-    static_assert(PTA % 2 == 0 && PTA * 16 * LD * 2 <= IN_BYTES && B_BYTES + OUT_BYTES <= A_BYTES, "region reuse");
+    static_assert(PTA % 2 == 0 && (LAY2 ? RH * MROW * 2 : PTA * 16 * LD * 2) <= IN_BYTES && B_BYTES + OUT_BYTES <= A_BYTES && RW * LDM <= MROW, "region reuse");
     __shared__ __attribute__((aligned(16))) unsigned char s_raw[IN_BYTES + A_BYTES];
     T *s_in = (T *)s_raw;                              // halo                       (phases 1-2)
     T *s_mid = (T *)s_raw;                             // block-A output tile        (phases 3-4)
@@ -2089,26 +2151,26 @@ __global__ __launch_bounds__(kThreads, 3) void dwpw2_kernel(DwPw2Args a) {
         const int p = ((wave >> 1) + 2 * i) * 16 + (lane & 15);
         const int pc = p < NR ? p : NR - 1;                            // tail lanes recompute the last pixel; never used past NR
         pa_yx[i] = ((p < NR ? pc / RW : 0x4000) << 16) | (pc % RW);   // poisoned row: fails the inside-the-map test
-        pa_base[i] = ((pc / RW) * HW + pc % RW) * LD + g * 16 + (kb & 1) * 8;
+        pa_base[i] = (pc / RW) * HROW + (pc % RW) * LD + g * 16 + (kb & 1) * 8;
     }
     // tap of chunk kc: 2 kc for lanes 0..31, 2 kc + 1 for lanes 32..63 (k = tap*16 + c): two compile-time offsets per chunk,
     // picked by the lane half when used (this kernel runs at 3 workgroups per CU: the 128-VGPR budget of a 4th spills 37 registers)
     const bool hi = lane >= 32;
-    auto tap_a = [&](int kc) -> int { const int t0 = 2 * kc, t1 = 2 * kc + 1; return hi ? (t1 < 9 ? ((t1 / 3) * HW + t1 % 3) * LD : -1) : ((t0 / 3) * HW + t0 % 3) * LD; };
-    auto tap_b = [&](int kc) -> int { const int t0 = 2 * kc, t1 = 2 * kc + 1; return hi ? (t1 < 9 ? ((t1 / 3) * RW + t1 % 3) * LD : -1) : ((t0 / 3) * RW + t0 % 3) * LD; };
+    auto tap_a = [&](int kc) -> int { const int t0 = 2 * kc, t1 = 2 * kc + 1; return hi ? (t1 < 9 ? (t1 / 3) * HROW + (t1 % 3) * LD : -1) : (t0 / 3) * HROW + (t0 % 3) * LD; };
+    auto tap_b = [&](int kc) -> int { const int t0 = 2 * kc, t1 = 2 * kc + 1; return hi ? (t1 < 9 ? (t1 / 3) * MROW + (t1 % 3) * LDM : -1) : (t0 / 3) * MROW + (t0 % 3) * LDM; };
     const int pb = (wave >> 1) * 16 + (lane & 15);                     // the wave's block-B pixel
-    const int pb_base = ((pb / TW) * 2 * RW + (pb % TW) * 2) * LD + g * 16 + (kb & 1) * 8;
+    const int pb_base = (pb / TW) * 2 * MROW + (pb % TW) * 2 * LDM + g * 16 + (kb & 1) * 8;
 
     // halo of a tile -> registers (unconditional buffer loads; rows / columns outside the map read as zero = depthwise A's padding)
     V pre[NPF];
-    int koff[NPF], kdx[NPF];
+    int koff[NPF], kdx[NPF];                                           // kdx: halo column | LDS offset of the item (halfs) << 8
 #pragma unroll
     for (int k = 0; k < NPF; k++) {
         int i = tid + k * kThreads;
         i = i < NH * 4 ? i : NH * 4 - 1;
         const int pix = i >> 2, cv = i & 3;
         koff[k] = (((pix / HW) * a.win + pix % HW) * CI + cv * 8) * 2;
-        kdx[k] = pix % HW;
+        kdx[k] = (pix % HW) | (((pix / HW) * HROW + (pix % HW) * LD + cv * 8) << 8);
     }
     const unsigned in_img_bytes = (unsigned)(a.hin * a.win * CI) * 2u;
     auto fetch = [&](int tx, int ty, int img) {
@@ -2117,7 +2179,7 @@ __global__ __launch_bounds__(kThreads, 3) void dwpw2_kernel(DwPw2Args a) {
         const int sbase = (iy0 * a.win + ix0) * CI * 2;
 #pragma unroll
         for (int k = 0; k < NPF; k++) {
-            const unsigned off = (unsigned)(ix0 + kdx[k]) < (unsigned)a.win ? (unsigned)(koff[k] + sbase) : kOobOffset;
+            const unsigned off = (unsigned)(ix0 + (kdx[k] & 0xff)) < (unsigned)a.win ? (unsigned)(koff[k] + sbase) : kOobOffset;
             pre[k] = buf_load16<V>(rs, off);
         }
     };
@@ -2133,7 +2195,7 @@ __global__ __launch_bounds__(kThreads, 3) void dwpw2_kernel(DwPw2Args a) {
 #pragma unroll
         for (int k = 0; k < NPF; k++) {
             const int i = tid + k * kThreads;
-            if (i < NH * 4) *(V *)(s_in + (i >> 2) * LD + (i & 3) * 8) = pre[k];
+            if (i < NH * 4) *(V *)(s_in + (kdx[k] >> 8)) = pre[k];
         }
         if (t + G < a.nblk) fetch(nxt.tx, nxt.ty, nxt.img);
         cur = nxt;
@@ -2181,7 +2243,7 @@ __global__ __launch_bounds__(kThreads, 3) void dwpw2_kernel(DwPw2Args a) {
                 }
             }
 #pragma unroll
-            for (int i = 0; i < UA; i++) store_acc<T, LD>(s_a, ones, dwa_b, acc[i], g, (wave >> 1) + 2 * i, lane, true);
+            for (int i = 0; i < UA; i++) store_acc<T, LDSA>(s_a, ones, dwa_b, acc[i], g, (wave >> 1) + 2 * i, lane, true);
         }
         RF_TRACE(5, 2);
         __syncthreads();
@@ -2190,16 +2252,21 @@ __global__ __launch_bounds__(kThreads, 3) void dwpw2_kernel(DwPw2Args a) {
         {
             Frag bf[UA];
 #pragma unroll
-            for (int i = 0; i < UA; i++) bf[i] = *(const Frag *)(s_a + (((wave >> 1) + 2 * i) * 16 + (lane & 15)) * LD + kb * 8);
+            for (int i = 0; i < UA; i++) bf[i] = *(const Frag *)(s_a + (((wave >> 1) + 2 * i) * 16 + (lane & 15)) * LDSA + kb * 8);
 #pragma unroll
             for (int i = 0; i < UA; i++) {
                 const M::Acc acc = M::mma(pwa, bf[i], pwa_b);
-                const int y = 2 * oy0 - 1 + (pa_yx[i] >> 16), x = 2 * ox0 - 1 + (pa_yx[i] & 0xffff);
+                const int ry = pa_yx[i] >> 16, rx = pa_yx[i] & 0xffff;
+                const int y = 2 * oy0 - 1 + ry, x = 2 * ox0 - 1 + rx;
                 const bool inside = (unsigned)y < (unsigned)a.hin && (unsigned)x < (unsigned)a.win;
                 uint2 h;
                 h.x = inside ? pack_f16(acc[0], acc[1], true) : 0u;
                 h.y = inside ? pack_f16(acc[2], acc[3], true) : 0u;
-                *(uint2 *)(s_mid + (((wave >> 1) + 2 * i) * 16 + (lane & 15)) * LD + acc_cout(g, lane, 0)) = h;     // the halo is dead since the last barrier
+                if constexpr (LAY2) {
+                    if (ry < 0x4000) *(uint2 *)(s_mid + ry * MROW + rx * LDM + acc_cout(g, lane, 0)) = h;     // (tail lanes own no pixel of the 2-D tile)
+                } else {
+                    *(uint2 *)(s_mid + (((wave >> 1) + 2 * i) * 16 + (lane & 15)) * LD + acc_cout(g, lane, 0)) = h;     // the halo is dead since the last barrier
+                }
             }
         }
         RF_TRACE(5, 3);
@@ -2241,6 +2308,242 @@ __global__ __launch_bounds__(kThreads, 3) void dwpw2_kernel(DwPw2Args a) {
     }
 }
 
+// =============================================================================================
+// K_b2c  dwpw2 with the depthwise -> pointwise hops CHAINED IN REGISTERS (round 4).
+//   In the swapped GEMM (D[cout][pixel]) a lane's accumulator registers hold 4 consecutive channels of the SAME pixel (column) the lane feeds
+//   as a B operand: D rows 4 kb .. 4 kb + 3 of two 16-channel groups ARE the lane's 8 K slots of the next GEMM, if that GEMM's K axis is
+//   ordered  k = 8 kb + e  <->  channel 4 kb + e (e < 4), 16 + 4 kb + (e - 4) (e >= 4).  The permutation is applied to the pointwise weights when
+//   their A fragments are loaded (two 8-byte loads instead of one 16-byte load, once per workgroup), so the depthwise result never goes through
+//   LDS: no s_a / s_b tiles, 13 -> 8 ds_write_b64 and 37 -> 30 ds_read_b128 per wave and tile, 5 -> 3 barriers.
+//   Why it matters: SQ_LDS_IDX_ACTIVE said the LDS pipe of K_b2 was busy 0.75 of the kernel's time, 0.41 in bank-conflict cycles
+//   (tools/gpu/r4_call22.sh): 4-way conflicts of every 8-byte epilogue write at a 96-byte pixel pitch, 2-way conflicts of the depthwise reads on
+//   tiles that wrap a halo row.  Layouts here: halo rows padded to 118 slots of 16 B (= 6 mod 16: a wrap looks like contiguous pixels, see K_b2);
+//   the block-A tile at an 80-byte pixel pitch and 88 slots per row (its only readers are block B's stride-2 depthwise fragments: conflict-free;
+//   writes 2-way instead of 4-way); the output tile at 144 bytes per pixel (2-way writes).
+//   Work split: phase A  wave w -> region pixel tiles w, w + 4, w + 8 (both channel groups, both output-channel tiles: 10 + 2 MFMAs per tile);
+//   phase B  wave w -> pixel tile w & 1, output-channel tiles 2 (w >> 1), +1 (the depthwise part is computed by both waves of a pixel tile).
+// =============================================================================================
+__global__ __launch_bounds__(kThreads, 3) void dwpw2c_kernel(DwPw2Args a) {
+    typedef half_t T;
+    typedef Mma<T> M;
+    typedef M::Frag Frag;
+    typedef f16x8 V;
+    constexpr int CI = 32, CB = 64;
+    constexpr int TH = 4, TW = 8, P = TH * TW;
+    constexpr int RH = 2 * TH + 1, RW = 2 * TW + 1, NR = RH * RW;      // block-A outputs the tile needs: 9 x 17 = 153
+    constexpr int HH = RH + 2, HW = RW + 2, NH = HH * HW;              // input halo: 11 x 19 = 209
+    constexpr int PTA = (NR + 15) / 16, UA = (PTA + 3) / 4;            // 10 region pixel tiles, up to 3 per wave
+    constexpr int LD = 48, HROW = HW * LD + 32;                        // halo: 96 B per pixel, 118 slots per row
+    constexpr int LDM = 40, MROW = 88 * 8;                             // block-A tile: 80 B per pixel, 88 slots per row
+    constexpr int LDO = 72;                                            // output tile: 144 B per pixel
+    constexpr int IN_BYTES = HH * HROW * 2, MID_BYTES = RH * MROW * 2, OUT_BYTES = P * LDO * 2;
+    constexpr int NPF = (NH * 4 + kThreads - 1) / kThreads;            // halo items (16 B) per thread: 4
+    // Per-phase constants live in LDS, not in registers (the kernel needs 212 VGPRs with them resident, 168 is the budget of 3 workgroups per CU and at
+    // 2 the chain is slower than K_b2: 127 vs 102 us): bias vectors [10][16] fp32, the chained pointwise fragments [2 + 4][64 lanes] and block B's
+    // depthwise dwords [2][5][64]; each phase reads its share once per tile (4 + 2 (+ 10 narrow) reads per wave).
+    constexpr int BIAS_BYTES = 10 * 16 * 4, PWF_BYTES = 6 * 64 * 16, DWB_BYTES = 2 * 2 * kDwMmaChunks * 64 * 4;
+    static_assert(RW * LDM <= MROW && IN_BYTES % 16 == 0 && MID_BYTES % 16 == 0 && OUT_BYTES % 16 == 0 && BIAS_BYTES % 16 == 0, "LDS carve");
+    __shared__ __attribute__((aligned(16))) unsigned char s_raw[IN_BYTES + MID_BYTES + OUT_BYTES + BIAS_BYTES + PWF_BYTES + DWB_BYTES];
+    T *s_in = (T *)s_raw;                              // halo                (written in phase 1, read in phase A)
+    T *s_mid = (T *)(s_raw + IN_BYTES);                // block-A output tile (written in phase A, read in phase B)
+    T *s_out = (T *)(s_raw + IN_BYTES + MID_BYTES);    // output tile         (written in phase B, read by the store)
+    float *s_bias = (float *)(s_raw + IN_BYTES + MID_BYTES + OUT_BYTES);                       // [dwa 0,1 | pwa 0,1 | dwb 0,1 | pwb 0..3][16]
+    Frag *s_pwf = (Frag *)(s_raw + IN_BYTES + MID_BYTES + OUT_BYTES + BIAS_BYTES);             // [pwa 0,1 | pwb 0..3][64]
+    uint32_t *s_dwb = (uint32_t *)(s_raw + IN_BYTES + MID_BYTES + OUT_BYTES + BIAS_BYTES + PWF_BYTES);      // [block A | block B][2][5][64]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int G = gridDim.x;
+    const int first = xcd_remap(blockIdx.x, G);
+    const int kb = lane >> 4, m16 = lane & 15;
+    const int dsel = dw_mma_dword_index(lane);
+    RF_TRACE_KEY(a.nblk);
+
+    // ---- once per workgroup: weights.  Pointwise A fragments in the chained K order: halves 0-3 = channels 4 kb .. of group 0, 4-7 = of group 1
+    for (int i = tid; i < 2 * kDwMmaChunks * 64; i += kThreads) { s_dwb[i] = a.dwa_mma[i]; s_dwb[2 * kDwMmaChunks * 64 + i] = a.dwb_mma[i]; }
+    auto chained_frag = [&](const half_t *packed, int ct) -> Frag {
+        const uint2 *w8 = (const uint2 *)packed;
+        const uint2 lo = w8[((ct * 64) + (kb >> 1) * 16 + m16) * 2 + (kb & 1)];
+        const uint2 hi = w8[((ct * 64) + (2 + (kb >> 1)) * 16 + m16) * 2 + (kb & 1)];
+        const uint4 u = {lo.x, lo.y, hi.x, hi.y};
+        return __builtin_bit_cast(Frag, u);
+    };
+    const int cp = wave >> 1;                                          // phase B: this wave's pair of output-channel tiles
+    if (wave < 2) s_pwf[wave * 64 + lane] = chained_frag(a.pwa_w, wave);
+    s_pwf[(2 + wave) * 64 + lane] = chained_frag(a.pwb_w, wave);
+    if (tid < 160) {
+        const int v = tid >> 4, c = tid & 15;
+        s_bias[tid] = v < 2 ? a.dwa_b[v * 16 + c] : v < 4 ? a.pwa_b[(v - 2) * 16 + c] : v < 6 ? a.dwb_b[(v - 4) * 16 + c] : a.pwb_b[(v - 6) * 16 + c];
+    }
+    auto bias_of = [&](int v) -> f32x4 { return *(const f32x4 *)(s_bias + v * 16 + kb * 4); };       // (first read after the loop's first barrier)
+    auto dw_frag = [&](uint32_t wd) -> Frag {          // diagonal depthwise A fragment from its one dword per lane
+        typedef uint32_t u32x4_ __attribute__((ext_vector_type(4)));
+        asm volatile("" : "+v"(wd));
+        u32x4_ wa;
+#pragma unroll
+        for (int d = 0; d < 4; d++) wa[d] = dsel == d ? wd : 0u;
+        return __builtin_bit_cast(Frag, wa);
+    };
+    auto chain = [&](const M::Acc &g0, const M::Acc &g1) -> Frag {     // two ReLU'd fp16 accumulator tiles = the next GEMM's B fragment
+        const uint4 u = {pack_f16(g0[0], g0[1], true), pack_f16(g0[2], g0[3], true), pack_f16(g1[0], g1[1], true), pack_f16(g1[2], g1[3], true)};
+        return __builtin_bit_cast(Frag, u);
+    };
+    // per-lane constants of the wave's phase-A pixel tiles
+    int pa_base[UA], pa_yx[UA];                                        // pa_yx: (ry << 16 | rx), ry poisoned for tail lanes (p >= NR)
+#pragma unroll
+    for (int i = 0; i < UA; i++) {
+        const int p = (wave + 4 * i) * 16 + m16;
+        const int pc = p < NR ? p : NR - 1;
+        const int ry = pc / RW, rx = pc % RW;
+        pa_yx[i] = ((p < NR ? ry : 0x4000) << 16) | rx;
+        pa_base[i] = ry * HROW + rx * LD + (kb & 1) * 8;
+    }
+    const bool hi = lane >= 32;                                        // chunk kc carries tap 2 kc (lanes 0..31) and 2 kc + 1 (lanes 32..63)
+    auto tap_a = [&](int kc) -> int { const int t0 = 2 * kc, t1 = 2 * kc + 1; return hi ? (t1 < 9 ? (t1 / 3) * HROW + (t1 % 3) * LD : -1) : (t0 / 3) * HROW + (t0 % 3) * LD; };
+    auto tap_b = [&](int kc) -> int { const int t0 = 2 * kc, t1 = 2 * kc + 1; return hi ? (t1 < 9 ? (t1 / 3) * MROW + (t1 % 3) * LDM : -1) : (t0 / 3) * MROW + (t0 % 3) * LDM; };
+    const int pb = (wave & 1) * 16 + m16;                              // phase B: the lane's output pixel
+    const int pb_base = ((pb / TW) * 2) * MROW + ((pb % TW) * 2) * LDM + (kb & 1) * 8;
+    const int pb_out = pb * LDO + kb * 4;
+
+    // halo of a tile -> registers (unconditional buffer loads; rows / columns outside the map read as zero = depthwise A's padding)
+    V pre[NPF];
+    int kdx[NPF];                                                      // halo column | halo row << 5 | LDS offset of the item (halfs) << 9
+#pragma unroll
+    for (int k = 0; k < NPF; k++) {
+        int i = tid + k * kThreads;
+        i = i < NH * 4 ? i : NH * 4 - 1;
+        const int pix = i >> 2, cv = i & 3;
+        kdx[k] = (pix % HW) | ((pix / HW) << 5) | (((pix / HW) * HROW + (pix % HW) * LD + cv * 8) << 9);
+    }
+    const int cv16 = (tid & 3) * 16;                                   // the item's 16-byte channel chunk (kThreads is a multiple of 4)
+    const unsigned in_img_bytes = (unsigned)(a.hin * a.win * CI) * 2u;
+    auto fetch = [&](int tx, int ty, int img) {
+        const auto rs = image_rsrc(a.in + (size_t)img * a.hin * a.win * CI, in_img_bytes);
+        const int iy0 = 2 * ty * TH - 2, ix0 = 2 * tx * TW - 2;
+        const int sbase = (iy0 * a.win + ix0) * CI * 2 + cv16;
+        const int rowb = a.win * CI * 2;
+#pragma unroll
+        for (int k = 0; k < NPF; k++) {
+            const int col = kdx[k] & 31, row = (kdx[k] >> 5) & 15;
+            const unsigned off = (unsigned)(ix0 + col) < (unsigned)a.win ? (unsigned)(row * rowb + col * (CI * 2) + sbase) : kOobOffset;
+            pre[k] = buf_load16<V>(rs, off);
+        }
+    };
+    const TileStep step(G, a.tiles_x, a.tiles_y);
+    TileCoord cur(first, a.tiles_x, a.tiles_y), nxt = cur;
+    step.advance(nxt);
+    if (first < a.nblk) fetch(cur.tx, cur.ty, cur.img);
+    __builtin_amdgcn_s_waitcnt(0x0F70);       // vmcnt(0): the once-per-workgroup loads have landed; in the loop only the prefetch is in flight
+
+    for (int t = first; t < a.nblk; t += G) {
+        const int oy0 = cur.ty * TH, ox0 = cur.tx * TW, img = cur.img;
+        // ---- phase 1: prefetched halo -> LDS, next tile's halo requested
+#pragma unroll
+        for (int k = 0; k < NPF; k++) {
+            const int i = tid + k * kThreads;
+            if (i < NH * 4) *(V *)(s_in + (kdx[k] >> 9)) = pre[k];
+        }
+        if (t + G < a.nblk) fetch(nxt.tx, nxt.ty, nxt.img);
+        cur = nxt;
+        step.advance(nxt);
+        __syncthreads();
+
+        // ---- phase A: depthwise A (both channel groups) -> registers -> pointwise A (both channel tiles) -> block-A tile, zero outside the map
+        {
+            M::Acc acc[UA][2];
+            {
+                const f32x4 b0 = bias_of(0), b1 = bias_of(1);
+#pragma unroll
+                for (int i = 0; i < UA; i++) { acc[i][0] = b0; acc[i][1] = b1; }
+            }
+            // one chunk's six B fragments ahead of the MFMAs, pinned: left alone the scheduler hoists all five chunks' reads (120 registers) and spills
+            Frag bf[2][UA][2];
+            uint32_t dwd[2][2];
+            auto load_chunk = [&](int kc, Frag (&b)[UA][2], uint32_t (&d)[2]) {
+#pragma unroll
+                for (int i = 0; i < UA; i++)
+#pragma unroll
+                    for (int g = 0; g < 2; g++) b[i][g] = tap_a(kc) >= 0 ? *(const Frag *)(s_in + pa_base[i] + tap_a(kc) + g * 16) : M::zero();
+                d[0] = s_dwb[kc * 64 + lane]; d[1] = s_dwb[(kDwMmaChunks + kc) * 64 + lane];
+            };
+            load_chunk(0, bf[0], dwd[0]);
+#pragma unroll
+            for (int kc = 0; kc < kDwMmaChunks; kc++) {
+                if (kc + 1 < kDwMmaChunks) load_chunk(kc + 1, bf[(kc + 1) & 1], dwd[(kc + 1) & 1]);
+                __builtin_amdgcn_sched_barrier(0);
+                const Frag af0 = dw_frag(dwd[kc & 1][0]), af1 = dw_frag(dwd[kc & 1][1]);
+#pragma unroll
+                for (int i = 0; i < UA; i++) {
+                    acc[i][0] = M::mma(af0, bf[kc & 1][i][0], acc[i][0]);
+                    acc[i][1] = M::mma(af1, bf[kc & 1][i][1], acc[i][1]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            const Frag pwa[2] = {s_pwf[lane], s_pwf[64 + lane]};
+            const f32x4 pwa_b[2] = {bias_of(2), bias_of(3)};
+#pragma unroll
+            for (int i = 0; i < UA; i++) {                 // (pixel tiles 10 and 11 of waves 2 and 3 do not exist: computed on the last pixel, never stored)
+                {
+                    const Frag x = chain(acc[i][0], acc[i][1]);
+                    const int ry = pa_yx[i] >> 16, rx = pa_yx[i] & 0xffff;
+                    const int y = 2 * oy0 - 1 + ry, xx = 2 * ox0 - 1 + rx;
+                    T *const dst = s_mid + ry * MROW + rx * LDM + kb * 4;
+                    const bool inside = (unsigned)y < (unsigned)a.hin && (unsigned)xx < (unsigned)a.win;
+#pragma unroll
+                    for (int ct = 0; ct < 2; ct++) {
+                        const M::Acc o = M::mma(pwa[ct], x, pwa_b[ct]);
+                        uint2 h;
+                        h.x = inside ? pack_f16(o[0], o[1], true) : 0u;
+                        h.y = inside ? pack_f16(o[2], o[3], true) : 0u;
+                        if (ry < 0x4000) *(uint2 *)(dst + ct * 16) = h;      // (tail lanes of the last tile own no pixel)
+                    }
+                }
+            }
+        }
+        __syncthreads();
+
+        // ---- phase B: depthwise B (stride 2, both groups) -> registers -> pointwise B (this wave's two channel tiles) -> output tile
+        {
+            M::Acc d0 = bias_of(4), d1 = bias_of(5);
+            uint32_t dwb[2][kDwMmaChunks];
+#pragma unroll
+            for (int g = 0; g < 2; g++)
+#pragma unroll
+                for (int kc = 0; kc < kDwMmaChunks; kc++) dwb[g][kc] = s_dwb[((2 + g) * kDwMmaChunks + kc) * 64 + lane];
+            const Frag pwb[2] = {s_pwf[(2 + 2 * cp) * 64 + lane], s_pwf[(3 + 2 * cp) * 64 + lane]};
+            const f32x4 pwb_b[2] = {bias_of(6 + 2 * cp), bias_of(7 + 2 * cp)};
+            Frag bf[kDwMmaChunks][2];
+#pragma unroll
+            for (int kc = 0; kc < kDwMmaChunks; kc++)
+#pragma unroll
+                for (int g = 0; g < 2; g++) bf[kc][g] = tap_b(kc) >= 0 ? *(const Frag *)(s_mid + pb_base + tap_b(kc) + g * 16) : M::zero();
+#pragma unroll
+            for (int kc = 0; kc < kDwMmaChunks; kc++) {
+                d0 = M::mma(dw_frag(dwb[0][kc]), bf[kc][0], d0);
+                d1 = M::mma(dw_frag(dwb[1][kc]), bf[kc][1], d1);
+            }
+            const Frag x = chain(d0, d1);
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                const M::Acc o = M::mma(pwb[j], x, pwb_b[j]);
+                uint2 h;
+                h.x = pack_f16(o[0], o[1], true);
+                h.y = pack_f16(o[2], o[3], true);
+                *(uint2 *)(s_out + pb_out + (2 * cp + j) * 16) = h;
+            }
+        }
+        __syncthreads();
+
+        // ---- store: 32 px x 64 ch tile -> HBM, one 16-byte item per thread (s_out is next written after two more barriers)
+        {
+            const auto ro = image_rsrc(a.out + (size_t)img * a.hout * a.wout * CB, (unsigned)(a.hout * a.wout * CB) * 2u);
+            const int p = tid >> 3, cv = tid & 7;
+            const int py = p / TW, px = p % TW;
+            const unsigned off = ox0 + px < a.wout ? (unsigned)((((oy0 + py) * a.wout + ox0 + px) * CB + cv * 8) * 2) : kOobOffset;
+            buf_store16(ro, off, *(const V *)(s_out + p * LDO + cv * 8));
+        }
+    }
+}
+
 void launch_dwpw2(hipStream_t s, const DwPw2Params &p) {
     DwPw2Args a;
     a.in = p.in; a.out = p.out;
@@ -2252,14 +2555,38 @@ void launch_dwpw2(hipStream_t s, const DwPw2Params &p) {
     static int ring = -1;
     if (ring < 0) { const char *e = getenv("RF_DWPW2_RING"); ring = e ? atoi(e) : 0; }      // measured and rejected: 107 -> 232 us (the ring costs 8 more registers than the 168-VGPR budget of 3 workgroups per CU has: spills)
     a.ring = ring;
+    static int chain = -1;
+    if (chain < 0) { const char *e = getenv("RF_DWPW2_CHAIN"); chain = e ? atoi(e) : 0; }   // probe knob: 1 = K_b2c, the register-chained form (measured: LDS cycles halved, 110.8 vs 100.5 us -- its serial chains are longer)
+    if (chain && !ring) {
+        static std::atomic<int> resident_cachec[kMaxDevices] = {};
+        const int resident = kernel_residency(resident_cachec, dwpw2c_kernel, 0);
+        hipLaunchKernelGGL(dwpw2c_kernel, dim3(persistent_grid(a.nblk, resident)), dim3(kThreads), 0, s, a);
+        return;
+    }
     static std::atomic<int> resident_cache[kMaxDevices] = {};
     if (ring) {
-        const int resident = kernel_residency(resident_cache, dwpw2_kernel<true>, 0);
-        hipLaunchKernelGGL(dwpw2_kernel<true>, dim3(persistent_grid(a.nblk, resident)), dim3(kThreads), 0, s, a);
+        const int resident = kernel_residency(resident_cache, dwpw2_kernel<true, true, false>, 0);
+        hipLaunchKernelGGL((dwpw2_kernel<true, true, false>), dim3(persistent_grid(a.nblk, resident)), dim3(kThreads), 0, s, a);
     } else {
-        static std::atomic<int> resident_cache0[kMaxDevices] = {};
-        const int resident = kernel_residency(resident_cache0, dwpw2_kernel<false>, 0);
-        hipLaunchKernelGGL(dwpw2_kernel<false>, dim3(persistent_grid(a.nblk, resident)), dim3(kThreads), 0, s, a);
+        static int hpad = -1;
+        if (hpad < 0) { const char *e = getenv("RF_DWPW2_HPAD"); hpad = e ? atoi(e) : 1; }      // probe knob: 0 = unpadded halo rows (round 3)
+        if (hpad) {
+            static std::atomic<int> resident_cache0[kMaxDevices] = {};
+            static int lay2 = -1;
+            if (lay2 < 0) { const char *e = getenv("RF_DWPW2_LAY2"); lay2 = e ? atoi(e) : 1; }      // probe knob: 0 = 96-byte pitches everywhere (round 3)
+            if (lay2) {
+                const int resident = kernel_residency(resident_cache0, dwpw2_kernel<false, true, true>, 0);
+                hipLaunchKernelGGL((dwpw2_kernel<false, true, true>), dim3(persistent_grid(a.nblk, resident)), dim3(kThreads), 0, s, a);
+            } else {
+                static std::atomic<int> resident_cache2[kMaxDevices] = {};
+                const int resident = kernel_residency(resident_cache2, dwpw2_kernel<false, true, false>, 0);
+                hipLaunchKernelGGL((dwpw2_kernel<false, true, false>), dim3(persistent_grid(a.nblk, resident)), dim3(kThreads), 0, s, a);
+            }
+        } else {
+            static std::atomic<int> resident_cache1[kMaxDevices] = {};
+            const int resident = kernel_residency(resident_cache1, dwpw2_kernel<false, false, false>, 0);
+            hipLaunchKernelGGL((dwpw2_kernel<false, false, false>), dim3(persistent_grid(a.nblk, resident)), dim3(kThreads), 0, s, a);
+        }
     }
 }
 
