@@ -815,7 +815,7 @@ struct Stem2Args {
     int ho, wo, ho4, wo4, tiles_x, tiles_y, nblk;   // ho x wo = conv0 / conv2 map (net / 2), ho4 x wo4 = conv4 map (net / 4)
 };
 
-template <int TW_, bool F16P, int PADKB = 0>
+template <int TW_, bool F16P, int PADKB = 0, int V2 = 1>
 __global__ __launch_bounds__((Stem2Cfg<TW_, F16P, PADKB>::THREADS), (Stem2Cfg<TW_, F16P, PADKB>::OCC)) void stem2_kernel(Stem2Args a) {
     typedef Stem2Cfg<TW_, F16P, PADKB> C;
     constexpr int NT = C::THREADS, NW = NT / 64;         // threads / waves per workgroup
@@ -836,6 +836,13 @@ __global__ __launch_bounds__((Stem2Cfg<TW_, F16P, PADKB>::THREADS), (Stem2Cfg<TW
     T *s_out = (T *)(s_raw + C::A1_BYTES);                       // conv4 tile                      (phases 6-7)
     float *s_c0 = (float *)(s_raw + C::REGION_A);                // fp32 conv0 tile                 (phases 2-3)
     T *s_c2 = (T *)(s_raw + C::REGION_A);                        // fp16 conv2 tile                 (phases 4-5)
+    // V2 (round 4, from the LDS counters: this kernel's LDS pipe is busy 0.79 of the time, 0.31 in conflict cycles): (1) the conv2 tile as two 8-channel
+    // PLANES of 16 bytes per pixel instead of 32-byte pixels -- its 8-byte epilogue writes were 4-way bank conflicts at the 32-byte pitch, 2-way now, the
+    // stride-2 fragment reads of conv3 are unchanged (2-way); (2) conv3 -> conv4 chained in registers (see K_b2c): conv4's K axis is re-ordered so that a
+    // lane's conv3 accumulator IS its conv4 B fragment {d0, d1, d0, d1} (hi | lo weights): no conv3 tile in LDS, one barrier less.
+    constexpr bool PLANAR = (V2 & 1) != 0, CHAIN = (V2 & 2) != 0;      // V2: bit 0 = (1), bit 1 = (2)
+    constexpr int C2_PLANE = PLANAR ? C::T2 * 16 * 8 + 8 : 0;    // halfs; an odd number of 16-byte slots, so the two planes' lanes never share a slot
+    static_assert(!PLANAR || 2 * C2_PLANE * 2 <= C::REGION_B, "planar conv2 tile fits region B");
     float *s_dw0 = (float *)(s_raw + C::REGION_A + C::REGION_B);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1036,13 +1043,28 @@ __global__ __launch_bounds__((Stem2Cfg<TW_, F16P, PADKB>::THREADS), (Stem2Cfg<TW
         uint2 h;
         h.x = inside ? pack_f16_floor(acc[0], acc[1], c2_floor.x) : c2_floor.x;
         h.y = inside ? pack_f16_floor(acc[2], acc[3], c2_floor.y) : c2_floor.y;
-        *(uint2 *)(s_c2 + i * 16 + kb * 4) = h;
+        if constexpr (PLANAR) *(uint2 *)(s_c2 + (kb >> 1) * C2_PLANE + i * 8 + (kb & 1) * 4) = h;
+        else *(uint2 *)(s_c2 + i * 16 + kb * 4) = h;
     }
     uint32_t dw1v[kDwMmaChunks];                             // phase 5's operands: requested before the barrier
 #pragma unroll
     for (int kc = 0; kc < kDwMmaChunks; kc++) dw1v[kc] = a.dw1_mma[kc * 64 + lane];
     const f32x4 dbias = *(const f32x4 *)(a.dw1_b + kb * 4);           // bias + mu2 * sum(taps) - mu3 (host)
     const uint2 c3_floor = *(const uint2 *)(a.c3_floor + kb * 2);     // the conv3 result is stored centred as well (conv4 is 1x1: its bias takes W mu3)
+    // V2: conv4's operands too (its A fragments in the chained K order: halves 0-3 = W_hi of channels 4 kb .., 4-7 = W_lo of the same channels)
+    M::Frag pw1c[2];
+    f32x4 pw1cb[2];
+    if constexpr (CHAIN) {
+        const uint2 *w8 = (const uint2 *)a.pw1_w;
+#pragma unroll
+        for (int ct = 0; ct < 2; ct++) {
+            const uint2 lo = w8[((ct * 64) + (kb >> 1) * 16 + (lane & 15)) * 2 + (kb & 1)];
+            const uint2 hi = w8[((ct * 64) + (2 + (kb >> 1)) * 16 + (lane & 15)) * 2 + (kb & 1)];
+            const uint4 u = {lo.x, lo.y, hi.x, hi.y};
+            pw1c[ct] = __builtin_bit_cast(M::Frag, u);
+            pw1cb[ct] = *(const f32x4 *)(a.pw1_b + ct * 16 + kb * 4);
+        }
+    }
     RF_TRACE(4, 4);
     __syncthreads();
 
@@ -1058,12 +1080,13 @@ __global__ __launch_bounds__((Stem2Cfg<TW_, F16P, PADKB>::THREADS), (Stem2Cfg<TW
         for (int pt = wave; pt < C::T4; pt += NW) {
             const int p = pt * 16 + (lane & 15);
             const int py = p / TW, px = p % TW;             // p >= P4: reads past the tile's last row (inside this workgroup's LDS), result never stored
-            const T *src = s_c2 + ((2 * py) * R2W + 2 * px) * 16 + (kb & 1) * 8;
+            constexpr int PXH = PLANAR ? 8 : 16;            // halfs per pixel of the tile (plane)
+            const T *src = PLANAR ? s_c2 + (kb & 1) * C2_PLANE + ((2 * py) * R2W + 2 * px) * 8 : s_c2 + ((2 * py) * R2W + 2 * px) * 16 + (kb & 1) * 8;
             M::Frag bf[kDwMmaChunks];
 #pragma unroll
             for (int kc = 0; kc < kDwMmaChunks; kc++) {
                 const int t0 = 2 * kc, t1 = 2 * kc + 1;
-                const int o0 = ((t0 / 3) * R2W + t0 % 3) * 16, o1 = t1 < 9 ? ((t1 / 3) * R2W + t1 % 3) * 16 : o0;      // tap 9 does not exist: its A columns are zero
+                const int o0 = ((t0 / 3) * R2W + t0 % 3) * PXH, o1 = t1 < 9 ? ((t1 / 3) * R2W + t1 % 3) * PXH : o0;      // tap 9 does not exist: its A columns are zero
                 bf[kc] = *(const M::Frag *)(src + (hi_tap ? o1 : o0));
             }
             f32x4 acc = dbias;
@@ -1079,13 +1102,27 @@ __global__ __launch_bounds__((Stem2Cfg<TW_, F16P, PADKB>::THREADS), (Stem2Cfg<TW
             uint2 h;
             h.x = pack_f16_floor(acc[0], acc[1], c3_floor.x);
             h.y = pack_f16_floor(acc[2], acc[3], c3_floor.y);
-            *(uint2 *)(s_a1 + p * LDA1 + kb * 4) = h;      // region A again: the conv1 result is dead since the barrier after phase 4
+            if constexpr (CHAIN) {
+                const uint4 u = {h.x, h.y, h.x, h.y};
+                const M::Frag x = __builtin_bit_cast(M::Frag, u);
+#pragma unroll
+                for (int ct = 0; ct < 2; ct++) {
+                    const f32x4 o = M::mma(pw1c[ct], x, pw1cb[ct]);
+                    uint2 g;
+                    g.x = pack_f16(o[0], o[1], true);
+                    g.y = pack_f16(o[2], o[3], true);
+                    *(uint2 *)(s_out + p * LDO + ct * 16 + kb * 4) = g;      // region A: the conv1 result is dead since the barrier after phase 4
+                }
+            } else {
+                *(uint2 *)(s_a1 + p * LDA1 + kb * 4) = h;      // region A again: the conv1 result is dead since the barrier after phase 4
+            }
         }
     }
-    const f16x8 pw1_frag0 = ((const f16x8 *)a.pw1_w)[lane], pw1_frag1 = ((const f16x8 *)a.pw1_w)[64 + lane];      // phase 6's operands
-    const f32x4 pw1_bias0 = *(const f32x4 *)(a.pw1_b + kb * 4), pw1_bias1 = *(const f32x4 *)(a.pw1_b + 16 + kb * 4);
     RF_TRACE(4, 5);
     __syncthreads();
+    if constexpr (!CHAIN) {
+    const f16x8 pw1_frag0 = ((const f16x8 *)a.pw1_w)[lane], pw1_frag1 = ((const f16x8 *)a.pw1_w)[64 + lane];      // phase 6's operands
+    const f32x4 pw1_bias0 = *(const f32x4 *)(a.pw1_b + kb * 4), pw1_bias1 = *(const f32x4 *)(a.pw1_b + 16 + kb * 4);
 
     // ---- phase 6: pointwise conv4 (16 -> 32) on MFMA: 2 channel tiles x T4 pixel tiles.  K = 16, and the MFMA has 32 slots: the
     //      weights ride as an fp16 hi | lo pair along K (both halves read the same 16 inputs), so their rounding costs nothing
@@ -1101,6 +1138,7 @@ __global__ __launch_bounds__((Stem2Cfg<TW_, F16P, PADKB>::THREADS), (Stem2Cfg<TW
     }
     RF_TRACE(4, 6);
     __syncthreads();
+    }
 
     // ---- phase 7: tile -> HBM, 16 B per lane; rows below the map fall outside the descriptor, columns need the test
     {
@@ -1133,16 +1171,23 @@ void launch_stem2(hipStream_t s, const Stem2Params &p) {
     const int tw = v == 2 ? 16 : 8;
     a.tiles_x = (a.wo4 + tw - 1) / tw; a.tiles_y = (a.ho4 + 6) / 7;
     a.nblk = p.n * a.tiles_x * a.tiles_y;
-    if (tw == 16) hipLaunchKernelGGL((stem2_kernel<16, false>), dim3(a.nblk), dim3(Stem2Cfg<16, false>::THREADS), 0, s, a);
-    else if (v == 3) hipLaunchKernelGGL((stem2_kernel<8, true>), dim3(a.nblk), dim3(kThreads), 0, s, a);
+    if (tw == 16) hipLaunchKernelGGL((stem2_kernel<16, false, 0, 0>), dim3(a.nblk), dim3(Stem2Cfg<16, false>::THREADS), 0, s, a);
+    else if (v == 3) hipLaunchKernelGGL((stem2_kernel<8, true, 0, 0>), dim3(a.nblk), dim3(kThreads), 0, s, a);
     else {
         // RF_STEM2_PAD (probe knob): 3 / 7 KB of unused LDS per workgroup = 7 / 6 workgroups per CU instead of 8: stem2 alone gets slower
         // (+3.5 % / +10 %), but at 8 it owns every wave slot of the chip and nothing of another lane can run beside it
         static int pad = -1;
         if (pad < 0) { const char *e = getenv("RF_STEM2_PAD"); pad = e ? atoi(e) : 0; }
-        if (pad == 3) hipLaunchKernelGGL((stem2_kernel<8, false, 3>), dim3(a.nblk), dim3(kThreads), 0, s, a);
-        else if (pad == 7) hipLaunchKernelGGL((stem2_kernel<8, false, 7>), dim3(a.nblk), dim3(kThreads), 0, s, a);
-        else hipLaunchKernelGGL((stem2_kernel<8, false>), dim3(a.nblk), dim3(kThreads), 0, s, a);
+        if (pad == 3) hipLaunchKernelGGL((stem2_kernel<8, false, 3, 0>), dim3(a.nblk), dim3(kThreads), 0, s, a);
+        else if (pad == 7) hipLaunchKernelGGL((stem2_kernel<8, false, 7, 0>), dim3(a.nblk), dim3(kThreads), 0, s, a);
+        else {
+            static int v2 = -1;
+            if (v2 < 0) { const char *e = getenv("RF_STEM2_V2"); v2 = e ? atoi(e) : 1; }      // probe knob: bit 0 = planar conv2 tile, bit 1 = conv3 -> conv4 chained in registers; 0 = round 3
+            if (v2 == 3) hipLaunchKernelGGL((stem2_kernel<8, false, 0, 3>), dim3(a.nblk), dim3(kThreads), 0, s, a);
+            else if (v2 == 2) hipLaunchKernelGGL((stem2_kernel<8, false, 0, 2>), dim3(a.nblk), dim3(kThreads), 0, s, a);
+            else if (v2 == 1) hipLaunchKernelGGL((stem2_kernel<8, false, 0, 1>), dim3(a.nblk), dim3(kThreads), 0, s, a);
+            else hipLaunchKernelGGL((stem2_kernel<8, false, 0, 0>), dim3(a.nblk), dim3(kThreads), 0, s, a);
+        }
     }
 }
 
