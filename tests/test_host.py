@@ -513,3 +513,23 @@ def test_bench_physical_fractions_pick_the_binding_resource():
     # without the SQ pass only the traffic is known
     r = bench.physical_fractions([dict(stem2, valu_quad=None, lds_quad=None, mfma_cycles=None)], 0.267, 1024)
     assert r["bound"] == "hbm" and "valu_active" not in r
+
+
+def test_lds_model_known_cases():
+    """tools/lds_model.py (the LDS-array cycle model behind dwpw2's and stem2's tile layouts): the guide's published cases and the
+    three dwpw2 layouts whose totals the SQ_LDS_IDX_ACTIVE counter confirmed on the GPU (521 / 449 / 365 cycles per wave and tile)."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import lds_model as m
+    # 64 lanes x 16 contiguous bytes: conflict-free in every instruction's lane groups
+    assert m.array_cycles("read_b128", lambda l: l * 16) == 4 and m.array_cycles("write_b128", lambda l: l * 16) == 8
+    # B fragments of 16 consecutive pixels: free at a pitch of 32 mod 64 bytes, 2-way at 80 bytes
+    frag = lambda pitch: (lambda l: (l & 15) * pitch + (l >> 4) * 16)
+    assert m.array_cycles("read_b128", frag(96)) == 4 and m.array_cycles("read_b128", frag(160)) == 4 and m.array_cycles("read_b128", frag(80)) == 8
+    # the 8-byte epilogue write of 16 pixels x 4 channels: 4-way at a multiple of 32 bytes, 2-way at an odd multiple of 16
+    epi = lambda pitch: (lambda l: (l & 15) * pitch + (l >> 4) * 8)
+    assert m.array_cycles("write_b64", epi(96)) == 16 and m.array_cycles("write_b64", epi(32)) == 16
+    assert m.array_cycles("write_b64", epi(80)) == 8 and m.array_cycles("write_b64", epi(144)) == 8 and m.array_cycles("write_b64", epi(16)) == 8
+    # identical addresses broadcast
+    assert m.array_cycles("read_b128", lambda l: 0) == 4
+    old, pad, new = (sum(m.dwpw2(**kw).values()) for kw in (dict(lay2=False, hpad=False), dict(lay2=False, hpad=True), dict(lay2=True, hpad=True)))
+    assert abs(old - 521) <= 0.06 * 521 and abs(pad - 449) <= 0.06 * 449 and abs(new - 365) <= 0.06 * 365, (old, pad, new)
