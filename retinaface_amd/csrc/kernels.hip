@@ -841,6 +841,7 @@ __global__ __launch_bounds__((Stem2Cfg<TW_, F16P, PADKB>::THREADS), (Stem2Cfg<TW
     // stride-2 fragment reads of conv3 are unchanged (2-way); (2) conv3 -> conv4 chained in registers (see K_b2c): conv4's K axis is re-ordered so that a
     // lane's conv3 accumulator IS its conv4 B fragment {d0, d1, d0, d1} (hi | lo weights): no conv3 tile in LDS, one barrier less.
     constexpr bool PLANAR = (V2 & 1) != 0, CHAIN = (V2 & 2) != 0;      // V2: bit 0 = (1), bit 1 = (2)
+    constexpr bool ROT = (V2 & 4) != 0 && C::R2W == 17 && NT == 256;   //     bit 2 = the depthwise-1 phase's thread -> pixel map (phase 3)
     constexpr int C2_PLANE = PLANAR ? C::T2 * 16 * 8 + 8 : 0;    // halfs; an odd number of 16-byte slots, so the two planes' lanes never share a slot
     static_assert(!PLANAR || 2 * C2_PLANE * 2 <= C::REGION_B, "planar conv2 tile fits region B");
     float *s_dw0 = (float *)(s_raw + C::REGION_A + C::REGION_B);
@@ -987,7 +988,20 @@ __global__ __launch_bounds__((Stem2Cfg<TW_, F16P, PADKB>::THREADS), (Stem2Cfg<TW
         for (int e = 0; e < 8; e++) dw_bias[e] = a.dw0_b[e];
 #pragma unroll 1
         for (int i = tid; i < C::T2 * 16; i += NT) {
-            const int ry = i / R2W, rx = i % R2W;
+            // which region pixel a thread computes.  V2 bit 2 (ROT, 17-wide regions): rows of 16 lanes with the column ROTATED by 3 per row, so that
+            // a lane's conv0-tile slot (19 ry + rx) mod 16 is its lane index mod 16 whatever the row -- every 16-lane group of the 18 ds_read_b128 per
+            // thread then meets 16 distinct slots; with pixel = thread index the groups straddled a 17-pixel row and every read was 2-way (tools/lds_model.py:
+            // 144 -> 72 LDS cycles per wave).  The 17th column goes to threads 240..254.  Same arithmetic per pixel: bit-identical.
+            auto pixel_of = [&](int &ry, int &rx) {
+                if constexpr (ROT) {
+                    if (i < 240) { ry = i >> 4; rx = ((i & 15) - 3 * ry) & 15; }
+                    else { ry = i - 240; rx = 16; }
+                } else {
+                    ry = i / R2W; rx = i % R2W;
+                }
+            };
+            int ry, rx;
+            pixel_of(ry, rx);
             float acc[8];
 #pragma unroll
             for (int e = 0; e < 8; e++) acc[e] = dw_bias[e];
@@ -1011,8 +1025,15 @@ __global__ __launch_bounds__((Stem2Cfg<TW_, F16P, PADKB>::THREADS), (Stem2Cfg<TW
                 hi[e] = (half_t)v;
                 lo[e] = (half_t)(v - (float)hi[e]);
             }
-            *(f16x8 *)(s_a + i * 16) = hi;           // region A: the staged patch is dead since the barrier after phase 2
-            *(f16x8 *)(s_a + i * 16 + 8) = lo;
+            int po = i;                               // the pixel's slot in the conv1 tile (recomputed here: one register less across the taps)
+            if constexpr (ROT) {
+                asm volatile("" ::: "memory");
+                int ry2, rx2;
+                pixel_of(ry2, rx2);
+                po = i < N2 ? ry2 * R2W + rx2 : i;        // (thread 255 owns no pixel: it keeps its old slot)
+            }
+            *(f16x8 *)(s_a + po * 16) = hi;          // region A: the staged patch is dead since the barrier after phase 2
+            *(f16x8 *)(s_a + po * 16 + 8) = lo;
         }
     }
     const f16x8 pw0_frag = ((const f16x8 *)a.pw0_w)[lane];            // phase 4's operands: requested before the barrier
@@ -1182,8 +1203,12 @@ void launch_stem2(hipStream_t s, const Stem2Params &p) {
         else if (pad == 7) hipLaunchKernelGGL((stem2_kernel<8, false, 7, 0>), dim3(a.nblk), dim3(kThreads), 0, s, a);
         else {
             static int v2 = -1;
-            if (v2 < 0) { const char *e = getenv("RF_STEM2_V2"); v2 = e ? atoi(e) : 1; }      // probe knob: bit 0 = planar conv2 tile, bit 1 = conv3 -> conv4 chained in registers; 0 = round 3
-            if (v2 == 3) hipLaunchKernelGGL((stem2_kernel<8, false, 0, 3>), dim3(a.nblk), dim3(kThreads), 0, s, a);
+            // probe knob: bit 0 = planar conv2 tile, bit 1 = conv3 -> conv4 chained in registers (off: re-rolls conv4's rounding), bit 2 = rotated thread -> pixel
+            // map of the depthwise-1 phase; 0 = round 3.  Default 5: both layout changes, bit-identical to round 3 (250.3 -> 246.5 -> 238.6 us, tools/gpu/r4_call30.sh, r4_call32.sh)
+            if (v2 < 0) { const char *e = getenv("RF_STEM2_V2"); v2 = e ? atoi(e) : 5; }
+            if (v2 == 5) hipLaunchKernelGGL((stem2_kernel<8, false, 0, 5>), dim3(a.nblk), dim3(kThreads), 0, s, a);
+            else if (v2 == 7) hipLaunchKernelGGL((stem2_kernel<8, false, 0, 7>), dim3(a.nblk), dim3(kThreads), 0, s, a);
+            else if (v2 == 3) hipLaunchKernelGGL((stem2_kernel<8, false, 0, 3>), dim3(a.nblk), dim3(kThreads), 0, s, a);
             else if (v2 == 2) hipLaunchKernelGGL((stem2_kernel<8, false, 0, 2>), dim3(a.nblk), dim3(kThreads), 0, s, a);
             else if (v2 == 1) hipLaunchKernelGGL((stem2_kernel<8, false, 0, 1>), dim3(a.nblk), dim3(kThreads), 0, s, a);
             else hipLaunchKernelGGL((stem2_kernel<8, false, 0, 0>), dim3(a.nblk), dim3(kThreads), 0, s, a);

@@ -187,7 +187,7 @@ def test_synthetic_batch8_against_golden(rfa, stem, prec):
 
 @pytest.mark.parametrize("knob", ["RF_STEM2=0", "RF_STEM2=2", "RF_STEM2=3", "RF_DWPW2=0", "RF_CONV3=0", "RF_STEM2_DC=0", "RF_SSHTAIL=0", "RF_CONV3WS=0", "RF_CONV3WS=32",
                                   "RF_CONV3UPWS=0", "RF_CONV3UPWS=3", "RF_CONV3UPWS=13", "RF_DWPWWS=3", "RF_DWPWWS=13", "RF_TILE256=1", "RF_DWPW2_RING=1",
-                                  "RF_DWPW2_CHAIN=1", "RF_DWPW2_LAY2=0", "RF_DWPW2_HPAD=0", "RF_STEM2_V2=0", "RF_STEM2_V2=3"])
+                                  "RF_DWPW2_CHAIN=1", "RF_DWPW2_LAY2=0", "RF_DWPW2_HPAD=0", "RF_STEM2_V2=0", "RF_STEM2_V2=1", "RF_STEM2_V2=7"])
 def test_probe_knob_kernel_variants_stay_correct(rfa, knob):
     """The measured-and-rejected kernel variants DESIGN.md cites stay selectable (RF_* probe knobs, read once per process): each
     is held to the same fp16 parity bar as the default path, in a subprocess so that the knob is seen at library start-up.
@@ -197,8 +197,8 @@ def test_probe_knob_kernel_variants_stay_correct(rfa, knob):
     RF_CONV3UPWS=0 / 3 / 13: the aggregation convs on K_c / with a producer wave / with per-wave LDS-DMA and three ring buffers; RF_DWPWWS=3: the
     64- and 128-channel blocks warp-specialised (13: the memory side spread over the four GEMM waves); RF_TILE256=1: 8 x 8 tiles for the 256-channel block;
     RF_DWPW2_RING=1: dwpw2's depthwise A as a ring; RF_DWPW2_CHAIN=1: dwpw2 with the depthwise -> pointwise hops chained in registers (permuted K order);
-    RF_DWPW2_LAY2=0 / RF_DWPW2_HPAD=0: dwpw2 with round 3's LDS pitches / unpadded halo rows; RF_STEM2_V2=0: stem2's conv2 tile as 32-byte pixels (round 3),
-    3: planar tile + conv3 -> conv4 chained in registers."""
+    RF_DWPW2_LAY2=0 / RF_DWPW2_HPAD=0: dwpw2 with round 3's LDS pitches / unpadded halo rows; RF_STEM2_V2=0: stem2's conv2 tile as 32-byte pixels and pixel = thread index
+    in its depthwise-1 phase (round 3), 1: planar conv2 tile only, 7: both layout changes + conv3 -> conv4 chained in registers."""
     code = (
         "import sys, json; sys.path.insert(0, %r)\n"
         "import retinaface_amd\n"
