@@ -533,3 +533,6 @@ def test_lds_model_known_cases():
     assert m.array_cycles("read_b128", lambda l: 0) == 4
     old, pad, new = (sum(m.dwpw2(**kw).values()) for kw in (dict(lay2=False, hpad=False), dict(lay2=False, hpad=True), dict(lay2=True, hpad=True)))
     assert abs(old - 521) <= 0.06 * 521 and abs(pad - 449) <= 0.06 * 449 and abs(new - 365) <= 0.06 * 365, (old, pad, new)
+    # stem2: the rotated thread -> pixel map of the depthwise-1 phase and the planar conv2 tile
+    assert m.stem2_dw1_tap_reads(False) == 144 and m.stem2_dw1_tap_reads(True) <= 84
+    assert m.stem2_conv2_tile_write(False) == 16 and m.stem2_conv2_tile_write(True) == 8

@@ -89,6 +89,32 @@ def dwpw2(lay2, hpad):
     return out
 
 
+# ---------------------------------------------------------------------------------------------------------------------------------------
+# stem2 (kernels.hip K_a''), depthwise-1 phase: 256 threads, 9 taps x 2 channel planes of the fp32 conv0 tile (19 pixels wide, 16 bytes per pixel
+# and plane) per thread; rot = rows of 16 lanes with the column rotated by 3 per row instead of pixel = thread index
+def stem2_dw1_tap_reads(rot):
+    R2W, R0W = 17, 19
+    tot = 0
+    for wave in range(4):
+        for t in range(9):
+            def pix(l, wave=wave):
+                i = wave * 64 + l
+                if not rot:
+                    i = min(i, 254)
+                    return i // R2W, i % R2W
+                if i < 240:
+                    return i >> 4, ((i & 15) - 3 * (i >> 4)) & 15
+                return min(i - 240, 14), 16
+            tot += 2 * cycles("read_b128", lambda l, t=t: ((pix(l)[0] + t // 3) * R0W + pix(l)[1] + t % 3) * 16, active=lambda l, wave=wave: wave * 64 + l < 255)
+    return tot / 4
+
+
+def stem2_conv2_tile_write(planar):
+    if planar:
+        return cycles("write_b64", lambda l: ((l >> 4) >> 1) * 4112 + (l & 15) * 16 + ((l >> 4) & 1) * 8)
+    return cycles("write_b64", lambda l: (l & 15) * 32 + (l >> 4) * 8)
+
+
 def main():
     for name, kw in (("round 3 (96-byte pitches, unpadded halo rows)", dict(lay2=False, hpad=False)), ("padded halo rows", dict(lay2=False, hpad=True)),
                      ("round 4 (LAY2 + padded rows)", dict(lay2=True, hpad=True))):
@@ -97,6 +123,11 @@ def main():
         for k, v in d.items():
             print("    %-36s %6.0f" % (k, v))
     print("measured (SQ_LDS_IDX_ACTIVE / (tiles x 4 waves), 25088 tiles per launch): 521 -> 449 -> 365")
+    print("stem2, depthwise-1 tap reads per wave and tile: pixel = thread index %.0f, rotated rows of 16 %.0f (conflict-free: 72)" %
+          (stem2_dw1_tap_reads(False), stem2_dw1_tap_reads(True)))
+    print("stem2, one 8-byte epilogue write of the conv2 tile: 32-byte pixels %d, two 8-channel planes %d LDS cycles (x 4 per wave and tile)" %
+          (stem2_conv2_tile_write(False), stem2_conv2_tile_write(True)))
+    print("measured, whole kernel (SQ_LDS_IDX_ACTIVE / (57344 tiles x 4 waves)): 532 -> 437 with both")
 
 
 if __name__ == "__main__":
