@@ -34,9 +34,23 @@ collected while the CPU baseline runs) its binding resource.  With N > 1 a short
 global batch of 256 int8 images per step split over the ranks) follows the weak-scaling measurement (`configs4_strong`), and
 `result_gather` says which backend carried the gather, the communicator size seen through an RCCL collective and the RCCL version.
 
+`configs` also carries north_star's batch x frame-size matrix (round 5): fp16 448x448 at batch 1 and 32, 1280x896 at batch 8 and 32 -- the
+cells that are not BASELINE.json configs themselves -- and every entry has `sync_batch`: ONE synchronous rf_detect_batch_device call of that
+batch at a time, the reference's own calling convention (RetinaFace.cpp:749-940).
+
 `roofline.frac` is the PHYSICAL fraction of the dominant kernel's binding resource (HBM bytes moved, VALU / MFMA / LDS issue cycles,
-measured by rocprofv3 --pmc in this run): always <= 1.  The layer-wise algorithmic-bytes figure of SURVEY.md 8d, which counts bytes
-a fused kernel never moves and therefore exceeds 1, stays beside it as `frac_layerwise_credit` / `hbm_layerwise`.
+measured by rocprofv3 --pmc in this run): always <= 1, and null when no counter pass ran (the layer-wise figure is never substituted).
+It is an OCCUPANCY of that resource, not an efficiency: `roofline.useful` says how much of the HBM and matrix peaks is work the layers
+require (compulsory bytes of the fused launch / time / 8 TB/s; layer MACs x 2 / time / dense MFMA peak), and `kernel_ms_in_pipeline`
+is the same kernel's average duration in a single-lane rocprofv3 kernel trace of the timed loop (what throughput is made of) beside the
+back-to-back HIP-event figure.  The layer-wise algorithmic-bytes figure of SURVEY.md 8d, which counts bytes a fused kernel never moves
+and therefore exceeds 1, stays as `frac_layerwise_credit` / `hbm_layerwise`.
+
+With N > 1 rank 0 finally runs the LIBRARY leg (`library_multi_device`): ONE handle over devices [0 .. N-1] (rf_options.devices, multi.cpp:
+one engine + host thread per GPU, contiguous image slices), every frame resident on GPU 0, BASELINE.json configs[4] as stated -- 256 int8
+images per rf_detect_batch_device call -- so that the in-library split and the xGMI peer scatter are measured by the same run that
+measures the ranks (peer-access matrix, bytes scattered per call, images/s).  `--library-devices N` runs that leg alone (rehearsal on one
+GPU: the ordinals repeat and RF_FORCE_SCATTER makes every frame travel).
 """
 from __future__ import annotations
 
@@ -93,6 +107,9 @@ def parse_args(argv=None):
     ap.add_argument("--extra-seconds", type=float, default=0.4,
                     help="timed region of each additional BASELINE.json config the default invocation also measures (`configs`); 0 = skip")
     ap.add_argument("--no-extra-configs", action="store_true", help="measure only the configuration named by the flags")
+    ap.add_argument("--library-devices", type=int, default=0,
+                    help="run ONLY the library leg: one handle over this many device ordinals (wrapping around the visible GPUs), 256 int8 images per call")
+    ap.add_argument("--no-pipeline-trace", action="store_true", help="skip the single-lane rocprofv3 --kernel-trace pass (roofline.kernel_ms_in_pipeline)")
     ap.add_argument("--master-port", type=int, default=0)
     return ap.parse_args(argv)
 
@@ -233,6 +250,13 @@ def main() -> int:
     import numpy as np
     import torch
     import torch.distributed as dist
+
+    if args.library_devices > 0 and env_world is None:
+        leg = library_leg(args, args.library_devices, float(args.threshold), seconds=max(args.min_seconds, 0.3))
+        print(json.dumps({"metric": "faces/sec", "value": leg.get("faces_per_sec"), "unit": "faces/s", "n_gpus": leg.get("visible_gpus", 0),
+                          "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "i8", "data": "synthetic",
+                          "config": {"workload": leg.get("workload", "library leg (dry)")}, "library_multi_device": leg}), flush=True)
+        return 0
 
     world = int(env_world or "1")
     rank = int(os.environ.get("RANK", "0"))
@@ -413,26 +437,16 @@ def main() -> int:
             lat.append(time.perf_counter() - t)
         extra["sync_call_ms"] = float(np.median(lat) * 1e3)
         # the same call without the Python binding's per-call work (argument arrays and result objects built once): what a C / C++
-        # caller of the C ABI sees
-        import ctypes as C
-        from retinaface_amd._lib import rf_face
-        pa, ra, ca = (C.c_void_p * B)(*ptrs), (C.c_int * B)(*rows), (C.c_int * B)(*cols)
-        sa = (C.c_int * B)(*[3 * x for x in cols])
-        outb, cnt = (rf_face * (B * det.max_detections))(), (C.c_int * B)()
-        lat_c = []
-        for _ in range(200):
-            t = time.perf_counter()
-            det._lib.rf_detect_batch_device(det._h, pa, ra, ca, sa, B, C.c_float(args.threshold), outb, det.max_detections, cnt)
-            lat_c.append(time.perf_counter() - t)
-        extra["sync_call_ms_c_abi"] = float(np.median(lat_c[20:]) * 1e3)
-        # the reference's metric point as the reference measures it: ONE synchronous detectBatchImages of B device-resident
-        # frames at a time (RetinaFace.cpp:757 -> :920), nothing in flight besides it
-        nf = sum(len(r) for r in det.detect_device(ptrs, rows, cols, args.threshold))
-        extra["sync_batch"] = {"batch": B, "ms_per_call": extra["sync_call_ms_c_abi"], "ms_per_call_python_binding": extra["sync_call_ms"],
-                               "images_per_sec": B / (extra["sync_call_ms_c_abi"] * 1e-3), "faces_per_sec": nf / (extra["sync_call_ms_c_abi"] * 1e-3),
-                               "note": "one synchronous rf_detect_batch_device call at a time (no pipelining, no coalescing); `value` is the pipelined rate"}
+        # caller of the C ABI sees = the reference's metric point as the reference measures it: ONE synchronous detectBatchImages of B
+        # device-resident frames at a time (RetinaFace.cpp:757 -> :920), nothing in flight besides it
+        extra["sync_batch"] = sync_batch_measure(det, ptrs, H, W, args.threshold, reps=240)
+        extra["sync_batch"]["ms_per_call_python_binding"] = extra["sync_call_ms"]
+        extra["sync_call_ms_c_abi"] = extra["sync_batch"]["ms_per_call"]
         if args.host_seconds > 0:
             extra["host_frames"] = host_frames(det, frames_np, args, slots, B, run, rank)
+
+    # N > 1 (the driver's SCALE run): after everything the ranks measure together, rank 0 times the in-library split over the same N devices
+    with_library_leg = world > 1 and not strong and not args.timed_only and not args.no_extra_configs and args.extra_seconds > 0
 
     tt = torch.tensor([dt, float(faces)], dtype=torch.float64, device=cdev)
     if world > 1:
@@ -475,6 +489,11 @@ def main() -> int:
                                     "records_gathered": int(gather_state["images"].item()), "expected": images_total}
         if strong_leg is not None:
             out["configs4_strong"] = strong_leg
+        if with_library_leg:
+            try:
+                out["library_multi_device"] = library_leg(args, world, thr)
+            except Exception as e:  # noqa: BLE001
+                out["library_multi_device"] = {"error": f"{type(e).__name__}: {e}"}
         if args.dry:
             out["dry"] = True
         elif args.timed_only:
@@ -482,27 +501,63 @@ def main() -> int:
         else:
             out.update(extra)
             out.update(device_side_report(args, det, frames, B, H, W, per_launch, prec, images_total, world, dt_max))
-            pmc_thread = None
-            if (world == 1 and not args.no_extra_configs and args.extra_seconds > 0 and
-                    baseline_config(args).startswith("BASELINE.json configs[1]")):
+            with_configs = (world == 1 and not args.no_extra_configs and args.extra_seconds > 0 and
+                            baseline_config(args).startswith("BASELINE.json configs[1]"))
+            if with_configs:
                 out["configs"] = [dict(id=1, workload=out["config"]["workload"], images_per_sec=out["images_per_sec"], faces_per_sec=out["value"],
                                        ms_per_step=out["ms_per_step"], dtype=out["dtype"], dominant_kernel=out["roofline"]["kernel_instance"],
                                        dominant_kernel_ms=out["roofline"]["kernel_ms"], bound=out["roofline"]["bound"],
                                        bound_frac=out["roofline"]["bound_frac"], hbm_frac_measured=out["roofline"]["hbm_frac_measured"],
+                                       useful=out["roofline"]["useful"], sync_batch=out["sync_batch"],
                                        note="the metric point: this line's `value`")]
                 out["configs"] += [measure_extra_config(c, args, frames, dev) for c in EXTRA_CONFIGS]
-                pmc_thread = start_extra_counters(args, out["configs"][1:])       # runs beside the CPU baseline (the GPU is idle then)
+                _FRAME_CACHE.clear()
+            # the CPU baseline has the host to itself: every profiler pass of this run has either finished (the metric point's counters, inside
+            # device_side_report) or starts after it (round 4 ran the extra configs' passes beside it: 47-51 -> 40-51 images/s)
             if world == 1 and not args.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline(frames_np[:B], args, det)
-            if pmc_thread is not None:
-                finish_extra_counters(pmc_thread, out["configs"][1:], torch.cuda.get_device_properties(0).multi_processor_count)
+                out["cpu_baseline"]["ran_alone"] = "no profiler pass or GPU measurement of this run overlapped it"
+            if with_configs:
+                counted = [e for e in out["configs"][1:] if "_pmc" in e]
+                finish_extra_counters(start_extra_counters(args, counted), counted, torch.cuda.get_device_properties(0).multi_processor_count)
+            if world == 1:
+                attach_pipeline_trace(out["roofline"], measure_pipeline_trace(args))
         assert out["n_gpus"] == args.gpus
         print(json.dumps(out), flush=True)
     det.close()
     if world > 1:
+        if with_library_leg:
+            # the other ranks released their engines above and wait HERE, on the rendezvous store (host side): rank 0 may still be in the library leg
+            import datetime
+            store = dist.distributed_c10d._get_default_store()
+            if rank == 0:
+                store.set("rf_library_leg", "done")
+            else:
+                store.wait(["rf_library_leg"], datetime.timedelta(seconds=900))
         dist.barrier()
         dist.destroy_process_group()
     return 0
+
+
+def sync_batch_measure(det, ptrs, H, W, thr, reps=120):
+    """The reference's own calling convention (RetinaFace.cpp:749-940, loop main.cpp:36-52): ONE synchronous rf_detect_batch_device call of
+    len(ptrs) device-resident frames at a time, nothing else in flight, timed at the C ABI (argument arrays and result buffers built once)."""
+    import ctypes as C
+    import numpy as np
+    from retinaface_amd._lib import rf_face
+    B = len(ptrs)
+    pa, ra, ca = (C.c_void_p * B)(*ptrs), (C.c_int * B)(*([H] * B)), (C.c_int * B)(*([W] * B))
+    sa = (C.c_int * B)(*([3 * W] * B))
+    outb, cnt = (rf_face * (B * det.max_detections))(), (C.c_int * B)()
+    lat = []
+    for _ in range(reps):
+        t = time.perf_counter()
+        det._lib.rf_detect_batch_device(det._h, pa, ra, ca, sa, B, C.c_float(thr), outb, det.max_detections, cnt)
+        lat.append(time.perf_counter() - t)
+    ms = float(np.median(lat[reps // 6:]) * 1e3)
+    nf = int(sum(cnt[i] for i in range(B)))
+    return {"batch": B, "ms_per_call": ms, "images_per_sec": B / (ms * 1e-3), "faces_per_sec": nf / (ms * 1e-3), "calls_timed": reps - reps // 6,
+            "note": "one synchronous rf_detect_batch_device call at a time (no pipelining, no coalescing)"}
 
 
 def host_frames(det, frames_np, args, slots, B, run, rank):
@@ -568,7 +623,15 @@ EXTRA_CONFIGS = [
     {"id": 3, "model": "mnet25", "precision": "fp16", "height": 896, "width": 1280, "batch": 1},
     {"id": 4, "model": "mnet25", "precision": "int8", "height": 448, "width": 448, "batch": 32,
      "note": "per-GPU shape of configs[4] (256 images = 32 per GPU x 8 GPUs); the 8-GPU job itself: `--gpus 8` (configs4_strong)"},
+    # north_star's target matrix "batch {1, 8, 32} on 448x448 and 1280x896" (fp16, mnet25): the cells that are not BASELINE.json configs themselves
+    # (448x448 b8 = configs[1] = `value`; 1280x896 b1 = configs[3]).  Timed region + the synchronous call; no per-kernel passes (same kernels).
+    {"id": "matrix 448x448 b1", "model": "mnet25", "precision": "fp16", "height": 448, "width": 448, "batch": 1, "matrix": True},
+    {"id": "matrix 448x448 b32", "model": "mnet25", "precision": "fp16", "height": 448, "width": 448, "batch": 32, "matrix": True},
+    {"id": "matrix 1280x896 b8", "model": "mnet25", "precision": "fp16", "height": 896, "width": 1280, "batch": 8, "matrix": True},
+    {"id": "matrix 1280x896 b32", "model": "mnet25", "precision": "fp16", "height": 896, "width": 1280, "batch": 32, "matrix": True},
 ]
+
+_FRAME_CACHE = {}      # (H, W) -> device tensor of distinct frames, shared by the extra configs of one run
 
 
 def measure_extra_config(cfg, args, frames_main, dev):
@@ -585,9 +648,10 @@ def measure_extra_config(cfg, args, frames_main, dev):
         frames, how = frames_main, "the metric point's ring"
     else:
         # frame synthesis is the slow part (0.15 s per 1280x896 frame): 24 seeded frames x 4 circular shifts = 96 distinct frames
-        base = synth_frames(H, W, 24, config=cfg["id"])
-        frames = torch.from_numpy(np.stack([np.roll(f, sh, axis=1) for sh in (0, W // 4, W // 2, 3 * W // 4) for f in base])).to(dev)
-        how = "24 seeded frames x 4 circular shifts"
+        if (H, W) not in _FRAME_CACHE:
+            base = synth_frames(H, W, 24, config=3)
+            _FRAME_CACHE[(H, W)] = torch.from_numpy(np.stack([np.roll(f, sh, axis=1) for sh in (0, W // 4, W // 2, 3 * W // 4) for f in base])).to(dev)
+        frames, how = _FRAME_CACHE[(H, W)], "24 seeded frames x 4 circular shifts"
     det = retinaface_amd.RetinaFace(os.path.join(ROOT, "assets"), "net3", 0.4, precision=prec, net_hw=(H, W), max_batch=B,
                                     model_stem=cfg["model"])
     slots = det.num_slots()
@@ -611,7 +675,15 @@ def measure_extra_config(cfg, args, frames_main, dev):
         if dt >= 0.7 * args.extra_seconds:
             break
         steps = -(-int(np.ceil(steps * 1.2 * args.extra_seconds / max(dt, 1e-6))) // slots) * slots
+    sync = sync_batch_measure(det, [frames[i % frames.shape[0]].data_ptr() for i in range(B)], H, W, float(args.threshold), reps=90)
     det.close()
+    if cfg.get("matrix"):
+        return {"id": cfg["id"], "workload": f"{cfg['model']} {cfg['precision']} HIP, {W}x{H}, batch {B} per GPU (north_star's batch x frame-size matrix)",
+                "images_per_sec": steps * B / dt, "faces_per_sec": faces / dt, "ms_per_step": dt / steps * 1e3, "steps": steps, "timed_seconds": dt,
+                "dtype": {"fp16": "f16", "fp32": "f32", "int8": "i8"}[cfg["precision"]],
+                "input": f"{frames.shape[0]} distinct HBM-resident frames ({frames.shape[0] * H * W * 3 / 1e6:.0f} MB; {how})",
+                "tickets_in_flight": slots, "sync_batch": sync,
+                "note": "same kernel instances as the BASELINE config of this frame size: no separate per-kernel / counter passes"}
     eager = retinaface_amd.RetinaFace(os.path.join(ROOT, "assets"), "net3", 0.4, precision=prec, net_hw=(H, W), max_batch=B,
                                       model_stem=cfg["model"], use_graph=False, lanes=1)
     n_prof = B * per_launch
@@ -627,6 +699,8 @@ def measure_extra_config(cfg, args, frames_main, dev):
            "dominant_kernel": dom["kernel"], "dominant_kernel_layers": dom["name"], "dominant_kernel_ms": dom["ms"],
            "dominant_kernel_share_of_gpu_time": dom["ms"] / kernel_ms,
            "frac_layerwise_credit": dom["alg_bytes"] / (dom["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+           "useful": useful_fractions(dom, cfg["precision"]), "whole_path_useful": useful_fractions(prof, cfg["precision"]),
+           "sync_batch": sync,
            "bound": None, "bound_frac": None, "hbm_frac_measured": None,
            "_pmc": {"n": n_prof, "precision": cfg["precision"], "model": cfg["model"], "H": H, "W": W, "B": B},
            "_kernels": {p["kernel"]: p["ms"] for p in prof}}
@@ -638,8 +712,8 @@ def measure_extra_config(cfg, args, frames_main, dev):
 def start_extra_counters(args, entries):
     """The additional configurations' hardware counters: ONE set of three rocprofv3 --pmc passes whose probe process runs the fp16
     1280x896 configuration and the int8 448x448 configuration one after the other (the two int8 configs launch the same kernel
-    instances on the same shapes: one measurement serves both).  Started in a thread: the passes use the GPU while the CPU baseline
-    (which follows) uses the host cores."""
+    instances on the same shapes: one measurement serves both).  Runs in a thread the caller joins right away (since round 5 AFTER the
+    CPU baseline: the passes start Python processes that build engines and read counter databases -- host work that biased the baseline)."""
     import threading
     seen, cfgs = set(), []
     for e in entries:
@@ -648,7 +722,7 @@ def start_extra_counters(args, entries):
             seen.add(key)
             cfgs.append(e["_pmc"])
     holder = {"result": None, "cfgs": cfgs}
-    th = threading.Thread(target=lambda: holder.__setitem__("result", measure_counters(args, cfgs)), daemon=True)
+    th = threading.Thread(target=lambda: holder.__setitem__("result", measure_counters(args, cfgs) if cfgs else None), daemon=True)
     th.start()
     holder["thread"] = th
     return holder
@@ -670,7 +744,7 @@ def finish_extra_counters(holder, entries, n_cu):
         e.update({"bound": phys["bound"], "bound_frac": phys["bound_frac"], "hbm_frac_measured": phys["hbm_frac_measured"],
                   "valu_active": phys.get("valu_active"), "mfma_busy": phys.get("mfma_busy"), "lds_active": phys.get("lds_active"),
                   "hbm_bytes_dominant_kernel": phys["hbm_bytes"],
-                  "counters": "rocprofv3 --pmc passes of this run (collected while the CPU baseline ran)" +
+                  "counters": "rocprofv3 --pmc passes of this run (collected after the CPU baseline)" +
                               ("; int8 kernel instances and shapes are the same for both int8 configs: one measurement" if pm["precision"] == "int8" else "")})
         path = [c for c in counters if c["dtype"] in (pm["precision"], "") and c["kernel"] in kern]
         if path and all(c.get("gpu_cycles") for c in path):
@@ -731,6 +805,74 @@ def strong_config4(args, world, rank, dev, cdev, barrier, frames, thr, G=256):
             "result_gather": {"gathers_in_timed_region": R.gs["gathers"], "records_gathered": int(R.gs["images"].item()), "expected": steps * G}}
 
 
+def library_leg(args, n_devices, thr, G=256, seconds=None):
+    """BASELINE.json configs[4] as stated THROUGH THE LIBRARY: one handle whose rf_options.devices lists `n_devices` ordinals (multi.cpp: one
+    engine + one host thread per entry, contiguous ceil(G / N) image slices), G = 256 mnet25 int8 448x448 frames that ALL live on GPU 0, one
+    synchronous rf_detect_batch_device call per step.  Slice g's engine finds its frames on another device (hipPointerGetAttributes, cached per
+    allocation) and pulls them over xGMI with one hipMemcpyPeerAsync each before it launches: north_star's "batch split" -- the part of the
+    multi-GPU design `--gpus N` alone (N independent ranks) never exercises.  With fewer visible GPUs than entries the ordinals wrap around and
+    RF_FORCE_SCATTER=1 makes every frame travel (peer copy device k -> device k): a rehearsal of the code path, not of xGMI."""
+    import numpy as np
+    import torch
+    if args.dry:
+        return {"dry": True, "devices": list(range(n_devices)), "global_batch": G, "images_per_engine": -(-G // n_devices)}
+    import retinaface_amd
+    from retinaface_amd.frames import synth_frames
+    H = W = 448
+    seconds = seconds if seconds is not None else max(args.extra_seconds, 0.3)
+    ndev = torch.cuda.device_count()
+    devices = [i % ndev for i in range(n_devices)]
+    forced = ndev < n_devices
+    distinct = sorted(set(devices))
+    peer = [[bool(i == j or torch.cuda.can_device_access_peer(i, j)) for j in distinct] for i in distinct]
+    with torch.cuda.device(0):
+        frames = torch.from_numpy(np.stack(synth_frames(H, W, 64, config=43))).to("cuda:0")
+        torch.cuda.synchronize()
+    ptrs = [frames[i % 64].data_ptr() for i in range(G)]
+    one = retinaface_amd.RetinaFace(os.path.join(ROOT, "assets"), "net3", 0.4, precision=2, net_hw=(H, W), max_batch=32, model_stem="mnet25", device=0)
+    want = one.detect_device(ptrs, [H] * G, [W] * G, thr)
+    t_one = []
+    for _ in range(5):
+        t = time.perf_counter()
+        one.detect_device(ptrs, [H] * G, [W] * G, thr)
+        t_one.append(time.perf_counter() - t)
+    one.close()
+    if forced:
+        os.environ["RF_FORCE_SCATTER"] = "1"
+    try:
+        multi = retinaface_amd.RetinaFace(os.path.join(ROOT, "assets"), "net3", 0.4, precision=2, net_hw=(H, W), max_batch=32, model_stem="mnet25",
+                                          devices=devices)
+    finally:
+        if forced:
+            os.environ.pop("RF_FORCE_SCATTER", None)
+    key = lambda res: [[(d.anchor_index, d.as_row().tobytes()) for d in r] for r in res]      # noqa: E731
+    got = multi.detect_device(ptrs, [H] * G, [W] * G, thr)
+    identical = key(got) == key(want)
+    multi.detect_device(ptrs, [H] * G, [W] * G, thr)
+    lat, faces, t0 = [], 0, time.perf_counter()
+    while len(lat) < 5 or time.perf_counter() - t0 < seconds:
+        t = time.perf_counter()
+        r = multi.detect_device(ptrs, [H] * G, [W] * G, thr)
+        lat.append(time.perf_counter() - t)
+        faces += sum(len(x) for x in r)
+    nd = multi.num_devices()
+    multi.close()
+    per = -(-G // n_devices)
+    travelled = G if forced else sum(min(per, max(0, G - g * per)) for g in range(n_devices) if devices[g] != 0)
+    med = float(np.median(lat))
+    return {"workload": f"mnet25 int8 HIP, 448x448, ONE handle over devices {devices}, {G} images per rf_detect_batch_device call, all frames resident on GPU 0 "
+                        "(BASELINE.json configs[4] as stated, through rf_options.devices / multi.cpp)",
+            "devices": devices, "engines": nd, "visible_gpus": ndev, "forced_scatter_rehearsal": forced, "peer_access": {"devices": distinct, "matrix": peer},
+            "images_per_call": G, "images_per_engine": per, "calls_timed": len(lat), "ms_per_call": med * 1e3, "images_per_sec": G / med,
+            "faces_per_sec": faces / sum(lat), "frames_scattered_per_call": travelled, "bytes_scattered_per_call": travelled * H * W * 3,
+            "scatter_GBs_at_this_rate": travelled * H * W * 3 / med / 1e9,
+            "single_engine_same_call": {"ms_per_call": float(np.median(t_one)) * 1e3, "images_per_sec": G / float(np.median(t_one)),
+                                        "note": "one engine on GPU 0 takes the same 256-image call (it chunks it into super-batches itself)"},
+            "detections_identical_to_single_engine": bool(identical), "dtype": "i8", "scaling": "strong",
+            "note": "one synchronous call at a time: the per-engine slice of 32 images is a small-batch launch sequence (latency-bound); the pipelined "
+                    "per-GPU rate is `configs`[id 4] / the N-rank `value`"}
+
+
 SQ_COUNTERS = "SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE"
 
 
@@ -786,6 +928,18 @@ def measure_counters(args, cfgs):
         return res or None
     except Exception:  # noqa: BLE001
         return None
+
+
+def useful_fractions(prof, precision):
+    """How much of the HBM and matrix peaks is work the layers REQUIRE, for one rf_profile entry or a list of them: compulsory bytes of the
+    (fused) launch / kernel time / 8 TB/s, and layer MACs x 2 / kernel time / the dense MFMA peak of the precision.  (`frac` of the roofline
+    is the measured occupancy of the binding resource -- issue slots, bytes moved -- whether or not the work was necessary.)"""
+    prof = prof if isinstance(prof, list) else [prof]
+    ms = sum(p["ms"] for p in prof)
+    cb, macs = sum(p["compulsory_bytes"] for p in prof), sum(p["macs"] for p in prof)
+    return {"hbm_compulsory_bytes": cb, "hbm_compulsory_GBs": cb / (ms * 1e-3) / 1e9, "hbm_compulsory_frac": cb / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "mfma_layer_TFLOPs": 2 * macs / (ms * 1e-3) / 1e12, "mfma_layer_frac": 2 * macs / (ms * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS[precision],
+            "is": "compulsory HBM bytes of the fused launch(es) / time / 8 TB/s; layer MACs x 2 / time / dense MFMA peak"}
 
 
 def physical_fractions(entries, ms, n_simd):
@@ -890,9 +1044,12 @@ def device_side_report(args, det, frames, B, H, W, per_launch, prec, images_tota
         "bound": bound or "unmeasured (no counter pass)",
         "kernel": dom["name"], "kernel_instance": dom["kernel"],
         "achieved": res_achieved, "peak": res_peak, "unit": res_unit,
-        "frac": (dom_phys["bound_frac"] if dom_phys else min(1.0, layerwise / HBM_PEAK_GBS)),
-        "frac_is": "physical fraction of the binding resource (rocprofv3 --pmc passes of this run)" if dom_phys else
-                   "layer-wise credit capped at 1 (no counter pass)",
+        "frac": (dom_phys["bound_frac"] if dom_phys else None),
+        "frac_is": "OCCUPANCY of the binding resource, measured (rocprofv3 --pmc passes of this run): issue cycles used / bytes moved, whether or not the "
+                   "layers require them -- see `useful` for the efficiency" if dom_phys else
+                   "null: no counter pass in this run (the layer-wise credit is under frac_layerwise_credit, never here)",
+        "useful": useful_fractions(dom, args.precision),
+        "kernel_ms_in_pipeline": None,
         "frac_layerwise_credit": layerwise / HBM_PEAK_GBS,
         "hbm_layerwise": {"achieved": layerwise, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": layerwise / HBM_PEAK_GBS,
                           "note": "SURVEY.md 8d layer-wise algorithmic bytes / kernel duration: > 1 = bytes fusion never moves"},
@@ -910,7 +1067,8 @@ def device_side_report(args, det, frames, B, H, W, per_launch, prec, images_tota
         "kernel_share_of_gpu_time": dom["ms"] / kernel_ms,
         "images_per_launch": n_prof,
         "whole_path": {
-            "kernels_ms_per_launch_sequence": kernel_ms, "launches": len(prof),
+            "kernels_ms_per_launch_sequence": kernel_ms, "launches": len(prof), "kernels_ms_in_pipeline": None,
+            "useful": useful_fractions(prof, args.precision),
             "alg_bytes_layerwise": alg_total, "frac_layerwise_credit": alg_total / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
             "end_to_end_frac_layerwise_credit": (alg_total / n_prof) * images_per_sec_gpu / 1e9 / HBM_PEAK_GBS,
             "hbm_bytes_per_image_measured": (path_phys["hbm_bytes"] / n_prof) if path_phys else None,
@@ -931,6 +1089,73 @@ def device_side_report(args, det, frames, B, H, W, per_launch, prec, images_tota
         json.dump({"per_launch_images": n_prof, "kernels": prof, "kernels_single_batch": prof8, "counters": counters}, f, indent=1)
     return {"split_ms_per_batch": {"pre": med["pre_ms"], "infer": med["infer_ms"], "post": med["post_ms"], "all": med["total_ms"]},
             "roofline": roofline}
+
+
+def measure_pipeline_trace(args):
+    """The launch sequence's kernels as they run IN the pipeline: `rocprofv3 --kernel-trace` over `bench.py --timed-only --lanes 1` of the same
+    configuration (one super-batch at a time on the GPU, so a kernel's duration is not stretched by another lane's persistent grid), summarised
+    per kernel instance.  rf_profile's HIP-event figure repeats ONE launch back to back (warm caches); throughput is made of these.
+    Returns {"kernels": [{kernel, grid, calls, launches_per_sequence, avg_ms}], "sum_ms"} or None."""
+    import shutil
+    import sqlite3
+    import tempfile
+    if args.no_pipeline_trace or args.no_pmc or shutil.which("rocprofv3") is None:
+        return None
+    if any(k.startswith(("ROCPROF", "ROCP_", "ROCTRACER", "ROCTX")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", ""):
+        return None
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    tmp = None
+    try:
+        import pmc_summary
+        tmp = tempfile.mkdtemp(prefix="rf_kt_", dir="/tmp")
+        cmd = ["rocprofv3", "--kernel-trace", "-d", tmp, "-o", "kt", "--", sys.executable, os.path.abspath(__file__), "--timed-only", "--lanes", "1",
+               "--no-pmc", "--no-cpu-baseline", "--no-extra-configs", "--regions", "1", "--min-seconds", "0.3", "--steps", "1", "--warmup", "96",
+               "--ring-mb", "160", "--batch", str(args.batch), "--height", str(args.height), "--width", str(args.width),
+               "--precision", args.precision, "--model", args.model, "--coalesce", str(args.coalesce)]
+        r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=240)
+        dbs = [os.path.join(d, f) for d, _, fs in os.walk(tmp) for f in fs if f.endswith(".db")]
+        if r.returncode != 0 or not dbs:
+            return None
+        rows = sqlite3.connect(dbs[0]).execute("select name, grid_x, count(*), avg(duration) from kernels group by name, grid_x").fetchall()
+        groups = {}
+        for name, grid, calls, avg in rows:
+            if "rf::" not in name and not name.startswith("_ZN2rf"):
+                continue
+            d = pmc_summary.descriptor(name)
+            if d not in groups or calls > groups[d]["calls"]:            # the steady-state grid of an instance = the one launched most often
+                groups[d] = {"kernel": d, "grid": int(grid), "calls": int(calls), "avg_ms": avg / 1e6}
+        if not groups:
+            return None
+        base = min(g["calls"] for g in groups.values())                  # a kernel launched once per sequence
+        for g in groups.values():
+            g["launches_per_sequence"] = max(1, round(g["calls"] / base))
+        ks = sorted(groups.values(), key=lambda g: -g["avg_ms"] * g["launches_per_sequence"])
+        return {"kernels": ks, "sum_ms": sum(g["avg_ms"] * g["launches_per_sequence"] for g in ks), "sequences_traced": base,
+                "method": "rocprofv3 --kernel-trace of `bench.py --timed-only --lanes 1` (this run), average duration per kernel instance"}
+    except Exception:  # noqa: BLE001
+        return None
+    finally:
+        if tmp:
+            shutil.rmtree(tmp, ignore_errors=True)
+
+
+def attach_pipeline_trace(roofline, trace):
+    """kernel_ms_in_pipeline beside the HIP-event kernel_ms, for the dominant kernel and for the launch sequence."""
+    if not trace:
+        roofline["kernel_ms_in_pipeline_note"] = "no kernel-trace pass in this run (rocprofv3 unavailable / --no-pipeline-trace / --no-pmc)"
+        return
+    mine = [g for g in trace["kernels"] if g["kernel"] == roofline["kernel_instance"]]
+    if mine:
+        ms = mine[0]["avg_ms"]
+        roofline["kernel_ms_in_pipeline"] = ms
+        roofline["useful_in_pipeline"] = {k: (v * roofline["kernel_ms"] / ms if isinstance(v, float) and k.endswith(("_frac", "_GBs", "_TFLOPs")) else v)
+                                          for k, v in roofline["useful"].items()}
+    roofline["kernel_ms_in_pipeline_method"] = trace["method"]
+    roofline["whole_path"]["kernels_ms_in_pipeline"] = trace["sum_ms"]
+    roofline["whole_path"]["images_per_sec_one_lane_from_trace"] = roofline["images_per_launch"] / (trace["sum_ms"] * 1e-3)
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", "bench_pipeline_trace.json"), "w") as f:
+        json.dump(trace, f, indent=1)
 
 
 def baseline_config(args) -> str:

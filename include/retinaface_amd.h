@@ -171,6 +171,14 @@ int rf_enqueue_batch(rf_handle h, const uint8_t *const *bgr, const int *rows, co
 int rf_host_register(rf_handle h, const void *ptr, size_t bytes);
 int rf_host_unregister(rf_handle h, const void *ptr);
 
+/* Where device frame pointers live (rf_detect_batch_device / rf_enqueue_batch_device on a node with several GPUs): the engine
+ * asks the HIP runtime once per ALLOCATION and remembers the answer (own device / host-visible: read in place; another GPU:
+ * peer copy over xGMI first); a remembered answer is re-checked against the runtime when it is older than 2 ms.  A caller that
+ * FREES or RE-ALLOCATES frame buffers while the handle lives (hipFree + hipMalloc may hand the same address out on another
+ * device) calls rf_invalidate_residency() after the free and before it passes pointers of the new allocation: the engine then
+ * looks every pointer up afresh.  Frames passed to an outstanding ticket must stay allocated until rf_wait returns. */
+int rf_invalidate_residency(rf_handle h);
+
 /* Engines behind the handle: 1, or options.n_devices for an image-sharding multi-device handle. */
 int rf_num_devices(rf_handle h);
 
@@ -204,6 +212,11 @@ long rf_debug_activation(rf_handle h, const char *blob_name, int image, float *d
                          int dims[3]);
 int rf_profile(rf_handle h, const void *const *d_bgr, int n, int iters, int cap,
                const char **names, const char **kernels, float *avg_ms, double *alg_bytes, double *macs);
+/* rf_profile_compulsory_bytes: for the same launches in the same order, the bytes each one has to move through HBM at the very
+ *   least GIVEN its fusion, for n images -- every tensor it reads from HBM once + every tensor it writes once (weights ignored).
+ *   bench.py's `useful` HBM fraction = these bytes / kernel time / peak (the layer-wise alg_bytes of rf_profile also count tensors
+ *   that never leave LDS).  Returns the number of launches. */
+int rf_profile_compulsory_bytes(rf_handle h, int n, int cap, double *bytes);
 
 /* Offline: pack <prototxt, caffemodel[, int8 table]> into a .rfw file (the analogue of the reference's
  * first-run engine serialisation, trtnetbase.cpp:231-243).  int8_table may be NULL. */

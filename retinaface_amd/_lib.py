@@ -58,6 +58,7 @@ SYMBOLS = {
                                    C.c_int, C.c_float, _PP(C.c_int)]),
     "rf_host_register": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     "rf_host_unregister": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "rf_invalidate_residency": (C.c_int, [C.c_void_p]),
     "rf_num_devices": (C.c_int, [C.c_void_p]),
     "rf_last_anchor_indices": (C.c_int, [C.c_void_p, C.c_int, _PP(C.c_int32), C.c_int]),
     "rf_last_candidate_counts": (C.c_int, [C.c_void_p, _PP(C.c_int), C.c_int]),
@@ -66,6 +67,7 @@ SYMBOLS = {
     "rf_debug_activation": (C.c_long, [C.c_void_p, C.c_char_p, C.c_int, _PP(C.c_float), C.c_size_t, _PP(C.c_int)]),
     "rf_profile": (C.c_int, [C.c_void_p, _PP(C.c_void_p), C.c_int, C.c_int, C.c_int, _PP(C.c_char_p), _PP(C.c_char_p),
                              _PP(C.c_float), _PP(C.c_double), _PP(C.c_double)]),
+    "rf_profile_compulsory_bytes": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _PP(C.c_double)]),
     "rf_convert_model": (C.c_int, [C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p]),
     "rf_plan_cache_probe": (C.c_int, [C.c_char_p, C.c_char_p, C.c_int, C.c_char_p, _PP(C.c_size_t)]),
     "rf_plan_folded": (C.c_int, [C.c_char_p, C.c_char_p, C.c_char_p, _PP(C.c_float), C.c_size_t, _PP(C.c_float),

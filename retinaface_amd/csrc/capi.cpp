@@ -226,6 +226,11 @@ int rf_host_unregister(rf_handle h, const void *ptr) {
     return guarded(h, [&]() -> int { h->eng->host_unregister(ptr); return RF_OK; });
 }
 
+int rf_invalidate_residency(rf_handle h) {
+    if (!h) return RF_ERR_INVALID_ARG;
+    return guarded(h, [&]() -> int { h->eng->invalidate_residency(); return RF_OK; });
+}
+
 int rf_num_devices(rf_handle h) { return h ? h->eng->num_devices() : RF_ERR_INVALID_ARG; }
 
 int rf_wait(rf_handle h, int ticket, rf_face *out, int cap_per_image, int *counts) {
@@ -272,6 +277,11 @@ int rf_profile(rf_handle h, const void *const *d_bgr, int n, int iters, int cap,
                float *avg_ms, double *alg_bytes, double *macs) {
     if (!h || !d_bgr) return RF_ERR_INVALID_ARG;
     return guarded(h, [&]() -> int { return h->eng->profile(d_bgr, n, iters, cap, names, kernels, avg_ms, alg_bytes, macs); });
+}
+
+int rf_profile_compulsory_bytes(rf_handle h, int n, int cap, double *bytes) {
+    if (!h) return RF_ERR_INVALID_ARG;
+    return guarded(h, [&]() -> int { return h->eng->compulsory_bytes(n, cap, bytes); });
 }
 
 int rf_convert_model(const char *prototxt, const char *caffemodel, const char *int8_table, const char *out_rfw) {

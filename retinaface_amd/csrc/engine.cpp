@@ -10,6 +10,7 @@
 #include <thread>
 
 #include "copier.h"
+#include "knobs.h"
 #include "pack.h"
 #include "weights.h"
 
@@ -26,7 +27,7 @@ namespace {
 
 // RF_HOST_TRACE=1 (probe): where the HOST time of a call goes -- per-stage wall-clock sums, printed when the engine is destroyed
 struct HostTrace {
-    bool on = getenv("RF_HOST_TRACE") != nullptr;
+    bool on = knob(K_HOST_TRACE) != 0;
     double sum[8] = {};
     long n[8] = {};
     static double now() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
@@ -152,12 +153,15 @@ public:
         if (device_ >= kMaxDevices) throw ArgError("device ordinal " + std::to_string(device_) + ": at most " + std::to_string(kMaxDevices) + " devices per process");
         // device frames are checked for residency whenever another device exists they could live on (RF_FORCE_SCATTER: test knob,
         // treats every device frame as foreign so the scatter path runs on a one-GPU box)
-        force_scatter_ = getenv("RF_FORCE_SCATTER") != nullptr;
-        if (const char *cs = getenv("RF_COPY_STREAMS")) copy_streams_ = atoi(cs) > 1 ? 2 : 1;       // probe knob (tools/probes/host_rate.py)
+        force_scatter_ = knob(K_FORCE_SCATTER) != 0;
+        copy_streams_ = knob(K_COPY_STREAMS) > 1 ? 2 : 1;       // probe knob RF_COPY_STREAMS (tools/probes/host_rate.py)
         check_residency_ = ndev > 1 || force_scatter_;
         DeviceGuard guard(device_);                  // the caller's current device is put back when construction ends
-        if (sizeof(T) == 1 && cvt_pk_u8_selfcheck() != 0)
-            throw Unsupported("int8: v_cvt_pk_u8_f32 on this device does not round to nearest even / saturate as the requantising epilogues assume");
+        if (sizeof(T) == 1) {
+            const int chk = cvt_pk_u8_selfcheck();
+            if (chk < 0) throw HipError("int8: the v_cvt_pk_u8_f32 rounding probe could not run on this device (allocation, launch or copy failed)");
+            if (chk > 0) throw Unsupported("int8: v_cvt_pk_u8_f32 on this device does not round to nearest even / saturate as the requantising epilogues assume");
+        }
         try { arena_.upload(); } catch (const std::exception &e) { throw HipError(e.what()); }
         // Lanes are built on first use: a caller that only makes synchronous calls of <= max_batch images keeps re-using lane 0 and
         // never pays for the other lanes' activation buffers (~13 MB per 448 x 448 image in fp16 x the super-batch size).  Lane 0
@@ -177,12 +181,11 @@ public:
         // in the middle of the asynchronous steady state: one latency spike per lane less for latency-sensitive callers).  A lane
         // that does not fit is dropped, as on first use.  num_slots() may therefore be smaller than lanes x coalesce: callers read it
         // after rf_create, and again if an enqueue ever fails with RF_ERR_HIP.
-        if (const char *pb = getenv("RF_PREBUILD_LANES")) {
-            if (atoi(pb) != 0)
-                for (int l = 1; l < (int)lanes_.size(); l++) {
-                    try { ensure_lane(l); }
-                    catch (const HipError &) { lanes_.resize(l); break; }
-                }
+        if (knob(K_PREBUILD_LANES)) {
+            for (int l = 1; l < (int)lanes_.size(); l++) {
+                try { ensure_lane(l); }
+                catch (const HipError &) { lanes_.resize(l); break; }
+            }
         }
         const int hw = (int)std::thread::hardware_concurrency();
         const int helpers = opt_.copy_threads > 0 ? opt_.copy_threads - 1 : std::max(0, std::min(8, hw / 4) - 1);
@@ -280,6 +283,7 @@ public:
     }
     void host_unregister(const void *ptr) override { drop_range(ptr, true); }
     void host_forget(const void *ptr) override { drop_range(ptr, false); }
+    void invalidate_residency() override { residency_.clear(); }
 
     // tickets the caller may keep outstanding before it has to wait: every lane can hold a full super-batch
     int num_slots() const override { return (int)lanes_.size() * opt_.coalesce; }
@@ -419,6 +423,14 @@ public:
             if (macs) macs[k] = n * l.ops[k].macs;
         }
         return (int)nops;
+    }
+
+    int compulsory_bytes(int n, int cap, double *bytes) override {
+        if (n < 0 || (cap > 0 && !bytes)) throw ArgError("null argument");
+        const Lane &l = lanes_[0];
+        for (size_t k = 0; k < l.ops.size() && (int)k < cap; k++)
+            bytes[k] = n * (l.ops[k].alg_u8_in + sizeof(T) * (l.ops[k].hbm_elems_in + l.ops[k].hbm_elems_out));
+        return (int)l.ops.size();
     }
 
 private:
@@ -610,6 +622,7 @@ private:
                 op.alg_elems_out = 8.0 * h * w + 8.0 * h * w + 16.0 * h * w + 16.0 * h4 * w4 + 32.0 * h4 * w4;     // conv0 .. conv4 outputs
                 op.macs = (plan.conv0.macs_per_out_pixel() + b0.dw.macs_per_out_pixel() + b0.pw.macs_per_out_pixel()) * h * w +
                           (b1.dw.macs_per_out_pixel() + b1.pw.macs_per_out_pixel()) * h4 * w4;
+                op.hbm_elems_out = 32.0 * h4 * w4;                        // the frame in (alg_u8_in), the 32-channel net/4 map out
                 op.launch = [sp](hipStream_t s, int n) { Stem2Params q = sp; q.n = n; launch_stem2(s, q); };
                 L.ops.push_back(op);
                 cur = out; c = b1.pw.cout; first_block = 2; h = h4; w = w4;
@@ -632,14 +645,15 @@ private:
                     o2.alg_elems_in = 32.0 * pa + 32.0 * pa + 32.0 * pa + 32.0 * pb;          // dw A, pw A, dw B, pw B inputs (layer-wise)
                     o2.alg_elems_out = 32.0 * pa + 32.0 * pa + 32.0 * pb + 64.0 * pb;
                     o2.macs = (ba.dw.macs_per_out_pixel() + ba.pw.macs_per_out_pixel()) * pa + (bb.dw.macs_per_out_pixel() + bb.pw.macs_per_out_pixel()) * pb;
+                    o2.hbm_elems_in = 32.0 * pa; o2.hbm_elems_out = 64.0 * pb;
                     o2.launch = [dp](hipStream_t s, int n) { DwPw2Params q = dp; q.n = n; launch_dwpw2(s, q); };
                     L.ops.push_back(o2);
                     cur = out2; c = bb.pw.cout; first_block = 4; h /= 2; w /= 2;
                 }
             }
-        } else if constexpr (sizeof(T) <= 2) {
-            // fp16 / int8 engines: preprocess + conv0 + the first depthwise/pointwise block are ONE launch (stem_kernel);
-            // it computes in fp16 and stores its 16-channel output in the engine's storage type
+        } else if constexpr (sizeof(T) == 1 || (sizeof(T) == 2 && kProbeBuild)) {
+            // int8 engine (and the fp16 engine of the probe build with RF_STEM2=0): preprocess + conv0 + the first depthwise/pointwise
+            // block are ONE launch (stem_kernel); it computes in fp16 and stores its 16-channel output in the engine's storage type
             const auto &blk = plan.blocks[0];
             T *out = act(blk.pw.out_blob, h, w, blk.pw.cout);
             StemParams<T> sp;
@@ -656,9 +670,12 @@ private:
             op.alg_elems_in = 8.0 * h * w + 8.0 * h * w;                       // dw input, pw input
             op.alg_elems_out = 8.0 * h * w + 8.0 * h * w + 16.0 * h * w;       // conv0, dw, pw outputs
             op.macs = (plan.conv0.macs_per_out_pixel() + blk.dw.macs_per_out_pixel() + blk.pw.macs_per_out_pixel()) * h * w;
+            op.hbm_elems_out = 16.0 * h * w;
             op.launch = [sp](hipStream_t s, int n) { StemParams<T> q = sp; q.n = n; launch_stem<T>(s, q); };
             L.ops.push_back(op);
             cur = out; c = blk.pw.cout; first_block = 1;
+        } else if constexpr (sizeof(T) == 2) {
+            throw Unsupported("fp16 engine without stem2: a probe-build configuration (RF_STEM2=0)");
         } else {
             cur = act(plan.conv0.out_blob, h, w, 8);
             OpInfo op;
@@ -667,6 +684,7 @@ private:
             op.alg_u8_in = 3.0 * P;
             op.alg_elems_out = 8.0 * h * w;
             op.macs = plan.conv0.macs_per_out_pixel() * h * w;
+            op.hbm_elems_out = 8.0 * h * w;
             const float *wp = arena_.template ptr<float>(c0_w_), *bp = arena_.template ptr<float>(c0_b_);
             const FrameDesc *fr = L.d_frames + mb;
             T *o = cur;
@@ -695,6 +713,7 @@ private:
             op.alg_elems_in = (double)c * h * w + (double)c * ho * wo;
             op.alg_elems_out = (double)c * ho * wo + (double)blk.pw.cout * ho * wo;
             op.macs = (blk.dw.macs_per_out_pixel() + blk.pw.macs_per_out_pixel()) * ho * wo;
+            op.hbm_elems_in = (double)c * h * w; op.hbm_elems_out = (double)blk.pw.cout * ho * wo;
             const int li = i == 4 ? 2 : i == 10 ? 1 : i == 12 ? 0 : -1;
             if (li >= 0) {          // the lateral 1x1 is computed from this block's output tile while it is in LDS
                 const FoldedConv &lf = plan.lateral[li];
@@ -705,6 +724,7 @@ private:
                 op.kernel.insert(op.kernel.size() - 1, ",lat");
                 op.alg_elems_in += (double)blk.pw.cout * ho * wo;
                 op.alg_elems_out += 64.0 * ho * wo;
+                op.hbm_elems_out += 64.0 * ho * wo;
                 op.macs += lf.macs_per_out_pixel() * ho * wo;
             }
             op.launch = [p](hipStream_t s, int n) { DwPwParams<T> q = p; q.n = n; launch_dwpw<T>(s, q); };
@@ -732,6 +752,7 @@ private:
             op.alg_elems_in = 64.0 * (fh / 2) * (fw / 2) + 64.0 * fh * fw;     // deconv input + conv input
             op.alg_elems_out = 64.0 * fh * fw + 64.0 * fh * fw;               // deconv output + conv output
             op.macs = plan.aggr[i].macs_per_out_pixel() * fh * fw + 16.0 * 64 * (fh / 2) * (fw / 2);
+            op.hbm_elems_in = 64.0 * (fh / 2) * (fw / 2) + 64.0 * fh * fw; op.hbm_elems_out = 64.0 * fh * fw;
             op.launch = [p](hipStream_t s, int n) { Conv3Params<T> q = p; q.n = n; launch_conv3x3<T>(s, &q, 1); };
             L.ops.push_back(op);
         }
@@ -761,6 +782,8 @@ private:
                 op.name += (op.name.empty() ? "" : " | ") + f.name;
                 op.alg_elems_in += (double)nlayers * cin * fh * fw;   // each merged sibling reads the input once, layer-wise
                 op.alg_elems_out += (double)f.cout * fh * fw;
+                op.hbm_elems_in += (double)cin * fh * fw;              // merged siblings share ONE read of the input
+                op.hbm_elems_out += (double)f.cout * fh * fw;
                 op.macs += f.macs_per_out_pixel() * fh * fw;
             };
             fill(lv_a.p[i], op_a, m.conv_a, ssh_w_[i][0], feat[i], 64, cat, 64, 0, 32, ctx1, 16, 0, 2);
@@ -790,6 +813,7 @@ private:
             op_h.name += (op_h.name.empty() ? "" : " | ") + m.head.name;
             op_h.alg_elems_in += 3.0 * 64 * fh * fw;
             op_h.alg_elems_out += 16.0 * head_a_ * fh * fw;
+            op_h.hbm_elems_in += 64.0 * fh * fw;                       // the concat tensor in; candidates out: a few KB
             op_h.macs += m.head.macs_per_out_pixel() * fh * fw;
             anchor_off += na_ * fh * fw;
         }
@@ -809,6 +833,8 @@ private:
                 op_t.alg_elems_in = op_b.alg_elems_in + op_c.alg_elems_in;       // layer-wise accounting, fused or not
                 op_t.alg_elems_out = op_b.alg_elems_out + op_c.alg_elems_out;
                 op_t.macs = op_b.macs + op_c.macs;
+                op_t.hbm_elems_in = op_b.hbm_elems_in;                 // context_conv1 in; context_conv3_1 stays in LDS
+                op_t.hbm_elems_out = op_b.hbm_elems_out + op_c.hbm_elems_out - op_c.hbm_elems_in;      // concat[32:64]: 16 + 16 channels
                 op_t.launch = [tl](hipStream_t s, int n) { Tail3 q = tl; for (auto &p : q.p) p.n = n; launch_ssh_tail<T>(s, q.p, 3); };
                 L.ops.push_back(op_t);
             }
@@ -862,13 +888,22 @@ private:
     // engine's kernels (its own device's memory, or pinned / managed host memory); >= 0: the ordinal of ANOTHER device of the
     // node -- the frame is then scattered to this device over xGMI before the launch (submit()).  Anything the runtime does not
     // know as device-accessible memory is refused here instead of faulting inside a kernel.
-    // The answer is cached per 2 MiB page of the address space (device allocations are at least that coarse; a camera ring or a
-    // frame tensor is looked up once, not once per frame per call): the cache is dropped whenever it has grown past a few thousand
-    // pages, and a pointer the runtime rejects is never cached (the caller may register / allocate it later).
-    int foreign_device_of(const uint8_t *p) {
-        const uintptr_t page = (uintptr_t)p >> 21;
-        auto hit = residency_.find(page);
-        if (hit != residency_.end()) return hit->second;
+    // The answer is cached per ALLOCATION (hipMemGetAddressRange: base + size of the allocation the pointer lies in), so a camera
+    // ring or a frame tensor costs one runtime lookup, not one per frame per call (hipPointerGetAttributes takes the runtime's
+    // allocation-map lock: ~1 us x 256 frames per super-batch).  Round 4 cached per 2 MiB page and never looked again: a buffer
+    // freed and re-allocated under the same address on another device kept its old answer.  Now (1) an entry covers
+    // exactly one allocation, so two small allocations sharing a page cannot alias; (2) an entry is re-validated against the
+    // runtime once it is older than kResidencyTtlUs -- base, size and owner must still match or the entry is dropped and the
+    // pointer looked up afresh -- which bounds the lifetime of a stale answer to 2 ms of wall clock and costs one runtime call
+    // per 2 ms per allocation; (3) rf_invalidate_residency() drops the cache at once for callers that free or re-home frame
+    // buffers while the handle lives (documented in include/retinaface_amd.h).  Host / managed memory and pointers the runtime
+    // rejects are never cached.
+    static constexpr double kResidencyTtlUs = 2000.0;
+    struct Residency { uintptr_t base; size_t bytes; int where; int owner; double checked_us; };
+    static double now_us() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+    // one runtime lookup; returns false for host / managed memory (answer in *where, not cacheable)
+    bool lookup_residency(const uint8_t *p, Residency *out) {
         hipPointerAttribute_t attr;
         memset(&attr, 0, sizeof(attr));
         if (hipPointerGetAttributes(&attr, p) != hipSuccess) {
@@ -876,16 +911,48 @@ private:
             throw ArgError("device frame pointer is not known to the HIP runtime (host memory passed to a *_device entry point?)");
         }
         if (attr.type == hipMemoryTypeUnregistered) throw ArgError("device frame pointer is unregistered host memory");
-        int where;
-        if (attr.type == hipMemoryTypeHost || attr.type == hipMemoryTypeManaged) where = -1;
-        else if (attr.device == device_) where = force_scatter_ ? device_ : -1;
-        else where = attr.device;
-        // host / managed memory can be unpinned and re-used under the same address: only device allocations are remembered
-        if (attr.type != hipMemoryTypeHost && attr.type != hipMemoryTypeManaged) {
-            if (residency_.size() > 4096) residency_.clear();
-            residency_[page] = where;
+        out->owner = attr.device;
+        out->checked_us = now_us();
+        if (attr.type == hipMemoryTypeHost || attr.type == hipMemoryTypeManaged) { out->where = -1; out->base = 0; out->bytes = 0; return false; }
+        out->where = attr.device == device_ ? (force_scatter_ ? device_ : -1) : attr.device;
+        hipDeviceptr_t base = nullptr;
+        size_t bytes = 0;
+        if (hipMemGetAddressRange(&base, &bytes, (hipDeviceptr_t)p) != hipSuccess || !base || !bytes) {
+            (void)hipGetLastError();
+            out->base = 0; out->bytes = 0;
+            return false;                       // a device pointer whose allocation cannot be delimited is looked up every time
         }
-        return where;
+        out->base = (uintptr_t)base; out->bytes = bytes;
+        return true;
+    }
+
+    int foreign_device_of(const uint8_t *p) {
+        const uintptr_t a = (uintptr_t)p;
+        auto it = residency_.upper_bound(a);
+        if (it != residency_.begin()) {
+            --it;
+            Residency &r = it->second;
+            if (a >= r.base && a < r.base + r.bytes) {
+                if (now_us() - r.checked_us <= kResidencyTtlUs) return r.where;
+                Residency fresh;                                  // stale: the allocation must still be the one that was cached
+                const bool cacheable = lookup_residency(p, &fresh);
+                if (cacheable && fresh.base == r.base && fresh.bytes == r.bytes && fresh.owner == r.owner) { r.checked_us = fresh.checked_us; return r.where; }
+                residency_.erase(it);
+                residency_revalidation_misses_++;
+                if (cacheable) residency_[fresh.base] = fresh;
+                return fresh.where;
+            }
+        }
+        Residency fresh;
+        if (lookup_residency(p, &fresh)) {
+            if (residency_.size() > 4096) residency_.clear();
+            // a new allocation may overlap stale entries of freed ones: drop every entry that intersects it
+            auto lo = residency_.lower_bound(fresh.base);
+            if (lo != residency_.begin()) { auto pv = std::prev(lo); if (pv->second.base + pv->second.bytes > fresh.base) lo = pv; }
+            while (lo != residency_.end() && lo->second.base < fresh.base + fresh.bytes) lo = residency_.erase(lo);
+            residency_[fresh.base] = fresh;
+        }
+        return fresh.where;
     }
 
     bool is_registered(const uint8_t *p, size_t bytes) const {
@@ -1201,7 +1268,8 @@ private:
     std::vector<Lane> lanes_;
     int next_lane_ = 0, last_lane_ = 0, last_first_image_ = 0, pending_lane_ = -1;
     unsigned long long launch_counter_ = 0;
-    std::unordered_map<uintptr_t, int> residency_;      // 2 MiB page of a device allocation -> where it lives (foreign_device_of)
+    std::map<uintptr_t, Residency> residency_;          // allocation base -> where it lives (foreign_device_of)
+    long residency_revalidation_misses_ = 0;            // cached entries whose allocation had changed when they were re-validated
     int cap_images_ = 0;                      // images per launch = max_batch * coalesce
     std::vector<Ticket> tickets_;
     int next_ticket_ = 0;
@@ -1229,7 +1297,7 @@ void prepare_pack(const std::string &model_dir, const EngineOptions &opt, Plan *
     for (const char *c = __DATE__ " " __TIME__ " " __FILE__; *c; c++) { key.build ^= (unsigned char)*c; key.build *= 1099511628211ull; }
     key.precision = opt.precision;
     key.stem2 = std::is_same<T, half_t>::value ? stem2_variant() : 0;
-    if (const char *dc = getenv("RF_STEM2_DC")) { if (atoi(dc) == 0) key.stem2 |= 0x100; }     // probe knob: another packed image
+    if (knob(K_STEM2_DC) == 0) key.stem2 |= 0x100;     // probe knob RF_STEM2_DC: another packed image
     const std::string path = opt.plan_cache_path.empty() ? plan_cache_path(model_dir, opt.model_stem, opt.precision) : opt.plan_cache_path;
     *from_cache = false;
     if (opt.plan_cache) {

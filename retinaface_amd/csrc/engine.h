@@ -51,6 +51,9 @@ struct OpInfo {
     double alg_elems_out = 0;    // per image: layer-wise output elements
     double alg_u8_in = 0;        // per image: bytes read as u8 (the frame), not scaled by the element size
     double macs = 0;             // per image
+    // per image: what the launch has to move through HBM at the very least GIVEN its fusion -- every tensor it reads from HBM once,
+    // every tensor it writes once (weights: < 1 MB per launch, ignored).  `useful` HBM fraction = these bytes / time / peak.
+    double hbm_elems_in = 0, hbm_elems_out = 0;
     std::function<void(hipStream_t, int)> launch;   // (stream, n_images)
 };
 
@@ -87,6 +90,8 @@ public:
     virtual void host_unregister(const void *ptr) = 0;
     virtual void host_adopt(const void *ptr, size_t bytes) = 0;
     virtual void host_forget(const void *ptr) = 0;
+    // drop what the engine remembers about where device frame pointers live (callers that free / re-home frame buffers)
+    virtual void invalidate_residency() = 0;
 
     virtual int last_anchor_indices(int image, int32_t *out, int cap) const = 0;
     virtual int last_candidate_counts(int *counts, int n) const = 0;
@@ -95,6 +100,8 @@ public:
     virtual long debug_activation(const std::string &blob, int image, float *dst, size_t cap, int dims[3]) = 0;
     virtual int profile(const void *const *d_frames, int n, int iters, int cap, const char **names, const char **kernels,
                         float *avg_ms, double *alg_bytes, double *macs) = 0;
+    // compulsory HBM bytes of every launch for n images (OpInfo::hbm_elems_*), in launch order; returns the number of launches
+    virtual int compulsory_bytes(int n, int cap, double *bytes) = 0;
 
     int net_h() const { return net_h_; }
     int net_w() const { return net_w_; }

@@ -11,6 +11,13 @@ namespace rf {
 
 typedef _Float16 half_t;
 
+// RF_PROBES: the probe build (make probe), which also holds the measured-and-rejected kernel variants and the RF_* probe knobs (knobs.h)
+#ifdef RF_PROBES
+constexpr bool kProbeBuild = true;
+#else
+constexpr bool kProbeBuild = false;
+#endif
+
 // a request the engine has no kernel instance / configuration for (C ABI: RF_ERR_UNSUPPORTED)
 struct Unsupported : std::runtime_error { using std::runtime_error::runtime_error; };
 
@@ -21,7 +28,8 @@ template <> struct DwWeightT<int8_t> { typedef float type; };
 // The launch helpers keep per-device state (CU count, LDS attribute / occupancy of each kernel instance); the engine tells
 // them which device the calling thread is bound to (engine.cpp DeviceGuard).
 void bind_launch_device(int device);
-// int8 engines: 0 when v_cvt_pk_u8_f32 on the bound device rounds to nearest even and saturates (what the requantising epilogues rely on)
+// int8 engines: 0 when v_cvt_pk_u8_f32 on the bound device rounds to nearest even and saturates (what the requantising epilogues rely on),
+// 1 when it does not (cached per device), -1 when the probe could not run (a runtime error: not cached)
 int cvt_pk_u8_selfcheck();
 constexpr int kMaxDevices = 64;      // device ordinals a process may use (per-device launch state is sized by it; engine / multi.cpp enforce it)
 

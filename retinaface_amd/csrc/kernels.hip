@@ -12,7 +12,13 @@
 
 #include <atomic>
 
+#include "knobs.h"
 #include "pack.h"
+
+// RF_PROBES (make probe -> libretinaface_amd_probe.so): the measured-and-rejected kernel variants DESIGN.md cites and the RF_* probe knobs that
+// select them.  The product library is compiled WITHOUT them: every `#ifdef RF_PROBES` block below is a variant that lost its A/B measurement
+// (profiles/r0N_*), kept buildable so the evidence stays reproducible (tests/test_gpu_parity.py::test_probe_knob_kernel_variants_stay_correct
+// runs them through the probe build).
 
 namespace rf {
 
@@ -145,16 +151,8 @@ static int num_cus() {
 }
 // Below `min_rounds` x resident tiles the hardware dispatcher's dynamic one-tile-per-workgroup schedule is at least as
 // good as walking two tiles in sequence, so the grid stays one workgroup per tile.
-static float persist_min_rounds() {
-    static float v = -1.f;
-    if (v < 0.f) {
-        const char *e = getenv("RF_PERSIST_MIN_ROUNDS");      // probe knob (tools/probes), default measured on MI355X
-        v = e ? (float)atof(e) : 1.0f;
-    }
-    return v;
-}
 static int persistent_grid(int tiles, int resident_per_cu) {
-    return persistent_grid_size(tiles, num_cus() * (resident_per_cu > 0 ? resident_per_cu : 1), persist_min_rounds());
+    return persistent_grid_size(tiles, num_cus() * (resident_per_cu > 0 ? resident_per_cu : 1), knob_persist_min_rounds());      // (probe knob RF_PERSIST_MIN_ROUNDS; 1 measured on MI355X)
 }
 template <typename F> static int resident_per_cu(F kern, size_t lds_bytes) {
     int nb = 0;
@@ -769,7 +767,9 @@ template <typename TO> void launch_stem(hipStream_t s, const StemParams<TO> &p) 
     a.nblk = p.n * a.tiles_x * a.tiles_y;
     hipLaunchKernelGGL(stem_kernel<TO>, dim3(a.nblk), dim3(kThreads), 0, s, a);
 }
-template void launch_stem<half_t>(hipStream_t, const StemParams<half_t> &);
+#ifdef RF_PROBES
+template void launch_stem<half_t>(hipStream_t, const StemParams<half_t> &);       // fp16 engine with RF_STEM2=0 (K_a' + separate blocks)
+#endif
 template void launch_stem<int8_t>(hipStream_t, const StemParams<int8_t> &);
 
 // =============================================================================================
@@ -1175,11 +1175,7 @@ __global__ __launch_bounds__((Stem2Cfg<TW_, F16P, PADKB>::THREADS), (Stem2Cfg<TW
     RF_TRACE(4, 7);
 }
 
-int stem2_variant() {
-    static int v = -1;
-    if (v < 0) { const char *e = getenv("RF_STEM2"); v = e ? atoi(e) : 1; }      // probe knob: 1 = 7x8 tiles, 2 = 7x16, 3 = 7x8 with the patch converted to fp16 at staging (7 workgroups / CU: measured slower)
-    return v;
-}
+int stem2_variant() { return knob(K_STEM2); }      // probe knob RF_STEM2: 1 = 7x8 tiles (the product), 0 = off, 2 = 7x16, 3 = 7x8 with the patch converted to fp16 at staging (7 workgroups / CU: measured slower)
 
 void launch_stem2(hipStream_t s, const Stem2Params &p) {
     Stem2Args a;
@@ -1188,32 +1184,37 @@ void launch_stem2(hipStream_t s, const Stem2Params &p) {
     a.dw1_mma = p.dw1_mma; a.dw1_b = p.dw1_b; a.pw1_w = p.pw1_w; a.pw1_b = p.pw1_b;
     a.c2_floor = p.c2_floor; a.c3_floor = p.c3_floor;
     a.ho = p.net_h / 2; a.wo = p.net_w / 2; a.ho4 = p.net_h / 4; a.wo4 = p.net_w / 4;
+    int tw = 8;
+#ifdef RF_PROBES
     const int v = stem2_variant();
-    const int tw = v == 2 ? 16 : 8;
+    tw = v == 2 ? 16 : 8;
+#endif
     a.tiles_x = (a.wo4 + tw - 1) / tw; a.tiles_y = (a.ho4 + 6) / 7;
     a.nblk = p.n * a.tiles_x * a.tiles_y;
-    if (tw == 16) hipLaunchKernelGGL((stem2_kernel<16, false, 0, 0>), dim3(a.nblk), dim3(Stem2Cfg<16, false>::THREADS), 0, s, a);
-    else if (v == 3) hipLaunchKernelGGL((stem2_kernel<8, true, 0, 0>), dim3(a.nblk), dim3(kThreads), 0, s, a);
-    else {
-        // RF_STEM2_PAD (probe knob): 3 / 7 KB of unused LDS per workgroup = 7 / 6 workgroups per CU instead of 8: stem2 alone gets slower
-        // (+3.5 % / +10 %), but at 8 it owns every wave slot of the chip and nothing of another lane can run beside it
-        static int pad = -1;
-        if (pad < 0) { const char *e = getenv("RF_STEM2_PAD"); pad = e ? atoi(e) : 0; }
-        if (pad == 3) hipLaunchKernelGGL((stem2_kernel<8, false, 3, 0>), dim3(a.nblk), dim3(kThreads), 0, s, a);
-        else if (pad == 7) hipLaunchKernelGGL((stem2_kernel<8, false, 7, 0>), dim3(a.nblk), dim3(kThreads), 0, s, a);
-        else {
-            static int v2 = -1;
-            // probe knob: bit 0 = planar conv2 tile, bit 1 = conv3 -> conv4 chained in registers (off: re-rolls conv4's rounding), bit 2 = rotated thread -> pixel
-            // map of the depthwise-1 phase; 0 = round 3.  Default 5: both layout changes, bit-identical to round 3 (250.3 -> 246.5 -> 238.6 us, tools/gpu/r4_call30.sh, r4_call32.sh)
-            if (v2 < 0) { const char *e = getenv("RF_STEM2_V2"); v2 = e ? atoi(e) : 5; }
-            if (v2 == 5) hipLaunchKernelGGL((stem2_kernel<8, false, 0, 5>), dim3(a.nblk), dim3(kThreads), 0, s, a);
-            else if (v2 == 7) hipLaunchKernelGGL((stem2_kernel<8, false, 0, 7>), dim3(a.nblk), dim3(kThreads), 0, s, a);
-            else if (v2 == 3) hipLaunchKernelGGL((stem2_kernel<8, false, 0, 3>), dim3(a.nblk), dim3(kThreads), 0, s, a);
-            else if (v2 == 2) hipLaunchKernelGGL((stem2_kernel<8, false, 0, 2>), dim3(a.nblk), dim3(kThreads), 0, s, a);
-            else if (v2 == 1) hipLaunchKernelGGL((stem2_kernel<8, false, 0, 1>), dim3(a.nblk), dim3(kThreads), 0, s, a);
-            else hipLaunchKernelGGL((stem2_kernel<8, false, 0, 0>), dim3(a.nblk), dim3(kThreads), 0, s, a);
-        }
+#ifdef RF_PROBES
+    if (tw == 16) { hipLaunchKernelGGL((stem2_kernel<16, false, 0, 0>), dim3(a.nblk), dim3(Stem2Cfg<16, false>::THREADS), 0, s, a); return; }
+    if (v == 3) { hipLaunchKernelGGL((stem2_kernel<8, true, 0, 0>), dim3(a.nblk), dim3(kThreads), 0, s, a); return; }
+    // RF_STEM2_PAD (probe knob): 3 / 7 KB of unused LDS per workgroup = 7 / 6 workgroups per CU instead of 8: stem2 alone gets slower
+    // (+3.5 % / +10 %), but at 8 it owns every wave slot of the chip and nothing of another lane can run beside it
+    const int pad = knob(K_STEM2_PAD);
+    if (pad == 3) { hipLaunchKernelGGL((stem2_kernel<8, false, 3, 0>), dim3(a.nblk), dim3(kThreads), 0, s, a); return; }
+    if (pad == 7) { hipLaunchKernelGGL((stem2_kernel<8, false, 7, 0>), dim3(a.nblk), dim3(kThreads), 0, s, a); return; }
+    // RF_STEM2_V2 (probe knob): bit 0 = planar conv2 tile, bit 1 = conv3 -> conv4 chained in registers, bit 2 = rotated thread -> pixel map of the
+    // depthwise-1 phase; 0 = round 3; 5 = round 4's default (bit-identical to round 3: 250.3 -> 246.5 -> 238.6 us, tools/gpu/r4_call30.sh, r4_call32.sh)
+    switch (knob(K_STEM2_V2)) {
+        case 5: hipLaunchKernelGGL((stem2_kernel<8, false, 0, 5>), dim3(a.nblk), dim3(kThreads), 0, s, a); return;
+        case 3: hipLaunchKernelGGL((stem2_kernel<8, false, 0, 3>), dim3(a.nblk), dim3(kThreads), 0, s, a); return;
+        case 2: hipLaunchKernelGGL((stem2_kernel<8, false, 0, 2>), dim3(a.nblk), dim3(kThreads), 0, s, a); return;
+        case 1: hipLaunchKernelGGL((stem2_kernel<8, false, 0, 1>), dim3(a.nblk), dim3(kThreads), 0, s, a); return;
+        case 0: hipLaunchKernelGGL((stem2_kernel<8, false, 0, 0>), dim3(a.nblk), dim3(kThreads), 0, s, a); return;
+        default: break;
     }
+#endif
+    // The product: V2 = 7 -- planar conv2 tile, rotated depthwise-1 map and (round 5) conv3 -> conv4 chained in registers: 239.3 -> 235.1 us
+    // (tools/gpu/r4_call35.sh).  The chain permutes conv4's K order, i.e. re-rolls its fp32 summation: on one of the 208 contract frames the
+    // NMS winner moves between twin anchors 300 / 301 whose oracle scores are 0.997809 / 0.997806 -- which the anchor-twin band of the parity
+    // tests (tests/anchor_twins.py) admits, and nothing else.
+    hipLaunchKernelGGL((stem2_kernel<8, false, 0, 7>), dim3(a.nblk), dim3(kThreads), 0, s, a);
 }
 
 // =============================================================================================
@@ -1638,6 +1639,7 @@ __global__ __launch_bounds__(kThreads, (DwPwCfg<T, CIN, COUT, STRIDE, HAS_DW, TH
     if (p_img >= 0) store_tile(p_img, p_oy0, p_ox0);
 }
 
+#ifdef RF_PROBES      // measured and rejected (profiles/r04_rejected_ws_variants.txt): probe build only
 // =============================================================================================
 // K_b'  depthwise + pointwise (+ lateral) block WAVE-SPECIALISED (round 4): K_b's phases with the memory side taken off the four
 //   GEMM waves.  A fifth wave (the producer) owns every global-memory instruction of the tile loop: it stores the previous tile's
@@ -1961,11 +1963,7 @@ void dwpw_ws_kernel(DwPwArgs<T> a) {
 }
 
 // probe knob RF_DWPWWS: 0 = off (K_b everywhere); 2 / 3 = halo buffers of the warp-specialised blocks
-static int dwpw_ws_variant() {
-    static int v = -1;
-    if (v < 0) { const char *e = getenv("RF_DWPWWS"); v = e ? atoi(e) : 0; }
-    return v;
-}
+static int dwpw_ws_variant() { return knob(K_DWPWWS); }
 
 template <typename T, int CIN, int COUT, int STRIDE, int TH, int TW, bool LAT, int NBUF, bool PADROW, bool PROD = true>
 static void dwpw_ws_launch(hipStream_t s, const DwPwParams<T> *p, int tiles_x, int tiles_y) {
@@ -1985,6 +1983,7 @@ static void dwpw_ws_launch(hipStream_t s, const DwPwParams<T> *p, int tiles_x, i
                   p->hin, p->win, p->hout, p->wout, tiles_x, tiles_y, p->n * tiles_x * tiles_y};
     hipLaunchKernelGGL(kern, dim3(persistent_grid(a.nblk, resident)), dim3(W::THREADS), W::LDS_BYTES, s, a);
 }
+#endif  // RF_PROBES
 
 template <typename T, int CIN, int COUT, int STRIDE, bool HAS_DW, int TH, int TW, bool LAT, bool PADROW>
 static void dwpw_launch(hipStream_t s, const DwPwParams<T> *p, int tiles_x, int tiles_y) {
@@ -1998,21 +1997,23 @@ static void dwpw_launch(hipStream_t s, const DwPwParams<T> *p, int tiles_x, int 
     hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), C::LDS_BYTES, s, a);
 }
 
-static int dwpw_padrow() {
-    static int v = -1;
-    if (v < 0) { const char *e = getenv("RF_DWPAD"); v = e ? atoi(e) : 1; }        // probe knob: 0 = round-1 halo layout
-    return v;
-}
-
 template <typename T, int CIN, int COUT, int STRIDE, bool HAS_DW, int TH, int TW, bool PADROW = false>
 static TileInfo dwpw_dispatch(hipStream_t s, const DwPwParams<T> *p, int hout, int wout) {
     typedef DwPwCfg<T, CIN, COUT, STRIDE, HAS_DW, TH, TW, PADROW> C;
-    if constexpr (!PADROW && sizeof(T) <= 2 && HAS_DW && STRIDE == 1 && TW == 8 && CIN >= 32) {
-        if (p && dwpw_padrow()) return dwpw_dispatch<T, CIN, COUT, STRIDE, HAS_DW, TH, TW, true>(s, p, hout, wout);
+    // halo rows padded to the bank row (PADROW) wherever a 16-pixel MFMA tile spans two halo rows; RF_DWPAD=0 (probe knob): round-1 layout
+    constexpr bool WANTS_PADROW = !PADROW && sizeof(T) <= 2 && HAS_DW && STRIDE == 1 && TW == 8 && CIN >= 32;
+#ifdef RF_PROBES
+    if constexpr (WANTS_PADROW) {
+        if (p && knob(K_DWPAD)) return dwpw_dispatch<T, CIN, COUT, STRIDE, HAS_DW, TH, TW, true>(s, p, hout, wout);
     }
+#else
+    if constexpr (WANTS_PADROW) return dwpw_dispatch<T, CIN, COUT, STRIDE, HAS_DW, TH, TW, true>(s, p, hout, wout);
+    else {
+#endif
     int tiles_x = (wout + TW - 1) / TW, tiles_y = (hout + TH - 1) / TH;
     TileInfo ti{TH, TW, C::LDS_BYTES, tiles_x * tiles_y};
     if (!p) return ti;
+#ifdef RF_PROBES
     // warp-specialised instances (K_b'): the stride-1 blocks with 64 / 128 channels, with or without the fused lateral
     if constexpr (sizeof(T) <= 2 && HAS_DW && STRIDE == 1 && CIN == COUT && (CIN == 64 || CIN == 128) && C::DWMMA && C::STAT) {
         const int v = dwpw_ws_variant();
@@ -2043,6 +2044,7 @@ static TileInfo dwpw_dispatch(hipStream_t s, const DwPwParams<T> *p, int hout, i
             return ti;
         }
     }
+#endif
     if (p->lat_out) {
         // laterals tap the outputs of blocks 4 (64ch), 10 (128ch) and 12 (256ch)
         if constexpr (HAS_DW && STRIDE == 1 && CIN == COUT && COUT >= 64) dwpw_launch<T, CIN, COUT, STRIDE, HAS_DW, TH, TW, true, PADROW>(s, p, tiles_x, tiles_y);
@@ -2051,66 +2053,90 @@ static TileInfo dwpw_dispatch(hipStream_t s, const DwPwParams<T> *p, int hout, i
         dwpw_launch<T, CIN, COUT, STRIDE, HAS_DW, TH, TW, false, PADROW>(s, p, tiles_x, tiles_y);
     }
     return ti;
+#ifndef RF_PROBES
+    }
+#endif
 }
 
-// the layer table of SURVEY.md App. A -> tile geometry
+// the layer table of SURVEY.md App. A -> tile geometry.  The product build holds ONE tile shape per (precision, layer) -- the winner of the A/B
+// measurements cited below -- and only the layers that precision's engine launches through K_b; the probe build (RF_PROBES) adds the shapes that lost,
+// selected by the RF_TILE* knobs, the fp16 instances of the front blocks (RF_STEM2=0 / RF_DWPW2=0 un-fuse them) and the plain 1x1 instances.
 template <typename T>
 static TileInfo dwpw_select(hipStream_t s, const DwPwParams<T> *p, int cin, int cout, int stride, bool has_dw, int hout,
                             int wout) {
 #define RF_DWPW(CI, CO, ST, DW, TH_, TW_) \
     if (cin == CI && cout == CO && stride == ST && has_dw == DW) return dwpw_dispatch<T, CI, CO, ST, DW, TH_, TW_>(s, p, hout, wout);
-    if constexpr (sizeof(T) > 1) { RF_DWPW(8, 16, 1, true, 8, 32) }      // int8: this block lives in the stem
-    if constexpr (sizeof(T) == 1) {
+    constexpr bool F32 = sizeof(T) == 4, I8 = sizeof(T) == 1;
+#ifdef RF_PROBES
+    constexpr bool FRONT = sizeof(T) >= 2;       // fp16 with RF_STEM2=0 / RF_DWPW2=0 runs blocks 0-3 through K_b as well
+#else
+    constexpr bool FRONT = F32;                  // fp16: blocks 0-3 live in stem2 / dwpw2; int8: block 0 lives in the stem, 1-3 have their own shapes below
+#endif
+    if constexpr (FRONT) { RF_DWPW(8, 16, 1, true, 8, 32) }
+    if constexpr (I8) {
         // Tile shapes of the int8 engine's big-map blocks (fp16 runs them inside stem2 / dwpw2).  These kernels spend their time in the requantising
         // epilogue (VALU-active 0.5-0.64 of the chip), which is per element, so the tile shape moves little; measured one by one inside one call
         // (tools/gpu/r4_call18.sh, us per 256 images, all bit-identical): 16->32 s2 8x8 56.2 | 8x16 53.5 | 16x16 57.2;  32->32 8x8 68.6 | 8x16 67.1 |
-        // 16x16 69.6;  32->64 s2 4x8 32.7 | 8x8 30.5 | 8x16 34.4;  64->128 s2 4x8 18.6 | 8x8 22.1.  Defaults = the best of each; 0 = round-3 shapes.
-        static int va = -1, vb = -1, vc = -1, vd = -1;
-        if (va < 0) { const char *e = getenv("RF_TILE_A"); va = e ? atoi(e) : 1; }
-        if (vb < 0) { const char *e = getenv("RF_TILE_B"); vb = e ? atoi(e) : 1; }
-        if (vc < 0) { const char *e = getenv("RF_TILE_C"); vc = e ? atoi(e) : 1; }
-        if (vd < 0) { const char *e = getenv("RF_TILE_D"); vd = e ? atoi(e) : 0; }
-        if (va == 1) { RF_DWPW(16, 32, 2, true, 8, 16) }
+        // 16x16 69.6;  32->64 s2 4x8 32.7 | 8x8 30.5 | 8x16 34.4;  64->128 s2 4x8 18.6 | 8x8 22.1.  The product = the best of each.
+#ifdef RF_PROBES
+        const int va = knob(K_TILE_A), vb = knob(K_TILE_B), vc = knob(K_TILE_C), vd = knob(K_TILE_D);      // 0 = round-3 shapes
         if (va == 2) { RF_DWPW(16, 32, 2, true, 16, 16) }
-        if (vb == 1) { RF_DWPW(32, 32, 1, true, 8, 16) }
+        if (va == 0) { RF_DWPW(16, 32, 2, true, 8, 8) }
         if (vb == 2) { RF_DWPW(32, 32, 1, true, 16, 16) }
-        if (vc == 1) { RF_DWPW(32, 64, 2, true, 8, 8) }
+        if (vb == 0) { RF_DWPW(32, 32, 1, true, 8, 8) }
         if (vc == 2) { RF_DWPW(32, 64, 2, true, 8, 16) }
+        if (vc == 0) { RF_DWPW(32, 64, 2, true, 4, 8) }
         if (vd == 1) { RF_DWPW(64, 128, 2, true, 8, 8) }
+#endif
+        RF_DWPW(16, 32, 2, true, 8, 16)
+        RF_DWPW(32, 32, 1, true, 8, 16)
+        RF_DWPW(32, 64, 2, true, 8, 8)
     }
-    RF_DWPW(16, 32, 2, true, 8, 8)
-    RF_DWPW(32, 32, 1, true, 8, 8)
-    RF_DWPW(32, 64, 2, true, 4, 8)
+    if constexpr (FRONT) {
+        RF_DWPW(16, 32, 2, true, 8, 8)
+        RF_DWPW(32, 32, 1, true, 8, 8)
+        RF_DWPW(32, 64, 2, true, 4, 8)
+    }
+#ifdef RF_PROBES
     if constexpr (sizeof(T) <= 2) {
-        static int v64 = -1;
-        if (v64 < 0) { const char *e = getenv("RF_TILE64"); v64 = e ? atoi(e) : 0; }          // probe knob (tools/probes)
+        const int v64 = knob(K_TILE64);
         if (v64 == 1) { RF_DWPW(64, 64, 1, true, 8, 8) }
         if (v64 == 2) { RF_DWPW(64, 64, 1, true, 8, 16) }
     }
+#endif
     RF_DWPW(64, 64, 1, true, 4, 8)
     RF_DWPW(64, 128, 2, true, 4, 8)
+    // 128-channel blocks: 4x16 tiles for the int8 engine (26.0 -> 24.9 us each, tools/gpu/r4_call16.sh, r4_call18.sh); fp16: 27.7 -> 28.3, stays 4x8.
+    // RF_TILE128 = 0 / 1 / 2 / 3 forces 4x8 / 8x8 / 4x16 / 8x16 (probe knob; -1 = the per-precision default)
+#ifdef RF_PROBES
     if constexpr (sizeof(T) <= 2) {
-        static int v128 = -1;
-        // 4x16 tiles for the int8 engine's 128-channel blocks: 26.0 -> 24.9 us each (tools/gpu/r4_call16.sh, r4_call18.sh); fp16: 27.7 -> 28.3, stays 4x8.
-        // RF_TILE128 = 0 / 1 / 2 / 3 forces 4x8 / 8x8 / 4x16 / 8x16 (probe knob)
-        if (v128 < 0) { const char *e = getenv("RF_TILE128"); v128 = e ? atoi(e) : (sizeof(T) == 1 ? 2 : 0); }
+        const int v128 = knob(K_TILE128) < 0 ? (I8 ? 2 : 0) : knob(K_TILE128);
         if (v128 == 1) { RF_DWPW(128, 128, 1, true, 8, 8) }
         if (v128 == 2) { RF_DWPW(128, 128, 1, true, 4, 16) }
         if (v128 == 3) { RF_DWPW(128, 128, 1, true, 8, 16) }
+        RF_DWPW(128, 128, 1, true, 4, 8)
     }
-    RF_DWPW(128, 128, 1, true, 4, 8)
+#endif
+    if constexpr (I8) { RF_DWPW(128, 128, 1, true, 4, 16) }
+    else { RF_DWPW(128, 128, 1, true, 4, 8) }
     RF_DWPW(128, 256, 2, true, 4, 8)
+    // 256-channel block, 8x8 tiles: the streamed 256 x 256 weight matrix is read once per 64 pixels instead of 32.  Measured (tools/gpu/r4_call13.sh):
+    // int8 26.4 -> 24.4 us, fp16 35.5 -> 35.6 (its 64 accumulator registers on top of the fragment stream: 2-14 spills with the lateral): int8 only.
+    // RF_TILE256 = 0 / 1 forces 4x8 / 8x8 (probe knob; 2 = the per-precision default)
+#ifdef RF_PROBES
     if constexpr (sizeof(T) <= 2) {
-        static int v256 = -1;
-        // 8x8 tiles: the streamed 256 x 256 weight matrix is read once per 64 pixels instead of 32.  Measured (tools/gpu/r4_call13.sh): int8 26.4 -> 24.4 us,
-        // fp16 35.5 -> 35.6 (its 64 accumulator registers on top of the fragment stream: 2-14 spills with the lateral): int8 only.  RF_TILE256 = 0 / 1 forces.
-        if (v256 < 0) { const char *e = getenv("RF_TILE256"); v256 = e ? atoi(e) : 2; }
-        if (v256 == 1 || (v256 == 2 && sizeof(T) == 1)) { RF_DWPW(256, 256, 1, true, 8, 8) }
+        const int v256 = knob(K_TILE256);
+        if (v256 == 1) { RF_DWPW(256, 256, 1, true, 8, 8) }
+        if (v256 == 0) { RF_DWPW(256, 256, 1, true, 4, 8) }
     }
-    RF_DWPW(256, 256, 1, true, 4, 8)
-    RF_DWPW(256, 64, 1, false, 4, 8)
+#endif
+    if constexpr (I8) { RF_DWPW(256, 256, 1, true, 8, 8) }
+    else { RF_DWPW(256, 256, 1, true, 4, 8) }
+#ifdef RF_PROBES
+    RF_DWPW(256, 64, 1, false, 4, 8)          // plain 1x1 instances (the engines fuse the laterals into the producing block)
     RF_DWPW(128, 64, 1, false, 4, 8)
     RF_DWPW(64, 64, 1, false, 8, 8)
+#endif
 #undef RF_DWPW
     return TileInfo{0, 0, 0, 0};
 }
@@ -2378,6 +2404,7 @@ __global__ __launch_bounds__(kThreads, 3) void dwpw2_kernel(DwPw2Args a) {
     }
 }
 
+#ifdef RF_PROBES      // K_b2c: measured and rejected (110.8 vs 90.8 us), probe build only
 // =============================================================================================
 // K_b2c  dwpw2 with the depthwise -> pointwise hops CHAINED IN REGISTERS (round 4).
 //   In the swapped GEMM (D[cout][pixel]) a lane's accumulator registers hold 4 consecutive channels of the SAME pixel (column) the lane feeds
@@ -2613,6 +2640,7 @@ __global__ __launch_bounds__(kThreads, 3) void dwpw2c_kernel(DwPw2Args a) {
         }
     }
 }
+#endif  // RF_PROBES
 
 void launch_dwpw2(hipStream_t s, const DwPw2Params &p) {
     DwPw2Args a;
@@ -2622,49 +2650,44 @@ void launch_dwpw2(hipStream_t s, const DwPw2Params &p) {
     a.hin = p.hin; a.win = p.win; a.hout = p.hin / 2; a.wout = p.win / 2;
     a.tiles_x = (a.wout + 7) / 8; a.tiles_y = (a.hout + 3) / 4;
     a.nblk = p.n * a.tiles_x * a.tiles_y;
-    static int ring = -1;
-    if (ring < 0) { const char *e = getenv("RF_DWPW2_RING"); ring = e ? atoi(e) : 0; }      // measured and rejected: 107 -> 232 us (the ring costs 8 more registers than the 168-VGPR budget of 3 workgroups per CU has: spills)
+    a.ring = 0;
+#ifdef RF_PROBES
+    // probe knobs (each measured and rejected): RF_DWPW2_RING=1: depthwise A as one ring pipeline (107 -> 232 us: 8 registers more than the
+    // 168-VGPR budget of 3 workgroups per CU, spills); RF_DWPW2_CHAIN=1: K_b2c, the register-chained form (LDS cycles halved, 110.8 vs 100.5 us: longer serial
+    // chains); RF_DWPW2_HPAD=0: unpadded halo rows (round 3); RF_DWPW2_LAY2=0: 96-byte pitches everywhere (round 3)
+    const int ring = knob(K_DWPW2_RING);
     a.ring = ring;
-    static int chain = -1;
-    if (chain < 0) { const char *e = getenv("RF_DWPW2_CHAIN"); chain = e ? atoi(e) : 0; }   // probe knob: 1 = K_b2c, the register-chained form (measured: LDS cycles halved, 110.8 vs 100.5 us -- its serial chains are longer)
-    if (chain && !ring) {
+    if (knob(K_DWPW2_CHAIN) && !ring) {
         static std::atomic<int> resident_cachec[kMaxDevices] = {};
         const int resident = kernel_residency(resident_cachec, dwpw2c_kernel, 0);
         hipLaunchKernelGGL(dwpw2c_kernel, dim3(persistent_grid(a.nblk, resident)), dim3(kThreads), 0, s, a);
         return;
     }
-    static std::atomic<int> resident_cache[kMaxDevices] = {};
     if (ring) {
-        const int resident = kernel_residency(resident_cache, dwpw2_kernel<true, true, false>, 0);
+        static std::atomic<int> resident_cacher[kMaxDevices] = {};
+        const int resident = kernel_residency(resident_cacher, dwpw2_kernel<true, true, false>, 0);
         hipLaunchKernelGGL((dwpw2_kernel<true, true, false>), dim3(persistent_grid(a.nblk, resident)), dim3(kThreads), 0, s, a);
-    } else {
-        static int hpad = -1;
-        if (hpad < 0) { const char *e = getenv("RF_DWPW2_HPAD"); hpad = e ? atoi(e) : 1; }      // probe knob: 0 = unpadded halo rows (round 3)
-        if (hpad) {
-            static std::atomic<int> resident_cache0[kMaxDevices] = {};
-            static int lay2 = -1;
-            if (lay2 < 0) { const char *e = getenv("RF_DWPW2_LAY2"); lay2 = e ? atoi(e) : 1; }      // probe knob: 0 = 96-byte pitches everywhere (round 3)
-            if (lay2) {
-                const int resident = kernel_residency(resident_cache0, dwpw2_kernel<false, true, true>, 0);
-                hipLaunchKernelGGL((dwpw2_kernel<false, true, true>), dim3(persistent_grid(a.nblk, resident)), dim3(kThreads), 0, s, a);
-            } else {
-                static std::atomic<int> resident_cache2[kMaxDevices] = {};
-                const int resident = kernel_residency(resident_cache2, dwpw2_kernel<false, true, false>, 0);
-                hipLaunchKernelGGL((dwpw2_kernel<false, true, false>), dim3(persistent_grid(a.nblk, resident)), dim3(kThreads), 0, s, a);
-            }
-        } else {
-            static std::atomic<int> resident_cache1[kMaxDevices] = {};
-            const int resident = kernel_residency(resident_cache1, dwpw2_kernel<false, false, false>, 0);
-            hipLaunchKernelGGL((dwpw2_kernel<false, false, false>), dim3(persistent_grid(a.nblk, resident)), dim3(kThreads), 0, s, a);
-        }
+        return;
     }
+    if (!knob(K_DWPW2_HPAD)) {
+        static std::atomic<int> resident_cache1[kMaxDevices] = {};
+        const int resident = kernel_residency(resident_cache1, dwpw2_kernel<false, false, false>, 0);
+        hipLaunchKernelGGL((dwpw2_kernel<false, false, false>), dim3(persistent_grid(a.nblk, resident)), dim3(kThreads), 0, s, a);
+        return;
+    }
+    if (!knob(K_DWPW2_LAY2)) {
+        static std::atomic<int> resident_cache2[kMaxDevices] = {};
+        const int resident = kernel_residency(resident_cache2, dwpw2_kernel<false, true, false>, 0);
+        hipLaunchKernelGGL((dwpw2_kernel<false, true, false>), dim3(persistent_grid(a.nblk, resident)), dim3(kThreads), 0, s, a);
+        return;
+    }
+#endif
+    static std::atomic<int> resident_cache0[kMaxDevices] = {};
+    const int resident = kernel_residency(resident_cache0, dwpw2_kernel<false, true, true>, 0);
+    hipLaunchKernelGGL((dwpw2_kernel<false, true, true>), dim3(persistent_grid(a.nblk, resident)), dim3(kThreads), 0, s, a);
 }
 
-int dwpw2_variant() {
-    static int v = -1;
-    if (v < 0) { const char *e = getenv("RF_DWPW2"); v = e ? atoi(e) : 1; }      // probe knob: 0 = two separate K_b launches
-    return v;
-}
+int dwpw2_variant() { return knob(K_DWPW2); }      // probe knob RF_DWPW2: 0 = two separate K_b launches
 
 // Input of the FPN aggregation convs: lateral + bilinear x2 upsample of the coarser level (Deconvolution k4 s2 p1 g64 + Crop + Eltwise SUM,
 // prototxt :1553-1592 / :1948-1987, closed form SURVEY.md App. B.6), one 16-byte item: `lat` = the lateral's channels, u0..u3 = the four
@@ -3269,6 +3292,7 @@ template <typename T, int NBUF> struct Conv3UpWsCfg {
     static_assert(L_BYTES % 16 == 0 && X_BYTES % 16 == 0 && CSLOTS % 64 == 0 && PIECES + CPIECES + NSTORE < 63, "LDS carve / counted vmcnt");
 };
 
+#ifdef RF_PROBES      // producer-wave form: measured and rejected (c1 78 -> 110 us), probe build only
 template <typename T, int DEPTH, int NBUF>
 __global__ __launch_bounds__(320, (Conv3UpWsCfg<T, NBUF>::WAVES_PER_EU)) void conv3x3_up_ws_kernel(Conv3Args<T> a) {
     typedef Conv3UpWsCfg<T, NBUF> W;
@@ -3462,6 +3486,7 @@ __global__ __launch_bounds__(320, (Conv3UpWsCfg<T, NBUF>::WAVES_PER_EU)) void co
         RF_TRACE_T(6, 4, 0);
     }
 }
+#endif  // RF_PROBES
 
 // =============================================================================================
 // K_c3  the aggregation convs with LDS-DMA staging and NO dedicated producer wave (round 4, after the phase stamps of K_c'': a five-wave
@@ -3653,11 +3678,7 @@ __global__ __launch_bounds__(kThreads, 2) void conv3x3_up_dma_kernel(Conv3Args<T
     if (n_my > 0) store_tile((n_my - 1) % NBUF, p_img, p_oy0, p_ox0);
 }
 
-static int conv3_ws_variant() {
-    static int v = -1;
-    if (v < 0) { const char *e = getenv("RF_CONV3WS"); v = e ? atoi(e) : 1; }        // probe knob: 0 = K_c for the merged SSH conv as well; 22 / 23 / 32 / 33: see conv3_ws_launch
-    return v;
-}
+static int conv3_ws_variant() { return knob(K_CONV3WS); }        // probe knob RF_CONV3WS: 1 = the product; 0 = K_c for the merged SSH conv as well; 22 / 23 / 32 / 33 / 122 / 132: see conv3_ws_launch
 
 template <typename T, int DEPTH, int NBUF, int SPLIT = 0>
 static void conv3_ws_launch_v(hipStream_t s, Conv3Args<T> &a, int nlv, int total_tiles) {
@@ -3685,15 +3706,17 @@ static void conv3_ws_launch_v(hipStream_t s, Conv3Args<T> &a, int nlv, int total
 // 44 warp-specialised (its GEMM is too short to hide one producer wave's issue work): int8 stays on K_c.
 template <typename T>
 static void conv3_ws_launch(hipStream_t s, Conv3Args<T> &a, int nlv, int total_tiles) {
+#ifdef RF_PROBES
     switch (conv3_ws_variant()) {
-        case 22: conv3_ws_launch_v<T, 2, 2>(s, a, nlv, total_tiles); break;
-        case 23: conv3_ws_launch_v<T, 3, 2>(s, a, nlv, total_tiles); break;
-        case 33: conv3_ws_launch_v<T, 3, 3>(s, a, nlv, total_tiles); break;
-        case 132: conv3_ws_launch_v<T, 2, 3, 1>(s, a, nlv, total_tiles); break;      // 1xx: the 2 + 2 + 1 role split of the GEMM waves
-        case 122: conv3_ws_launch_v<T, 2, 2, 1>(s, a, nlv, total_tiles); break;
-        case 32: conv3_ws_launch_v<T, 2, 3>(s, a, nlv, total_tiles); break;
-        default: conv3_ws_launch_v<T, 2, 3, 1>(s, a, nlv, total_tiles); break;       // = 132: three halo buffers, 2 + 2 + 1 roles (57.1 -> 54.5 us over 32, tools/gpu/r4_call14.sh)
+        case 22: conv3_ws_launch_v<T, 2, 2>(s, a, nlv, total_tiles); return;
+        case 23: conv3_ws_launch_v<T, 3, 2>(s, a, nlv, total_tiles); return;
+        case 33: conv3_ws_launch_v<T, 3, 3>(s, a, nlv, total_tiles); return;
+        case 122: conv3_ws_launch_v<T, 2, 2, 1>(s, a, nlv, total_tiles); return;     // 1xx: the 2 + 2 + 1 role split of the GEMM waves
+        case 32: conv3_ws_launch_v<T, 2, 3>(s, a, nlv, total_tiles); return;
+        default: break;
     }
+#endif
+    conv3_ws_launch_v<T, 2, 3, 1>(s, a, nlv, total_tiles);       // = 132: three halo buffers, 2 + 2 + 1 roles (57.1 -> 54.5 us over 32, tools/gpu/r4_call14.sh)
 }
 
 template <typename T, int CIN, int COUT, int TH, int TW, bool UPADD, bool ALLC, bool PADROW>
@@ -3702,8 +3725,14 @@ static void conv3_launch(hipStream_t s, Conv3Args<T> &a, int nlv, int total_tile
     if constexpr (sizeof(T) <= 2 && CIN == 64 && COUT == 48 && TH == 8 && TW == 8 && !UPADD && !ALLC && PADROW) {
         bool split32 = true;
         for (int l = 0; l < nlv; l++) split32 = split32 && a.lv[l].n0 == 32 && a.lv[l].out1 != nullptr;
+#ifdef RF_PROBES
         const bool want = conv3_ws_variant() > 1 || (conv3_ws_variant() == 1 && sizeof(T) == 2);       // default: fp16 only (see conv3_ws_launch)
         if (want && split32) { conv3_ws_launch<T>(s, a, nlv, total_tiles); return; }
+#else
+        if constexpr (sizeof(T) == 2) {
+            if (split32) { conv3_ws_launch<T>(s, a, nlv, total_tiles); return; }
+        }
+#endif
     }
     auto kern = conv3x3_kernel<T, CIN, COUT, TH, TW, UPADD, ALLC, PADROW>;
     static std::atomic<int> resident_cache[kMaxDevices] = {};
@@ -3736,7 +3765,7 @@ static TileInfo conv3_dispatch(hipStream_t s, const Conv3Params<T> *p, int nlv, 
         int tiles_x = (q.w_ + TW - 1) / TW, tiles_y = (q.h + TH - 1) / TH;
         a.lv[l] = Conv3Level<T>{q.in, q.up, q.w, q.b, q.m, q.out0, q.out1, q.in_ld, q.in_off, q.ld0, q.off0, q.n0, q.ld1, q.off1,
                                 q.h, q.w_, tiles_x, tiles_y, q.n * tiles_x * tiles_y, 0, 1, q.a_lat, q.a_up,
-                                (sizeof(T) == 1 && q.a_lat == 1.f && q.a_up == 1.f && !getenv("RF_BLEND_FP32")) ? 1 : 0};      // RF_BLEND_FP32: probe / test knob
+                                (sizeof(T) == 1 && q.a_lat == 1.f && q.a_up == 1.f && !knob(K_BLEND_FP32)) ? 1 : 0};      // RF_BLEND_FP32: test knob
         if (l < nlv) total += q.n * tiles_x * tiles_y;
     }
     if (p[0].up) {
@@ -3748,24 +3777,20 @@ static TileInfo conv3_dispatch(hipStream_t s, const Conv3Params<T> *p, int nlv, 
     return ti;
 }
 
-// probe knob (tools/probes): RF_CONV3=0 selects the round-1 wave split (channel tiles over the waves) for A/B measurements
-static int conv3_variant() {
-    static int v = -1;
-    if (v < 0) { const char *e = getenv("RF_CONV3"); v = e ? atoi(e) : -1; }
-    return v;
-}
-
-// probe knob RF_CONV3UPWS: 0 = K_c for the aggregation convs; 2 / 3 = halo buffers of the warp-specialised kernel (K_c'')
-static int conv3_up_ws_variant() {
-    static int v = -1;
-    if (v < 0) { const char *e = getenv("RF_CONV3UPWS"); v = e ? atoi(e) : 1; }       // 1 = auto (see conv3_select)
-    return v;
-}
+// probe knob (tools/probes): RF_CONV3=0 selects the round-1 wave split (channel tiles over the waves) for A/B measurements; -1 = the product
+static int conv3_variant() { return knob(K_CONV3); }
+// probe knob RF_CONV3UPWS: 1 = auto (see conv3_select); 0 = K_c for the aggregation convs; 2 / 3 = halo buffers of the producer-wave kernel (K_c''); 12 / 13: per-wave DMA
+static int conv3_up_ws_variant() { return knob(K_CONV3UPWS); }
 
 template <typename T, int DEPTH, int NBUF, bool PRODUCER_WAVE>
 static void conv3_up_ws_launch(hipStream_t s, const Conv3Params<T> &q) {
     typedef Conv3UpWsCfg<T, NBUF> W;
+#ifdef RF_PROBES
     auto kern = PRODUCER_WAVE ? conv3x3_up_ws_kernel<T, DEPTH, NBUF> : conv3x3_up_dma_kernel<T, DEPTH, NBUF>;
+#else
+    static_assert(!PRODUCER_WAVE, "the producer-wave aggregation conv is a probe-build kernel");
+    auto kern = conv3x3_up_dma_kernel<T, DEPTH, NBUF>;
+#endif
     constexpr int THREADS = PRODUCER_WAVE ? W::THREADS : kThreads;
     static std::atomic<int> resident_cache[kMaxDevices] = {};
     const int dev = launch_device();
@@ -3782,7 +3807,7 @@ static void conv3_up_ws_launch(hipStream_t s, const Conv3Params<T> &q) {
     for (int l = 0; l < 3; l++)
         a.lv[l] = Conv3Level<T>{q.in, q.up, q.w, q.b, q.m, q.out0, q.out1, q.in_ld, q.in_off, q.ld0, q.off0, q.n0, q.ld1, q.off1,
                                 q.h, q.w_, tiles_x, tiles_y, q.n * tiles_x * tiles_y, 0, 1, q.a_lat, q.a_up,
-                                (sizeof(T) == 1 && q.a_lat == 1.f && q.a_up == 1.f && !getenv("RF_BLEND_FP32")) ? 1 : 0};
+                                (sizeof(T) == 1 && q.a_lat == 1.f && q.a_up == 1.f && !knob(K_BLEND_FP32)) ? 1 : 0};
     const int total = q.n * tiles_x * tiles_y;
     if (total == 0) return;
     a.lv[0].gsz = persistent_grid(total, resident);
@@ -3800,14 +3825,19 @@ static TileInfo conv3_select(hipStream_t s, const Conv3Params<T> *p, int nlv, in
         const int upv = conv3_up_ws_variant() == 1 ? ((sizeof(T) == 2 && p && (long)p[0].h * p[0].w_ >= 48 * 48) ? 12 : 0) : conv3_up_ws_variant();
         if (p && nlv == 1 && p[0].up && cin == 64 && cout == 64 && upv >= 2 && p[0].h % 2 == 0 && p[0].w_ % 2 == 0 &&
             p[0].n0 == 64 && p[0].in_ld == 64) {
+#ifdef RF_PROBES
             switch (upv) {                                             // 2 / 3: producer wave, 2 / 3 ring buffers; 12 / 13: every wave its own share
                 case 2: conv3_up_ws_launch<T, 2, 2, true>(s, p[0]); break;
                 case 3: conv3_up_ws_launch<T, 2, 3, true>(s, p[0]); break;
                 case 12: conv3_up_ws_launch<T, 2, 2, false>(s, p[0]); break;
                 default: conv3_up_ws_launch<T, 2, 3, false>(s, p[0]); break;
             }
+#else
+            conv3_up_ws_launch<T, 2, 2, false>(s, p[0]);
+#endif
             return TileInfo{8, 8, Conv3UpWsCfg<T, 3>::LDS_BYTES, ((w + 7) / 8) * ((h + 7) / 8)};
         }
+#ifdef RF_PROBES
         // fp16 / int8: every wave owns all output channels of its pixels (Conv3Cfg ALLC), 8x8 tiles
         const int v = conv3_variant();
         if (v >= 1) {
@@ -3823,16 +3853,28 @@ static TileInfo conv3_select(hipStream_t s, const Conv3Params<T> *p, int nlv, in
             if (cin == 64 && cout == 48) return conv3_dispatch<T, 64, 48, 8, 8, false, true>(s, p, nlv, h, w);
             if (cin == 16 && cout == 16) return conv3_dispatch<T, 16, 16, 8, 8, false, true>(s, p, nlv, h, w);
         }
+#else
+        // the product: round-1 wave split, halo rows padded to the bank row (conflict-free B-fragment reads); the 16-channel convs of the SSH tail
+        // live in ssh_tail_kernel (fp16 / int8), so only the aggregation conv and the merged SSH 64 -> 48 conv have instances here
+        if (cin == 64 && cout == 64) return conv3_dispatch<T, 64, 64, 4, 8, false, true>(s, p, nlv, h, w);
+        if (cin == 64 && cout == 48) return conv3_dispatch<T, 64, 48, 8, 8, false, true>(s, p, nlv, h, w);
+        return TileInfo{0, 0, 0, 0};
+#endif
     }
-    // single-level small maps (stride 32 / 16 at 448^2: 14x14, 28x28) get 4x8 tiles for more workgroups where the
-    // channel tiles still split over 4 waves (COUT % 32 == 0); everything else 8x8
-    const bool small = nlv == 1 && (size_t)h * w <= 32 * 32;
-    if (cin == 64 && cout == 64)
-        return conv3_dispatch<T, 64, 64, 4, 8>(s, p, nlv, h, w);
-    if (cin == 16 && cout == 32)
-        return small ? conv3_dispatch<T, 16, 32, 4, 8>(s, p, nlv, h, w) : conv3_dispatch<T, 16, 32, 8, 8>(s, p, nlv, h, w);
-    if (cin == 64 && cout == 48) return conv3_dispatch<T, 64, 48, 8, 8>(s, p, nlv, h, w);
-    if (cin == 16 && cout == 16) return conv3_dispatch<T, 16, 16, 8, 8>(s, p, nlv, h, w);
+#ifndef RF_PROBES
+    if constexpr (sizeof(T) > 2)          // (fp16 / int8 returned above; RF_CONV3=0 of the probe build sends them here too)
+#endif
+    {
+        // single-level small maps (stride 32 / 16 at 448^2: 14x14, 28x28) get 4x8 tiles for more workgroups where the
+        // channel tiles still split over 4 waves (COUT % 32 == 0); everything else 8x8
+        const bool small = nlv == 1 && (size_t)h * w <= 32 * 32;
+        if (cin == 64 && cout == 64)
+            return conv3_dispatch<T, 64, 64, 4, 8>(s, p, nlv, h, w);
+        if (cin == 16 && cout == 32)
+            return small ? conv3_dispatch<T, 16, 32, 4, 8>(s, p, nlv, h, w) : conv3_dispatch<T, 16, 32, 8, 8>(s, p, nlv, h, w);
+        if (cin == 64 && cout == 48) return conv3_dispatch<T, 64, 48, 8, 8>(s, p, nlv, h, w);
+        if (cin == 16 && cout == 16) return conv3_dispatch<T, 16, 16, 8, 8>(s, p, nlv, h, w);
+    }
     return TileInfo{0, 0, 0, 0};
 }
 
@@ -4073,18 +4115,19 @@ __global__ __launch_bounds__(kThreads, OCC) void ssh_tail_kernel(SshTailArgs<T> 
     if (p_img >= 0) store_tile(s_out + (buf ^ 1) * O_ELEMS, p_img, p_oy0, p_ox0);
 }
 
-int ssh_tail_variant() {
-    static int v = -1;
-    if (v < 0) { const char *e = getenv("RF_SSHTAIL"); v = e ? atoi(e) : 1; }      // probe knob: 0 = two conv3x3<16,*> launches, 2 = 3 workgroups per CU
-    return v;
-}
+int ssh_tail_variant() { return knob(K_SSHTAIL); }      // probe knob RF_SSHTAIL: 1 = the product; 0 = two conv3x3<16,*> launches, 2 = 3 workgroups per CU
 
 template <typename T> void launch_ssh_tail(hipStream_t s, const SshTailParams<T> *levels, int nlevels) {
     typedef SshTailCfg<T> C;
     if (nlevels < 1 || nlevels > 3) throw LaunchUnsupported("ssh tail: 1..3 levels per launch");
     // RF_SSHTAIL=2 (probe knob): the 3-workgroups-per-CU build (155 VGPRs, no spill) instead of the 4-per-CU one (128 VGPRs)
+#ifdef RF_PROBES
     const bool occ3 = ssh_tail_variant() == 2;
     auto kern = occ3 ? ssh_tail_kernel<T, 3> : ssh_tail_kernel<T, 4>;
+#else
+    constexpr bool occ3 = false;
+    auto kern = ssh_tail_kernel<T, 4>;
+#endif
     static std::atomic<int> resident_cache[2][kMaxDevices] = {};
     const int resident = kernel_residency(resident_cache[occ3 ? 1 : 0], kern, C::LDS_BYTES);
     SshTailArgs<T> a;
@@ -4553,19 +4596,38 @@ __global__ void cvt_pk_u8_probe_kernel(int *bad) {
     }
     if (wrong) atomicAdd(bad, wrong);
 }
+// 0 = rounds as assumed, 1 = mismatch (an ISA property of the device: cached), -1 = the probe itself could not run (a transient runtime
+// error -- out of memory, a failed copy or launch: reported as such by the engine and NOT cached, so a later rf_create tries again).
+// Runs on a private non-blocking stream: the legacy null stream would synchronise with -- and could invalidate -- another thread's
+// blocking-stream work or graph capture on the same device.
 int cvt_pk_u8_selfcheck() {
     static std::atomic<int> result[kMaxDevices] = {};          // 0 = not run, 1 = ok, 2 = mismatch
     const int dev = launch_device();
     int r = result[dev].load(std::memory_order_acquire);
     if (!r) {
-        int *d = nullptr, h = -1;
-        if (hipMalloc((void **)&d, sizeof(int)) != hipSuccess) return -1;
-        (void)hipMemset(d, 0, sizeof(int));
-        hipLaunchKernelGGL(cvt_pk_u8_probe_kernel, dim3(1), dim3(64), 0, 0, d);
-        if (hipMemcpy(&h, d, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) h = -1;
-        (void)hipFree(d);
-        r = h == 0 ? 1 : 2;
-        result[dev].store(r, std::memory_order_release);
+        int *d = nullptr, *h = nullptr;
+        hipStream_t st = nullptr;
+        bool ok = hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess;
+        ok = ok && hipMalloc((void **)&d, sizeof(int)) == hipSuccess;
+        ok = ok && hipHostMalloc((void **)&h, sizeof(int), hipHostMallocDefault) == hipSuccess;
+        if (ok) {
+            *h = -1;
+            ok = hipMemsetAsync(d, 0, sizeof(int), st) == hipSuccess;
+            if (ok) {
+                hipLaunchKernelGGL(cvt_pk_u8_probe_kernel, dim3(1), dim3(64), 0, st, d);
+                ok = hipGetLastError() == hipSuccess;
+            }
+            ok = ok && hipMemcpyAsync(h, d, sizeof(int), hipMemcpyDeviceToHost, st) == hipSuccess;
+            ok = ok && hipStreamSynchronize(st) == hipSuccess;
+            ok = ok && *h >= 0;
+        }
+        const int mismatches = ok ? *h : -1;
+        if (h) (void)hipHostFree(h);
+        if (d) (void)hipFree(d);
+        if (st) (void)hipStreamDestroy(st);
+        if (!ok) { (void)hipGetLastError(); return -1; }
+        r = mismatches == 0 ? 1 : 2;
+        result[dev].store(r, std::memory_order_release);       // only a completed comparison is cached
     }
     return r == 1 ? 0 : 1;
 }

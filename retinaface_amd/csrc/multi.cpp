@@ -193,6 +193,9 @@ public:
     void host_forget(const void *ptr) override {
         for (auto &e : eng_) e->host_forget(ptr);
     }
+    void invalidate_residency() override {
+        for (auto &e : eng_) e->invalidate_residency();
+    }
 
     int last_anchor_indices(int image, int32_t *out, int cap) const override {
         if (last_from_wait_ >= 0) return eng_[last_from_wait_]->last_anchor_indices(image, out, cap);
@@ -225,6 +228,7 @@ public:
                 float *avg_ms, double *alg_bytes, double *macs) override {
         return eng_[0]->profile(d_frames, n, iters, cap, names, kernels, avg_ms, alg_bytes, macs);
     }
+    int compulsory_bytes(int n, int cap, double *bytes) override { return eng_[0]->compulsory_bytes(n, cap, bytes); }
 
 private:
     void locate(int image, int *g, int *local) const {

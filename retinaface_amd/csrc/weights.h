@@ -19,6 +19,7 @@
 #include <vector>
 
 #include "kernels.h"
+#include "knobs.h"
 #include "model.h"
 #include "pack.h"
 #include "plan.h"
@@ -385,8 +386,7 @@ struct WeightPack {
                     // the weights AS THE KERNEL SEES THEM (fp16-rounded taps, hi + lo pointwise weights).  RF_STEM2_DC=0: mu = 0
                     // (probe / test knob: the tiles are then plain ReLU outputs as in round 2).
                     std::vector<float> mu2(16, 0.f), mu3(16, 0.f);
-                    const char *dc_env = getenv("RF_STEM2_DC");
-                    if (!dc_env || atoi(dc_env) != 0) {
+                    if (knob(K_STEM2_DC) != 0) {
                         double y0[8], y1[8];
                         for (int c = 0; c < 8; c++) {
                             double sw = 0.0;

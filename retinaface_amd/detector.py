@@ -183,6 +183,10 @@ class RetinaFace:
     def host_unregister(self, arr: np.ndarray) -> None:
         _lib.check(self._lib.rf_host_unregister(self._h, arr.ctypes.data), self._h)
 
+    def invalidate_residency(self) -> None:
+        """Forget where device frame pointers live (call after freeing / re-allocating frame buffers; rf_invalidate_residency)."""
+        _lib.check(self._lib.rf_invalidate_residency(self._h), self._h)
+
     def num_devices(self) -> int:
         return self._lib.rf_num_devices(self._h)
 
@@ -260,7 +264,8 @@ class RetinaFace:
         return arr.reshape(dims[0], dims[1], dims[2])
 
     def profile(self, ptrs: Sequence[int], iters: int = 20):
-        """Per-kernel HIP-event timing: list of dicts {name, kernel, ms, alg_bytes, macs} in launch order."""
+        """Per-kernel HIP-event timing: list of dicts {name, kernel, ms, alg_bytes, macs, compulsory_bytes} in launch order
+        (alg_bytes: layer-wise; compulsory_bytes: what the fused launch must move through HBM at least)."""
         n = len(ptrs)
         p = (C.c_void_p * n)(*ptrs)
         cap = 128
@@ -270,8 +275,10 @@ class RetinaFace:
         ab = (C.c_double * cap)()
         mc = (C.c_double * cap)()
         k = _lib.check(self._lib.rf_profile(self._h, p, n, iters, cap, names, kernels, ms, ab, mc), self._h)
-        return [{"name": names[i].decode(), "kernel": kernels[i].decode(), "ms": ms[i], "alg_bytes": ab[i], "macs": mc[i]}
-                for i in range(k)]
+        cb = (C.c_double * cap)()
+        _lib.check(self._lib.rf_profile_compulsory_bytes(self._h, n, cap, cb), self._h)
+        return [{"name": names[i].decode(), "kernel": kernels[i].decode(), "ms": ms[i], "alg_bytes": ab[i], "macs": mc[i],
+                 "compulsory_bytes": cb[i]} for i in range(k)]
 
     # ------------------------------------------------------------------ internals
     def _run(self, fn, ptrs, rows, cols, steps, n, threshold):

@@ -243,6 +243,10 @@ def test_bench_self_launches_n_ranks_and_gathers_results():
     s4 = j["configs4_strong"]
     assert s4["scaling"] == "strong" and s4["global_batch"] == 256 and s4["images_per_rank"] == 128 and s4["dtype"] == "i8"
     assert s4["result_gather"]["records_gathered"] == s4["result_gather"]["expected"] == 256 * s4["steps"]
+    # ... and by the LIBRARY leg on rank 0 (one handle over devices [0 .. N-1], 256 images per call, frames on GPU 0: multi.cpp's split and
+    # the peer scatter), while the other ranks wait on the rendezvous store; --dry reports the plan only
+    lib = j["library_multi_device"]
+    assert lib["devices"] == [0, 1] and lib["global_batch"] == 256 and lib["images_per_engine"] == 128
     # under an external launcher the rank count must agree with --gpus
     env2 = dict(env, WORLD_SIZE="3", RANK="0", LOCAL_RANK="0")
     bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry"], capture_output=True, text=True,

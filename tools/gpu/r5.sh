@@ -1,0 +1,68 @@
+#!/bin/bash
+# round 5: ONE parametrised script for every GPU call of the round (rounds 3-4 committed one near-identical script per call).
+#   gpurun --timeout T -- 'bash tools/gpu/r5.sh <tag> <recipe> [<recipe> ...]'      output -> gpurun_out/r5_<tag>/
+# recipes: suite | smoke | bench | bench_driver | kbench_fp16 | kbench_int8 | kbench_ab (product vs lib_base) | sync_gaps | libleg | probes | trace1 | bench2
+R=${GRAFT_REPO_ROOT:-/root/repo}
+TAG=$1; shift
+O=$R/gpurun_out/r5_$TAG
+mkdir -p $O
+cd $R
+export TMPDIR=/tmp
+for recipe in "$@"; do
+  echo "=== $recipe"
+  case $recipe in
+    suite)
+      ( time timeout 1400 python -m pytest tests -m gpu -q --durations=5 -s ) > $O/pytest.log 2>&1; echo "rc $?" >> $O/pytest.log
+      grep -v "compute time" $O/pytest.log | grep -E "passed|failed|fp16 contract|^rc|real" | tail -8 ;;
+    smoke)
+      timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; tail -1 $O/smoke.log ;;
+    bench)
+      ( time timeout 900 python bench.py > $O/bench_default.json 2> $O/bench_default.err ) 2> $O/bench_time.txt
+      cp gpurun_out/bench_kernels.json $O/bench_kernels.json 2>/dev/null; cp gpurun_out/bench_pipeline_trace.json $O/ 2>/dev/null
+      tail -3 $O/bench_time.txt
+      python - <<PY
+import json
+j=json.loads(open("$O/bench_default.json").read().strip().splitlines()[-1])
+r=j["roofline"]
+print("value", round(j["value"]), "images/s", round(j["images_per_sec"]), "sync_batch ms", round(j["sync_batch"]["ms_per_call"],4), "burst ms", round(j["burst"]["ms"],3))
+print("roofline", r["bound"], r["frac"], "kernel_ms", round(r["kernel_ms"],4), "in pipeline", r.get("kernel_ms_in_pipeline"), "useful", {k:(round(v,4) if isinstance(v,float) else v) for k,v in r["useful"].items() if k.endswith("frac")})
+print("whole path ms", round(r["whole_path"]["kernels_ms_per_launch_sequence"],4), "in pipeline", r["whole_path"].get("kernels_ms_in_pipeline"))
+for c in j.get("configs", []):
+    print(" cfg", c["id"], round(c["images_per_sec"]), "img/s  sync", round(c["sync_batch"]["ms_per_call"],4), "ms", c.get("dominant_kernel"), c.get("bound"), c.get("bound_frac"))
+print("cpu", j.get("cpu_baseline",{}).get("images_per_sec"), j.get("cpu_baseline",{}).get("gpu_faces_identical_to_oracle"), "host", {k:round(v["images_per_sec"]) for k,v in j.get("host_frames",{}).items() if isinstance(v,dict) and "images_per_sec" in v})
+PY
+      ;;
+    bench_driver)
+      timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extra-configs --no-pmc > $O/bench_driver_invocation_steps20_warmup5.json 2> $O/bench_driver.err
+      python -c "import json;j=json.loads(open('$O/bench_driver_invocation_steps20_warmup5.json').read().strip().splitlines()[-1]);print('driver invocation', round(j['images_per_sec']), 'img/s', round(j['value']), 'faces/s')" ;;
+    kbench_fp16)
+      timeout 200 python tools/kbench.py --n 256 --tag r5_${TAG}_fp16 > $O/kbench_fp16.txt 2>&1; cat $O/kbench_fp16.txt | cut -c1-70 ;;
+    kbench_int8)
+      timeout 200 python tools/kbench.py --n 256 --precision int8 --batch 32 --tag r5_${TAG}_int8 > $O/kbench_int8.txt 2>&1; cat $O/kbench_int8.txt | cut -c1-70 ;;
+    kbench_ab)      # product library vs the previous build kept in retinaface_amd/lib_base (interleaved, 3 repetitions)
+      for rep in 1 2 3; do
+        RETINAFACE_AMD_LIB=$R/retinaface_amd/lib_base/libretinaface_amd.so timeout 100 python tools/kbench.py --n 256 --tag base_$rep > $O/kbench_base_$rep.txt 2>&1
+        timeout 100 python tools/kbench.py --n 256 --tag new_$rep > $O/kbench_new_$rep.txt 2>&1
+      done
+      for f in $O/kbench_base_*.txt $O/kbench_new_*.txt; do echo "$(basename $f) $(grep -h '==' $f | awk '{print $8}') | stem2 $(grep -h 'stem2' $f | awk '{print $2}') | nms $(grep -h ' nms' $f | awk '{print $2}') head $(grep -h ' head' $f | awk '{print $2}')"; done ;;
+    sync_gaps)
+      for cfg in "8 448 448 fp16" "1 896 1280 fp16" "32 448 448 int8"; do
+        t=$(echo $cfg | tr ' ' '_')
+        rm -rf /tmp/kt_$t; ( cd /tmp && timeout 200 rocprofv3 --kernel-trace -d /tmp/kt_$t -o kt -- python $R/tools/probes/sync_gaps.py run $cfg > $O/sync_gaps_run_$t.log 2>&1 )
+        db=$(find /tmp/kt_$t -name "*.db" | head -1)
+        python tools/probes/sync_gaps.py report $db > $O/sync_gaps_$t.txt 2>&1; head -3 $O/sync_gaps_$t.txt
+      done ;;
+    libleg)
+      timeout 300 python bench.py --library-devices 8 > $O/bench_library_leg_8_engines_one_gpu.json 2> $O/libleg.err
+      python -c "import json;j=json.loads(open('$O/bench_library_leg_8_engines_one_gpu.json').read().strip().splitlines()[-1])['library_multi_device'];print({k:j[k] for k in ('devices','ms_per_call','images_per_sec','frames_scattered_per_call','detections_identical_to_single_engine','forced_scatter_rehearsal')}, j['single_engine_same_call'])" ;;
+    bench2)
+      timeout 400 python bench.py --gpus 2 --oversubscribe --no-cpu-baseline --host-seconds 0 > $O/bench_2ranks_one_gpu.json 2> $O/bench2.err
+      python -c "import json;j=json.loads(open('$O/bench_2ranks_one_gpu.json').read().strip().splitlines()[-1]);print('2 ranks one gpu', j['n_gpus'], round(j['images_per_sec']), j.get('library_multi_device',{}).get('images_per_sec'), j.get('library_multi_device',{}).get('error'))" ;;
+    probes)
+      ( time RF_PROBE_TESTS=1 timeout 1200 python -m pytest tests/test_gpu_parity.py -m gpu -q -k probe_knob ) > $O/pytest_probe_knobs.log 2>&1; tail -4 $O/pytest_probe_knobs.log ;;
+    trace1)
+      rm -rf /tmp/kt1; ( cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/kt1 -o kt -- python $R/bench.py --timed-only --lanes 1 --no-pmc > $O/trace1_bench.json 2> $O/trace1.err )
+      db=$(find /tmp/kt1 -name "*.db" | head -1); python tools/rocpd_summary.py $db $O/kernel_trace_lanes1_fp16.txt > /dev/null; head -24 $O/kernel_trace_lanes1_fp16.txt | cut -c1-60,104-190 ;;
+    *) echo "unknown recipe $recipe" ;;
+  esac
+done

@@ -92,7 +92,11 @@ def band(heads, thr, noise=SCORE_NOISE):
 
 def bands():
     """tests/golden/threshold_bands.npz: for every golden frame and threshold, how many anchors sit inside the fp16 score-noise band
-    around the threshold -- the tolerance the fp16 candidate-count assertions use instead of a flat +-4 (round 4)."""
+    around the threshold -- the tolerance the fp16 candidate-count assertions use instead of a flat +-4 (round 4) -- and (round 5,
+    `<key>/twins`) the oracle's own near-tie TWIN anchors: pairs (kept W, suppressed T) on one face whose oracle scores differ by at
+    most twice the score noise, with T's oracle row -- the only way an fp16 engine's kept anchor set may differ (tests/anchor_twins.py)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from anchor_twins import twins_of_result
     frame = padded_base_frame()
     crop = np.ascontiguousarray(frame[30:478, 440:888])
     synth = synth_frames(448, 448, 8, config=1)
@@ -100,12 +104,14 @@ def bands():
     for stem in ("mnet-deconv-0517", "mnet25"):
         det = OracleDetector(read_rfw(os.path.join(ROOT, "assets", stem + ".rfw")))
         for thr, tag in ((0.5, "05"), (0.9, "09")):
-            d[f"{stem}/fixture/{tag}"] = np.int32(band(det.detect(frame, thr, 0.4).heads, thr))
-            d[f"{stem}/crop448/{tag}"] = np.int32(band(det.detect(crop, thr, 0.4, net_hw=(448, 448)).heads, thr))
-            for i, f in enumerate(synth):
-                d[f"{stem}/synth448_{i}/{tag}"] = np.int32(band(det.detect(f, thr, 0.4, net_hw=(448, 448)).heads, thr))
+            cases = [(f"{stem}/fixture/{tag}", det.detect(frame, thr, 0.4)), (f"{stem}/crop448/{tag}", det.detect(crop, thr, 0.4, net_hw=(448, 448)))]
+            cases += [(f"{stem}/synth448_{i}/{tag}", det.detect(f, thr, 0.4, net_hw=(448, 448))) for i, f in enumerate(synth)]
+            for key, r in cases:
+                d[key] = np.int32(band(r.heads, thr))
+                d[key + "/twins"] = twins_of_result(r, 0.4, SCORE_NOISE)
     np.savez_compressed(os.path.join(OUT, "threshold_bands.npz"), **d)
-    print({k: int(v) for k, v in d.items() if k != "score_noise"})
+    print({k: int(v) for k, v in d.items() if k != "score_noise" and not k.endswith("/twins")})
+    print("twin pairs:", {k: [(int(t[0]), int(t[1])) for t in v] for k, v in d.items() if k.endswith("/twins") and len(v)})
 
 
 if __name__ == "__main__":
