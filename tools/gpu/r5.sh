@@ -39,12 +39,12 @@ PY
       timeout 200 python tools/kbench.py --n 256 --tag r5_${TAG}_fp16 > $O/kbench_fp16.txt 2>&1; cat $O/kbench_fp16.txt | cut -c1-70 ;;
     kbench_int8)
       timeout 200 python tools/kbench.py --n 256 --precision int8 --batch 32 --tag r5_${TAG}_int8 > $O/kbench_int8.txt 2>&1; cat $O/kbench_int8.txt | cut -c1-70 ;;
-    kbench_ab)      # product library vs the previous build kept in retinaface_amd/lib_base (interleaved, 3 repetitions)
-      for rep in 1 2 3; do
-        RETINAFACE_AMD_LIB=$R/retinaface_amd/lib_base/libretinaface_amd.so timeout 100 python tools/kbench.py --n 256 --tag base_$rep > $O/kbench_base_$rep.txt 2>&1
-        timeout 100 python tools/kbench.py --n 256 --tag new_$rep > $O/kbench_new_$rep.txt 2>&1
-      done
-      for f in $O/kbench_base_*.txt $O/kbench_new_*.txt; do echo "$(basename $f) $(grep -h '==' $f | awk '{print $8}') | stem2 $(grep -h 'stem2' $f | awk '{print $2}') | nms $(grep -h ' nms' $f | awk '{print $2}') head $(grep -h ' head' $f | awk '{print $2}')"; done ;;
+    kbench_ab)      # A/B inside one call through the PROBE build: $AB_KNOB=$AB_A vs $AB_KNOB=$AB_B (default: stem2 without / with the conv3 -> conv4 register chain), interleaved
+      K=${AB_KNOB:-RF_STEM2_V2}; A=${AB_A:-5}; B=${AB_B:-7}; P=${AB_PREC:-fp16}; BT=${AB_BATCH:-8}
+      for rep in 1 2 3; do for v in $A $B; do
+        env RETINAFACE_AMD_LIB=$R/retinaface_amd/lib/libretinaface_amd_probe.so $K=$v timeout 100 python tools/kbench.py --n 256 --precision $P --batch $BT --tag ${K}_${v}_$rep > $O/kbench_${K}_${v}_$rep.txt 2>&1
+      done; done
+      for f in $O/kbench_${K}_*.txt; do echo "$(basename $f) total $(grep -h '==' $f | awk '{print $8}') | $(grep -h -E "${AB_GREP:-stem2}" $f | awk '{printf "%s %s  ", $1, $2}')"; done ;;
     sync_gaps)
       for cfg in "8 448 448 fp16" "1 896 1280 fp16" "32 448 448 int8"; do
         t=$(echo $cfg | tr ' ' '_')
