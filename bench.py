@@ -1121,9 +1121,10 @@ def measure_pipeline_trace(args):
         for name, grid, calls, avg in rows:
             if "rf::" not in name and not name.startswith("_ZN2rf"):
                 continue
-            d = pmc_summary.descriptor(name)
-            if d not in groups or calls > groups[d]["calls"]:            # the steady-state grid of an instance = the one launched most often
-                groups[d] = {"kernel": d, "grid": int(grid), "calls": int(calls), "avg_ms": avg / 1e6}
+            # one entry per kernel SYMBOL (two instances may share an op descriptor: the c2 / c1 aggregation convs run different kernels);
+            # the steady-state grid of a symbol = the one launched most often (warm-up launches use other grids)
+            if name not in groups or calls > groups[name]["calls"]:
+                groups[name] = {"kernel": pmc_summary.descriptor(name), "grid": int(grid), "calls": int(calls), "avg_ms": avg / 1e6}
         if not groups:
             return None
         base = min(g["calls"] for g in groups.values())                  # a kernel launched once per sequence
@@ -1146,7 +1147,7 @@ def attach_pipeline_trace(roofline, trace):
         return
     mine = [g for g in trace["kernels"] if g["kernel"] == roofline["kernel_instance"]]
     if mine:
-        ms = mine[0]["avg_ms"]
+        ms = max(g["avg_ms"] for g in mine)
         roofline["kernel_ms_in_pipeline"] = ms
         roofline["useful_in_pipeline"] = {k: (v * roofline["kernel_ms"] / ms if isinstance(v, float) and k.endswith(("_frac", "_GBs", "_TFLOPs")) else v)
                                           for k, v in roofline["useful"].items()}

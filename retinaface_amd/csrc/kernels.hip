@@ -644,10 +644,12 @@ __global__ __launch_bounds__(kThreads, (StemCfg<TO>::OCC)) void stem_kernel(Stem
                 w1 &= bmask(hi - 4) & ~bmask(lo - 4);
                 w2 &= bmask(hi - 8) & ~bmask(lo - 8);
             }
+            // 12 bytes -> 4 BGRX dwords.  The X byte is left as it falls (the next pixel's B): its K slot meets a zero weight in both the hi
+            // and the lo fragment and (0x6400 | X) is a finite fp16, so the product is an exact +0 -- three v_and_b32 per item less (round 5)
             uint4 o4;
-            o4.x = w0 & 0x00ffffffu;
-            o4.y = ((w0 >> 24) | (w1 << 8)) & 0x00ffffffu;
-            o4.z = ((w1 >> 16) | (w2 << 16)) & 0x00ffffffu;
+            o4.x = w0;
+            o4.y = __builtin_amdgcn_alignbyte(w1, w0, 3);
+            o4.z = __builtin_amdgcn_alignbyte(w2, w1, 2);
             o4.w = w2 >> 8;
             *(uint4 *)(s_in + r * ST_ROWD + g * 4) = o4;
         }
@@ -909,10 +911,11 @@ __global__ __launch_bounds__((Stem2Cfg<TW_, F16P, PADKB>::THREADS), (Stem2Cfg<TW
                 w1 &= bmask(hi - 4) & ~bmask(lo - 4);
                 w2 &= bmask(hi - 8) & ~bmask(lo - 8);
             }
+            // 12 bytes -> 4 BGRX dwords; the X byte is left as it falls (see K_a': zero weight x finite fp16 = exact +0): three v_and_b32 per item less
             uint4 o4;
-            o4.x = w0 & 0x00ffffffu;
-            o4.y = ((w0 >> 24) | (w1 << 8)) & 0x00ffffffu;
-            o4.z = ((w1 >> 16) | (w2 << 16)) & 0x00ffffffu;
+            o4.x = F16P ? (w0 & 0x00ffffffu) : w0;
+            o4.y = F16P ? (((w0 >> 24) | (w1 << 8)) & 0x00ffffffu) : __builtin_amdgcn_alignbyte(w1, w0, 3);
+            o4.z = F16P ? (((w1 >> 16) | (w2 << 16)) & 0x00ffffffu) : __builtin_amdgcn_alignbyte(w2, w1, 2);
             o4.w = w2 >> 8;
             // u8 -> fp16 HERE, once per input pixel (conv0 reads every pixel 2.25 times on average: converting in phase 2 was
             // 12 of its 30 VALU instructions per MFMA tile); the X byte becomes the half 0 = the K padding
@@ -1639,6 +1642,250 @@ __global__ __launch_bounds__(kThreads, (DwPwCfg<T, CIN, COUT, STRIDE, HAS_DW, TH
     if (p_img >= 0) store_tile(p_img, p_oy0, p_ox0);
 }
 
+// =============================================================================================
+// K_b(8)  the 256-channel block (conv25 + conv26 + rf_c3_lateral) with EIGHT waves per workgroup and every weight stationary (round 5).
+//   K_b's 4-wave form cannot hold the 256 x 256 pointwise matrix in registers (128 KB = 128 VGPRs per thread of 256): it streams the A
+//   fragments from L2 for every 32-pixel tile (GemmPipe) at ONE workgroup = one wave per SIMD per CU -- nothing hides the stream's latency,
+//   and the counters say so: HBM 0.20, VALU 0.13, MFMA 0.13 of the chip for 37-42 us per 256 images (profiles/r04_kernels_and_counters_*).
+//   With 512 threads the same matrix is 64 VGPRs per thread: wave w owns output-channel tiles {w, w + 8} for both pixel tiles of a 4 x 8
+//   tile (2 x 8 K-chunks = 16 A fragments), the 64 x 256 lateral is one channel tile x one pixel tile per wave (8 fragments), the depthwise
+//   stencil two 16-channel groups per wave -- the tile loop has no global load except the halo prefetch, and the CU runs two waves per SIMD.
+//   Same arithmetic, same summation order per output as K_b (K-chunks in order, bias as the initial accumulator): bit-identical results.
+// =============================================================================================
+constexpr int kWideThreads = 512;
+
+template <typename T, int CIN, int COUT, int TH, int TW, bool LAT, bool PADROW>
+__global__ __launch_bounds__(kWideThreads, 1) void dwpw_wide_kernel(DwPwArgs<T> a) {
+    typedef DwPwCfg<T, CIN, COUT, 1, true, TH, TW, PADROW> C;
+    typedef typename Vec<T>::type V;
+    typedef Mma<T> M;
+    typedef typename M::Frag Frag;
+    constexpr int NW = kWideThreads / 64;
+    constexpr int VEC = C::VEC, P = C::P, HC = C::HC, LDA = C::LDA, LDO = C::LDO, LDIN = C::LDIN, ROWP = C::ROWP;
+    constexpr int CPV = CIN / VEC, PT = C::PT, KCH = C::KCH;
+    constexpr int NT = COUT / 16, NI = NT / NW, NJ = PT;
+    constexpr int NG = CIN / 16, GW = NG / NW, PW = PT, DKCH = kDwMmaChunks;
+    constexpr int LKCH = (COUT + M::K - 1) / M::K, LNJ = LAT ? PT / (NW / 4) : 1;
+    constexpr int NPF = (C::STAGE_ITEMS + kWideThreads - 1) / kWideThreads;
+    static_assert(sizeof(T) == 2 && C::DWMMA && NT % NW == 0 && NG % NW == 0 && (!LAT || PT % (NW / 4) == 0), "shape does not split over 8 waves");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    T *s_in = (T *)smem;
+    T *s_a = (T *)(smem + C::IN_BYTES + C::DW_BYTES);
+    T *s_out = (T *)(smem + C::IN_BYTES + C::DW_BYTES + C::A_BYTES);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int G = gridDim.x;
+    const int first = xcd_remap(blockIdx.x, G);
+
+    // ---- once per workgroup: every weight this wave will ever multiply by
+    Frag wst[NI][KCH];
+    {
+        const Frag *wsrc = (const Frag *)a.pw_w + (size_t)wave * KCH * 64 + lane;
+#pragma unroll
+        for (int i = 0; i < NI; i++)
+#pragma unroll
+            for (int kc = 0; kc < KCH; kc++) wst[i][kc] = wsrc[((i * NW) * KCH + kc) * 64];
+    }
+    f32x4 pw_bias[NI];
+#pragma unroll
+    for (int i = 0; i < NI; i++) pw_bias[i] = *(const f32x4 *)(a.pw_b + acc_cout(wave + i * NW, lane, 0));
+    const int lct = wave & 3, lp0 = (wave >> 2) * LNJ;      // lateral: channel tile, first pixel tile of this wave
+    Frag lst[1][LAT ? LKCH : 1];
+    f32x4 lat_bias = vzero<f32x4, 4>();
+    if constexpr (LAT) {
+        const Frag *lsrc = (const Frag *)a.lat_w + (size_t)lct * LKCH * 64 + lane;
+#pragma unroll
+        for (int kc = 0; kc < LKCH; kc++) lst[0][kc] = lsrc[kc * 64];
+        lat_bias = *(const f32x4 *)(a.lat_b + acc_cout(lct, lane, 0));
+    }
+    uint32_t dwv[GW][DKCH];
+    f32x4 dwb4[GW];
+    int dpix[PW], dtap[DKCH];
+    const int dsel = dw_mma_dword_index(lane);
+#pragma unroll
+    for (int gi = 0; gi < GW; gi++) {
+        const int g = wave + NW * gi;
+#pragma unroll
+        for (int kc = 0; kc < DKCH; kc++) dwv[gi][kc] = a.dw_mma[(g * DKCH + kc) * 64 + lane];
+        dwb4[gi] = *(const f32x4 *)(a.dw_b + acc_cout(g, lane, 0));
+    }
+#pragma unroll
+    for (int pi = 0; pi < PW; pi++) {
+        const int p = acc_pixel(pi, lane);
+        dpix[pi] = (p / TW) * ROWP + (p % TW) * LDIN + ((lane >> 4) & 1) * 8;
+    }
+#pragma unroll
+    for (int kc = 0; kc < DKCH; kc++) {
+        const int tap = kc * 2 + (lane >> 5);
+        dtap[kc] = tap < 9 ? (tap / 3) * ROWP + (tap % 3) * LDIN : -1;
+    }
+
+    // ---- halo of a tile -> registers (K_b's scheme: unconditional buffer loads, padding by the range check / a poisoned offset)
+    V pre[NPF];
+    int koff[NPF], kdx[NPF];
+#pragma unroll
+    for (int k = 0; k < NPF; k++) {
+        int i = tid + k * kWideThreads;
+        i = i < C::STAGE_ITEMS ? i : C::STAGE_ITEMS - 1;
+        const int pix = i / CPV, cv = i % CPV;
+        const int dy = pix / HC, dx = pix % HC;
+        koff[k] = ((dy * a.win + dx) * CIN + cv * VEC) * (int)sizeof(T);
+        kdx[k] = dx;
+    }
+    const unsigned in_img_bytes = (unsigned)(a.hin * a.win * CIN) * (unsigned)sizeof(T);
+    const unsigned out_img_bytes = (unsigned)(a.hout * a.wout * COUT) * (unsigned)sizeof(T);
+    auto fetch = [&](int tx, int ty, int img) {
+        const auto rs = image_rsrc(a.in + (size_t)img * a.hin * a.win * CIN, in_img_bytes);
+        const int iy0 = ty * TH - 1, ix0 = tx * TW - 1;
+        const int sbase = (iy0 * a.win + ix0) * CIN * (int)sizeof(T);
+#pragma unroll
+        for (int k = 0; k < NPF; k++) {
+            const unsigned off = (unsigned)(ix0 + kdx[k]) < (unsigned)a.win ? (unsigned)(koff[k] + sbase) : kOobOffset;
+            pre[k] = buf_load16<V>(rs, off);
+        }
+    };
+    auto store_tile = [&](int img, int oy0, int ox0) {
+        constexpr int OPV = COUT / VEC;
+        const auto ro = image_rsrc(a.out + (size_t)img * a.hout * a.wout * COUT, out_img_bytes);
+        const int obase = (oy0 * a.wout + ox0) * COUT * (int)sizeof(T);
+        for (int i = tid; i < P * OPV; i += kWideThreads) {
+            const int p = i / OPV, cv = i % OPV;
+            const int py = p / TW, px = p % TW;
+            const unsigned off = ox0 + px < a.wout ? (unsigned)(((py * a.wout + px) * COUT + cv * VEC) * (int)sizeof(T) + obase) : kOobOffset;
+            buf_store16(ro, off, *(const V *)(s_out + p * LDO + cv * VEC));
+        }
+        if constexpr (LAT) {
+            constexpr int LDL = 64 + VEC, LPV = 64 / VEC;
+            const auto rl = image_rsrc(a.lat_out + (size_t)img * a.hout * a.wout * 64, (unsigned)(a.hout * a.wout * 64) * (unsigned)sizeof(T));
+            const int lbase = (oy0 * a.wout + ox0) * 64 * (int)sizeof(T);
+            for (int i = tid; i < P * LPV; i += kWideThreads) {
+                const int p = i / LPV, cv = i % LPV;
+                const int py = p / TW, px = p % TW;
+                const unsigned off = ox0 + px < a.wout ? (unsigned)(((py * a.wout + px) * 64 + cv * VEC) * (int)sizeof(T) + lbase) : kOobOffset;
+                buf_store16(rl, off, *(const V *)(s_a + p * LDL + cv * VEC));
+            }
+        }
+    };
+    const TileStep step(G, a.tiles_x, a.tiles_y);
+    TileCoord cur(first, a.tiles_x, a.tiles_y), nxt = cur;
+    step.advance(nxt);
+    if (first < a.nblk) fetch(cur.tx, cur.ty, cur.img);
+    __builtin_amdgcn_s_waitcnt(0x0F70);       // vmcnt(0): every once-per-workgroup load has landed; inside the loop only the prefetch is in flight
+
+    int p_img = -1, p_oy0 = 0, p_ox0 = 0;
+    for (int t = first; t < a.nblk; t += G) {
+        const int tx = cur.tx, ty = cur.ty, img = cur.img;
+        // ---- staged registers -> LDS, next tile's loads issued, previous tile -> HBM (its lateral result shares s_a with the stencil: before the barrier)
+#pragma unroll
+        for (int k = 0; k < NPF; k++) {
+            const int i = tid + k * kWideThreads;
+            if (i < C::STAGE_ITEMS) *(V *)(s_in + ((i / CPV) / HC) * ROWP + ((i / CPV) % HC) * LDIN + (i % CPV) * VEC) = pre[k];
+        }
+        if (t + G < a.nblk) fetch(nxt.tx, nxt.ty, nxt.img);
+        cur = nxt;
+        step.advance(nxt);
+        if (p_img >= 0) store_tile(p_img, p_oy0, p_ox0);
+        __syncthreads();
+        p_img = img; p_oy0 = ty * TH; p_ox0 = tx * TW;
+
+        // ---- depthwise 3x3 as a diagonal-weight implicit GEMM per 16-channel group (K_b phase 2), two groups per wave
+#pragma unroll
+        for (int gi = 0; gi < GW; gi++) {
+            const int g = wave + NW * gi;
+            typename M::Acc dacc[PW];
+#pragma unroll
+            for (int pi = 0; pi < PW; pi++) dacc[pi] = acc_init<T>(dwb4[gi]);
+            constexpr int NB = DKCH * PW, DDEPTH = NB < 4 ? NB : 4;
+            Frag bq[DDEPTH];
+            auto bload = [&](int idx) -> Frag {
+                const int kc = idx / PW, pi = idx % PW;
+                return dtap[kc] >= 0 ? *(const Frag *)(s_in + dpix[pi] + dtap[kc] + g * 16) : M::zero();
+            };
+#pragma unroll
+            for (int d = 0; d < DDEPTH - 1; d++) bq[d] = bload(d);
+#pragma unroll
+            for (int kc = 0; kc < DKCH; kc++) {
+                typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+                u32x4 wa;
+                uint32_t wd = dwv[gi][kc];
+                asm volatile("" : "+v"(wd));
+#pragma unroll
+                for (int d = 0; d < 4; d++) wa[d] = dsel == d ? wd : 0u;
+                const Frag af = __builtin_bit_cast(Frag, wa);
+#pragma unroll
+                for (int pi = 0; pi < PW; pi++) {
+                    const int idx = kc * PW + pi;
+                    if (idx + DDEPTH - 1 < NB) bq[(idx + DDEPTH - 1) % DDEPTH] = bload(idx + DDEPTH - 1);
+                    dacc[pi] = M::mma(af, bq[idx % DDEPTH], dacc[pi]);
+                }
+            }
+            const f32x4 ones = {1.f, 1.f, 1.f, 1.f};
+#pragma unroll
+            for (int pi = 0; pi < PW; pi++) store_acc<T, LDA>(s_a, ones, dwb4[gi], dacc[pi], g, pi, lane, true);
+        }
+        __syncthreads();
+
+        // ---- pointwise GEMM, weights in registers: D[cout][pixel], K = CIN
+        {
+            typename M::Acc acc[NI][NJ];
+#pragma unroll
+            for (int i = 0; i < NI; i++)
+#pragma unroll
+                for (int j = 0; j < NJ; j++) acc[i][j] = acc_init<T>(pw_bias[i]);
+            auto xf = [&](int j, int kc) -> Frag {
+                const int kb = kc * M::K + (lane >> 4) * M::KPL;
+                return *(const Frag *)(s_a + acc_pixel(j, lane) * LDA + kb);
+            };
+            gemm_stationary<T, NI, NJ, KCH>(acc, wst, xf);
+            const f32x4 ones = {1.f, 1.f, 1.f, 1.f};
+#pragma unroll
+            for (int i = 0; i < NI; i++)
+#pragma unroll
+                for (int j = 0; j < NJ; j++) store_acc<T, LDO>(s_out, ones, pw_bias[i], acc[i][j], wave + i * NW, j, lane, true);
+        }
+        __syncthreads();
+
+        if constexpr (LAT) {
+            // ---- fused lateral 64 x COUT on the LDS-resident output tile; s_a (dead since the barrier above) takes the result
+            static_assert(LDA >= 64 + VEC, "lateral result tile must fit the depthwise tile");
+            constexpr int LDL = 64 + VEC;
+            typename M::Acc acc2[1][LNJ];
+#pragma unroll
+            for (int j = 0; j < LNJ; j++) acc2[0][j] = acc_init<T>(lat_bias);
+            auto lf = [&](int j, int kc) -> Frag {
+                const int kb = kc * M::K + (lane >> 4) * M::KPL;
+                return *(const Frag *)(s_out + acc_pixel(lp0 + j, lane) * LDO + kb);
+            };
+            gemm_stationary<T, 1, LNJ, LKCH>(acc2, lst, lf);
+            const f32x4 ones = {1.f, 1.f, 1.f, 1.f};
+#pragma unroll
+            for (int j = 0; j < LNJ; j++) store_acc<T, LDL>(s_a, ones, lat_bias, acc2[0][j], lct, lp0 + j, lane, true);
+            __syncthreads();
+        }
+    }
+    if (p_img >= 0) store_tile(p_img, p_oy0, p_ox0);
+}
+
+template <typename T, int CIN, int COUT, int TH, int TW, bool LAT, bool PADROW>
+static void dwpw_wide_launch(hipStream_t s, const DwPwParams<T> *p, int tiles_x, int tiles_y) {
+    typedef DwPwCfg<T, CIN, COUT, 1, true, TH, TW, PADROW> C;
+    auto kern = dwpw_wide_kernel<T, CIN, COUT, TH, TW, LAT, PADROW>;
+    static std::atomic<int> resident_cache[kMaxDevices] = {};
+    const int dev = launch_device();
+    int resident = resident_cache[dev].load(std::memory_order_acquire);
+    if (!resident) {
+        set_max_lds(kern, C::LDS_BYTES);
+        int nb = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *)kern, kWideThreads, C::LDS_BYTES) != hipSuccess || nb < 1) nb = 1;
+        resident = nb;
+        resident_cache[dev].store(resident, std::memory_order_release);
+    }
+    DwPwArgs<T> a{p->in, p->out, p->dw_w, p->dw_b, p->dw_mma, p->pw_w, p->pw_b, p->lat_w, p->lat_b, p->lat_out, p->pw_m, p->lat_m, p->dw_m,
+                  p->hin, p->win, p->hout, p->wout, tiles_x, tiles_y, p->n * tiles_x * tiles_y};
+    hipLaunchKernelGGL(kern, dim3(persistent_grid(a.nblk, resident)), dim3(kWideThreads), C::LDS_BYTES, s, a);
+}
+
 #ifdef RF_PROBES      // measured and rejected (profiles/r04_rejected_ws_variants.txt): probe build only
 // =============================================================================================
 // K_b'  depthwise + pointwise (+ lateral) block WAVE-SPECIALISED (round 4): K_b's phases with the memory side taken off the four
@@ -2047,6 +2294,10 @@ static TileInfo dwpw_dispatch(hipStream_t s, const DwPwParams<T> *p, int hout, i
 #endif
     if (p->lat_out) {
         // laterals tap the outputs of blocks 4 (64ch), 10 (128ch) and 12 (256ch)
+        // fp16 256-channel block: eight waves, every weight stationary (K_b(8), round 5); RF_WIDE256=0 (probe knob): K_b with the streamed matrix
+        if constexpr (sizeof(T) == 2 && HAS_DW && STRIDE == 1 && CIN == 256 && COUT == 256 && TH == 4 && TW == 8) {
+            if (knob(K_WIDE256)) { dwpw_wide_launch<T, CIN, COUT, TH, TW, true, PADROW>(s, p, tiles_x, tiles_y); return ti; }
+        }
         if constexpr (HAS_DW && STRIDE == 1 && CIN == COUT && COUT >= 64) dwpw_launch<T, CIN, COUT, STRIDE, HAS_DW, TH, TW, true, PADROW>(s, p, tiles_x, tiles_y);
         else throw LaunchUnsupported("fused lateral: only stride-1 blocks with cin == cout >= 64 have a kernel instance");
     } else {

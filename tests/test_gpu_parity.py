@@ -4,8 +4,13 @@ size-independent properties (batch-composition invariance, determinism, graph ==
 
 Tolerances (stated once, used everywhere):
   fp32 engine : anchor indices identical, candidate counts identical, box IoU >= 1 - 1e-5, |score| <= 1e-5
-  fp16 engine : anchor indices identical AND in the oracle's order, box IoU >= 1 - 1e-3 (north_star's bound), |score| <= 2e-3,
-                landmarks within 0.15 px.  Anchor SET (round 5): identical, except that a detection may sit on the TWIN of the oracle's
+  fp16 engine : anchor indices identical AND in the oracle's order, box IoU >= 1 - 1e-3 (north_star's bound), landmarks within 0.15 px,
+                |score - oracle| <= LOGIT_NOISE * p (1 - p) + 1e-5 (round 5): the score is a sigmoid of the logit difference, so a logit error
+                moves it by p (1 - p) times itself; LOGIT_NOISE = 0.028 is what PLAIN fp16 storage is predicted to cost the classification
+                output in logit space (tools/fp16_error_budget.py replayed over the golden frames, minted into threshold_bands.npz by
+                tools/make_golden.py --bands) -- the same "no worse than plain fp16 storage" bar the per-layer check uses.  That is 9e-5 at
+                p = 0.997 (where the flat 2e-3 of rounds 1-4 tested nothing) and 4.3e-3 at p = 0.81, where the engine measured 2.02e-3
+                (a logit error of 0.013).  Anchor SET (round 5): identical, except that a detection may sit on the TWIN of the oracle's
                 anchor -- a candidate of the oracle itself that suppresses / is suppressed by it and whose oracle score is within twice the
                 score noise (tests/anchor_twins.py; fires on 1 of the 208 contract frames, anchors 300 / 301 at 0.997809 / 0.997806); the
                 box is then held to the same 1e-3 against the oracle's box of that twin.  Candidate count: within the number of anchors whose oracle probability lies inside the
@@ -38,7 +43,14 @@ pytestmark = pytest.mark.gpu
 
 FP32, FP16 = 0, 1
 TOL = {FP32: dict(iou=1e-5, score=1e-5, lm=2e-3), FP16: dict(iou=1e-3, score=2e-3, lm=0.15)}
-SCORE_NOISE = TOL[FP16]["score"]          # an fp16 score is within this of the oracle's: the width of the threshold band
+SCORE_NOISE = TOL[FP16]["score"]          # the width of the threshold / order / twin bands: fp16 score noise where the sigmoid is steepest (a logit error of 8e-3)
+
+
+def score_tol(prec, p):
+    """Bound on |engine score - oracle score| for a detection whose oracle score is p (see the module docstring)."""
+    if prec != FP16:
+        return TOL[prec]["score"]
+    return float(golden("threshold_bands.npz")["logit_noise"]) * float(p) * (1.0 - float(p)) + 1e-5
 LAYER_ERR_FACTOR = 1.0                    # fp16 per-layer bar = the error-budget tool's prediction for plain fp16 storage (measured: 0.14-0.37 of it)
 
 
@@ -112,7 +124,7 @@ def compare(got, ref_rows, ref_idx, prec, twins=None):
         assert got_idx == list(ref_idx), (got_idx, list(ref_idx))
     for g, r in zip(got, ref_rows):
         assert iou_plus1(g.rect, r[1:5]) >= 1 - t["iou"], (g.rect, r[1:5])
-        assert abs(g.score - r[0]) <= t["score"]
+        assert abs(g.score - r[0]) <= score_tol(prec, r[0]), (g.score, r[0])
         assert np.abs(g.as_row()[5:] - r[5:]).max() <= t["lm"]
 
 
@@ -257,7 +269,7 @@ def test_probe_knob_kernel_variants_stay_correct(rfa, knob):
             assert canon == list(ref_idx), (knob, i)
         for got, ref in zip(res[i], ref_rows):
             assert iou_plus1(got[2:6], ref[1:5]) >= 1 - t["iou"], (knob, i)
-            assert abs(got[1] - ref[0]) <= t["score"]
+            assert abs(got[1] - ref[0]) <= score_tol(FP16, ref[0])
 
 
 @pytest.mark.parametrize("thr", [0.5, 0.1, 0.02, 0.004, 0.0015])
@@ -546,7 +558,7 @@ def test_fp16_contract_over_200_frames_both_models_both_sizes(rfa, oracles):
     every frame (up to the oracle's own near-tie twin anchors, tests/anchor_twins.py: counted, printed and capped), worst 1 - IoU <= 9e-4 (the bound is 1e-3; the margin is asserted, not hoped for), candidate counts within the
     threshold band.  The distribution is printed so a kernel change is judged by its margin."""
     from retinaface_amd.frames import synth_frames
-    worst_all, rows, bands, twin_frames = [], [], [], []
+    worst_all, rows, bands, twin_frames, logit_errs = [], [], [], [], []
     for stem in STEMS:
         for hw, plan in (((448, 448), ((32, 400), (8, 401), (8, 402), (8, 403), (8, 404))), ((896, 1280), ((32, 410), (8, 411)))):
             for nb, cfg in plan:
@@ -570,7 +582,9 @@ def test_fp16_contract_over_200_frames_both_models_both_sizes(rfa, oracles):
                     bands.append(band)
                     assert abs(ncand[i] - len(ref.candidates)) <= band, (stem, hw, cfg, i, ncand[i], len(ref.candidates), band)
                     for d, r in zip(got[i], ref_rows):
-                        assert abs(d.score - r[0]) <= SCORE_NOISE, (stem, hw, cfg, i, d.anchor_index)
+                        assert abs(d.score - r[0]) <= score_tol(FP16, r[0]), (stem, hw, cfg, i, d.anchor_index, d.score, r[0])
+                        if 0.02 < r[0] < 0.98:
+                            logit_errs.append(abs(np.log(d.score / (1 - d.score)) - np.log(float(r[0]) / (1 - float(r[0])))))
                     w = max([1 - iou_plus1(d.rect, r[1:5]) for d, r in zip(got[i], ref_rows)], default=0.0)
                     worst_all.append(w)
                     rows.append((w, f"{stem} {hw[1]}x{hw[0]} b{nb} cfg{cfg} #{i}"))
@@ -580,6 +594,8 @@ def test_fp16_contract_over_200_frames_both_models_both_sizes(rfa, oracles):
           + "; ".join(f"{w:.2e} {n}" for w, n in rows[:4]))
     print(f"fp16 contract: candidate-count bands (anchors within {SCORE_NOISE} of the threshold): max {max(bands)}, mean {np.mean(bands):.2f}, "
           f"{sum(b == 0 for b in bands)} of {len(bands)} frames with an empty band (count must then be identical)")
+    print(f"fp16 contract: logit error of the {len(logit_errs)} unsaturated detections (0.02 < p < 0.98): max {max(logit_errs, default=0.0):.4f} of the "
+          f"{float(golden('threshold_bands.npz')['logit_noise']):.4f} plain fp16 storage is predicted to cost")
     print(f"fp16 contract: anchor-twin band fired on {len(twin_frames)} of {len(ws)} frames: " + "; ".join(f"{n}: engine {g} oracle {r}" for n, g, r in twin_frames))
     assert len(ws) >= 200 and ws.max() <= 9e-4, rows[:6]
     assert len(twin_frames) <= 2, twin_frames            # a near-tie of two oracle candidates within 4e-3 on the same face: 1 of 208 frames
@@ -668,7 +684,7 @@ def test_pad32_variant_is_the_reference_caffe_build_detect(rfa, oracles, base_fr
         ref = od.detect(f, 0.5, 0.4)                             # net_hw=None: the Caffe variant
         assert len(ref.detections) >= 1 and len(g) == len(ref.detections), (f.shape, len(g), len(ref.detections))
         for a, r in zip(g, ref.rows()):
-            assert iou_plus1(a.rect, r[1:5]) >= 1 - t["iou"] and abs(a.score - r[0]) <= t["score"]
+            assert iou_plus1(a.rect, r[1:5]) >= 1 - t["iou"] and abs(a.score - r[0]) <= score_tol(prec, r[0])
             assert a.rect[2] <= (f.shape[1] + 31) // 32 * 32 - 1 and a.rect[3] <= (f.shape[0] + 31) // 32 * 32 - 1
 
 

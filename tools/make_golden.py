@@ -90,6 +90,30 @@ def band(heads, thr, noise=SCORE_NOISE):
     return n
 
 
+def predicted_logit_noise(frames):
+    """What PLAIN fp16 storage (every activation and weight rounded to fp16 where the engine stores one, fp32 accumulation) is predicted to
+    cost the classification output, in LOGIT space: max |logit(p_fp16) - logit(p_fp32)| over the anchors whose foreground probability is not
+    saturated (0.02 < p < 0.98, where the logit is well conditioned), from tools/fp16_error_budget.py's replay of the fused-op sequence.  A
+    score moves by p (1 - p) times the logit error, so this one number bounds the fp16 engine's score error at every p:
+    |score - oracle| <= logit_noise * p (1 - p).  The -m gpu tests hold the real engine to 1.0 x this prediction, as they do per layer."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from fp16_error_budget import Sim
+    worst = 0.0
+    for stem in ("mnet-deconv-0517", "mnet25"):
+        sim = Sim(stem)
+        acts, wts = sim.all_points(frames[0])
+        for f in frames:
+            wide, narrow = sim.forward(f, set()), sim.forward(f, set(acts) | set(wts))
+            for s_ in HEAD_STRIDES:
+                p0, p1 = np.asarray(wide[head_names(s_)[0]], np.float64), np.asarray(narrow[head_names(s_)[0]], np.float64)
+                a = p0.shape[1] // 2
+                f0, f1 = p0[:, a:].ravel(), np.clip(p1[:, a:].ravel(), 1e-9, 1 - 1e-9)
+                m = (f0 > 0.02) & (f0 < 0.98)
+                if m.any():
+                    worst = max(worst, float(np.abs(np.log(f0[m] / (1 - f0[m])) - np.log(f1[m] / (1 - f1[m]))).max()))
+    return worst
+
+
 def bands():
     """tests/golden/threshold_bands.npz: for every golden frame and threshold, how many anchors sit inside the fp16 score-noise band
     around the threshold -- the tolerance the fp16 candidate-count assertions use instead of a flat +-4 (round 4) -- and (round 5,
@@ -109,8 +133,10 @@ def bands():
             for key, r in cases:
                 d[key] = np.int32(band(r.heads, thr))
                 d[key + "/twins"] = twins_of_result(r, 0.4, SCORE_NOISE)
+    d["logit_noise"] = np.float32(predicted_logit_noise([crop] + list(synth)))
     np.savez_compressed(os.path.join(OUT, "threshold_bands.npz"), **d)
-    print({k: int(v) for k, v in d.items() if k != "score_noise" and not k.endswith("/twins")})
+    print("logit noise of plain fp16 storage (max over the golden 448x448 frames, both models):", float(d["logit_noise"]))
+    print({k: int(v) for k, v in d.items() if k not in ("score_noise", "logit_noise") and not k.endswith("/twins")})
     print("twin pairs:", {k: [(int(t[0]), int(t[1])) for t in v] for k, v in d.items() if k.endswith("/twins") and len(v)})
 
 
