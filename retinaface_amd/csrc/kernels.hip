@@ -1654,8 +1654,8 @@ __global__ __launch_bounds__(kThreads, (DwPwCfg<T, CIN, COUT, STRIDE, HAS_DW, TH
 // =============================================================================================
 constexpr int kWideThreads = 512;
 
-template <typename T, int CIN, int COUT, int TH, int TW, bool LAT, bool PADROW>
-__global__ __launch_bounds__(kWideThreads, 1) void dwpw_wide_kernel(DwPwArgs<T> a) {
+template <typename T, int CIN, int COUT, int TH, int TW, bool LAT, bool PADROW, int OCC = 1>
+__global__ __launch_bounds__(kWideThreads, OCC) void dwpw_wide_kernel(DwPwArgs<T> a) {
     typedef DwPwCfg<T, CIN, COUT, 1, true, TH, TW, PADROW> C;
     typedef typename Vec<T>::type V;
     typedef Mma<T> M;
@@ -1867,10 +1867,10 @@ __global__ __launch_bounds__(kWideThreads, 1) void dwpw_wide_kernel(DwPwArgs<T> 
     if (p_img >= 0) store_tile(p_img, p_oy0, p_ox0);
 }
 
-template <typename T, int CIN, int COUT, int TH, int TW, bool LAT, bool PADROW>
+template <typename T, int CIN, int COUT, int TH, int TW, bool LAT, bool PADROW, int OCC = 1>
 static void dwpw_wide_launch(hipStream_t s, const DwPwParams<T> *p, int tiles_x, int tiles_y) {
     typedef DwPwCfg<T, CIN, COUT, 1, true, TH, TW, PADROW> C;
-    auto kern = dwpw_wide_kernel<T, CIN, COUT, TH, TW, LAT, PADROW>;
+    auto kern = dwpw_wide_kernel<T, CIN, COUT, TH, TW, LAT, PADROW, OCC>;
     static std::atomic<int> resident_cache[kMaxDevices] = {};
     const int dev = launch_device();
     int resident = resident_cache[dev].load(std::memory_order_acquire);
@@ -2288,6 +2288,22 @@ static TileInfo dwpw_dispatch(hipStream_t s, const DwPwParams<T> *p, int hout, i
                 if (v == 2) dwpw_ws_launch<T, CIN, COUT, STRIDE, TH, TW, false, 2, PADROW>(s, p, tiles_x, tiles_y);
                 else dwpw_ws_launch<T, CIN, COUT, STRIDE, TH, TW, false, 3, PADROW>(s, p, tiles_x, tiles_y);
             }
+            return ti;
+        }
+    }
+#endif
+#ifdef RF_PROBES
+    // RF_WIDE128 (probe knob): the fp16 128-channel blocks on K_b(8) as well -- eight waves, 2 (=1) / 3 (=2) workgroups per CU
+    if constexpr (sizeof(T) == 2 && HAS_DW && STRIDE == 1 && CIN == 128 && COUT == 128 && TH == 4 && TW == 8) {
+        const int v = knob(K_WIDE128);
+        if (v == 1) {
+            if (p->lat_out) dwpw_wide_launch<T, CIN, COUT, TH, TW, true, PADROW, 2>(s, p, tiles_x, tiles_y);
+            else dwpw_wide_launch<T, CIN, COUT, TH, TW, false, PADROW, 2>(s, p, tiles_x, tiles_y);
+            return ti;
+        }
+        if (v == 2) {
+            if (p->lat_out) dwpw_wide_launch<T, CIN, COUT, TH, TW, true, PADROW, 3>(s, p, tiles_x, tiles_y);
+            else dwpw_wide_launch<T, CIN, COUT, TH, TW, false, PADROW, 3>(s, p, tiles_x, tiles_y);
             return ti;
         }
     }

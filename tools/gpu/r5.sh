@@ -63,6 +63,8 @@ PY
     trace1)
       rm -rf /tmp/kt1; ( cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/kt1 -o kt -- python $R/bench.py --timed-only --lanes 1 --no-pmc > $O/trace1_bench.json 2> $O/trace1.err )
       db=$(find /tmp/kt1 -name "*.db" | head -1); python tools/rocpd_summary.py $db $O/kernel_trace_lanes1_fp16.txt > /dev/null; head -24 $O/kernel_trace_lanes1_fp16.txt | cut -c1-60,104-190 ;;
+    floor)
+      ( cd tools/probes && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 launch_floor.cpp -o launch_floor.bin 2>/dev/null; timeout 120 ./launch_floor.bin ) > $O/launch_floor.txt 2>&1; cat $O/launch_floor.txt ;;
     *) echo "unknown recipe $recipe" ;;
   esac
 done
