@@ -438,6 +438,7 @@ private:
         bool built = false;
         std::vector<void *> dev_allocs, host_allocs;      // what build_lane allocated for this lane
         hipStream_t stream = nullptr;
+        int cus = 0;                          // CUs the stream may use (0 = all): persistent grids of this lane's launches are sized by it
         unsigned long long launch_seq = 0;    // order of this lane's last launch among all launches of the engine (pick_lane)
         // host-frame uploads from the pinned staging block alternate between the lane's stream and a second one (a second SDMA
         // engine); the launch waits for both.  RF_COPY_STREAMS=1 (probe knob) switches the second stream off
@@ -560,7 +561,18 @@ private:
         const int mb = cap_images_;           // images per launch: max_batch * coalesce
         const int H = net_h_, W = net_w_;
         const double P = (double)H * W;
-        RF_HIP(hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking));
+        // RF_CU_SPLIT=1 (probe knob): lane l runs on one half of every XCD's CUs (the mask's low / high 128 bits: measured with
+        // tools/probes/cu_mask.cpp -- 128 distinct CUs, all 8 XCDs, honoured by graph replays), halves alternating by lane, so that two lanes'
+        // DIFFERENT kernels (a VALU-bound stem beside an HBM-bound block) share the chip spatially instead of queueing for each other's slots
+        const int lane_index = (int)(&L - lanes_.data());
+        if (knob(K_CU_SPLIT) == 1 && lanes_.size() > 1) {
+            uint32_t mask[8];
+            for (int i = 0; i < 8; i++) mask[i] = ((lane_index & 1) == 0) == (i < 4) ? 0xffffffffu : 0u;
+            RF_HIP(hipExtStreamCreateWithCUMask(&L.stream, 8, mask));
+            L.cus = 128;
+        } else {
+            RF_HIP(hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking));
+        }
         for (auto &e : L.time_ev) RF_HIP(hipEventCreate(&e));
         RF_HIP(hipEventCreateWithFlags(&L.done, hipEventDisableTiming));
         if (copy_streams_ > 1) {
@@ -1083,6 +1095,8 @@ private:
         }
         const bool eager_timed = s.timed;
         if (eager_timed) RF_HIP(hipEventRecord(s.time_ev[1], s.stream));
+        bind_launch_cus(s.cus);
+        struct Unbind { ~Unbind() { bind_launch_cus(0); } } unbind;
         if (opt_.use_graph && s.warmed.count(n)) {
             auto it = s.graphs.find(n);
             if (it == s.graphs.end()) it = s.graphs.emplace(n, capture(s, n)).first;

@@ -28,6 +28,8 @@ template <> struct DwWeightT<int8_t> { typedef float type; };
 // The launch helpers keep per-device state (CU count, LDS attribute / occupancy of each kernel instance); the engine tells
 // them which device the calling thread is bound to (engine.cpp DeviceGuard).
 void bind_launch_device(int device);
+// ... and how many CUs the stream it is about to launch on may use (0 = all of the device's): persistent grids are sized by it
+void bind_launch_cus(int cus);
 // int8 engines: 0 when v_cvt_pk_u8_f32 on the bound device rounds to nearest even and saturates (what the requantising epilogues rely on),
 // 1 when it does not (cached per device), -1 when the probe could not run (a runtime error: not cached)
 int cvt_pk_u8_selfcheck();

@@ -138,7 +138,11 @@ typedef Unsupported LaunchUnsupported;
 // Persistent grid: as many workgroups as the chip keeps resident (CUs x RESIDENT), trimmed so every workgroup walks the
 // same number of tiles (no nearly-empty last round).  Launches with fewer tiles than that get one tile per workgroup.
 static std::atomic<int> g_num_cus[kMaxDevices] = {};
+// a lane whose stream is confined to a subset of the CUs (hipExtStreamCreateWithCUMask, engine.cpp RF_CU_SPLIT) sizes its persistent grids for that subset
+static thread_local int t_launch_cus = 0;
+void bind_launch_cus(int cus) { t_launch_cus = cus; }
 static int num_cus() {
+    if (t_launch_cus > 0) return t_launch_cus;
     const int dev = launch_device();
     int cus = g_num_cus[dev].load(std::memory_order_relaxed);
     if (!cus) {
@@ -2292,22 +2296,16 @@ static TileInfo dwpw_dispatch(hipStream_t s, const DwPwParams<T> *p, int hout, i
         }
     }
 #endif
-#ifdef RF_PROBES
-    // RF_WIDE128 (probe knob): the fp16 128-channel blocks on K_b(8) as well -- eight waves, 2 (=1) / 3 (=2) workgroups per CU
+    // K_b(8) for the fp16 128-channel block WITH the fused lateral (conv21 + conv22 + rf_c2_lateral): at 126 VGPRs two 8-wave workgroups share a
+    // CU (16 waves) where K_b's 182-VGPR build has two 4-wave ones: 34.8 -> 33.0 us; the plain 128-channel blocks measured 27.7 -> 28.0 us on it
+    // and stay on K_b (A/B inside one call, tools/gpu/r5.sh c4: profiles/r05_wide_blocks_ab.txt).  RF_WIDE128 (probe knob): 0 = none, 2 = all five.
     if constexpr (sizeof(T) == 2 && HAS_DW && STRIDE == 1 && CIN == 128 && COUT == 128 && TH == 4 && TW == 8) {
         const int v = knob(K_WIDE128);
-        if (v == 1) {
-            if (p->lat_out) dwpw_wide_launch<T, CIN, COUT, TH, TW, true, PADROW, 2>(s, p, tiles_x, tiles_y);
-            else dwpw_wide_launch<T, CIN, COUT, TH, TW, false, PADROW, 2>(s, p, tiles_x, tiles_y);
-            return ti;
-        }
-        if (v == 2) {
-            if (p->lat_out) dwpw_wide_launch<T, CIN, COUT, TH, TW, true, PADROW, 3>(s, p, tiles_x, tiles_y);
-            else dwpw_wide_launch<T, CIN, COUT, TH, TW, false, PADROW, 3>(s, p, tiles_x, tiles_y);
-            return ti;
-        }
-    }
+        if (v >= 1 && p->lat_out) { dwpw_wide_launch<T, CIN, COUT, TH, TW, true, PADROW, 2>(s, p, tiles_x, tiles_y); return ti; }
+#ifdef RF_PROBES
+        if (v == 2 && !p->lat_out) { dwpw_wide_launch<T, CIN, COUT, TH, TW, false, PADROW, 2>(s, p, tiles_x, tiles_y); return ti; }
 #endif
+    }
     if (p->lat_out) {
         // laterals tap the outputs of blocks 4 (64ch), 10 (128ch) and 12 (256ch)
         // fp16 256-channel block: eight waves, every weight stationary (K_b(8), round 5); RF_WIDE256=0 (probe knob): K_b with the streamed matrix

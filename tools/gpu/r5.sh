@@ -65,6 +65,13 @@ PY
       db=$(find /tmp/kt1 -name "*.db" | head -1); python tools/rocpd_summary.py $db $O/kernel_trace_lanes1_fp16.txt > /dev/null; head -24 $O/kernel_trace_lanes1_fp16.txt | cut -c1-60,104-190 ;;
     floor)
       ( cd tools/probes && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 launch_floor.cpp -o launch_floor.bin 2>/dev/null; timeout 120 ./launch_floor.bin ) > $O/launch_floor.txt 2>&1; cat $O/launch_floor.txt ;;
+    cumask)
+      ( cd tools/probes && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 cu_mask.cpp -o cu_mask.bin 2>/dev/null; timeout 120 ./cu_mask.bin ) > $O/cu_mask.txt 2>&1; cat $O/cu_mask.txt ;;
+    cusplit)        # lanes confined to complementary halves of every XCD's CUs (RF_CU_SPLIT=1, probe build) vs the whole chip per lane, interleaved
+      for rep in 1 2; do for cfg in "0 3" "1 2" "1 4" "0 2" "1 6"; do set -- $cfg
+        env RETINAFACE_AMD_LIB=$R/retinaface_amd/lib/libretinaface_amd_probe.so RF_CU_SPLIT=$1 timeout 200 python bench.py --lanes $2 --no-cpu-baseline --no-extra-configs --no-pmc --no-pipeline-trace --host-seconds 0 --regions 2 > $O/bench_split$1_lanes$2_$rep.json 2> $O/bench_split$1_lanes$2_$rep.err
+        python -c "import json;j=json.loads(open('$O/bench_split$1_lanes$2_$rep.json').read().strip().splitlines()[-1]);print('split $1 lanes $2 rep $rep:', round(j['images_per_sec']), 'img/s  burst', round(j['burst']['ms'],3), 'ms  sync', round(j['sync_batch']['ms_per_call'],4))" 2>&1 | tail -1
+      done; done ;;
     *) echo "unknown recipe $recipe" ;;
   esac
 done
