@@ -1668,10 +1668,12 @@ __global__ __launch_bounds__(kWideThreads, OCC) void dwpw_wide_kernel(DwPwArgs<T
     constexpr int VEC = C::VEC, P = C::P, HC = C::HC, LDA = C::LDA, LDO = C::LDO, LDIN = C::LDIN, ROWP = C::ROWP;
     constexpr int CPV = CIN / VEC, PT = C::PT, KCH = C::KCH;
     constexpr int NT = COUT / 16, NI = NT / NW, NJ = PT;
-    constexpr int NG = CIN / 16, GW = NG / NW, PW = PT, DKCH = kDwMmaChunks;
+    constexpr bool I8 = sizeof(T) == 1;
+    constexpr int NG = CIN / 16, GW = NG / NW, PW = PT, DKCH = I8 ? kDwMmaChunksI8 : kDwMmaChunks;
+    constexpr int DPARTS = I8 ? 2 : 1;                               // int8: 15-bit taps as hi and lo fragments per chunk (K_b)
     constexpr int LKCH = (COUT + M::K - 1) / M::K, LNJ = LAT ? PT / (NW / 4) : 1;
     constexpr int NPF = (C::STAGE_ITEMS + kWideThreads - 1) / kWideThreads;
-    static_assert(sizeof(T) == 2 && C::DWMMA && NT % NW == 0 && NG % NW == 0 && (!LAT || PT % (NW / 4) == 0), "shape does not split over 8 waves");
+    static_assert(sizeof(T) <= 2 && C::DWMMA && NT % NW == 0 && NG % NW == 0 && (!LAT || PT % (NW / 4) == 0), "shape does not split over 8 waves");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     T *s_in = (T *)smem;
     T *s_a = (T *)(smem + C::IN_BYTES + C::DW_BYTES);
@@ -1691,37 +1693,44 @@ __global__ __launch_bounds__(kWideThreads, OCC) void dwpw_wide_kernel(DwPwArgs<T
 #pragma unroll
             for (int kc = 0; kc < KCH; kc++) wst[i][kc] = wsrc[((i * NW) * KCH + kc) * 64];
     }
-    f32x4 pw_bias[NI];
+    f32x4 pw_bias[NI], pw_mult[NI];
 #pragma unroll
-    for (int i = 0; i < NI; i++) pw_bias[i] = *(const f32x4 *)(a.pw_b + acc_cout(wave + i * NW, lane, 0));
+    for (int i = 0; i < NI; i++) {
+        pw_bias[i] = *(const f32x4 *)(a.pw_b + acc_cout(wave + i * NW, lane, 0));
+        pw_mult[i] = load_mult(a.pw_m, acc_cout(wave + i * NW, lane, 0));
+    }
     const int lct = wave & 3, lp0 = (wave >> 2) * LNJ;      // lateral: channel tile, first pixel tile of this wave
     Frag lst[1][LAT ? LKCH : 1];
-    f32x4 lat_bias = vzero<f32x4, 4>();
+    f32x4 lat_bias = vzero<f32x4, 4>(), lat_mult = vzero<f32x4, 4>();
     if constexpr (LAT) {
         const Frag *lsrc = (const Frag *)a.lat_w + (size_t)lct * LKCH * 64 + lane;
 #pragma unroll
         for (int kc = 0; kc < LKCH; kc++) lst[0][kc] = lsrc[kc * 64];
         lat_bias = *(const f32x4 *)(a.lat_b + acc_cout(lct, lane, 0));
+        lat_mult = load_mult(a.lat_m, acc_cout(lct, lane, 0));
     }
-    uint32_t dwv[GW][DKCH];
-    f32x4 dwb4[GW];
+    uint32_t dwv[GW][DKCH][DPARTS];
+    f32x4 dwb4[GW], dwm4[GW];
     int dpix[PW], dtap[DKCH];
-    const int dsel = dw_mma_dword_index(lane);
+    const int dsel = I8 ? dw_mma_dword_index_i8(lane) : dw_mma_dword_index(lane);
 #pragma unroll
     for (int gi = 0; gi < GW; gi++) {
         const int g = wave + NW * gi;
 #pragma unroll
-        for (int kc = 0; kc < DKCH; kc++) dwv[gi][kc] = a.dw_mma[(g * DKCH + kc) * 64 + lane];
+        for (int kc = 0; kc < DKCH; kc++)
+#pragma unroll
+            for (int hl = 0; hl < DPARTS; hl++) dwv[gi][kc][hl] = a.dw_mma[((g * DKCH + kc) * DPARTS + hl) * 64 + lane];
         dwb4[gi] = *(const f32x4 *)(a.dw_b + acc_cout(g, lane, 0));
+        dwm4[gi] = load_mult(I8 ? a.dw_m : nullptr, acc_cout(g, lane, 0));
     }
 #pragma unroll
     for (int pi = 0; pi < PW; pi++) {
         const int p = acc_pixel(pi, lane);
-        dpix[pi] = (p / TW) * ROWP + (p % TW) * LDIN + ((lane >> 4) & 1) * 8;
+        dpix[pi] = (p / TW) * ROWP + (p % TW) * LDIN + (I8 ? 0 : ((lane >> 4) & 1) * 8);      // fp16: a lane's 8 k's are half of a tap's 16 channels; int8: all 16
     }
 #pragma unroll
     for (int kc = 0; kc < DKCH; kc++) {
-        const int tap = kc * 2 + (lane >> 5);
+        const int tap = I8 ? kc * 4 + (lane >> 4) : kc * 2 + (lane >> 5);
         dtap[kc] = tap < 9 ? (tap / 3) * ROWP + (tap % 3) * LDIN : -1;
     }
 
@@ -1797,9 +1806,11 @@ __global__ __launch_bounds__(kWideThreads, OCC) void dwpw_wide_kernel(DwPwArgs<T
 #pragma unroll
         for (int gi = 0; gi < GW; gi++) {
             const int g = wave + NW * gi;
-            typename M::Acc dacc[PW];
+            typename M::Acc dacc[DPARTS][PW];
 #pragma unroll
-            for (int pi = 0; pi < PW; pi++) dacc[pi] = acc_init<T>(dwb4[gi]);
+            for (int hl = 0; hl < DPARTS; hl++)
+#pragma unroll
+                for (int pi = 0; pi < PW; pi++) dacc[hl][pi] = acc_init<T>(dwb4[gi]);
             constexpr int NB = DKCH * PW, DDEPTH = NB < 4 ? NB : 4;
             Frag bq[DDEPTH];
             auto bload = [&](int idx) -> Frag {
@@ -1811,22 +1822,35 @@ __global__ __launch_bounds__(kWideThreads, OCC) void dwpw_wide_kernel(DwPwArgs<T
 #pragma unroll
             for (int kc = 0; kc < DKCH; kc++) {
                 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-                u32x4 wa;
-                uint32_t wd = dwv[gi][kc];
-                asm volatile("" : "+v"(wd));
+                Frag af[DPARTS];
 #pragma unroll
-                for (int d = 0; d < 4; d++) wa[d] = dsel == d ? wd : 0u;
-                const Frag af = __builtin_bit_cast(Frag, wa);
+                for (int hl = 0; hl < DPARTS; hl++) {
+                    u32x4 wa;
+                    uint32_t wd = dwv[gi][kc][hl];
+                    asm volatile("" : "+v"(wd));
+#pragma unroll
+                    for (int d = 0; d < 4; d++) wa[d] = dsel == d ? wd : 0u;
+                    af[hl] = __builtin_bit_cast(Frag, wa);
+                }
 #pragma unroll
                 for (int pi = 0; pi < PW; pi++) {
                     const int idx = kc * PW + pi;
                     if (idx + DDEPTH - 1 < NB) bq[(idx + DDEPTH - 1) % DDEPTH] = bload(idx + DDEPTH - 1);
-                    dacc[pi] = M::mma(af, bq[idx % DDEPTH], dacc[pi]);
+#pragma unroll
+                    for (int hl = 0; hl < DPARTS; hl++) dacc[hl][pi] = M::mma(af[hl], bq[idx % DDEPTH], dacc[hl][pi]);
                 }
             }
-            const f32x4 ones = {1.f, 1.f, 1.f, 1.f};
 #pragma unroll
-            for (int pi = 0; pi < PW; pi++) store_acc<T, LDA>(s_a, ones, dwb4[gi], dacc[pi], g, pi, lane, true);
+            for (int pi = 0; pi < PW; pi++) {
+                if constexpr (I8) {
+                    typename M::Acc tot;
+#pragma unroll
+                    for (int r = 0; r < 4; r++) tot[r] = dacc[0][pi][r] * 128 + dacc[DPARTS - 1][pi][r];      // taps = 128 * hi + lo
+                    store_acc<T, LDA>(s_a, dwm4[gi], dwb4[gi], tot, g, pi, lane, true);
+                } else {
+                    store_acc<T, LDA>(s_a, dwm4[gi], dwb4[gi], dacc[0][pi], g, pi, lane, true);
+                }
+            }
         }
         __syncthreads();
 
@@ -1842,11 +1866,10 @@ __global__ __launch_bounds__(kWideThreads, OCC) void dwpw_wide_kernel(DwPwArgs<T
                 return *(const Frag *)(s_a + acc_pixel(j, lane) * LDA + kb);
             };
             gemm_stationary<T, NI, NJ, KCH>(acc, wst, xf);
-            const f32x4 ones = {1.f, 1.f, 1.f, 1.f};
 #pragma unroll
             for (int i = 0; i < NI; i++)
 #pragma unroll
-                for (int j = 0; j < NJ; j++) store_acc<T, LDO>(s_out, ones, pw_bias[i], acc[i][j], wave + i * NW, j, lane, true);
+                for (int j = 0; j < NJ; j++) store_acc<T, LDO>(s_out, pw_mult[i], pw_bias[i], acc[i][j], wave + i * NW, j, lane, true);
         }
         __syncthreads();
 
@@ -1862,9 +1885,8 @@ __global__ __launch_bounds__(kWideThreads, OCC) void dwpw_wide_kernel(DwPwArgs<T
                 return *(const Frag *)(s_out + acc_pixel(lp0 + j, lane) * LDO + kb);
             };
             gemm_stationary<T, 1, LNJ, LKCH>(acc2, lst, lf);
-            const f32x4 ones = {1.f, 1.f, 1.f, 1.f};
 #pragma unroll
-            for (int j = 0; j < LNJ; j++) store_acc<T, LDL>(s_a, ones, lat_bias, acc2[0][j], lct, lp0 + j, lane, true);
+            for (int j = 0; j < LNJ; j++) store_acc<T, LDL>(s_a, lat_mult, lat_bias, acc2[0][j], lct, lp0 + j, lane, true);
             __syncthreads();
         }
     }
@@ -2299,8 +2321,8 @@ static TileInfo dwpw_dispatch(hipStream_t s, const DwPwParams<T> *p, int hout, i
     // K_b(8) for the fp16 128-channel block WITH the fused lateral (conv21 + conv22 + rf_c2_lateral): at 126 VGPRs two 8-wave workgroups share a
     // CU (16 waves) where K_b's 182-VGPR build has two 4-wave ones: 34.8 -> 33.0 us; the plain 128-channel blocks measured 27.7 -> 28.0 us on it
     // and stay on K_b (A/B inside one call, tools/gpu/r5.sh c4: profiles/r05_wide_blocks_ab.txt).  RF_WIDE128 (probe knob): 0 = none, 2 = all five.
-    if constexpr (sizeof(T) == 2 && HAS_DW && STRIDE == 1 && CIN == 128 && COUT == 128 && TH == 4 && TW == 8) {
-        const int v = knob(K_WIDE128);
+    if constexpr (HAS_DW && STRIDE == 1 && CIN == 128 && COUT == 128 && ((sizeof(T) == 2 && TH == 4 && TW == 8) || (sizeof(T) == 1 && TH == 4 && TW == 16))) {
+        const int v = sizeof(T) == 2 ? knob(K_WIDE128) : knob(K_WIDE_I8);
         if (v >= 1 && p->lat_out) { dwpw_wide_launch<T, CIN, COUT, TH, TW, true, PADROW, 2>(s, p, tiles_x, tiles_y); return ti; }
 #ifdef RF_PROBES
         if (v == 2 && !p->lat_out) { dwpw_wide_launch<T, CIN, COUT, TH, TW, false, PADROW, 2>(s, p, tiles_x, tiles_y); return ti; }
@@ -2309,8 +2331,8 @@ static TileInfo dwpw_dispatch(hipStream_t s, const DwPwParams<T> *p, int hout, i
     if (p->lat_out) {
         // laterals tap the outputs of blocks 4 (64ch), 10 (128ch) and 12 (256ch)
         // fp16 256-channel block: eight waves, every weight stationary (K_b(8), round 5); RF_WIDE256=0 (probe knob): K_b with the streamed matrix
-        if constexpr (sizeof(T) == 2 && HAS_DW && STRIDE == 1 && CIN == 256 && COUT == 256 && TH == 4 && TW == 8) {
-            if (knob(K_WIDE256)) { dwpw_wide_launch<T, CIN, COUT, TH, TW, true, PADROW>(s, p, tiles_x, tiles_y); return ti; }
+        if constexpr (HAS_DW && STRIDE == 1 && CIN == 256 && COUT == 256 && ((sizeof(T) == 2 && TH == 4 && TW == 8) || (sizeof(T) == 1 && TH == 8 && TW == 8))) {
+            if (sizeof(T) == 2 ? knob(K_WIDE256) : knob(K_WIDE_I8)) { dwpw_wide_launch<T, CIN, COUT, TH, TW, true, PADROW>(s, p, tiles_x, tiles_y); return ti; }
         }
         if constexpr (HAS_DW && STRIDE == 1 && CIN == COUT && COUT >= 64) dwpw_launch<T, CIN, COUT, STRIDE, HAS_DW, TH, TW, true, PADROW>(s, p, tiles_x, tiles_y);
         else throw LaunchUnsupported("fused lateral: only stride-1 blocks with cin == cout >= 64 have a kernel instance");

@@ -72,6 +72,13 @@ PY
         env RETINAFACE_AMD_LIB=$R/retinaface_amd/lib/libretinaface_amd_probe.so RF_CU_SPLIT=$1 timeout 200 python bench.py --lanes $2 --no-cpu-baseline --no-extra-configs --no-pmc --no-pipeline-trace --host-seconds 0 --regions 2 > $O/bench_split$1_lanes$2_$rep.json 2> $O/bench_split$1_lanes$2_$rep.err
         python -c "import json;j=json.loads(open('$O/bench_split$1_lanes$2_$rep.json').read().strip().splitlines()[-1]);print('split $1 lanes $2 rep $rep:', round(j['images_per_sec']), 'img/s  burst', round(j['burst']['ms'],3), 'ms  sync', round(j['sync_batch']['ms_per_call'],4))" 2>&1 | tail -1
       done; done ;;
+    wide_i8)        # int8 engine on K_b(8): bit-identity of the variants, then the A/B
+      RETINAFACE_AMD_LIB=$R/retinaface_amd/lib/libretinaface_amd_probe.so timeout 300 python tools/probes/knob_equal.py --precision 2 --model mnet25 --n 32 RF_WIDE_I8=1 RF_WIDE_I8=2 > $O/knob_equal_wide_i8.txt 2>&1; cat $O/knob_equal_wide_i8.txt
+      RETINAFACE_AMD_LIB=$R/retinaface_amd/lib/libretinaface_amd_probe.so timeout 300 python tools/probes/knob_equal.py --precision 1 --model mnet25 --n 16 RF_WIDE256=0 RF_WIDE128=0 RF_WIDE128=2 > $O/knob_equal_wide_fp16.txt 2>&1; cat $O/knob_equal_wide_fp16.txt
+      for rep in 1 2 3; do for v in 0 1 2; do
+        env RETINAFACE_AMD_LIB=$R/retinaface_amd/lib/libretinaface_amd_probe.so RF_WIDE_I8=$v timeout 100 python tools/kbench.py --n 256 --precision int8 --batch 32 --tag wide_i8_${v}_$rep > $O/kbench_wide_i8_${v}_$rep.txt 2>&1
+      done; done
+      for f in $O/kbench_wide_i8_*.txt; do echo "$(basename $f) total $(grep -h '==' $f | awk '{print $8}') | $(grep -h -E "dwpw<128,128|dwpw<256" $f | awk '{printf "%s %s  ", $1, $2}')"; done ;;
     *) echo "unknown recipe $recipe" ;;
   esac
 done
