@@ -2318,21 +2318,29 @@ static TileInfo dwpw_dispatch(hipStream_t s, const DwPwParams<T> *p, int hout, i
         }
     }
 #endif
-    // K_b(8) for the fp16 128-channel block WITH the fused lateral (conv21 + conv22 + rf_c2_lateral): at 126 VGPRs two 8-wave workgroups share a
-    // CU (16 waves) where K_b's 182-VGPR build has two 4-wave ones: 34.8 -> 33.0 us; the plain 128-channel blocks measured 27.7 -> 28.0 us on it
-    // and stay on K_b (A/B inside one call, tools/gpu/r5.sh c4: profiles/r05_wide_blocks_ab.txt).  RF_WIDE128 (probe knob): 0 = none, 2 = all five.
+    // K_b(8) for the 128-channel blocks, where it measured faster (A/B inside one call each, tools/gpu/r5.sh c4 / c7, profiles/r05_wide_blocks_ab.txt;
+    // every variant bit-identical, tools/probes/knob_equal.py):
+    //   fp16: the block WITH the fused lateral (conv21 + conv22 + rf_c2_lateral) -- at 126 VGPRs two 8-wave workgroups share a CU (16 waves) where K_b's
+    //         182-VGPR build has two 4-wave ones: 34.8 -> 33.0 us; the plain blocks 27.7 -> 28.0 us: they stay on K_b;
+    //   int8: the other way round -- the four plain blocks 25.0 -> 23.1 us each (121 VGPRs), the lateral block 29.0 -> 30.6 us (148 VGPRs: one workgroup per CU).
+    // Probe knobs: RF_WIDE128 (fp16) 0 = none, 1 = lateral block, 2 = all five; RF_WIDE_I8 bit 0 = 256-channel block, bit 1 = plain blocks, bit 2 = lateral block.
     if constexpr (HAS_DW && STRIDE == 1 && CIN == 128 && COUT == 128 && ((sizeof(T) == 2 && TH == 4 && TW == 8) || (sizeof(T) == 1 && TH == 4 && TW == 16))) {
-        const int v = sizeof(T) == 2 ? knob(K_WIDE128) : knob(K_WIDE_I8);
-        if (v >= 1 && p->lat_out) { dwpw_wide_launch<T, CIN, COUT, TH, TW, true, PADROW, 2>(s, p, tiles_x, tiles_y); return ti; }
-#ifdef RF_PROBES
-        if (v == 2 && !p->lat_out) { dwpw_wide_launch<T, CIN, COUT, TH, TW, false, PADROW, 2>(s, p, tiles_x, tiles_y); return ti; }
-#endif
+        constexpr bool I8W = sizeof(T) == 1;
+        const int v = I8W ? knob(K_WIDE_I8) : knob(K_WIDE128);
+        const bool lat_wide = I8W ? (v & 4) != 0 : v >= 1, plain_wide = I8W ? (v & 2) != 0 : v == 2;
+        if constexpr (!I8W || kProbeBuild) {
+            if (lat_wide && p->lat_out) { dwpw_wide_launch<T, CIN, COUT, TH, TW, true, PADROW, 2>(s, p, tiles_x, tiles_y); return ti; }
+        }
+        if constexpr (I8W || kProbeBuild) {
+            if (plain_wide && !p->lat_out) { dwpw_wide_launch<T, CIN, COUT, TH, TW, false, PADROW, 2>(s, p, tiles_x, tiles_y); return ti; }
+        }
     }
     if (p->lat_out) {
         // laterals tap the outputs of blocks 4 (64ch), 10 (128ch) and 12 (256ch)
         // fp16 256-channel block: eight waves, every weight stationary (K_b(8), round 5); RF_WIDE256=0 (probe knob): K_b with the streamed matrix
         if constexpr (HAS_DW && STRIDE == 1 && CIN == 256 && COUT == 256 && ((sizeof(T) == 2 && TH == 4 && TW == 8) || (sizeof(T) == 1 && TH == 8 && TW == 8))) {
-            if (sizeof(T) == 2 ? knob(K_WIDE256) : knob(K_WIDE_I8)) { dwpw_wide_launch<T, CIN, COUT, TH, TW, true, PADROW>(s, p, tiles_x, tiles_y); return ti; }
+            // fp16 37.3 -> 26.6 us (tools/gpu/r5.sh c2), int8 23.6 -> 20.4 us (c7)
+            if (sizeof(T) == 2 ? knob(K_WIDE256) != 0 : (knob(K_WIDE_I8) & 1) != 0) { dwpw_wide_launch<T, CIN, COUT, TH, TW, true, PADROW>(s, p, tiles_x, tiles_y); return ti; }
         }
         if constexpr (HAS_DW && STRIDE == 1 && CIN == COUT && COUT >= 64) dwpw_launch<T, CIN, COUT, STRIDE, HAS_DW, TH, TW, true, PADROW>(s, p, tiles_x, tiles_y);
         else throw LaunchUnsupported("fused lateral: only stride-1 blocks with cin == cout >= 64 have a kernel instance");

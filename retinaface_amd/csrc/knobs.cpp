@@ -56,7 +56,7 @@ const Spec kSpecs[K_COUNT] = {
     {"RF_SSHTAIL", false, 1, {0, 1, 2, kAny}},
     {"RF_COPY_STREAMS", false, 2, {1, 2, kAny}},
     {"RF_CU_SPLIT", false, 0, {0, 1, kAny}},
-    {"RF_WIDE_I8", false, 0, {0, 1, 2, kAny}},
+    {"RF_WIDE_I8", false, 3, {0, 1, 2, 3, 4, 5, 6, 7, kAny}},
     {"RF_WIDE128", false, 1, {0, 1, 2, kAny}},
     {"RF_WIDE256", false, 1, {0, 1, kAny}},
 };

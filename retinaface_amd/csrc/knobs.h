@@ -38,7 +38,7 @@ enum Knob {
     K_SSHTAIL,             // 1 default; 0 two conv3x3<16,*> launches; 2 = 3 workgroups per CU
     K_COPY_STREAMS,        // 1 | 2 upload streams for staged host frames
     K_CU_SPLIT,            // 0 default; 1: lane l's stream is confined to half of every XCD's CUs (hipExtStreamCreateWithCUMask), halves alternate by lane
-    K_WIDE_I8,             // int8 engine: 0 = K_b everywhere; 1: the 256-channel block and the 128-channel lateral block on K_b(8); 2: all 128-channel blocks too
+    K_WIDE_I8,             // int8 engine on K_b(8): bit 0 = the 256-channel block, bit 1 = the plain 128-channel blocks, bit 2 = the 128-channel lateral block; default 3
     K_WIDE128,             // 1 default: the fp16 128-channel block with the fused lateral on K_b(8); 0 = none, 2 = all five 128-channel blocks
     K_WIDE256,             // 1 default: the fp16 256-channel block on the 8-wave weights-stationary kernel (round 5); 0 = K_b, matrix streamed from L2
     K_COUNT

@@ -863,6 +863,55 @@ def test_device_frames_resident_elsewhere_are_scattered_to_the_slices_device(rfa
         os.environ.pop("RF_FORCE_SCATTER", None)
 
 
+def test_residency_cache_follows_freed_and_reallocated_frame_buffers(rfa):
+    """Where a device frame lives is remembered per ALLOCATION (hipMemGetAddressRange) and re-validated against the runtime after 2 ms;
+    rf_invalidate_residency() drops it at once (round 4 cached per 2 MiB page, for ever -- a buffer freed and re-allocated elsewhere kept
+    its old answer, and a freed one was launched on instead of being refused).  One-GPU rehearsal with RF_FORCE_SCATTER=1 (the lookup is only made
+    when frames could live elsewhere): a frame tensor in an allocation of its own is used, freed (torch.cuda.empty_cache() returns the segment to
+    the runtime), and the stale pointer must then be REFUSED -- after an explicit invalidate, and after the TTL alone -- not handed to a peer copy;
+    a new allocation (possibly at the same address) is looked up afresh and gives the right detections."""
+    import time
+    import torch
+    from retinaface_amd.frames import synth_frames
+    frames = np.stack(synth_frames(448, 448, 8, config=23))
+    one = engine(rfa, "mnet25", FP16, (448, 448))
+    want = _key(one.detectBatchImages(list(frames), 0.5))
+    os.environ["RF_FORCE_SCATTER"] = "1"
+    try:
+        det = rfa.RetinaFace(ASSETS, "net3", 0.4, precision=FP16, net_hw=(448, 448), model_stem="mnet25")
+    finally:
+        os.environ.pop("RF_FORCE_SCATTER", None)
+
+    def own_allocation():
+        # > 10 MB: the caching allocator gives it a segment of its own, which empty_cache() returns to the runtime once the tensor is gone
+        t = torch.empty((64 << 20,), dtype=torch.uint8, device="cuda")
+        t[:frames.size] = torch.from_numpy(frames.reshape(-1)).cuda()
+        torch.cuda.synchronize()
+        return t
+
+    for how in ("invalidate", "ttl"):
+        t = own_allocation()
+        ptrs = [t.data_ptr() + i * 448 * 448 * 3 for i in range(8)]
+        for _ in range(3):                                   # first call looks the allocation up, the others are served from the cache
+            assert _key(det.detect_device(ptrs, [448] * 8, [448] * 8, 0.5)) == want
+        del t
+        torch.cuda.empty_cache()
+        if how == "invalidate":
+            det.invalidate_residency()
+        else:
+            time.sleep(0.02)                                 # > the 2 ms TTL: the entry is re-validated before it is trusted again
+        with pytest.raises(rfa._lib.RFError):
+            det.detect_device(ptrs[:1], [448], [448], 0.5)
+        # the handle stays usable, and a new allocation is looked up afresh
+        t2 = own_allocation()
+        ptrs2 = [t2.data_ptr() + i * 448 * 448 * 3 for i in range(8)]
+        assert _key(det.detect_device(ptrs2, [448] * 8, [448] * 8, 0.5)) == want
+        del t2
+        torch.cuda.empty_cache()
+        det.invalidate_residency()
+    det.close()
+
+
 def test_configs4_rehearsal_eight_engines_share_the_one_gpu(rfa):
     """BASELINE.json configs[4] (mnet25 int8, 448 x 448, batch 256 sharded over 8 GPUs) through the LIBRARY on the one-GPU box: a handle
     over devices [0] * 8 -- eight engines, eight host threads, contiguous slices of 32 -- takes ONE rf_detect_batch_device call of 256

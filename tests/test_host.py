@@ -206,6 +206,41 @@ def test_no_gpu_means_loud_failure(built_lib):
         retinaface_amd.RetinaFace(ASSETS)
 
 
+def test_knob_table_validates_and_separates_probe_from_product(tmp_path):
+    """csrc/knobs.cpp (round 5): ONE table for every RF_* knob.  Probe knobs select measured-and-rejected kernel variants and exist in the probe
+    build only: the product returns the default and says so on stderr; a value the dispatch code has no case for is reported and replaced by the
+    default in either build (round 4: ~30 function-local getenv()s, unknown values silently fell through to some variant); semantic knobs work
+    everywhere and are re-read on every query."""
+    src = os.path.join(ROOT, "tests", "csrc", "test_knobs.cpp")
+    exes = {}
+    for tag, flags in (("product", []), ("probe", ["-DRF_PROBES"])):
+        exes[tag] = str(tmp_path / f"test_knobs_{tag}")
+        subprocess.check_call(["g++", "-O1", "-std=c++17", "-pthread"] + flags + ["-o", exes[tag], src])
+
+    def run(tag, **env):
+        e = {k: v for k, v in os.environ.items() if not k.startswith("RF_")}
+        e.update(env)
+        r = subprocess.run([exes[tag]], env=e, capture_output=True, text=True, timeout=60)
+        assert r.returncode == 0, r.stderr
+        return dict(l.split() for l in r.stdout.splitlines()), r.stderr
+
+    d, err = run("product")
+    assert d["probes"] == "0" and d["RF_STEM2_V2"] == "7" and d["RF_CONV3WS"] == "1" and d["RF_TILE128"] == "-1" and d["RF_WIDE_I8"] == "3" and err == ""
+    assert d["RF_FORCE_SCATTER"] == "0" and d["RF_PREBUILD_LANES"] == "0" and d["RF_BLEND_FP32"] == "0" and d["min_rounds"] == "1.00"
+    # a probe knob in the product build: ignored, loudly; a semantic knob: honoured
+    d, err = run("product", RF_STEM2_V2="5", RF_FORCE_SCATTER="1", RF_PREBUILD_LANES="1", RF_PERSIST_MIN_ROUNDS="3")
+    assert d["RF_STEM2_V2"] == "7" and "RF_STEM2_V2=5 ignored" in err and "libretinaface_amd_probe.so" in err
+    assert d["RF_FORCE_SCATTER"] == "1" and d["RF_PREBUILD_LANES"] == "1" and d["min_rounds"] == "1.00"
+    # the probe build takes the values the dispatch code knows ...
+    d, err = run("probe", RF_STEM2_V2="5", RF_CONV3WS="132", RF_TILE128="2", RF_WIDE_I8="6", RF_PERSIST_MIN_ROUNDS="3")
+    assert d["probes"] == "1" and d["RF_STEM2_V2"] == "5" and d["RF_CONV3WS"] == "132" and d["RF_TILE128"] == "2" and d["RF_WIDE_I8"] == "6" and err == ""
+    assert d["min_rounds"] == "3.00"
+    # ... and refuses the ones it does not (round 4: RF_STEM2_V2=4 silently selected round 3's layout, RF_CONV3WS=5 the int8 kernel)
+    d, err = run("probe", RF_STEM2_V2="4", RF_CONV3WS="5", RF_TILE128="banana")
+    assert d["RF_STEM2_V2"] == "7" and d["RF_CONV3WS"] == "1" and d["RF_TILE128"] == "-1"
+    assert err.count("is not a value this knob knows") == 3
+
+
 def test_pack_index_math_host_emulation(tmp_path):
     exe = str(tmp_path / "test_pack")
     subprocess.check_call(["g++", "-O1", "-std=c++17", "-o", exe, os.path.join(ROOT, "tests", "csrc", "test_pack.cpp")])
