@@ -79,6 +79,13 @@ PY
         env RETINAFACE_AMD_LIB=$R/retinaface_amd/lib/libretinaface_amd_probe.so RF_WIDE_I8=$v timeout 100 python tools/kbench.py --n 256 --precision int8 --batch 32 --tag wide_i8_${v}_$rep > $O/kbench_wide_i8_${v}_$rep.txt 2>&1
       done; done
       for f in $O/kbench_wide_i8_*.txt; do echo "$(basename $f) total $(grep -h '==' $f | awk '{print $8}') | $(grep -h -E "dwpw<128,128|dwpw<256" $f | awk '{printf "%s %s  ", $1, $2}')"; done ;;
+    kbench_libs)    # the product library of this tree vs the previous build kept in retinaface_amd/lib_base (git-ignored, travels with the snapshot), interleaved
+      P=${AB_PREC:-fp16}; BT=${AB_BATCH:-8}
+      for rep in 1 2 3; do
+        RETINAFACE_AMD_LIB=$R/retinaface_amd/lib_base/libretinaface_amd.so timeout 100 python tools/kbench.py --n 256 --precision $P --batch $BT --tag base_${P}_$rep > $O/kbench_base_${P}_$rep.txt 2>&1
+        timeout 100 python tools/kbench.py --n 256 --precision $P --batch $BT --tag new_${P}_$rep > $O/kbench_new_${P}_$rep.txt 2>&1
+      done
+      for f in $O/kbench_base_${P}_*.txt $O/kbench_new_${P}_*.txt; do echo "$(basename $f) total $(grep -h '==' $f | awk '{print $8}') | $(grep -h -E "${AB_GREP:-head}" $f | awk '{printf "%s %s  ", $1, $2}')"; done ;;
     *) echo "unknown recipe $recipe" ;;
   esac
 done
