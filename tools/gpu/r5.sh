@@ -86,6 +86,12 @@ PY
         timeout 100 python tools/kbench.py --n 256 --precision $P --batch $BT --tag new_${P}_$rep > $O/kbench_new_${P}_$rep.txt 2>&1
       done
       for f in $O/kbench_base_${P}_*.txt $O/kbench_new_${P}_*.txt; do echo "$(basename $f) total $(grep -h '==' $f | awk '{print $8}') | $(grep -h -E "${AB_GREP:-head}" $f | awk '{printf "%s %s  ", $1, $2}')"; done ;;
+    bench_libs)     # pipeline throughput (the metric point, three lanes) of this tree's product library vs retinaface_amd/lib_base, interleaved
+      for rep in 1 2 3; do for which in base new; do
+        L=$R/retinaface_amd/lib/libretinaface_amd.so; [ $which = base ] && L=$R/retinaface_amd/lib_base/libretinaface_amd.so
+        RETINAFACE_AMD_LIB=$L timeout 200 python bench.py ${BENCH_ARGS} --no-cpu-baseline --no-extra-configs --no-pmc --no-pipeline-trace --host-seconds 0 --regions 2 > $O/bench_${which}_$rep.json 2> $O/bench_${which}_$rep.err
+        python -c "import json;j=json.loads(open('$O/bench_${which}_$rep.json').read().strip().splitlines()[-1]);print('$which rep $rep:', round(j['images_per_sec']), 'img/s  burst', round(j['burst']['ms'],3), 'ms  sync', round(j['sync_batch']['ms_per_call'],4), ' dominant', j['roofline']['kernel_instance'], round(j['roofline']['kernel_ms']*1e3,1), 'us  sum', round(j['roofline']['whole_path']['kernels_ms_per_launch_sequence']*1e3,1))" 2>&1 | tail -1
+      done; done ;;
     *) echo "unknown recipe $recipe" ;;
   esac
 done
