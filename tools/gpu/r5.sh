@@ -92,6 +92,12 @@ PY
         RETINAFACE_AMD_LIB=$L timeout 200 python bench.py ${BENCH_ARGS} --no-cpu-baseline --no-extra-configs --no-pmc --no-pipeline-trace --host-seconds 0 --regions 2 > $O/bench_${which}_$rep.json 2> $O/bench_${which}_$rep.err
         python -c "import json;j=json.loads(open('$O/bench_${which}_$rep.json').read().strip().splitlines()[-1]);print('$which rep $rep:', round(j['images_per_sec']), 'img/s  burst', round(j['burst']['ms'],3), 'ms  sync', round(j['sync_batch']['ms_per_call'],4), ' dominant', j['roofline']['kernel_instance'], round(j['roofline']['kernel_ms']*1e3,1), 'us  sum', round(j['roofline']['whole_path']['kernels_ms_per_launch_sequence']*1e3,1))" 2>&1 | tail -1
       done; done ;;
+    trace_int8)
+      rm -rf /tmp/kt8; ( cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/kt8 -o kt -- python $R/bench.py --timed-only --lanes 1 --no-pmc --precision int8 --batch 32 > $O/trace_int8_bench.json 2> $O/trace_int8.err )
+      db=$(find /tmp/kt8 -name "*.db" | head -1); python tools/rocpd_summary.py $db $O/kernel_trace_lanes1_int8.txt > /dev/null; head -24 $O/kernel_trace_lanes1_int8.txt | cut -c1-60,104-190 ;;
+    bench_int8)
+      timeout 600 python bench.py --precision int8 --batch 32 --no-cpu-baseline --host-seconds 0 > $O/bench_int8_mnet25_b32.json 2> $O/bench_int8.err; cp gpurun_out/bench_kernels.json $O/bench_kernels_int8.json 2>/dev/null
+      python -c "import json;j=json.loads(open('$O/bench_int8_mnet25_b32.json').read().strip().splitlines()[-1]);r=j['roofline'];print('int8 mnet25 b32', round(j['images_per_sec']), 'img/s', r['bound'], r['frac'], 'sum', r['whole_path']['kernels_ms_per_launch_sequence'], 'in pipeline', r['whole_path'].get('kernels_ms_in_pipeline'))" ;;
     *) echo "unknown recipe $recipe" ;;
   esac
 done

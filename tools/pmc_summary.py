@@ -16,6 +16,15 @@ def descriptor(mangled: str) -> str:
     if m:
         cin, cout, st, dw, th, tw, lat = m.groups()
         return f"dwpw<{cin},{cout},s{st}{',lat' if lat == '1' else ''}>"
+    # K_b(8), the 8-wave weights-stationary form of the same op (round 5): dwpw_wide_kernel<T, CIN, COUT, TH, TW, LAT, PADROW, OCC>, always stride 1
+    m = re.search(r"dwpw_wide_kernelI(?:DF16_|f|a)Li(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELb(\d)E", mangled)
+    if m:
+        cin, cout, th, tw, lat = m.groups()
+        return f"dwpw<{cin},{cout},s1{',lat' if lat == '1' else ''}>"
+    m = re.search(r"dwpw_wide_kernel<[^,]+, (\d+), (\d+), (\d+), (\d+), (true|false)", mangled)
+    if m:
+        cin, cout, th, tw, lat = m.groups()
+        return f"dwpw<{cin},{cout},s1{',lat' if lat == 'true' else ''}>"
     m = re.search(r"conv3x3_kernelI(?:DF16_|f|a)Li(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELb(\d)E", mangled)
     if m:
         cin, cout, th, tw, up = m.groups()
