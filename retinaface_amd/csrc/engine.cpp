@@ -189,7 +189,7 @@ public:
         }
         const int hw = (int)std::thread::hardware_concurrency();
         const int helpers = opt_.copy_threads > 0 ? opt_.copy_threads - 1 : std::max(0, std::min(8, hw / 4) - 1);
-        copier_.reset(new ParallelCopier(helpers));
+        copier_.reset(new ParallelCopier(helpers, knob(K_NT_COPY) != 0));       // RF_NT_COPY=0 (probe knob): plain memcpy into the staging block
     }
 
     ~EngineImpl() override {

@@ -36,6 +36,7 @@ enum Knob {
     K_CONV3WS,             // 1 default (fp16: 132); 0 lock-step; 22 23 32 33 122 132
     K_CONV3UPWS,           // 1 auto; 0 lock-step; 2 3 producer wave; 12 13 per-wave DMA
     K_SSHTAIL,             // 1 default; 0 two conv3x3<16,*> launches; 2 = 3 workgroups per CU
+    K_NT_COPY,             // 1 default: host frames are staged into pinned memory with non-temporal stores (copier.h); 0 = memcpy
     K_COPY_STREAMS,        // 1 | 2 upload streams for staged host frames
     K_CU_SPLIT,            // 0 default; 1: lane l's stream is confined to half of every XCD's CUs (hipExtStreamCreateWithCUMask), halves alternate by lane
     K_WIDE_I8,             // int8 engine on K_b(8): bit 0 = the 256-channel block, bit 1 = the plain 128-channel blocks, bit 2 = the 128-channel lateral block; default 3

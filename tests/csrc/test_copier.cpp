@@ -12,8 +12,10 @@ static int fails = 0;
 
 int main() {
     std::mt19937 rng(7);
+    for (int mode = 0; mode < 2; mode++)
     for (int helpers : {0, 1, 3, 7}) {
-        rf::ParallelCopier pc(helpers);
+        rf::ParallelCopier pc(helpers, mode == 1);            // plain memcpy, then the non-temporal (AVX2 streaming-store) copy
+        if (mode == 1 && helpers == 0) std::printf("streaming copy %s\n", pc.streaming() ? "on" : "unavailable on this CPU (memcpy)");
         for (int round = 0; round < 40; round++) {              // many rounds back to back: late-waking helpers must not race the next one
             const int nframes = 1 + (int)(rng() % 8);
             std::vector<std::vector<uint8_t>> src(nframes);

@@ -98,6 +98,10 @@ PY
     bench_int8)
       timeout 600 python bench.py --precision int8 --batch 32 --no-cpu-baseline --host-seconds 0 > $O/bench_int8_mnet25_b32.json 2> $O/bench_int8.err; cp gpurun_out/bench_kernels.json $O/bench_kernels_int8.json 2>/dev/null
       python -c "import json;j=json.loads(open('$O/bench_int8_mnet25_b32.json').read().strip().splitlines()[-1]);r=j['roofline'];print('int8 mnet25 b32', round(j['images_per_sec']), 'img/s', r['bound'], r['frac'], 'sum', r['whole_path']['kernels_ms_per_launch_sequence'], 'in pipeline', r['whole_path'].get('kernels_ms_in_pipeline'))" ;;
+    hostcopy)       # host-frame pipeline (rf_enqueue_batch from pageable / registered caller memory): staging copy with memcpy (RF_NT_COPY=0) vs non-temporal stores (1), probe build, interleaved
+      for rep in 1 2 3; do for v in 0 1; do
+        env RETINAFACE_AMD_LIB=$R/retinaface_amd/lib/libretinaface_amd_probe.so RF_NT_COPY=$v timeout 120 python tools/probes/host_rate.py 1.5 2>/dev/null | sed "s/^RF_COPY_STREAMS=[0-9]*/RF_NT_COPY=$v rep $rep/" | tee -a $O/host_rate_nt_copy.txt
+      done; done ;;
     *) echo "unknown recipe $recipe" ;;
   esac
 done
