@@ -102,6 +102,10 @@ PY
       for rep in 1 2 3; do for v in 0 1; do
         env RETINAFACE_AMD_LIB=$R/retinaface_amd/lib/libretinaface_amd_probe.so RF_NT_COPY=$v timeout 120 python tools/probes/host_rate.py 1.5 2>/dev/null | sed "s/^RF_COPY_STREAMS=[0-9]*/RF_NT_COPY=$v rep $rep/" | tee -a $O/host_rate_nt_copy.txt
       done; done ;;
+    bench_others)   # the dedicated lines of configs [2] and [3] (three regions of >= 1 s each)
+      timeout 600 python bench.py --precision int8 --model mnet-deconv-0517 --batch 32 --no-cpu-baseline --host-seconds 0 --no-pipeline-trace > $O/bench_int8_0517_b32.json 2> $O/bench_0517.err
+      timeout 600 python bench.py --height 896 --width 1280 --batch 1 --no-cpu-baseline --host-seconds 0 --no-pipeline-trace > $O/bench_1280x896_b1_fp16.json 2> $O/bench_1280.err
+      for f in $O/bench_int8_0517_b32.json $O/bench_1280x896_b1_fp16.json; do python -c "import json;j=json.loads(open('$f').read().strip().splitlines()[-1]);r=j['roofline'];print('$(basename $f)', round(j['images_per_sec']), 'img/s', round(j['value']), 'faces/s', r['kernel_instance'], round(r['kernel_ms']*1e3,1), r['bound'], r['frac'])"; done ;;
     *) echo "unknown recipe $recipe" ;;
   esac
 done
