@@ -859,7 +859,7 @@ def library_leg(args, n_devices, thr, G=256, seconds=None):
             "frames_scattered_per_call": travelled, "bytes_scattered_per_call": travelled * H * W * 3,
             "scatter_GBs_at_this_rate": travelled * H * W * 3 / med / 1e9,
             "single_engine_same_call": {"ms_per_call": sync_one["ms_per_call"], "images_per_sec": sync_one["images_per_sec"],
-                                        "note": "one engine on GPU 0 takes the same 256-image call (eight 32-image chunks, up to three in flight)"},
+                                        "note": "one engine on GPU 0 takes the same 256-image call (its eight 32-image chunks coalesce into one 256-image launch sequence)"},
             "detections_identical_to_single_engine": bool(identical), "dtype": "i8", "scaling": "strong",
             "note": "one synchronous call at a time: the per-engine slice of 32 images is a small-batch launch sequence (latency-bound); the pipelined "
                     "per-GPU rate is `configs`[id 4] / the N-rank `value`"}
