@@ -827,7 +827,6 @@ __global__ __launch_bounds__((Stem2Cfg<TW_, F16P, PADKB>::THREADS), (Stem2Cfg<TW
     constexpr int NT = C::THREADS, NW = NT / 64;         // threads / waves per workgroup
     typedef half_t T;
     typedef Mma<T> M;
-    typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
     constexpr int TW = C::TW, P4 = C::P4, R2W = C::R2W, N2 = C::N2, R0W = C::R0W;
     constexpr int ROWD = C::ROWD, GRP = C::GRP, IR = C::IR, LDA1 = C::LDA1, LDO = C::LDO;
     // fp32 conv0 tile as two channel planes [channels 0-3 | channels 4-7][pixel][4]: 16 consecutive pixels of a plane are 256
@@ -2361,11 +2360,11 @@ static TileInfo dwpw_select(hipStream_t s, const DwPwParams<T> *p, int cin, int 
                             int wout) {
 #define RF_DWPW(CI, CO, ST, DW, TH_, TW_) \
     if (cin == CI && cout == CO && stride == ST && has_dw == DW) return dwpw_dispatch<T, CI, CO, ST, DW, TH_, TW_>(s, p, hout, wout);
-    constexpr bool F32 = sizeof(T) == 4, I8 = sizeof(T) == 1;
+    constexpr bool I8 = sizeof(T) == 1;
 #ifdef RF_PROBES
     constexpr bool FRONT = sizeof(T) >= 2;       // fp16 with RF_STEM2=0 / RF_DWPW2=0 runs blocks 0-3 through K_b as well
 #else
-    constexpr bool FRONT = F32;                  // fp16: blocks 0-3 live in stem2 / dwpw2; int8: block 0 lives in the stem, 1-3 have their own shapes below
+    constexpr bool FRONT = sizeof(T) == 4;                  // fp16: blocks 0-3 live in stem2 / dwpw2; int8: block 0 lives in the stem, 1-3 have their own shapes below
 #endif
     if constexpr (FRONT) { RF_DWPW(8, 16, 1, true, 8, 32) }
     if constexpr (I8) {
@@ -3973,7 +3972,9 @@ __global__ __launch_bounds__(kThreads, 2) void conv3x3_up_dma_kernel(Conv3Args<T
     if (n_my > 0) store_tile((n_my - 1) % NBUF, p_img, p_oy0, p_ox0);
 }
 
+#ifdef RF_PROBES
 static int conv3_ws_variant() { return knob(K_CONV3WS); }        // probe knob RF_CONV3WS: 1 = the product; 0 = K_c for the merged SSH conv as well; 22 / 23 / 32 / 33 / 122 / 132: see conv3_ws_launch
+#endif
 
 template <typename T, int DEPTH, int NBUF, int SPLIT = 0>
 static void conv3_ws_launch_v(hipStream_t s, Conv3Args<T> &a, int nlv, int total_tiles) {
@@ -4073,7 +4074,9 @@ static TileInfo conv3_dispatch(hipStream_t s, const Conv3Params<T> *p, int nlv, 
 }
 
 // probe knob (tools/probes): RF_CONV3=0 selects the round-1 wave split (channel tiles over the waves) for A/B measurements; -1 = the product
+#ifdef RF_PROBES
 static int conv3_variant() { return knob(K_CONV3); }
+#endif
 // probe knob RF_CONV3UPWS: 1 = auto (see conv3_select); 0 = K_c for the aggregation convs; 2 / 3 = halo buffers of the producer-wave kernel (K_c''); 12 / 13: per-wave DMA
 static int conv3_up_ws_variant() { return knob(K_CONV3UPWS); }
 
