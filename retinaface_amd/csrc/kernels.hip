@@ -410,7 +410,7 @@ __device__ __forceinline__ void gemm_stationary(typename Mma<T>::Acc (&acc)[NI][
         // Pin the software pipeline (round 4): left to itself hipcc's scheduler sinks every B-fragment read to just before the MFMA that
         // consumes it (one register set, `ds_read; s_waitcnt lgkmcnt(0); v_mfma` per MFMA: the ISA of round 3's 3x3 convs exposed one LDS
         // round trip per one or two MFMAs).  Nothing may cross these two fences, so the reads of chunk kc + DEPTH - 1 are in flight while the
-        // MFMAs of chunk kc issue.  PIN is a per-call-site choice, measured (tools/gpu/r4_call3.sh): the long K loops of the 64-channel 3x3
+        // MFMAs of chunk kc issue.  PIN is a per-call-site choice, measured (tools/gpu/rounds_3_4.sh r4_call3): the long K loops of the 64-channel 3x3
         // convs gain 10 %, the 5-chunk loops of ssh_tail and the fused laterals lose (44 -> 50 us, +1.4 us): their reads are better left
         // where the compiler puts them.
         if constexpr (PIN) __builtin_amdgcn_sched_barrier(0);
@@ -1206,7 +1206,7 @@ void launch_stem2(hipStream_t s, const Stem2Params &p) {
     if (pad == 3) { hipLaunchKernelGGL((stem2_kernel<8, false, 3, 0>), dim3(a.nblk), dim3(kThreads), 0, s, a); return; }
     if (pad == 7) { hipLaunchKernelGGL((stem2_kernel<8, false, 7, 0>), dim3(a.nblk), dim3(kThreads), 0, s, a); return; }
     // RF_STEM2_V2 (probe knob): bit 0 = planar conv2 tile, bit 1 = conv3 -> conv4 chained in registers, bit 2 = rotated thread -> pixel map of the
-    // depthwise-1 phase; 0 = round 3; 5 = round 4's default (bit-identical to round 3: 250.3 -> 246.5 -> 238.6 us, tools/gpu/r4_call30.sh, r4_call32.sh)
+    // depthwise-1 phase; 0 = round 3; 5 = round 4's default (bit-identical to round 3: 250.3 -> 246.5 -> 238.6 us, tools/gpu/rounds_3_4.sh r4_call30, r4_call32)
     switch (knob(K_STEM2_V2)) {
         case 5: hipLaunchKernelGGL((stem2_kernel<8, false, 0, 5>), dim3(a.nblk), dim3(kThreads), 0, s, a); return;
         case 3: hipLaunchKernelGGL((stem2_kernel<8, false, 0, 3>), dim3(a.nblk), dim3(kThreads), 0, s, a); return;
@@ -1217,7 +1217,7 @@ void launch_stem2(hipStream_t s, const Stem2Params &p) {
     }
 #endif
     // The product: V2 = 7 -- planar conv2 tile, rotated depthwise-1 map and (round 5) conv3 -> conv4 chained in registers: 239.3 -> 235.1 us
-    // (tools/gpu/r4_call35.sh).  The chain permutes conv4's K order, i.e. re-rolls its fp32 summation: on one of the 208 contract frames the
+    // (tools/gpu/rounds_3_4.sh r4_call35).  The chain permutes conv4's K order, i.e. re-rolls its fp32 summation: on one of the 208 contract frames the
     // NMS winner moves between twin anchors 300 / 301 whose oracle scores are 0.997809 / 0.997806 -- which the anchor-twin band of the parity
     // tests (tests/anchor_twins.py) admits, and nothing else.
     hipLaunchKernelGGL((stem2_kernel<8, false, 0, 7>), dim3(a.nblk), dim3(kThreads), 0, s, a);
@@ -1488,7 +1488,7 @@ __global__ __launch_bounds__(kThreads, (DwPwCfg<T, CIN, COUT, STRIDE, HAS_DW, TH
         // which follows the epilogue that wrote it) and rewritten by this tile's epilogue after the depthwise barrier.  With a
         // lateral the result tile of the lateral shares s_a with the stencil, so the store has to stay ahead of the barrier.
         // int8 only: per kernel it is 1.5-2 % in both precisions, but the fp16 three-lane pipeline measured 289.5 -> 287.6 k images/s with
-        // it (int8: 363.2 -> 366.1 k; tools/gpu/r3_call14.sh, two interleaved repetitions each)
+        // it (int8: 363.2 -> 366.1 k; tools/gpu/rounds_3_4.sh r3_call14, two interleaved repetitions each)
         constexpr bool LATE_STORE = HAS_DW && !LAT && sizeof(T) == 1;
         if constexpr (!LATE_STORE) {
             if (p_img >= 0) store_tile(p_img, p_oy0, p_ox0);
@@ -2370,7 +2370,7 @@ static TileInfo dwpw_select(hipStream_t s, const DwPwParams<T> *p, int cin, int 
     if constexpr (I8) {
         // Tile shapes of the int8 engine's big-map blocks (fp16 runs them inside stem2 / dwpw2).  These kernels spend their time in the requantising
         // epilogue (VALU-active 0.5-0.64 of the chip), which is per element, so the tile shape moves little; measured one by one inside one call
-        // (tools/gpu/r4_call18.sh, us per 256 images, all bit-identical): 16->32 s2 8x8 56.2 | 8x16 53.5 | 16x16 57.2;  32->32 8x8 68.6 | 8x16 67.1 |
+        // (tools/gpu/rounds_3_4.sh r4_call18, us per 256 images, all bit-identical): 16->32 s2 8x8 56.2 | 8x16 53.5 | 16x16 57.2;  32->32 8x8 68.6 | 8x16 67.1 |
         // 16x16 69.6;  32->64 s2 4x8 32.7 | 8x8 30.5 | 8x16 34.4;  64->128 s2 4x8 18.6 | 8x8 22.1.  The product = the best of each.
 #ifdef RF_PROBES
         const int va = knob(K_TILE_A), vb = knob(K_TILE_B), vc = knob(K_TILE_C), vd = knob(K_TILE_D);      // 0 = round-3 shapes
@@ -2400,7 +2400,7 @@ static TileInfo dwpw_select(hipStream_t s, const DwPwParams<T> *p, int cin, int 
 #endif
     RF_DWPW(64, 64, 1, true, 4, 8)
     RF_DWPW(64, 128, 2, true, 4, 8)
-    // 128-channel blocks: 4x16 tiles for the int8 engine (26.0 -> 24.9 us each, tools/gpu/r4_call16.sh, r4_call18.sh); fp16: 27.7 -> 28.3, stays 4x8.
+    // 128-channel blocks: 4x16 tiles for the int8 engine (26.0 -> 24.9 us each, tools/gpu/rounds_3_4.sh r4_call16, r4_call18); fp16: 27.7 -> 28.3, stays 4x8.
     // RF_TILE128 = 0 / 1 / 2 / 3 forces 4x8 / 8x8 / 4x16 / 8x16 (probe knob; -1 = the per-precision default)
 #ifdef RF_PROBES
     if constexpr (sizeof(T) <= 2) {
@@ -2414,7 +2414,7 @@ static TileInfo dwpw_select(hipStream_t s, const DwPwParams<T> *p, int cin, int 
     if constexpr (I8) { RF_DWPW(128, 128, 1, true, 4, 16) }
     else { RF_DWPW(128, 128, 1, true, 4, 8) }
     RF_DWPW(128, 256, 2, true, 4, 8)
-    // 256-channel block, 8x8 tiles: the streamed 256 x 256 weight matrix is read once per 64 pixels instead of 32.  Measured (tools/gpu/r4_call13.sh):
+    // 256-channel block, 8x8 tiles: the streamed 256 x 256 weight matrix is read once per 64 pixels instead of 32.  Measured (tools/gpu/rounds_3_4.sh r4_call13):
     // int8 26.4 -> 24.4 us, fp16 35.5 -> 35.6 (its 64 accumulator registers on top of the fragment stream: 2-14 spills with the lateral): int8 only.
     // RF_TILE256 = 0 / 1 forces 4x8 / 8x8 (probe knob; 2 = the per-precision default)
 #ifdef RF_PROBES
@@ -2492,7 +2492,7 @@ __global__ __launch_bounds__(kThreads, 3) void dwpw2_kernel(DwPw2Args a) {
     // Halo rows are padded by 4 slots of 16 B (HROW = 118 slots = 6 mod 16): a depthwise-A pixel tile is 16 consecutive pixels of the 17-wide region, so
     // nearly every tile wraps from one halo row to the next; with the plain 19-pixel pitch (114 slots = 2 mod 16) the wrap shifted the second part of
     // the tile by 12 slots and its ds_read_b128 lane groups collided 2-way (SQ_LDS_BANK_CONFLICT 0.42 of this kernel's cycles, LDS busy 0.75:
-    // tools/gpu/r4_call22.sh); 118 makes the wrap look like 17 contiguous pixels to the bank function (6 slots per pixel).
+    // tools/gpu/rounds_3_4.sh r4_call22); 118 makes the wrap look like 17 contiguous pixels to the bank function (6 slots per pixel).
     constexpr int HROW = HW * LD + (HPAD ? 32 : 0);                    // halfs per halo row
     constexpr int IN_BYTES = HH * HROW * 2, A_BYTES = PTA * 16 * LDSA * 2, B_BYTES = P * LD * 2, OUT_BYTES = P * LDO * 2;
     constexpr int NPF = (NH * 4 + kThreads - 1) / kThreads;            // halo items (16 B) per thread: 4
@@ -2707,7 +2707,7 @@ __global__ __launch_bounds__(kThreads, 3) void dwpw2_kernel(DwPw2Args a) {
 //   their A fragments are loaded (two 8-byte loads instead of one 16-byte load, once per workgroup), so the depthwise result never goes through
 //   LDS: no s_a / s_b tiles, 13 -> 8 ds_write_b64 and 37 -> 30 ds_read_b128 per wave and tile, 5 -> 3 barriers.
 //   Why it matters: SQ_LDS_IDX_ACTIVE said the LDS pipe of K_b2 was busy 0.75 of the kernel's time, 0.41 in bank-conflict cycles
-//   (tools/gpu/r4_call22.sh): 4-way conflicts of every 8-byte epilogue write at a 96-byte pixel pitch, 2-way conflicts of the depthwise reads on
+//   (tools/gpu/rounds_3_4.sh r4_call22): 4-way conflicts of every 8-byte epilogue write at a 96-byte pixel pitch, 2-way conflicts of the depthwise reads on
 //   tiles that wrap a halo row.  Layouts here: halo rows padded to 118 slots of 16 B (= 6 mod 16: a wrap looks like contiguous pixels, see K_b2);
 //   the block-A tile at an 80-byte pixel pitch and 88 slots per row (its only readers are block B's stride-2 depthwise fragments: conflict-free;
 //   writes 2-way instead of 4-way); the output tile at 144 bytes per pixel (2-way writes).
@@ -3096,7 +3096,7 @@ template <typename T, int CIN, int COUT, int TH, int TW, bool ALLC = false, bool
     // halo tile and the result tile are separate LDS regions (and the GEMM -> epilogue barrier disappears).  DB: BOTH regions
     // double buffered, which leaves ONE barrier per tile (see the tile loop).  Built and measured in round 3, correct (the whole
     // -m gpu suite) and OFF: c1 87.4 -> 86.7 us, c2 29.7 -> 29.3, the SSH 64 -> 48 conv 103.6 -> 105.8 (fp16, A/B inside one call,
-    // tools/gpu/r3_call13.sh; int8 unchanged) for twice the LDS -- these tile loops do not wait at their barriers, they wait for
+    // tools/gpu/rounds_3_4.sh r3_call13; int8 unchanged) for twice the LDS -- these tile loops do not wait at their barriers, they wait for
     // the dependent LDS -> MFMA -> LDS chain inside each wave.
     static constexpr bool DB = false;
     static constexpr size_t LDS_BYTES = (DB ? 2 : 1) * (IN_BYTES + O_BYTES);
@@ -3997,7 +3997,7 @@ static void conv3_ws_launch_v(hipStream_t s, Conv3Args<T> &a, int nlv, int total
     hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), W::LDS_BYTES, s, a);
 }
 // RF_CONV3WS = 10 * halo buffers + B-fragment prefetch depth (probe knob): 22, 23, 32, 33; 1 = the default = 32.  Measured per 256 images
-// (tools/gpu/r4_call5.sh, 4 repetitions each, profiles/r04_ws_conv_ab.txt): fp16 lock-step 87-90 us (100-104 before its pipeline was pinned),
+// (tools/gpu/rounds_3_4.sh r4_call5, 4 repetitions each, profiles/r04_ws_conv_ab.txt): fp16 lock-step 87-90 us (100-104 before its pipeline was pinned),
 // two halo buffers 75-85 (bimodal: the interval is then one memory round trip), THREE 56-58 at either depth; int8 37.2 lock-step, 39-41 /
 // 44 warp-specialised (its GEMM is too short to hide one producer wave's issue work): int8 stays on K_c.
 template <typename T>
@@ -4012,7 +4012,7 @@ static void conv3_ws_launch(hipStream_t s, Conv3Args<T> &a, int nlv, int total_t
         default: break;
     }
 #endif
-    conv3_ws_launch_v<T, 2, 3, 1>(s, a, nlv, total_tiles);       // = 132: three halo buffers, 2 + 2 + 1 roles (57.1 -> 54.5 us over 32, tools/gpu/r4_call14.sh)
+    conv3_ws_launch_v<T, 2, 3, 1>(s, a, nlv, total_tiles);       // = 132: three halo buffers, 2 + 2 + 1 roles (57.1 -> 54.5 us over 32, tools/gpu/rounds_3_4.sh r4_call14)
 }
 
 template <typename T, int CIN, int COUT, int TH, int TW, bool UPADD, bool ALLC, bool PADROW>
@@ -4119,7 +4119,7 @@ static TileInfo conv3_select(hipStream_t s, const Conv3Params<T> *p, int nlv, in
         // parities are thread constants) and a single output tensor
         // Default (RF_CONV3UPWS unset = 1): fp16 maps of >= 48 x 48 pixels take the variant where every wave issues its own share of the
         // LDS-DMA (two ring buffers): rf_c1_aggr 77.8 -> 73.6 us per 256 images; the 28 x 28 map of rf_c2_aggr and the int8 engine measured
-        // equal or slower and stay on K_c (tools/gpu/r4_call12.sh, profiles/r04_rejected_ws_variants.txt).
+        // equal or slower and stay on K_c (tools/gpu/rounds_3_4.sh r4_call12, profiles/r04_rejected_ws_variants.txt).
         const int upv = conv3_up_ws_variant() == 1 ? ((sizeof(T) == 2 && p && (long)p[0].h * p[0].w_ >= 48 * 48) ? 12 : 0) : conv3_up_ws_variant();
         if (p && nlv == 1 && p[0].up && cin == 64 && cout == 64 && upv >= 2 && p[0].h % 2 == 0 && p[0].w_ % 2 == 0 &&
             p[0].n0 == 64 && p[0].in_ld == 64) {
