@@ -106,6 +106,12 @@ PY
       timeout 600 python bench.py --precision int8 --model mnet-deconv-0517 --batch 32 --no-cpu-baseline --host-seconds 0 --no-pipeline-trace > $O/bench_int8_0517_b32.json 2> $O/bench_0517.err
       timeout 600 python bench.py --height 896 --width 1280 --batch 1 --no-cpu-baseline --host-seconds 0 --no-pipeline-trace > $O/bench_1280x896_b1_fp16.json 2> $O/bench_1280.err
       for f in $O/bench_int8_0517_b32.json $O/bench_1280x896_b1_fp16.json; do python -c "import json;j=json.loads(open('$f').read().strip().splitlines()[-1]);r=j['roofline'];print('$(basename $f)', round(j['images_per_sec']), 'img/s', round(j['value']), 'faces/s', r['kernel_instance'], round(r['kernel_ms']*1e3,1), r['bound'], r['frac'])"; done ;;
+    cpol)           # cache policy of the activation stores (build-time RF_STORE_CPOL: retinaface_amd/lib_cpol{2,16,17}) vs the default write-back, pipeline throughput + kernel sum, interleaved
+      for rep in 1 2; do for which in ${CPOL_SET:-0 2 16 17}; do
+        L=$R/retinaface_amd/lib/libretinaface_amd.so; [ $which != 0 ] && L=$R/retinaface_amd/lib_cpol$which/libretinaface_amd.so
+        RETINAFACE_AMD_LIB=$L timeout 200 python bench.py --no-cpu-baseline --no-extra-configs --no-pmc --no-pipeline-trace --host-seconds 0 --regions 2 > $O/bench_cpol${which}_$rep.json 2> $O/bench_cpol${which}_$rep.err
+        python -c "import json;j=json.loads(open('$O/bench_cpol${which}_$rep.json').read().strip().splitlines()[-1]);print('cpol $which rep $rep:', round(j['images_per_sec']), 'img/s  burst', round(j['burst']['ms'],3), 'ms  sync', round(j['sync_batch']['ms_per_call'],4), ' sum', round(j['roofline']['whole_path']['kernels_ms_per_launch_sequence']*1e3,1))" 2>&1 | tail -1
+      done; done ;;
     *) echo "unknown recipe $recipe" ;;
   esac
 done
