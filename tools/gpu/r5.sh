@@ -112,6 +112,11 @@ PY
         RETINAFACE_AMD_LIB=$L timeout 200 python bench.py --no-cpu-baseline --no-extra-configs --no-pmc --no-pipeline-trace --host-seconds 0 --regions 2 > $O/bench_cpol${which}_$rep.json 2> $O/bench_cpol${which}_$rep.err
         python -c "import json;j=json.loads(open('$O/bench_cpol${which}_$rep.json').read().strip().splitlines()[-1]);print('cpol $which rep $rep:', round(j['images_per_sec']), 'img/s  burst', round(j['burst']['ms'],3), 'ms  sync', round(j['sync_batch']['ms_per_call'],4), ' sum', round(j['roofline']['whole_path']['kernels_ms_per_launch_sequence']*1e3,1))" 2>&1 | tail -1
       done; done ;;
+    coalesce)       # super-batch size: enqueued batch-8 tickets merged per launch (default 32 = 256 images), interleaved
+      for rep in 1 2; do for c in ${COALESCE_SET:-32 24 20 28 40}; do
+        timeout 200 python bench.py --coalesce $c --no-cpu-baseline --no-extra-configs --no-pmc --no-pipeline-trace --host-seconds 0 --regions 2 > $O/bench_coalesce${c}_$rep.json 2> $O/bench_coalesce${c}_$rep.err
+        python -c "import json;j=json.loads(open('$O/bench_coalesce${c}_$rep.json').read().strip().splitlines()[-1]);print('coalesce $c rep $rep:', round(j['images_per_sec']), 'img/s  burst', round(j['burst']['ms'],3), 'ms for', j['burst']['images'], 'images')" 2>&1 | tail -1
+      done; done ;;
     *) echo "unknown recipe $recipe" ;;
   esac
 done
