@@ -154,6 +154,7 @@ public:
         // device frames are checked for residency whenever another device exists they could live on (RF_FORCE_SCATTER: test knob,
         // treats every device frame as foreign so the scatter path runs on a one-GPU box)
         force_scatter_ = knob(K_FORCE_SCATTER) != 0;
+        head_start_max_ = knob(K_HEAD_START) ? opt_.max_batch : 0;      // launches of up to max_batch images = synchronous calls and un-coalesced tickets
         copy_streams_ = knob(K_COPY_STREAMS) > 1 ? 2 : 1;       // probe knob RF_COPY_STREAMS (tools/probes/host_rate.py)
         check_residency_ = ndev > 1 || force_scatter_;
         DeviceGuard guard(device_);                  // the caller's current device is put back when construction ends
@@ -1102,7 +1103,15 @@ private:
         if (eager_timed) RF_HIP(hipEventRecord(s.time_ev[1], s.stream));
         bind_launch_cus(s.cus);
         struct Unbind { ~Unbind() { bind_launch_cus(0); } } unbind;
-        if (opt_.use_graph && s.warmed.count(n)) {
+        if (opt_.use_graph && s.warmed.count(n) && n <= head_start_max_ && s.ops.size() > 2) {
+            // Head start for small launches (round 5, RF_HEAD_START): hipGraphLaunch costs the host ~16 us before the first kernel can start, a
+            // tenth of a synchronous batch-8 call.  The first kernel (the stem: the longest of a small launch, 13 us at batch 8) is launched
+            // eagerly -- ~3 us of host time -- and the graph of the remaining launches is submitted while it runs.
+            auto it = s.graphs.find(-n);
+            if (it == s.graphs.end()) it = s.graphs.emplace(-n, capture(s, n, 1)).first;
+            s.ops[0].launch(s.stream, n);
+            RF_HIP(hipGraphLaunch(it->second, s.stream));
+        } else if (opt_.use_graph && s.warmed.count(n)) {
             auto it = s.graphs.find(n);
             if (it == s.graphs.end()) it = s.graphs.emplace(n, capture(s, n)).first;
             RF_HIP(hipGraphLaunch(it->second, s.stream));
@@ -1249,13 +1258,13 @@ private:
         return id;
     }
 
-    hipGraphExec_t capture(Lane &L, int n) {
+    hipGraphExec_t capture(Lane &L, int n, size_t first_op = 0) {
         hipGraph_t g = nullptr;
         hipGraphExec_t ge = nullptr;
         RF_HIP(hipStreamBeginCapture(L.stream, hipStreamCaptureModeThreadLocal));
         std::string err;
         try {
-            for (size_t k = 0; k < L.ops.size(); k++) L.ops[k].launch(L.stream, n);
+            for (size_t k = first_op; k < L.ops.size(); k++) L.ops[k].launch(L.stream, n);
         } catch (const std::exception &e) { err = e.what(); }
         hipError_t end = hipStreamEndCapture(L.stream, &g);
         if (!err.empty() || end != hipSuccess || !g)
@@ -1271,6 +1280,7 @@ private:
     HostTrace trace_;
     bool check_residency_ = false, force_scatter_ = false;
     int copy_streams_ = 2;
+    int head_start_max_ = 0;                   // launches of at most this many images start their first kernel eagerly ahead of the graph
     long scattered_frames_ = 0;               // device frames that arrived from another device (peer copies issued)
     std::vector<float> ratios_;                // the network preset's anchor ratios (empty: a preset without anchors)
     int na_ = 2;                               // anchors per cell the preset decodes (head_a_: what the model's heads carry)

@@ -54,6 +54,7 @@ const Spec kSpecs[K_COUNT] = {
     {"RF_CONV3WS", false, 1, {0, 1, 22, 23, 32, 33, 122, 132, kAny}},
     {"RF_CONV3UPWS", false, 1, {0, 1, 2, 3, 12, 13, kAny}},
     {"RF_SSHTAIL", false, 1, {0, 1, 2, kAny}},
+    {"RF_HEAD_START", false, 0, {0, 1, kAny}},
     {"RF_NT_COPY", false, 1, {0, 1, kAny}},
     {"RF_COPY_STREAMS", false, 2, {1, 2, kAny}},
     {"RF_CU_SPLIT", false, 0, {0, 1, kAny}},

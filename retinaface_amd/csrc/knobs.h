@@ -36,6 +36,7 @@ enum Knob {
     K_CONV3WS,             // 1 default (fp16: 132); 0 lock-step; 22 23 32 33 122 132
     K_CONV3UPWS,           // 1 auto; 0 lock-step; 2 3 producer wave; 12 13 per-wave DMA
     K_SSHTAIL,             // 1 default; 0 two conv3x3<16,*> launches; 2 = 3 workgroups per CU
+    K_HEAD_START,          // 1: launches of <= max_batch images start their first kernel eagerly and submit the graph of the rest while it runs; 0 = one graph
     K_NT_COPY,             // 1 default: host frames are staged into pinned memory with non-temporal stores (copier.h); 0 = memcpy
     K_COPY_STREAMS,        // 1 | 2 upload streams for staged host frames
     K_CU_SPLIT,            // 0 default; 1: lane l's stream is confined to half of every XCD's CUs (hipExtStreamCreateWithCUMask), halves alternate by lane

@@ -117,6 +117,10 @@ PY
         timeout 200 python bench.py --coalesce $c --no-cpu-baseline --no-extra-configs --no-pmc --no-pipeline-trace --host-seconds 0 --regions 2 > $O/bench_coalesce${c}_$rep.json 2> $O/bench_coalesce${c}_$rep.err
         python -c "import json;j=json.loads(open('$O/bench_coalesce${c}_$rep.json').read().strip().splitlines()[-1]);print('coalesce $c rep $rep:', round(j['images_per_sec']), 'img/s  burst', round(j['burst']['ms'],3), 'ms for', j['burst']['images'], 'images')" 2>&1 | tail -1
       done; done ;;
+    headstart)      # synchronous call latency with the first kernel launched eagerly ahead of the graph of the rest (RF_HEAD_START=1) vs one graph (0), probe build, interleaved
+      for rep in 1 2 3; do for v in 0 1; do for b in 8 1; do
+        env RETINAFACE_AMD_LIB=$R/retinaface_amd/lib/libretinaface_amd_probe.so RF_HEAD_START=$v timeout 100 python tools/probes/sync_latency.py $b 1 2>/dev/null | grep "sync call" | sed "s/^/RF_HEAD_START=$v rep $rep: /" | tee -a $O/sync_latency_head_start.txt
+      done; done; done ;;
     *) echo "unknown recipe $recipe" ;;
   esac
 done
