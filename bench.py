@@ -834,13 +834,14 @@ def library_leg(args, n_devices, thr, G=256, seconds=None):
     want = one.detect_device(ptrs, [H] * G, [W] * G, thr)
     sync_one = sync_batch_measure(one, ptrs, H, W, thr, reps=12)           # timed at the C ABI: the Python binding spends ~3 ms building 256 images' result objects
     one.close()
+    had = os.environ.get("RF_FORCE_SCATTER")
     if forced:
-        os.environ["RF_FORCE_SCATTER"] = "1"
+        os.environ["RF_FORCE_SCATTER"] = "1"          # read by the engines when they are built
     try:
         multi = retinaface_amd.RetinaFace(os.path.join(ROOT, "assets"), "net3", 0.4, precision=2, net_hw=(H, W), max_batch=32, model_stem="mnet25",
                                           devices=devices)
     finally:
-        if forced:
+        if forced and had is None:
             os.environ.pop("RF_FORCE_SCATTER", None)
     key = lambda res: [[(d.anchor_index, d.as_row().tobytes()) for d in r] for r in res]      # noqa: E731
     got = multi.detect_device(ptrs, [H] * G, [W] * G, thr)
