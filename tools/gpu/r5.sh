@@ -121,6 +121,9 @@ PY
       for rep in 1 2 3; do for v in 0 1; do for b in 8 1; do
         env RETINAFACE_AMD_LIB=$R/retinaface_amd/lib/libretinaface_amd_probe.so RF_HEAD_START=$v timeout 100 python tools/probes/sync_latency.py $b 1 2>/dev/null | grep "sync call" | sed "s/^/RF_HEAD_START=$v rep $rep: /" | tee -a $O/sync_latency_head_start.txt
       done; done; done ;;
+    lds)            # LDS-array counters per kernel of the final tree (one --pmc pass, no trace flags)
+      rm -rf /tmp/lds1; ( cd /tmp && timeout 300 rocprofv3 --pmc SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_INSTS_LDS GRBM_GUI_ACTIVE -d /tmp/lds1 -o pmc -- python $R/tools/probes/pmc_probe.py 256 > $O/lds_probe.log 2>&1 )
+      db=$(find /tmp/lds1 -name "*.db" | head -1); python tools/probes/lds_counters.py $db SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_INSTS_LDS > $O/lds_counters_fp16.txt 2>&1; cat $O/lds_counters_fp16.txt | cut -c1-140 ;;
     *) echo "unknown recipe $recipe" ;;
   esac
 done
