@@ -125,7 +125,7 @@ PY
       rm -rf /tmp/lds1; ( cd /tmp && timeout 300 rocprofv3 --pmc SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_INSTS_LDS GRBM_GUI_ACTIVE -d /tmp/lds1 -o pmc -- python $R/tools/probes/pmc_probe.py 256 > $O/lds_probe.log 2>&1 )
       db=$(find /tmp/lds1 -name "*.db" | head -1); python tools/probes/lds_counters.py $db SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_INSTS_LDS > $O/lds_counters_fp16.txt 2>&1; cat $O/lds_counters_fp16.txt | cut -c1-140 ;;
     lanes)          # launches in flight: 2 / 3 / 4 lanes (default 3)
-      for rep in 1 2; do for l in 3 2 4; do
+      for rep in 1 2 3; do for l in ${LANES_SET:-3 2 4}; do
         timeout 200 python bench.py --lanes $l --no-cpu-baseline --no-extra-configs --no-pmc --no-pipeline-trace --host-seconds 0 --regions 2 > $O/bench_lanes${l}_$rep.json 2> $O/bench_lanes${l}_$rep.err
         python -c "import json;j=json.loads(open('$O/bench_lanes${l}_$rep.json').read().strip().splitlines()[-1]);print('lanes $l rep $rep:', round(j['images_per_sec']), 'img/s')" 2>&1 | tail -1
       done; done ;;
