@@ -122,7 +122,9 @@ int rf_get_net_size(rf_handle h, int *net_h, int *net_w, int *max_batch);
  * (options.oversize_resize: area average as in the NPP build, or bilinear as in the build without NPP).  Unlike the reference (which returns void and drops faceInfo, RetinaFace.cpp:726-747)
  * results are returned: out[i*cap_per_image + k], k < min(counts[i], cap_per_image), score-descending,
  * coordinates in network-input pixels (as in the reference).  A NULL/0x0 frame yields count 0
- * (img.empty() early return, RetinaFace.cpp:578-580). */
+ * (img.empty() early return, RetinaFace.cpp:578-580).  n may exceed max_batch (the reference overruns its buffers there,
+ * trtretinafacenet.cpp:21): the call is cut into chunks of max_batch images, and the chunks join launch sequences of up to
+ * max_batch x options.coalesce images instead of being launched one by one. */
 int rf_detect_batch(rf_handle h, const uint8_t *const *bgr, const int *rows, const int *cols,
                     const int *steps, int n, float threshold,
                     rf_face *out, int cap_per_image, int *counts);
