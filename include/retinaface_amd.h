@@ -232,6 +232,22 @@ int rf_convert_model(const char *prototxt, const char *caffemodel, const char *i
 int rf_plan_folded(const char *model_dir, const char *stem, const char *op, float *w, size_t cap_w,
                    float *b, size_t cap_b, int dims[4]);
 
+/* Host-only hook of the int8 calibration tool (tools/calibrate_int8.py --gptq; SURVEY 8f rank 3, reference INT8-Calibration-Tool/
+ * calibrationtable.cpp:399-583 + TensorRT's own weight handling): one fused dense convolution of the int8 plan compiled from
+ * <model_dir>/<stem> and the calibration table at `int8_table` (NULL: the one the model carries), BEFORE rounding: quanta[cout][ktot] = w * in_scale / row_scale (K order (ky, kx, c)),
+ * in_scale[cin] (per input channel, as the engine applies it: a depthwise mid already carries the 127/255 of its 0..255 quanta),
+ * row_scale[cout] (the weight grid), out_scale[cout] (1 for the heads).  dims = {cout, ktot, cin, input_is_u8_mid}.  op = the fused
+ * op's name (reference layer names, '+'-joined when siblings are merged); op = "?<i>" enumerates: the i-th name comes back in `quanta`
+ * (bytes) with its length in dims[0], RF_ERR_INVALID_ARG past the end.  NULL buffers are skipped. */
+int rf_plan_int8_gemm(const char *model_dir, const char *stem, const char *int8_table, const char *op, float *quanta, size_t cap_q,
+                      float *in_scale, size_t cap_in, float *row_scale, float *out_scale, size_t cap_out, int dims[4]);
+
+/* Offline: <model_dir>/<stem> (an .rfw or prototxt + caffemodel) re-packed into out_rfw with a new calibration: int8_table (text,
+ * the reference's format; NULL keeps the model's) and qweights ("<stem>.qweights.int8", the calibrated int8 weights tools/
+ * calibrate_int8.py --gptq writes; NULL keeps the model's unless the table changed, which drops them).  The result is checked by
+ * compiling and packing the int8 plan on the host; no GPU needed. */
+int rf_attach_calibration(const char *model_dir, const char *stem, const char *int8_table, const char *qweights, const char *out_rfw);
+
 /* Host-only test hook: the host half of rf_create (plan cache or model -> packed weight image) for <model_dir>/<stem> at a
  * precision, with the cache file at cache_path (NULL = the default place).  Returns 1 when the image came from the cache, 0 when it was
  * built from the model (and the cache written), or a negative rf_status. */

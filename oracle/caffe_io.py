@@ -224,6 +224,9 @@ class NetSpec:
     input_shape: Tuple[int, int, int, int]   # N, C, H, W as written in the prototxt
     layers: List[LayerSpec]
     int8_scales: Dict[str, float] = field(default_factory=dict)
+    # calibrated int8 weights per fused dense conv: fused-op name ('+'-joined reference layer names) -> (q int8 [cout, ktot] in the
+    # K order (ky, kx, c), bias_delta float32 [cout]); written by tools/calibrate_int8.py --gptq, empty = round to nearest
+    int8_qweights: Dict[str, Tuple[np.ndarray, np.ndarray]] = field(default_factory=dict)
 
     def layer(self, name: str) -> LayerSpec:
         for l in self.layers:
@@ -310,6 +313,48 @@ def read_int8_table(path: str) -> Dict[str, float]:
     return scales
 
 
+def _pack_qweights(qw: Dict[str, Tuple[np.ndarray, np.ndarray]]) -> bytes:
+    """u32 n, then per op: str name, u32 cout, u32 ktot, i8 q[cout * ktot], f32 bias_delta[cout]"""
+    out = bytearray(struct.pack("<I", len(qw)))
+    for name, (q, db) in qw.items():
+        q = np.ascontiguousarray(q, np.int8)
+        assert q.ndim == 2 and db.shape == (q.shape[0],) and q.min() >= -127
+        _wstr(out, name)
+        out += struct.pack("<II", q.shape[0], q.shape[1])
+        out += q.tobytes() + np.ascontiguousarray(db, "<f4").tobytes()
+    return bytes(out)
+
+
+def _unpack_qweights(r: "_Reader") -> Dict[str, Tuple[np.ndarray, np.ndarray]]:
+    qw: Dict[str, Tuple[np.ndarray, np.ndarray]] = {}
+    for _ in range(r.u32()):
+        name = r.str()
+        cout, ktot = r.u32(), r.u32()
+        q = np.frombuffer(r.buf, dtype=np.int8, count=cout * ktot, offset=r.pos).reshape(cout, ktot).copy()
+        r.pos += cout * ktot
+        qw[name] = (q, np.array(r.floats(cout), dtype=np.float32))
+    return qw
+
+
+def read_int8_qweights(path: str) -> Dict[str, Tuple[np.ndarray, np.ndarray]]:
+    """<stem>.qweights.int8 (RFQ1): the calibrated int8 weights that travel next to the activation table"""
+    with open(path, "rb") as f:
+        buf = f.read()
+    if buf[:4] != b"RFQ1":
+        raise ValueError(f"{path}: not an RFQ1 file")
+    r = _Reader(buf)
+    r.pos = 4
+    qw = _unpack_qweights(r)
+    if r.pos != len(buf):
+        raise ValueError(f"{path}: trailing bytes")
+    return qw
+
+
+def write_int8_qweights(qw: Dict[str, Tuple[np.ndarray, np.ndarray]], path: str) -> None:
+    with open(path, "wb") as f:
+        f.write(b"RFQ1" + _pack_qweights(qw))
+
+
 def load_caffe_model(prototxt: str, caffemodel: str, int8_table: Optional[str] = None) -> NetSpec:
     net = read_prototxt(prototxt)
     blobs = read_caffemodel(caffemodel)
@@ -336,6 +381,7 @@ def load_caffe_model(prototxt: str, caffemodel: str, int8_table: Optional[str] =
 #       u32 n_blobs, per blob: u32 layout (0 = as-is, 1 = conv weight stored O,H,W,I),
 #                              u32 ndim, u32 dims[ndim] (logical Caffe dims), f32 data[]
 #   u32 n_scales, per scale: str tensor_name, f32 scale
+#   [optional, round 6] u32 n_q, per fused dense conv: str op_name, u32 cout, u32 ktot, i8 q[cout*ktot], f32 bias_delta[cout]
 #   str = u32 length + bytes
 # --------------------------------------------------------------------------------------
 
@@ -383,6 +429,8 @@ def write_rfw(net: NetSpec, path: str) -> None:
     for k, v in net.int8_scales.items():
         _wstr(out, k)
         out += struct.pack("<f", v)
+    if net.int8_qweights:
+        out += _pack_qweights(net.int8_qweights)
     with open(path, "wb") as f:
         f.write(bytes(out))
 
@@ -463,5 +511,6 @@ def read_rfw(path: str) -> NetSpec:
     for _ in range(r.u32()):
         k = r.str()
         scales[k] = r.f32()
+    qw = _unpack_qweights(r) if r.pos < len(buf) else {}
     return NetSpec(name=name, input_name=input_name, input_shape=shape, layers=layers,
-                   int8_scales=scales)
+                   int8_scales=scales, int8_qweights=qw)

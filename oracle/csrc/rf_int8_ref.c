@@ -10,6 +10,8 @@
  *     y    = fmaf((float)acc, mult[c], bias[c])            ONE rounding (libm fmaf is correctly rounded)
  *     q    = (int8) rint(clamp(y, 0, 127))                 ReLU'd outputs; round half to even
  *          = (int8) clamp(rint(y), -127, 127)              outputs without ReLU
+ *          = (int8) (rint(clamp(y, 0, 255)) - 128)         depthwise outputs ("mids", round 6): ReLU'd quanta 0..255 of amax / 255, stored
+ *                                                          minus 128; the pointwise bias carries mult * 128 * sum_k w_q (fmaf, rfi8_bias_u8)
  *
  * Built by oracle/build.py with -ffp-contract=off: the only fused operation is the explicit fmaf().
  */
@@ -23,10 +25,16 @@ void rfi8_requant(const int32_t *acc, const float *mult, const float *bias, long
         for (int ch = 0; ch < c; ch++) {
             const float y = fmaf((float)acc[p * c + ch], mult[ch], bias[ch]);
             float r;
-            if (relu) r = rintf(fminf(fmaxf(y, 0.f), 127.f));
+            if (relu == 2) r = rintf(fminf(fmaxf(y, 0.f), 255.f)) - 128.f;
+            else if (relu) r = rintf(fminf(fmaxf(y, 0.f), 127.f));
             else r = fminf(fmaxf(rintf(y), -127.f), 127.f);
             q[p * c + ch] = (int8_t)(int)r;
         }
+}
+
+/* bias of a 1x1 conv whose input is a mid stored as q - 128: bias[c] = fmaf(mult[c], (float)(128 * qsum[c]), bias[c]) */
+void rfi8_bias_u8(const float *mult, const long *qsum, int c, float *bias) {
+    for (int ch = 0; ch < c; ch++) bias[ch] = fmaf(mult[ch], (float)(128 * qsum[ch]), bias[ch]);
 }
 
 /* heads: real-valued outputs (no requantisation), y = fmaf(acc, mult, bias) */

@@ -17,6 +17,12 @@ code and of the C++ weight packer:
   depthwise  wf = w * s_in[c] / s_mid[c] (fp32), s_t[c] = max_t |wf| / 16256, taps = clamp(rne(wf / s_t), -16256, 16256)
            (15-bit integer taps), mult = s_t, bias = b / s_mid
   epilogue q = rne(clamp(fmaf(acc, mult, bias), 0, 127))     (oracle/csrc/rf_int8_ref.c)
+  mids     (round 6) a depthwise output is read by a 1x1 conv only (no zero padding), so it uses all 8 bits: s_mid = table scale *
+           fp32(127/255), q = rne(clamp(y, 0, 255)) - 128; the pointwise conv sums w_q * (q - 128) and its bias becomes
+           fmaf(mult, 128 * sum_k w_q, bias) -- exact integer algebra, one more bit on the tensors that carried most of the
+           activation noise of the box deltas
+  calibrated weights  (round 6) when the model carries `int8_qweights` for a fused op, w_q is taken from there (error-compensated
+           rounding chosen by tools/calibrate_int8.py --gptq on the SAME grid s_w) and bias = (b + bias_delta) / s_out
   add      lateral + bilinear x2 upsample of the coarser level, requantised to the `_plus` scale (rfi8_upadd)
 
 Every accumulation is an exact integer, every float step is a single IEEE operation in a fixed order, so the HIP engine must
@@ -46,6 +52,7 @@ _lib = None
 
 F32 = np.float32
 DW_RANGE = 127 * 128          # 15-bit depthwise taps
+MID_U8 = np.float32(127.0 / 255.0)   # a depthwise output's quantum relative to its table scale (0..255 quanta, see the header)
 
 
 def build(force: bool = False) -> str:
@@ -64,7 +71,8 @@ def lib() -> C.CDLL:
         _lib.rfi8_dequant.argtypes = [vp, vp, vp, l, i, vp]
         _lib.rfi8_conv.argtypes = [vp, i, i, i, vp, i, i, i, i, i, vp]
         _lib.rfi8_upadd.argtypes = [vp, vp, i, i, i, f, f, i, vp]
-        for fn in (_lib.rfi8_requant, _lib.rfi8_dequant, _lib.rfi8_conv, _lib.rfi8_upadd):
+        _lib.rfi8_bias_u8.argtypes = [vp, vp, i, vp]
+        for fn in (_lib.rfi8_requant, _lib.rfi8_dequant, _lib.rfi8_conv, _lib.rfi8_upadd, _lib.rfi8_bias_u8):
             fn.restype = None
     return _lib
 
@@ -110,16 +118,29 @@ def _bn_of(net: NetSpec, conv: str) -> Optional[str]:
 class QGemm:
     """one quantised dense conv (1x1 or 3x3): int weights [cout][k][k][cin] + fp32 epilogue constants"""
 
-    def __init__(self, w: np.ndarray, b: np.ndarray, s_in: np.ndarray, s_out: Optional[np.ndarray], relu: bool = True):
+    def __init__(self, w: np.ndarray, b: np.ndarray, s_in: np.ndarray, s_out: Optional[np.ndarray], relu: bool = True,
+                 in_u8: bool = False, calibrated: Optional[Tuple[np.ndarray, np.ndarray]] = None):
         cout, k, _, cin = w.shape
-        ws_in = (w * s_in.astype(F32).reshape(1, 1, 1, cin)).astype(F32)
+        s_in = (s_in.astype(F32) * MID_U8).astype(F32) if in_u8 else s_in.astype(F32)
+        ws_in = (w * s_in.reshape(1, 1, 1, cin)).astype(F32)
         amax = np.abs(ws_in).reshape(cout, -1).max(axis=1).astype(F32)
         s_w = np.where(amax > 0, amax / F32(127), F32(1)).astype(F32)
         q = np.rint((ws_in / s_w.reshape(cout, 1, 1, 1)).astype(F32))          # np.rint = round half to even = nearbyintf
         self.wq = np.clip(q, -127, 127).astype(np.int32)
         os_ = np.ones(cout, F32) if s_out is None else s_out.astype(F32)
         self.mult = (s_w / os_).astype(F32)
-        self.bias = (b.astype(F32) / os_).astype(F32)
+        b = b.astype(F32)
+        if calibrated is not None:                       # integers + bias correction chosen by the calibration run, same grid
+            cq, db = calibrated
+            assert cq.shape == (cout, k * k * cin) and db.shape == (cout,)
+            self.wq = cq.astype(np.int32).reshape(cout, k, k, cin)
+            b = (b + db.astype(F32)).astype(F32)
+        self.bias = (b / os_).astype(F32)
+        if in_u8:
+            qsum = np.ascontiguousarray(self.wq.reshape(cout, -1).sum(axis=1).astype(np.int64))
+            bias = np.ascontiguousarray(self.bias)
+            lib().rfi8_bias_u8(_p(np.ascontiguousarray(self.mult)), _p(qsum), cout, _p(bias))
+            self.bias = bias
         self.k, self.relu, self.cout, self.cin = k, relu, cout, cin
 
 
@@ -129,7 +150,8 @@ class QDw:
     def __init__(self, w: np.ndarray, b: np.ndarray, s_in: np.ndarray, s_mid: np.ndarray, stride: int):
         c = w.shape[0]
         w9 = w.reshape(c, 9).astype(F32)
-        wf = ((w9 * s_in.astype(F32).reshape(c, 1)).astype(F32) / s_mid.astype(F32).reshape(c, 1)).astype(F32)
+        s_mid = (s_mid.astype(F32) * MID_U8).astype(F32)                          # 0..255 quanta of amax / 255
+        wf = ((w9 * s_in.astype(F32).reshape(c, 1)).astype(F32) / s_mid.reshape(c, 1)).astype(F32)
         amax = np.abs(wf).max(axis=1).astype(F32)
         s_t = np.where(amax > 0, amax / F32(DW_RANGE), F32(1)).astype(F32)
         wi = np.rint((wf / s_t.reshape(c, 1)).astype(F32))
@@ -152,6 +174,7 @@ class Int8Net:
         self.table = net.int8_scales
         self.per_channel = "_plus0#0" in self.table
         S = self.scales
+        cal = lambda *names: net.int8_qweights.get("+".join(names))               # noqa: E731  (fused-op name as in plan.h)
         # ---- backbone
         self.dw: List[QDw] = []
         self.pw: List[QGemm] = []
@@ -173,7 +196,7 @@ class Int8Net:
             wd, bd = fold(net, dn, _bn_of(net, dn))
             wp, bp = fold(net, pn, _bn_of(net, pn))
             self.dw.append(QDw(wd, bd, s_prev, s_mid, self.BLOCK_STRIDE[i]))
-            self.pw.append(QGemm(wp, bp, s_mid, s_out))
+            self.pw.append(QGemm(wp, bp, s_mid, s_out, in_u8=True, calibrated=cal(pn)))
             s_prev, c = s_out, cout
             self.s_block[i] = s_out
         # ---- FPN
@@ -188,14 +211,14 @@ class Int8Net:
             s_lat[0] = s_lat[1] = s_plus[0] = m0
             m1 = np.maximum(s_aggr[0], np.maximum(s_lat[2], s_plus[1]))
             s_aggr[0] = s_lat[2] = s_plus[1] = m1
-        self.lat = [QGemm(*fold(net, n, _bn_of(net, n)), s_tap[i], s_lat[i]) for i, n in enumerate(lat_names)]
+        self.lat = [QGemm(*fold(net, n, _bn_of(net, n)), s_tap[i], s_lat[i], calibrated=cal(n)) for i, n in enumerate(lat_names)]
         self.lat_blobs = [n + "_relu" for n in lat_names]
         s_feat = [s_lat[0], s_aggr[0], s_aggr[1]]
         self.aggr, self.a_lat, self.a_up = [], [], []
         for i, n in enumerate(("rf_c2_aggr", "rf_c1_aggr")):
             self.a_lat.append(F32(1) if self.per_channel else F32(s_lat[i + 1][0]) / F32(s_plus[i][0]))
             self.a_up.append(F32(1) if self.per_channel else F32(s_feat[i][0]) / F32(s_plus[i][0]))
-            self.aggr.append(QGemm(*fold(net, n, _bn_of(net, n)), s_plus[i], s_aggr[i]))
+            self.aggr.append(QGemm(*fold(net, n, _bn_of(net, n)), s_plus[i], s_aggr[i], calibrated=cal(n)))
         self.aggr_blobs = ["rf_c2_aggr_relu", "rf_c1_aggr_relu"]
         self.scale_of_blob: Dict[str, np.ndarray] = {b: s for b, s in zip(self.lat_blobs, s_lat)}
         self.scale_of_blob.update({b: s for b, s in zip(self.aggr_blobs, s_aggr)})
@@ -218,10 +241,12 @@ class Int8Net:
             wc, bc = fold(net, pre + "context_conv3_2", _bn_of(net, pre + "context_conv3_2"))
             wh, bh = merged([f"face_rpn_cls_score_{st}", f"face_rpn_bbox_pred_{st}", f"face_rpn_landmark_pred_{st}"])
             self.ssh.append(dict(
-                a=QGemm(wa, ba, s_feat[i], np.concatenate([s_cat[:32], s_c1])),
-                b=QGemm(wb, bb, s_c1, np.concatenate([s_cat[32:48], s_c31])),
-                c=QGemm(wc, bc, s_c31, s_cat[48:64]),
-                head=QGemm(wh, bh, s_cat, None, relu=False), pre=pre, stride=(32, 16, 8)[i]))
+                a=QGemm(wa, ba, s_feat[i], np.concatenate([s_cat[:32], s_c1]), calibrated=cal(pre + "conv1", pre + "context_conv1")),
+                b=QGemm(wb, bb, s_c1, np.concatenate([s_cat[32:48], s_c31]), calibrated=cal(pre + "context_conv2", pre + "context_conv3_1")),
+                c=QGemm(wc, bc, s_c31, s_cat[48:64], calibrated=cal(pre + "context_conv3_2")),
+                head=QGemm(wh, bh, s_cat, None, relu=False,
+                           calibrated=cal(f"face_rpn_cls_score_{st}", f"face_rpn_bbox_pred_{st}", f"face_rpn_landmark_pred_{st}")),
+                pre=pre, stride=(32, 16, 8)[i]))
             self.scale_of_blob[pre + "concat_relu"] = s_cat
             self.scale_of_blob[pre + "context_conv1_relu"] = s_c1
             self.scale_of_blob[pre + "context_conv3_1_relu"] = s_c31
@@ -267,14 +292,14 @@ class Int8Net:
         acc = np.ascontiguousarray(acc, np.int32)
         out = np.empty((h, w, c), np.int8)
         m, b = np.ascontiguousarray(mult, F32), np.ascontiguousarray(bias, F32)
-        lib().rfi8_requant(_p(acc), _p(m), _p(b), h * w, c, 1 if relu else 0, _p(out))
+        lib().rfi8_requant(_p(acc), _p(m), _p(b), h * w, c, int(relu), _p(out))
         return out
 
     def gemm(self, x: np.ndarray, g: QGemm) -> np.ndarray:
         return self._requant(self._conv(x, g.wq, 1, g.k // 2, 1), g.mult, g.bias, g.relu)
 
     def depthwise(self, x: np.ndarray, d: QDw) -> np.ndarray:
-        return self._requant(self._conv(x, d.wq, d.stride, 1, d.c), d.mult, d.bias, True)
+        return self._requant(self._conv(x, d.wq, d.stride, 1, d.c), d.mult, d.bias, 2)         # 2: 0..255 quanta stored - 128
 
     def upadd(self, lat: np.ndarray, up: np.ndarray, i: int) -> np.ndarray:
         h, w, c = lat.shape

@@ -72,6 +72,9 @@ SYMBOLS = {
     "rf_plan_cache_probe": (C.c_int, [C.c_char_p, C.c_char_p, C.c_int, C.c_char_p, _PP(C.c_size_t)]),
     "rf_plan_folded": (C.c_int, [C.c_char_p, C.c_char_p, C.c_char_p, _PP(C.c_float), C.c_size_t, _PP(C.c_float),
                                  C.c_size_t, _PP(C.c_int)]),
+    "rf_plan_int8_gemm": (C.c_int, [C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, _PP(C.c_float), C.c_size_t, _PP(C.c_float), C.c_size_t,
+                                    _PP(C.c_float), _PP(C.c_float), C.c_size_t, _PP(C.c_int)]),
+    "rf_attach_calibration": (C.c_int, [C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p]),
 }
 
 ABI_VERSION = 2      # include/retinaface_amd.h RF_ABI_VERSION

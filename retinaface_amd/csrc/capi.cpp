@@ -352,4 +352,59 @@ int rf_plan_folded(const char *model_dir, const char *stem, const char *op, floa
     });
 }
 
+int rf_attach_calibration(const char *model_dir, const char *stem, const char *int8_table, const char *qweights, const char *out_rfw) {
+    return guarded(nullptr, [&]() -> int {
+        if (!model_dir || !out_rfw) throw rf::ArgError("null argument");
+        rf::Model m = rf::load_model_dir(model_dir, stem && *stem ? stem : "mnet-deconv-0517");
+        if (int8_table && *int8_table) {
+            rf::attach_int8_table(m, int8_table);
+            m.int8_qweights.clear();                   // calibrated weights belong to the table they were chosen under
+        }
+        if (qweights && *qweights) rf::attach_int8_qweights(m, qweights);
+        rf::Plan p = rf::compile_plan(m);              // refuses a model the engine could not run
+        if (!m.int8_scales.empty()) {
+            rf::WeightPack<int8_t> wp;
+            wp.pack(p);                                // ... and a table / weight file that does not fit it (missing tensors, wrong shapes)
+        }
+        rf::save_rfw(m, out_rfw);
+        return RF_OK;
+    });
+}
+
+int rf_plan_int8_gemm(const char *model_dir, const char *stem, const char *int8_table, const char *op, float *quanta, size_t cap_q,
+                      float *in_scale, size_t cap_in, float *row_scale, float *out_scale, size_t cap_out, int dims[4]) {
+    return guarded(nullptr, [&]() -> int {
+        if (!model_dir || !op) throw rf::ArgError("null argument");
+        rf::Model m = rf::load_model_dir(model_dir, stem && *stem ? stem : "mnet-deconv-0517");
+        if (int8_table && *int8_table) rf::attach_int8_table(m, int8_table);
+        m.int8_qweights.clear();                       // the grid and the unrounded quanta do not depend on an earlier calibration
+        rf::Plan p = rf::compile_plan(m);
+        rf::WeightPack<int8_t> wp;
+        std::map<std::string, rf::WeightPack<int8_t>::GemmRecord> rec;
+        wp.record_ = &rec;
+        wp.pack(p);                                    // host only: nothing is uploaded
+        auto it = rec.find(op);
+        if (it == rec.end()) {
+            // "?<i>": enumerate -- the i-th fused dense conv's name is returned through `dims` as its length and (when quanta != NULL) its bytes
+            if (op[0] == '?') {
+                size_t i = (size_t)std::atoi(op + 1);
+                if (i >= rec.size()) return RF_ERR_INVALID_ARG;
+                auto jt = rec.begin();
+                std::advance(jt, (long)i);
+                if (dims) dims[0] = (int)jt->first.size();
+                if (quanta) { if (cap_q * 4 < jt->first.size()) throw rf::ArgError("name buffer too small"); memcpy(quanta, jt->first.data(), jt->first.size()); }
+                return RF_OK;
+            }
+            throw rf::ArgError("the int8 plan has no fused dense conv '" + std::string(op) + "'");
+        }
+        const auto &r = it->second;
+        if (dims) { dims[0] = r.cout; dims[1] = r.ktot; dims[2] = r.cin; dims[3] = r.in_u8; }
+        if (quanta) { if (cap_q < r.quanta.size()) throw rf::ArgError("quanta too small"); memcpy(quanta, r.quanta.data(), r.quanta.size() * 4); }
+        if (in_scale) { if (cap_in < r.in_scale.size()) throw rf::ArgError("in_scale too small"); memcpy(in_scale, r.in_scale.data(), r.in_scale.size() * 4); }
+        if (row_scale) { if (cap_out < r.row_scale.size()) throw rf::ArgError("row_scale too small"); memcpy(row_scale, r.row_scale.data(), r.row_scale.size() * 4); }
+        if (out_scale) { if (cap_out < r.out_scale.size()) throw rf::ArgError("out_scale too small"); memcpy(out_scale, r.out_scale.data(), r.out_scale.size() * 4); }
+        return RF_OK;
+    });
+}
+
 }  // extern "C"

@@ -518,6 +518,17 @@ __device__ __forceinline__ void store_acc(T *s_out, f32x4 mult, f32x4 bv, ACC ac
     }
 }
 
+// int8 engine, depthwise output ("mid", never leaves LDS, read by the pointwise 1 x 1 only): ReLU'd quanta 0..255 of amax / 255, stored as
+// q - 128 for the signed i8 MFMA (the pointwise bias carries 128 * sum(w_q): weights.h kMidU8).  v_cvt_pk_u8_f32 = clamp(rint(x), 0, 255)
+// is the whole requantisation -- no v_med3 -- and ONE xor per four values moves them to two's complement.
+template <int LDO, typename ACC>
+__device__ __forceinline__ void store_mid_u8(int8_t *s_out, f32x4 mult, f32x4 bv, ACC acc, int ct, int pt, int lane) {
+    uint32_t packed = 0;
+#pragma unroll
+    for (int r = 0; r < 4; r++) packed = __builtin_amdgcn_cvt_pk_u8_f32(fmaf((float)acc[r], mult[r], bv[r]), r, packed);
+    *(uint32_t *)(s_out + acc_pixel(pt, lane) * LDO + acc_cout(ct, lane, 0)) = packed ^ 0x80808080u;
+}
+
 __device__ __forceinline__ f32x4 load_mult(const float *m, int c0) {
     const f32x4 ones = {1.f, 1.f, 1.f, 1.f};
     return m ? *(const f32x4 *)(m + c0) : ones;
@@ -1563,7 +1574,7 @@ __global__ __launch_bounds__(kThreads, (DwPwCfg<T, CIN, COUT, STRIDE, HAS_DW, TH
                         typename M::Acc tot;
 #pragma unroll
                         for (int r = 0; r < 4; r++) tot[r] = dacc[0][pi][r] * 128 + dacc[DPARTS - 1][pi][r];      // taps = 128*hi + lo
-                        store_acc<T, LDA>(s_a, dwm4[gi], dwb4[gi], tot, g, pt, lane, true);
+                        store_mid_u8<LDA>(s_a, dwm4[gi], dwb4[gi], tot, g, pt, lane);
                     } else {
                         store_acc<T, LDA>(s_a, dwm4[gi], dwb4[gi], dacc[0][pi], g, pt, lane, true);
                     }
@@ -1593,7 +1604,10 @@ __global__ __launch_bounds__(kThreads, (DwPwCfg<T, CIN, COUT, STRIDE, HAS_DW, TH
                 }
                 V r;
 #pragma unroll
-                for (int e = 0; e < VEC; e++) r[e] = to_T<T>(fmaxf(acc[e], 0.f));
+                for (int e = 0; e < VEC; e++) {
+                    if constexpr (sizeof(T) == 1) r[e] = (int8_t)((int)fminf(fmaxf(rintf(acc[e]), 0.f), 255.f) - 128);      // mid on 0..255 quanta, stored - 128 (store_mid_u8)
+                    else r[e] = to_T<T>(fmaxf(acc[e], 0.f));
+                }
                 *(V *)(s_a + p * LDA + cv * VEC) = r;
             }
             RF_TRACE(2, 3);
@@ -1858,7 +1872,7 @@ __global__ __launch_bounds__(kWideThreads, OCC) void dwpw_wide_kernel(DwPwArgs<T
                     typename M::Acc tot;
 #pragma unroll
                     for (int r = 0; r < 4; r++) tot[r] = dacc[0][pi][r] * 128 + dacc[DPARTS - 1][pi][r];      // taps = 128 * hi + lo
-                    store_acc<T, LDA>(s_a, dwm4[gi], dwb4[gi], tot, g, pi, lane, true);
+                    store_mid_u8<LDA>(s_a, dwm4[gi], dwb4[gi], tot, g, pi, lane);
                 } else {
                     store_acc<T, LDA>(s_a, dwm4[gi], dwb4[gi], dacc[0][pi], g, pi, lane, true);
                 }
@@ -2203,7 +2217,7 @@ void dwpw_ws_kernel(DwPwArgs<T> a) {
                     typename M::Acc tot;
 #pragma unroll
                     for (int r = 0; r < 4; r++) tot[r] = dacc[0][pi][r] * 128 + dacc[DPARTS - 1][pi][r];
-                    store_acc<T, LDA>(s_a, dwm4[gi], dwb4[gi], tot, g, pt, lane, true);
+                    store_mid_u8<LDA>(s_a, dwm4[gi], dwb4[gi], tot, g, pt, lane);
                 } else {
                     store_acc<T, LDA>(s_a, dwm4[gi], dwb4[gi], dacc[0][pi], g, pt, lane, true);
                 }

@@ -363,6 +363,42 @@ bool is_ohwi(const Layer &l, size_t bi, const Blob &blob) {
     return (l.type == "Convolution" || l.type == "Deconvolution") && bi == 0 && blob.dims.size() == 4;
 }
 
+
+// u32 n, then per op: str name, u32 cout, u32 ktot, i8 q[cout * ktot], f32 bias_delta[cout]
+void write_qweights(Out &o, const Model &m) {
+    o.u32((uint32_t)m.int8_qweights.size());
+    for (const auto &qw : m.int8_qweights) {
+        o.str(qw.op);
+        o.u32((uint32_t)qw.cout);
+        o.u32((uint32_t)qw.ktot);
+        o.b.append((const char *)qw.q.data(), qw.q.size());
+        o.b.append((const char *)qw.bias_delta.data(), qw.bias_delta.size() * 4);
+    }
+}
+void read_qweights(In &in, Model &m) {
+    const uint32_t n = in.count(12);
+    m.int8_qweights.clear();
+    for (uint32_t i = 0; i < n; i++) {
+        QWeights qw;
+        qw.op = in.str();
+        const uint32_t cout = in.u32(), ktot = in.u32();
+        if (cout == 0 || ktot == 0 || cout > 4096 || ktot > (1u << 20)) throw ModelError("qweights: bad dims for '" + qw.op + "'");
+        qw.cout = (int)cout;
+        qw.ktot = (int)ktot;
+        const size_t nq = (size_t)cout * ktot;
+        in.need(nq + (size_t)cout * 4);
+        qw.q.resize(nq);
+        memcpy(qw.q.data(), in.b.data() + in.p, nq);
+        in.p += nq;
+        qw.bias_delta.resize(cout);
+        memcpy(qw.bias_delta.data(), in.b.data() + in.p, (size_t)cout * 4);
+        in.p += (size_t)cout * 4;
+        for (int8_t v : qw.q)
+            if (v == -128) throw ModelError("qweights: weight outside [-127, 127] in '" + qw.op + "'");
+        m.int8_qweights.push_back(std::move(qw));
+    }
+}
+
 }  // namespace
 
 void save_rfw(const Model &m, const std::string &path) {
@@ -413,6 +449,7 @@ void save_rfw(const Model &m, const std::string &path) {
     }
     o.u32((uint32_t)m.int8_scales.size());
     for (const auto &kv : m.int8_scales) { o.str(kv.first); o.f32(kv.second); }
+    if (!m.int8_qweights.empty()) write_qweights(o, m);        // optional trailing section (files without it end here)
     std::ofstream f(path, std::ios::binary);
     if (!f) throw IoError("cannot write '" + path + "'");
     f.write(o.b.data(), (std::streamsize)o.b.size());
@@ -486,7 +523,27 @@ Model load_rfw(const std::string &path) {
         float v = in.f32();
         m.int8_scales.emplace_back(k, v);
     }
+    if (in.p < buf.size()) read_qweights(in, m);              // optional trailing section: calibrated int8 weights
     return m;
+}
+
+void attach_int8_qweights(Model &m, const std::string &path) {
+    std::string buf = slurp(path, true);
+    if (buf.size() < 8 || buf.compare(0, 4, "RFQ1") != 0) throw ModelError("'" + path + "' is not an RFQ1 file");
+    In in(buf);
+    in.p = 4;
+    read_qweights(in, m);
+    if (in.p != buf.size()) throw ModelError("qweights: trailing bytes in '" + path + "'");
+}
+
+void save_int8_qweights(const Model &m, const std::string &path) {
+    Out o;
+    o.b.append("RFQ1");
+    write_qweights(o, m);
+    std::ofstream f(path, std::ios::binary);
+    if (!f) throw IoError("cannot write '" + path + "'");
+    f.write(o.b.data(), (std::streamsize)o.b.size());
+    if (!f) throw IoError("short write to '" + path + "'");
 }
 
 bool file_exists(const std::string &p) {
@@ -507,6 +564,7 @@ Model load_model_dir(const std::string &dir, const std::string &stem) {
     if (file_exists(base + ".table.int8")) attach_int8_table(m, base + ".table.int8");
     else if (file_exists(dir + "/mnet-deconv-0517.table.int8"))
         attach_int8_table(m, dir + "/mnet-deconv-0517.table.int8");
+    if (file_exists(base + ".qweights.int8")) attach_int8_qweights(m, base + ".qweights.int8");
     return m;
 }
 
@@ -531,6 +589,7 @@ uint64_t model_source_hash(const std::string &dir, const std::string &stem) {
     fnv1a(h, slurp(base + ".caffemodel", true));
     if (file_exists(base + ".table.int8")) fnv1a(h, slurp(base + ".table.int8", true));
     else if (file_exists(dir + "/mnet-deconv-0517.table.int8")) fnv1a(h, slurp(dir + "/mnet-deconv-0517.table.int8", true));
+    if (file_exists(base + ".qweights.int8")) fnv1a(h, slurp(base + ".qweights.int8", true));
     return h;
 }
 

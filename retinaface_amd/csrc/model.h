@@ -32,11 +32,24 @@ struct Layer {
     std::vector<Blob> blobs;
 };
 
+// Calibrated int8 weights of one fused dense convolution (round 6): what tools/calibrate_int8.py --gptq writes next to the activation
+// table.  The reference's calibration cache holds activation scales only and TensorRT rounds the weights itself (closed source); this
+// engine's default is round-to-nearest on the per-output-channel grid (weights.h put_gemm), and a calibration run may replace the
+// rounding DIRECTION of each weight by an error-compensated one chosen on the calibration activations (the grid, i.e. the row scales,
+// stays what put_gemm derives from the model + table), plus a bias correction for the residual mean error.
+struct QWeights {
+    std::string op;                    // fused-op name (plan.h FoldedConv::name: reference layer names, '+'-joined when merged)
+    int cout = 0, ktot = 0;            // ktot = k*k*cin, K order of FoldedConv::w
+    std::vector<int8_t> q;             // [cout][ktot], each in [-127, 127]
+    std::vector<float> bias_delta;     // [cout], added to the folded bias (real units)
+};
+
 struct Model {
     std::string name, input_name = "data";
     int input_shape[4] = {1, 3, 0, 0};
     std::vector<Layer> layers;
     std::vector<std::pair<std::string, float>> int8_scales;   // file order preserved
+    std::vector<QWeights> int8_qweights;                       // optional (empty: round to nearest)
 
     const Layer *find(const std::string &layer_name) const;
     const Layer &get(const std::string &layer_name) const;     // throws ModelError
@@ -50,6 +63,9 @@ struct ModelError : std::runtime_error { using std::runtime_error::runtime_error
 Model load_prototxt(const std::string &path);
 void attach_caffemodel(Model &m, const std::string &path);
 void attach_int8_table(Model &m, const std::string &path);
+// "<stem>.qweights.int8" (RFQ1: "RFQ1", u32 n, then per op: str name, u32 cout, u32 ktot, i8 q[cout*ktot], f32 bias_delta[cout])
+void attach_int8_qweights(Model &m, const std::string &path);
+void save_int8_qweights(const Model &m, const std::string &path);
 
 // RFW1 packed container (layout documented in oracle/caffe_io.py and DESIGN.md)
 Model load_rfw(const std::string &path);
@@ -57,7 +73,7 @@ void save_rfw(const Model &m, const std::string &path);
 
 // model_dir resolution used by rf_create: <dir>/<stem>.rfw, else <dir>/<stem>.prototxt + .caffemodel
 // (+ <dir>/<stem>.table.int8, falling back to <dir>/mnet-deconv-0517.table.int8 as the reference
-// hard-codes that one table: trtnetbase.cpp:13).
+// hard-codes that one table: trtnetbase.cpp:13; + <dir>/<stem>.qweights.int8 when it exists).
 Model load_model_dir(const std::string &dir, const std::string &stem);
 
 // FNV-1a 64 over the bytes of exactly the files load_model_dir would read for (dir, stem): the plan cache's validity key

@@ -243,6 +243,7 @@ Plan compile_plan(const Model &m) {
         s.conv_c.out_blob = cat_out;
     }
     p.int8_scales = m.int8_scales;
+    p.int8_qweights = m.int8_qweights;
     return p;
 }
 

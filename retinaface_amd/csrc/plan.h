@@ -44,6 +44,8 @@ struct Plan {
     // TensorRT calibration cache: tensor (blob) name -> per-tensor activation scale, real ~= q * scale (SURVEY App. B.7;
     // consumed by the int8 engine).  Empty when the model carries no table.
     std::vector<std::pair<std::string, float>> int8_scales;
+    // calibrated int8 weights per fused dense conv (model.h QWeights; empty: the int8 engine rounds to nearest)
+    std::vector<QWeights> int8_qweights;
 };
 
 Plan compile_plan(const Model &m);        // throws ModelError when the graph is not the expected topology

@@ -79,7 +79,7 @@ template <typename T> constexpr int mma_kpl() { return sizeof(T) == 1 ? 16 : siz
 
 
 // ---------------------------------------------------------------------------------------------------- byte archive
-constexpr uint32_t kPlanCacheVersion = 7;      // bump when the packing / layout of anything below changes
+constexpr uint32_t kPlanCacheVersion = 8;      // bump when the packing / layout of anything below changes
 
 struct ArOut {
     std::string b;
@@ -172,10 +172,37 @@ struct WeightPack {
     }
     const float *mult_ptr(const GemmW &g) const { return g.m == kNone ? nullptr : arena_.ptr<float>(g.m); }
 
+    // int8, round 6: a depthwise stage's output ("mid") never leaves LDS and is read by a 1 x 1 convolution only, so it needs no zero
+    // padding and can use all 8 bits: ReLU'd quanta 0..255 of HALF the calibrated quantum (amax / 255 instead of amax / 127), stored as
+    // q - 128 so the signed i8 MFMA reads it unchanged; the constant 128 * sum_k w_q[o][k] goes into the pointwise bias (exact integer
+    // algebra).  One bit more on the tensors that carried ~60 % of the activation-quantisation noise of the box deltas
+    // (tools/probes/int8_mix_sim.py), and one VALU instruction LESS per value (v_cvt_pk_u8_f32 saturates at 255 by itself).
+    static constexpr float kMidU8 = (float)(127.0 / 255.0);
+    static Sc mid_u8_scale(const Sc &s) {
+        Sc v(s);
+        for (float &x : v) x *= kMidU8;
+        return v;
+    }
+    const QWeights *qweights_for(const Plan &plan, const FoldedConv &f, int ktot) const {
+        for (const auto &qw : plan.int8_qweights)
+            if (qw.op == f.name) {
+                if (qw.cout != f.cout || qw.ktot != ktot)
+                    throw ModelError("int8: calibrated weights of '" + f.name + "' have the wrong shape");
+                return &qw;
+            }
+        return nullptr;
+    }
+    // what put_gemm decided for one fused op (host-only hook for the calibration tool: rf_plan_int8_gemm)
+    struct GemmRecord { std::vector<float> quanta, in_scale, row_scale, out_scale; int cout = 0, ktot = 0, cin = 0, in_u8 = 0; };
+    std::map<std::string, GemmRecord> *record_ = nullptr;
+    const Plan *plan_ = nullptr;            // the plan being packed (calibrated weights are looked up by fused-op name)
+
     // fp16 / fp32: weights as they are.  int8: per-output-channel symmetric weight quantisation (w_scale = amax / 127, what
     // TensorRT does with a per-tensor activation table); the epilogue computes acc * mult + bias with
     //   mult[c] = w_scale[c] * in_scale / out_scale[c],  bias[c] = b[c] / out_scale[c]     (out_scale = 1: real output)
-    GemmW put_gemm(const FoldedConv &f, const Sc &in_scale = {}, const Sc &out_scale = {}) {
+    // Rounding: to nearest, or -- when the model carries calibrated weights for this op (Plan::int8_qweights) -- the integers the
+    // calibration chose on the SAME grid, with its bias correction.  in_u8: the input tensor is a depthwise mid (see kMidU8).
+    GemmW put_gemm(const FoldedConv &f, const Sc &in_scale_table = {}, const Sc &out_scale = {}, bool in_u8 = false) {
         const int cin_g = f.cin / f.group;
         const int ktot = f.k * f.k * cin_g;
         GemmW g;
@@ -183,9 +210,11 @@ struct WeightPack {
             g.w = arena_.put(pack_gemm<T>(f.w, f.cout, ktot, mma_k<T>(), mma_kpl<T>()));
             g.b = arena_.put(f.b);
         } else {
+            const Sc in_scale = in_u8 ? mid_u8_scale(in_scale_table) : in_scale_table;
             if (!in_scale.empty() && (int)in_scale.size() != cin_g) throw ModelError("int8: input scale count does not match " + f.name);
             if (!out_scale.empty() && (int)out_scale.size() != f.cout) throw ModelError("int8: output scale count does not match " + f.name);
-            std::vector<float> ws_in(f.w), q(f.w.size()), mult(f.cout), bias(f.cout);
+            const QWeights *qw = plan_ ? qweights_for(*plan_, f, ktot) : nullptr;
+            std::vector<float> ws_in(f.w), q(f.w.size()), mult(f.cout), bias(f.cout), row(f.cout);
             if (!in_scale.empty())
                 for (int o = 0; o < f.cout; o++)
                     for (int k = 0; k < ktot; k++) ws_in[(size_t)o * ktot + k] *= in_scale[k % cin_g];       // k = tap*cin + c
@@ -193,11 +222,29 @@ struct WeightPack {
                 float amax = 0.f;
                 for (int k = 0; k < ktot; k++) amax = std::max(amax, std::fabs(ws_in[(size_t)o * ktot + k]));
                 const float ws = amax > 0.f ? amax / 127.f : 1.f;
-                for (int k = 0; k < ktot; k++)
-                    q[(size_t)o * ktot + k] = std::min(127.f, std::max(-127.f, std::nearbyintf(ws_in[(size_t)o * ktot + k] / ws)));
+                row[o] = ws;
+                long qsum = 0;
+                for (int k = 0; k < ktot; k++) {
+                    const float rtn = std::min(127.f, std::max(-127.f, std::nearbyintf(ws_in[(size_t)o * ktot + k] / ws)));
+                    const float v = qw ? (float)qw->q[(size_t)o * ktot + k] : rtn;
+                    q[(size_t)o * ktot + k] = v;
+                    qsum += (long)v;
+                }
                 const float os = out_scale.empty() ? 1.f : out_scale[o];
                 mult[o] = ws / os;
-                bias[o] = f.b[o] / os;
+                bias[o] = (qw ? f.b[o] + qw->bias_delta[o] : f.b[o]) / os;
+                if (in_u8) bias[o] = std::fmaf(mult[o], (float)(128 * qsum), bias[o]);      // |128 * qsum| < 2^24: exact in fp32
+            }
+            if (record_) {
+                GemmRecord r;
+                r.cout = f.cout; r.ktot = ktot; r.cin = cin_g; r.in_u8 = in_u8 ? 1 : 0;
+                r.quanta.resize(ws_in.size());
+                for (int o = 0; o < f.cout; o++)
+                    for (int k = 0; k < ktot; k++) r.quanta[(size_t)o * ktot + k] = ws_in[(size_t)o * ktot + k] / row[o];
+                r.in_scale = in_scale.empty() ? Sc(cin_g, 1.f) : in_scale;
+                r.row_scale = row;
+                r.out_scale = out_scale.empty() ? Sc(f.cout, 1.f) : out_scale;
+                (*record_)[f.name] = std::move(r);
             }
             g.w = arena_.put(pack_gemm<T>(q, f.cout, ktot, mma_k<T>(), mma_kpl<T>()));
             g.b = arena_.put(bias);
@@ -242,8 +289,9 @@ struct WeightPack {
 
     // depthwise weights [c][3][3][1] -> [tap][c].  int8: fp32 weights pre-scaled so the stencil maps input quanta straight to
     // output quanta: w * in_scale / mid_scale, b / mid_scale
-    DwW put_dw(const FoldedConv &dw, const Sc &in_scale = {}, const Sc &mid_scale = {}) {
+    DwW put_dw(const FoldedConv &dw, const Sc &in_scale = {}, const Sc &mid_scale_table = {}) {
         const int c = dw.cout;
+        const Sc mid_scale = kInt8 ? mid_u8_scale(mid_scale_table) : mid_scale_table;      // int8: 0..255 quanta of amax / 255 (kMidU8)
         std::vector<DWT> w((size_t)9 * c);
         std::vector<float> b(dw.b);
         for (int ch = 0; ch < c; ch++)
@@ -304,6 +352,7 @@ struct WeightPack {
 
     // Fold-independent part of engine start-up: BN-folded weights -> storage type -> MFMA fragment order, one contiguous image.
     void pack(const Plan &plan) {
+        plan_ = &plan;
         if constexpr (kInt8)
             if (plan.int8_scales.empty()) throw Unsupported("int8 precision needs a calibration table (<stem>.table.int8)");
         c0_w_ = arena_.put(plan.conv0.w);
@@ -461,7 +510,7 @@ struct WeightPack {
                 pw_w_.push_back(put_gemm(pwq, s_mid, s_out));
             } else {
                 dw_w_.push_back(put_dw(blk.dw, s_prev, s_mid));
-                pw_w_.push_back(put_gemm(blk.pw, s_mid, s_out));
+                pw_w_.push_back(put_gemm(blk.pw, s_mid, s_out, kInt8));
             }
             s_prev = s_out;
             if constexpr (kInt8) act_scale_[blk.pw.out_blob] = s_out;
@@ -539,6 +588,7 @@ struct WeightPack {
             for (int i = 0; i < 2; i++) act_scale_[plan.aggr[i].out_blob] = s_feat[i + 1];
         }
         head_a_ = plan.anchors_per_cell;
+        plan_ = nullptr;
     }
 
 

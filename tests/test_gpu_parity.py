@@ -473,24 +473,28 @@ def test_int8_engine_is_bit_exact_against_the_integer_oracle(rfa, nets, oracles,
 
 
 def test_calibration_tool_end_to_end(rfa, nets, oracles, tmp_path):
-    """SURVEY 8f rank 3, the INT8 calibration-table generator, as a whole: tools/calibrate_int8.py (per-channel, amax rule, a small
-    built-in calibration set that shows only fixture faces 0 / 2 / 4) collects activations from the fp32 HIP engine and writes a
-    table in the reference's text format; the table goes into a model container, the int8 engine built from it must (a) be
-    BIT-exact against the integer oracle built from the same table and (b) find the fp32 oracle's faces on held-out frames
-    (faces 1 / 3 / 5) at the int8 bar.  (TensorRT's calibrator is closed source: the tool's thresholds themselves stay
-    "parity unpinned"; what is pinned is that a table it writes drives the int8 path correctly.)"""
-    from oracle.caffe_io import read_int8_table, read_rfw, write_rfw
+    """SURVEY 8f rank 3, the INT8 calibration-table generator, as a whole: tools/calibrate_int8.py (per-channel, amax rule with head-room,
+    a small built-in calibration set that shows only fixture faces 0 / 2 / 4) collects activations from the fp32 HIP engine, writes a
+    table in the reference's text format, calibrates the WEIGHTS on the same activations (error-compensated rounding + bias correction,
+    round 6) and packs model + table + weights into an .rfw through the C ABI (rf_attach_calibration).  The int8 engine built from that
+    file must (a) be BIT-exact against the integer oracle built from the same file (the oracle reads the container with its own reader)
+    and (b) find the fp32 oracle's faces on held-out frames (faces 1 / 3 / 5) at the int8 bar.  (TensorRT's calibrator is closed source:
+    the tool's thresholds themselves stay "parity unpinned"; what is pinned is that what it writes drives the int8 path correctly.)"""
+    from oracle.caffe_io import read_int8_qweights, read_int8_table, read_rfw
     from oracle.int8_forward import Int8Net
     from retinaface_amd.frames import synth_frames
     table = tmp_path / "mnet25.table.int8"
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "calibrate_int8.py"), "--model", "mnet25", "--per-channel", "--rule", "amax",
-                          "--frames", "12", "--config", "91", "--out", str(table)], capture_output=True, text=True, timeout=900)
+                          "--margin", "1.25", "--frames", "12", "--config", "91", "--gptq", "--out", str(table),
+                          "--out-rfw", str(tmp_path / "mnet25.rfw")], capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-2000:]
     scales = read_int8_table(str(table))
     assert "mobilenet0_relu2_fwd" in scales and "mobilenet0_relu2_fwd#15" in scales and "_plus1#63" in scales and len(scales) > 1000
-    net = read_rfw(os.path.join(ASSETS, "mnet25.rfw"))
-    net.int8_scales = scales
-    write_rfw(net, str(tmp_path / "mnet25.rfw"))
+    net = read_rfw(str(tmp_path / "mnet25.rfw"))
+    loose = read_int8_qweights(str(tmp_path / "mnet25.qweights.int8"))
+    assert len(net.int8_qweights) == 29 and set(loose) == set(net.int8_qweights)          # 12 pointwise + 3 lateral + 2 aggr + 3 x 4 SSH / head
+    assert all(np.array_equal(loose[k][0], v[0]) and np.array_equal(loose[k][1], v[1]) for k, v in net.int8_qweights.items())
+    assert all(abs(net.int8_scales[k] - np.float32(v)) == 0 for k, v in scales.items())
     det = rfa.RetinaFace(str(tmp_path), "net3", 0.4, precision=INT8, net_hw=(448, 448), model_stem="mnet25", max_batch=8, keep_outputs=True,
                          use_graph=False, plan_cache=False)
     q = Int8Net(net)

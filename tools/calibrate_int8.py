@@ -14,7 +14,13 @@ Activations come from THIS repo's fp32 HIP engine (debug_activation of every fus
 kernels never materialise are rebuilt on the host from those: the depthwise outputs (3x3 stencil with the BN-folded
 weights from rf_plan_folded) and the upsample+add tensors `_plus0/_plus1` (closed-form bilinear x2).  Needs a GPU.
 
+Round 6: `--margin` widens every threshold (per-channel amax statistics of a few dozen frames under-estimate unseen data by
+10-25 % at the 90th percentile: tools/probes/int8_mix_sim.py), and `--gptq` also calibrates the WEIGHTS: error-compensated
+rounding + bias correction per fused dense conv on the calibration activations (retinaface_amd/calibrate.py), written to
+`<out stem>.qweights.int8`; `--out-rfw` packs model + table + weights into one .rfw (rf_attach_calibration).
+
 usage: python tools/calibrate_int8.py --model mnet25 --out gpurun_out/mnet25.table.int8 [--frames 48] [--compare table]
+                                      [--per-channel --rule amax --margin 1.25 --gptq --out-rfw gpurun_out/mnet25.rfw]
 """
 import argparse
 import ctypes as C
@@ -102,6 +108,10 @@ def main():
     ap.add_argument("--faces", default="0,2,4", help="fixture faces the built-in calibration set may use (the held-out int8 parity "
                                                      "test uses the others); 'all' = every face")
     ap.add_argument("--config", type=int, default=77, help="seed block of the built-in synthetic calibration frames")
+    ap.add_argument("--margin", type=float, default=1.0, help="multiply every threshold by this (head-room for data the set did not show)")
+    ap.add_argument("--gptq", action="store_true", help="also calibrate the weights: error-compensated rounding + bias correction per fused "
+                                                        "dense conv, written next to --out as <stem>.qweights.int8")
+    ap.add_argument("--out-rfw", default=None, help="pack <model> + the new table (+ weights) into this .rfw")
     ap.add_argument("--per-channel", action="store_true", help="also write per-channel scales as `tensor#<c>: hex` lines (an extension "
                     "the engine understands; TensorRT-style readers ignore them): needs a percentile or amax --rule")
     args = ap.parse_args()
@@ -197,8 +207,30 @@ def main():
                 amax_c[n] = np.maximum(amax_c.get(n, 0.0), m)
     hist = {n: np.zeros(NBINS, np.int64) for n in amax}
     hist_c = {n: np.zeros((len(amax_c[n]), NBINS), np.int64) for n in amax_c}
+    # fused dense convs of the int8 plan -> (input tensor, kernel size): what --gptq needs the Gram matrices of
+    gemm_inputs = {}
+    for i in range(1, 13):
+        gemm_inputs[f"mobilenet0_conv{2 * i + 2}_fwd"] = (dw_names[i], 1)
+    for nm, tap in (("rf_c3_lateral", 12), ("rf_c2_lateral", 10), ("rf_c1_red_conv", 4)):
+        gemm_inputs[nm] = (pw_names[tap], 1)
+    gemm_inputs["rf_c2_aggr"], gemm_inputs["rf_c1_aggr"] = ("_plus0", 3), ("_plus1", 3)
+    for c, feat, st in ((3, "rf_c3_lateral_relu", 32), (2, "rf_c2_aggr_relu", 16), (1, "rf_c1_aggr_relu", 8)):
+        pre = f"rf_c{c}_det_"
+        gemm_inputs[f"{pre}conv1+{pre}context_conv1"] = (feat, 3)
+        gemm_inputs[f"{pre}context_conv2+{pre}context_conv3_1"] = (pre + "context_conv1_relu", 3)
+        gemm_inputs[f"{pre}context_conv3_2"] = (pre + "context_conv3_1_relu", 3)
+        gemm_inputs[f"face_rpn_cls_score_stride{st}+face_rpn_bbox_pred_stride{st}+face_rpn_landmark_pred_stride{st}"] = (pre + "concat_relu", 1)
+    grams = {}
+    from retinaface_amd import calibrate as cal
     for f in frames:
-        for n, a in tensors(f).items():
+        acts = tensors(f)
+        if args.gptq:
+            for op, (src, k) in gemm_inputs.items():
+                a = acts[src]
+                if op not in grams:
+                    grams[op] = cal.Gram(k * k * a.shape[-1])
+                grams[op].add(a, k)
+        for n, a in acts.items():
             h, _ = np.histogram(np.abs(a), bins=NBINS, range=(0.0, max(amax[n], 1e-12)))
             hist[n] += h
             if args.per_channel:
@@ -218,7 +250,7 @@ def main():
         pct = {q: (int(np.searchsorted(cdf, q)) + 1) * bw for q in (0.999, 0.9999, 0.99999)}
         variants[n] = {"kl": t_kl, "kl_keep0": entropy_threshold(h0, bw), **{f"p{q}": v for q, v in pct.items()},
                        "kl_or_p0.9999": max(t_kl, pct[0.9999]), "amax": amax[n]}
-        scales[n] = variants[n][args.rule] / 127.0
+        scales[n] = variants[n][args.rule] * args.margin / 127.0
         if args.per_channel:
             if args.rule == "amax":
                 t_c = amax_c[n].astype(np.float64)
@@ -231,7 +263,7 @@ def main():
             else:
                 raise SystemExit("--per-channel needs --rule amax or p0.xxx")
             # a channel that is (almost) dead in the calibration set must not get a vanishing quantum: floor at 1/64 of the tensor's
-            scales_c[n] = np.maximum(t_c, variants[n][args.rule] / 64.0) / 127.0
+            scales_c[n] = np.maximum(t_c, variants[n][args.rule] / 64.0) * args.margin / 127.0
 
     other = {}
     if args.compare:
@@ -257,6 +289,63 @@ def main():
                 for c, s in enumerate(sc):
                     fo.write(f"{n}#{c}: {struct.pack('>f', np.float32(s)).hex()}\n")
         print("wrote", args.out)
+    if args.gptq or args.out_rfw:
+        if not args.out:
+            raise SystemExit("--gptq / --out-rfw need --out (the table the weights are calibrated under)")
+        qpath = None
+        if args.gptq:
+            qpath = args.out[:-len(".table.int8")] + ".qweights.int8" if args.out.endswith(".table.int8") else args.out + ".qweights.int8"
+            qw = calibrate_weights(lib, assets, args.model, args.out, grams)
+            cal.write_qweights(qw, qpath)
+            print("wrote", qpath)
+        if args.out_rfw:
+            st = lib.rf_attach_calibration(assets.encode(), args.model.encode(), args.out.encode(), qpath.encode() if qpath else None, args.out_rfw.encode())
+            if st != 0:
+                raise SystemExit(f"rf_attach_calibration failed: {st} {lib.rf_last_error(None)}")
+            print("wrote", args.out_rfw)
+
+
+def calibrate_weights(lib, model_dir, stem, table_path, grams):
+    """Error-compensated rounding of every fused dense conv of the int8 plan under the table at `table_path` (retinaface_amd/calibrate.py)."""
+    from retinaface_amd import calibrate as cal
+    F = C.POINTER(C.c_float)
+    names = []
+    while True:
+        dims = (C.c_int * 4)()
+        buf = np.zeros(64, np.float32)
+        if lib.rf_plan_int8_gemm(model_dir.encode(), stem.encode(), table_path.encode(), f"?{len(names)}".encode(), buf.ctypes.data_as(F), buf.size,
+                                 None, 0, None, None, 0, dims) != 0:
+            break
+        names.append(buf.tobytes()[:dims[0]].decode())
+    missing = [n for n in names if n not in grams]
+    if missing:
+        raise SystemExit(f"no calibration inputs collected for the fused ops {missing}")
+    out = {}
+    tot_rtn = tot_cal = 0.0
+    for op in names:
+        dims = (C.c_int * 4)()
+        assert lib.rf_plan_int8_gemm(model_dir.encode(), stem.encode(), table_path.encode(), op.encode(), None, 0, None, 0, None, None, 0, dims) == 0
+        cout, ktot, cin, _ = dims
+        quanta, s_in = np.empty(cout * ktot, np.float32), np.empty(cin, np.float32)
+        s_row, s_out = np.empty(cout, np.float32), np.empty(cout, np.float32)
+        assert lib.rf_plan_int8_gemm(model_dir.encode(), stem.encode(), table_path.encode(), op.encode(), quanta.ctypes.data_as(F), quanta.size,
+                                     s_in.ctypes.data_as(F), cin, s_row.ctypes.data_as(F), s_out.ctypes.data_as(F), cout, dims) == 0
+        quanta = quanta.reshape(cout, ktot)
+        g = grams[op]
+        if g.g.shape[0] != ktot:
+            raise SystemExit(f"{op}: Gram matrix of size {g.g.shape[0]} for K = {ktot}")
+        sk = np.tile(s_in.astype(np.float64), ktot // cin)                     # k = tap * cin + c
+        hq, mq = (g.g / g.n) / np.outer(sk, sk), (g.s / g.n) / sk               # real units -> input quanta
+        q, mean_err = cal.gptq_round(quanta, hq, mq)
+        rtn = np.clip(np.rint(quanta), -127, 127)
+        e_rtn, e_cal = cal.output_error(quanta, rtn, hq).sum(), cal.output_error(quanta, q, hq).sum()
+        tot_rtn += e_rtn
+        tot_cal += e_cal
+        out[op] = (q, (-mean_err * s_row.astype(np.float64)).astype(np.float32))        # row-grid units -> real units
+        print(f"  {op[:60]:60s} {cout:3d} x {ktot:4d}: output error on the calibration set  rtn {e_rtn:10.3f} -> {e_cal:10.3f}  "
+              f"({(q != rtn).mean() * 100:4.1f} % of the weights moved)")
+    print(f"weights calibrated: {len(out)} fused convs, summed output error (grid units^2) {tot_rtn:.1f} -> {tot_cal:.1f}")
+    return out
 
 
 if __name__ == "__main__":
