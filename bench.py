@@ -75,12 +75,17 @@ MALL_BYTES = 256 << 20
 GATHER_CAP = 16                # faces per image in the gathered record (count is exact; frames carry <= 6 faces)
 
 
+FRAC_KIND = {"valu_issue": "valu_issue_occupancy", "lds_issue": "lds_issue_occupancy", "mfma": "mfma_busy_occupancy", "hbm": "hbm_bytes_moved_over_peak"}
+
+
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=400)
     ap.add_argument("--min-seconds", type=float, default=1.0, help="lower bound on the timed region (0 = exactly --steps)")
+    ap.add_argument("--exact-steps", action="store_true", help="time EXACTLY --steps steps in ONE region (no --min-seconds stretch, no repeats): the "
+                                                               "line then says burst_only = true -- at the driver's --steps 20 that is 0.5 ms of pipeline fill, not throughput")
     ap.add_argument("--batch", type=int, default=8, help="images per GPU per step")
     ap.add_argument("--height", type=int, default=448)
     ap.add_argument("--width", type=int, default=448)
@@ -355,6 +360,8 @@ def main() -> int:
     warm_dt = time.perf_counter() - t0
     # at least --steps, at least --min-seconds (estimated from the warm-up rate), in whole super-batches
     steps = args.steps
+    if args.exact_steps:
+        args.min_seconds, args.regions = 0.0, 1
     if args.min_seconds > 0 and not args.dry:
         est = warm_dt / max(args.warmup, 1)
         steps = max(steps, int(np.ceil(args.min_seconds / max(est, 1e-7))))
@@ -465,6 +472,7 @@ def main() -> int:
             "n_gpus": world, "steps": steps, "steps_requested": args.steps, "warmup": args.warmup,
             "ms_per_step": dt_max / steps * 1e3, "timed_seconds": dt_max,
             "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
+            "burst_only": bool(args.exact_steps),
             "regions": {"n": len(region_rates), "value_is": "median region", "faces_per_sec": region_rates,
                         "min": min(region_rates), "median": sorted(region_rates)[len(region_rates) // 2], "max": max(region_rates)},
             "dtype": {"fp16": "f16", "fp32": "f32", "int8": "i8"}[args.precision], "data": "synthetic",
@@ -1038,6 +1046,15 @@ def device_side_report(args, det, frames, B, H, W, per_launch, prec, images_tota
         "kernel": dom["name"], "kernel_instance": dom["kernel"],
         "achieved": res_achieved, "peak": res_peak, "unit": res_unit,
         "frac": (dom_phys["bound_frac"] if dom_phys else None),
+        "frac_kind": FRAC_KIND.get(bound, "unmeasured"),
+        # the contract's whole-path fractions AT THE REPORTED RATE (`value`'s images/s), next to the dominant kernel's occupancy:
+        #   layer-wise algorithmic bytes per image (27 615 616 B at 448 x 448 fp16) x images/s / 8 TB/s  -- > 1 = fusion credit
+        #   HBM bytes the counters saw per image x images/s / 8 TB/s                                               -- the physical figure
+        #   layer MACs x 2 per image x images/s / dense MFMA peak of the dtype                                     -- useful matrix work
+        "hbm_layerwise_frac_at_value": (alg_total / n_prof) * images_per_sec_gpu / 1e9 / HBM_PEAK_GBS,
+        "hbm_measured_frac_at_value": (path_phys["hbm_bytes"] / n_prof * images_per_sec_gpu / 1e9 / HBM_PEAK_GBS) if path_phys else None,
+        "mfma_useful_frac_at_value": 2 * sum(p["macs"] for p in prof) / n_prof * images_per_sec_gpu / 1e12 / MFMA_PEAK_TFLOPS[args.precision],
+        "alg_bytes_per_image": alg_total / n_prof, "macs_per_image": sum(p["macs"] for p in prof) / n_prof,
         "frac_is": "OCCUPANCY of the binding resource, measured (rocprofv3 --pmc passes of this run): issue cycles used / bytes moved, whether or not the "
                    "layers require them -- see `useful` for the efficiency" if dom_phys else
                    "null: no counter pass in this run (the layer-wise credit is under frac_layerwise_credit, never here)",

@@ -8,7 +8,10 @@
  * class verbatim on top of it.  No torch / OpenCV / HIP types appear in any signature.
  *
  * Threading: one handle = one caller thread at a time (the reference is single-threaded and
- * not re-entrant either: shared staging buffers, RetinaFace.cpp:323-336).
+ * not re-entrant either: shared staging buffers, RetinaFace.cpp:323-336).  The rule is enforced: a
+ * call that enters while another thread's call on the same handle is in flight returns
+ * RF_ERR_INVALID_ARG at once ("handle in use by another thread" from rf_last_error on the refused
+ * thread) and leaves the call in flight undisturbed.  Different handles are independent.
  * Errors: every call returns RF_OK (0) or a negative rf_status; rf_last_error() gives text.
  * (The reference abort()s / exit(0)s / bare-throws instead: trtutility.h:9-16,
  * trtnetbase.cpp:201-204, RetinaFace.cpp:327-335.)

@@ -1,5 +1,6 @@
 // capi.cpp -- extern "C" boundary (include/retinaface_amd.h) over rf::Engine.  Exceptions never cross it.
 #include <algorithm>
+#include <atomic>
 #include <cstddef>
 #include <cstdlib>
 #include <cstring>
@@ -13,11 +14,14 @@
 
 namespace {
 thread_local std::string g_create_error;
+thread_local const void *g_busy_handle = nullptr;      // the handle this thread's last call was refused on (see guarded)
+const char kBusyText[] = "handle in use by another thread (one handle = one caller thread at a time)";
 }
 
 struct rf_engine {
     std::unique_ptr<rf::Engine> eng;
     std::string error;
+    std::atomic_flag in_call = ATOMIC_FLAG_INIT;       // set for the duration of every call that touches the engine's state
     // rf_detect_batch_pad32: one engine per padded frame size, most recently used first
     std::string model_dir, network;
     float nms = 0.4f;
@@ -27,7 +31,21 @@ struct rf_engine {
 
 namespace {
 
+// The boundary's contract is "one handle = one caller thread at a time" (include/retinaface_amd.h): lanes, tickets and staging buffers are
+// unsynchronised by design.  A second thread entering while a call is in flight would corrupt them silently (the reference is equally
+// unsafe, RetinaFace.cpp shared staging buffers -- but this library advertises a serving loop), so the entry points refuse it: the
+// intruder gets RF_ERR_INVALID_ARG and rf_last_error() on ITS thread says why; the call in flight is not disturbed.
+struct InCall {
+    rf_engine *h;
+    bool ok;
+    explicit InCall(rf_engine *e) : h(e), ok(!e || !e->in_call.test_and_set(std::memory_order_acquire)) {}
+    ~InCall() { if (h && ok) h->in_call.clear(std::memory_order_release); }
+};
+
 template <typename F> int guarded(rf_engine *h, F &&f) {
+    InCall guard(h);
+    if (!guard.ok) { g_busy_handle = h; return RF_ERR_INVALID_ARG; }
+    if (h && g_busy_handle == h) g_busy_handle = nullptr;
     std::string &err = h ? h->error : g_create_error;
     try {
         return f();
@@ -99,7 +117,10 @@ int rf_preset_anchors(const char *network, int stride, float *out4, int cap_boxe
 
 void rf_destroy(rf_handle h) { delete h; }
 
-const char *rf_last_error(rf_handle h) { return h ? h->error.c_str() : g_create_error.c_str(); }
+const char *rf_last_error(rf_handle h) {
+    if (h && g_busy_handle == h) return kBusyText;
+    return h ? h->error.c_str() : g_create_error.c_str();
+}
 
 int rf_get_net_size(rf_handle h, int *net_h, int *net_w, int *max_batch) {
     if (!h) return RF_ERR_INVALID_ARG;

@@ -325,17 +325,89 @@ def _match(got, ref_rows):
     return [max([iou_plus1(g.rect, r[1:5]) for g in got] or [0.0]) for r in ref_rows]
 
 
-# int8 bars per model (per face, vs the fp32 CPU oracle): minimum IoU, minimum anchor-index agreement rate over the set, |dscore|.
-#   0517  : the TensorRT cache the reference ships (per tensor, calibrated by its authors at 320 x 320 on their own data).
-#   mnet25: the reference ships none; assets/mnet25.table.int8 comes from tools/calibrate_int8.py --per-channel --rule amax on 48
-#           frames that show only fixture faces 0, 2, 4 (the others greyed out) -- the held-out frames below use faces 1, 3, 5 and
-#           other seeds.  Per-channel activation scales are what lifts the worst face from 0.90 (round 1, per tensor) to >= 0.95.
-#   These bars are the REPORTED DISTANCE of int8 to fp32, not the parity bar (that is the bit-exact integer oracle below): a 1-LSB
-#   flip of a handful of first-layer quanta (any change of the float front end's summation order) can hand one face's NMS win to
-#   the neighbouring anchor, which moves that face's IoU from ~0.97 to ~0.92 while every other number stays put -- round 3's
-#   offset-folded conv0 did exactly that to one of the 70 held-out mnet25 faces (worst 0.955 -> 0.918, anchor agreement 0.986).
-INT8_BAR = {"mnet-deconv-0517": dict(iou=0.93, heldout_iou=0.87, anchors=0.78, score=0.03),
-            "mnet25": dict(iou=0.95, heldout_iou=0.90, anchors=0.90, score=0.03)}
+# The int8 engine's DISTANCE to the fp32 oracle (reported and gated; the PARITY bar of the int8 engine is the bit-exact integer oracle below).
+# Metrics: tests/int8_contract.py.  Calibration (round 6, tools/calibrate_int8.py --per-channel --rule amax --margin 1.25 --gptq, both models):
+# per-channel activation scales with 25 % head-room, error-compensated weight rounding + bias correction on 48 frames that show only fixture
+# faces 0 / 2 / 4; every frame below uses faces 1 / 3 / 5 and other seeds (held out).  Depthwise outputs carry 8 bits (0..255 quanta).
+#   same-anchor IoU  the regression error alone (engine's box vs the ORACLE'S box of the same anchor): the number north_star's "1e-3 IoU" is
+#                    about; fp16 scores 0.9993-0.9995 on this metric, int8 0.968-0.981 at worst over 280 faces (round 5 tables: 0.947-0.949).
+#   anchor agreement fraction of faces kept on the oracle's anchor.  Neighbouring anchors of one face score within ~1e-3 of each other in the
+#                    oracle itself, so any logit noise flips some winners (the fp16 engine: 2 of 280 on 0517); a flip shows up as a per-face
+#                    IoU of 0.88-0.95 although both boxes are the network's own predictions -- the per-face IoU is printed, and gated only loosely.
+# A 1-LSB change of a handful of first-layer quanta moves these statistics by +-0.015 (agreement) / +-0.005 (worst IoU): the gates sit that far
+# below the measured values (profiles/r06_int8_contract.json).
+INT8_BAR = dict(anchor_iou=0.96, anchor_iou_p01=0.968, agreement=0.92, iou_mean=0.985, iou_floor=0.86, dscore=0.06)
+INT8_TARGET = dict(anchor_iou=0.97, agreement=0.95)          # VERDICT r5's "done" line, printed beside the measured numbers
+
+
+def _check_int8(stem, what, s, bar=INT8_BAR, min_faces=1):
+    from int8_contract import fmt
+    print(f"[{what}] " + fmt(stem, s) + f"  | targets: same-anchor IoU >= {INT8_TARGET['anchor_iou']}, agreement >= {INT8_TARGET['agreement']}")
+    assert s["same_count"] == s["frames"] and s["faces"] >= min_faces and s["unmatched"] == 0, (stem, what, s)
+    assert s["anchor_iou_worst"] >= bar["anchor_iou"] and s["iou_worst"] >= bar["iou_floor"] and s["dscore_max"] <= bar["dscore"], (stem, what, s)
+    if s["faces"] >= 100:
+        assert s["anchor_agreement"] >= bar["agreement"] and s["anchor_iou_p01"] >= bar["anchor_iou_p01"] and s["iou_mean"] >= bar["iou_mean"], (stem, what, s)
+
+
+@pytest.mark.parametrize("stem", STEMS)
+def test_int8_engine_against_the_fp32_oracle(rfa, oracles, base_frame, stem):
+    """int8 engine (symmetric quantisation, i8 MFMA for every contraction incl. the depthwise stencil with 15-bit taps) against the fp32
+    oracle on three small sets: held-out synthetic frames at batch 32 in one call (configs[2]'s shape), the same frames through a batch-8
+    engine (batch composition must not matter), and the reference photo at 1280 x 896.  Same number of faces on every frame, the
+    regression error per anchor and the score error bounded (INT8_BAR); the 208-frame contract below carries the statistics."""
+    from int8_contract import frame_rows, summarize
+    from retinaface_amd.frames import synth_frames
+    held = synth_frames(448, 448, 32, config=300, faces=[1, 3, 5])
+    det32 = engine(rfa, stem, INT8, (448, 448), max_batch=32)
+    res = det32.detectBatchImages(held, 0.5)
+    refs = [oracles[stem].detect(f, 0.5, 0.4, net_hw=(448, 448)) for f in held]
+    _check_int8(stem, "held-out b32", summarize([dict(same_count=len(g) == len(r.detections), rows=frame_rows(g, r)) for g, r in zip(res, refs)]), min_faces=60)
+    det8 = engine(rfa, stem, INT8, (448, 448))
+    assert _key(det8.detectBatchImages(held, 0.5)) == _key(res)
+    big = engine(rfa, stem, INT8, (896, 1280), max_batch=2)
+    got = big.detect(base_frame, 0.5)
+    ref = oracles[stem].detect(base_frame, 0.5, 0.4, net_hw=(896, 1280))
+    assert len(got) == 6
+    _check_int8(stem, "fixture photo", summarize([dict(same_count=len(got) == len(ref.detections), rows=frame_rows(got, ref))]), min_faces=6)
+
+
+@pytest.mark.parametrize("stem", STEMS)
+def test_int8_contract_over_200_frames(rfa, oracles, stem):
+    """The fp16 contract's frame plan (both models x {448 x 448: 32 + 4 x 8 frames, 1280 x 896: 32 + 8 frames} = 104 frames per model, 208 in
+    all) for the int8 engine, on held-out faces: identical face count on every frame, same-anchor IoU, anchor agreement, per-face IoU
+    distribution and |dscore| -- printed against VERDICT r5's targets and gated at INT8_BAR."""
+    from int8_contract import run_contract
+    s = run_contract(lambda hw, nb: engine(rfa, stem, INT8, hw, max_batch=nb), oracles[stem])
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", f"int8_contract_{stem}.json"), "w") as f:
+        json.dump(s, f, indent=1)
+    assert s["frames"] == 104
+    _check_int8(stem, "contract", s, min_faces=250)
+
+
+def test_int8_engine_with_the_reference_tensorrt_table(rfa, nets, tmp_path):
+    """The calibration cache the REFERENCE ships (model/mnet-deconv-0517.table.int8, per tensor, TensorRT's own: assets/ keeps it verbatim)
+    still drives the engine: packed into a container through the C ABI (rf_attach_calibration drops the calibrated weights, which belong to
+    the repo's own table), the engine is bit-exact against the integer oracle built from the same file -- the per-tensor code path: scalar
+    scale ratios in the fused upsample + add (fp32 blend), one scale per concat."""
+    import copy
+    from oracle.caffe_io import read_int8_table, read_rfw
+    from oracle.int8_forward import Int8Net
+    from retinaface_amd.frames import synth_frames
+    stem = "mnet-deconv-0517"
+    lib = rfa.load_library()
+    out = str(tmp_path / (stem + ".rfw"))
+    assert lib.rf_attach_calibration(ASSETS.encode(), stem.encode(), os.path.join(ASSETS, stem + ".table.int8").encode(), None, out.encode()) == 0
+    net = read_rfw(out)
+    assert net.int8_qweights == {} and net.int8_scales == read_int8_table(os.path.join(ASSETS, stem + ".table.int8")) and "_plus0#0" not in net.int8_scales
+    q = Int8Net(net)
+    assert not q.per_channel
+    det = rfa.RetinaFace(str(tmp_path), "net3", 0.4, precision=INT8, net_hw=(448, 448), model_stem=stem, max_batch=8, keep_outputs=True,
+                         use_graph=False, plan_cache=False)
+    frames = synth_frames(448, 448, 8, config=300, faces=[1, 3, 5])
+    res = det.detectBatchImages(frames, 0.5)
+    assert sum(_assert_int8_image_bit_exact(det, q, i, (448, 448), 0.5, res[i]) for i in range(8)) >= 8
+    det.close()
 
 
 def _int8_stats(res, refs):
@@ -350,41 +422,6 @@ def _int8_stats(res, refs):
             same_anchor += bool(best) and best.anchor_index == r_idx
             ds = max(ds, abs(best.score - r_score) if best else 1.0)
     return same, min(ious), same_anchor / max(faces, 1), ds
-
-
-@pytest.mark.parametrize("stem", STEMS)
-def test_int8_engine_against_the_fp32_oracle(rfa, oracles, base_frame, stem):
-    """int8 engine (TensorRT-style symmetric quantisation, i8 MFMA for every contraction incl. the depthwise stencil with 15-bit
-    taps).  Quantisation noise moves boxes by ~1 px and can hand the NMS win to a neighbouring anchor, so the bar is per face:
-    same number of faces on every frame, every oracle face matched above the model's IoU bar, and the anchor-index agreement
-    rate is reported and bounded (INT8_BAR).  Three sets: the golden synthetic batch, HELD-OUT synthetic frames (faces and seeds
-    the calibration never saw) at batch 32 = BASELINE configs[2]'s shape, and the reference photo at 1280 x 896."""
-    from retinaface_amd.frames import synth_frames
-    bar = INT8_BAR[stem]
-    det = engine(rfa, stem, INT8, (448, 448))
-    g = golden(f"synth448_{stem}.npz")
-    res = det.detectBatchImages(synth_frames(448, 448, 8, config=1), 0.5)
-    refs = [[(r[1:5], r[0], int(i)) for r, i in zip(g[f"det05_{k}"], g[f"idx05_{k}"])] for k in range(8)]
-    same, worst, agree, ds = _int8_stats(res, refs)
-    assert same and worst >= bar["iou"] and agree >= bar["anchors"] and ds <= bar["score"], (stem, same, worst, agree, ds)
-    # held-out, batch 32 in one call (configs[2]: int8, 448 x 448, batch 32)
-    held = synth_frames(448, 448, 32, config=300, faces=[1, 3, 5])
-    det32 = engine(rfa, stem, INT8, (448, 448), max_batch=32)
-    res = det32.detectBatchImages(held, 0.5)
-    refs = []
-    for f in held:
-        o = oracles[stem].detect(f, 0.5, 0.4, net_hw=(448, 448))
-        refs.append([(d.rect, d.score, d.anchor_index) for d in o.detections])
-    same, worst, agree, ds = _int8_stats(res, refs)
-    assert same and worst >= bar["heldout_iou"] and agree >= bar["anchors"] and ds <= bar["score"], (stem, same, worst, agree, ds)
-    # batch composition must not matter in int8 either: the same frames through the batch-8 engine
-    res8 = det.detectBatchImages(held, 0.5)
-    assert _key(res8) == _key(res)
-    big = engine(rfa, stem, INT8, (896, 1280), max_batch=2)
-    got = big.detect(base_frame, 0.5)
-    gf = golden(f"fixture_{stem}.npz")
-    same, worst, agree, ds = _int8_stats([got], [[(r[1:5], r[0], int(i)) for r, i in zip(gf["det"], gf["det_idx"])]])
-    assert same and len(got) == 6 and worst >= bar["iou"] and ds <= bar["score"], (stem, worst, agree, ds)
 
 
 def _int8_start_blob(det):
@@ -556,53 +593,117 @@ def test_int8_layers_stay_within_quantisation_noise(rfa, oracles, crop448):
             assert np.abs(det.get_output(n) - golden("crop448_mnet-deconv-0517.npz")[n]).max() <= 0.5, n
 
 
-def test_fp16_contract_over_200_frames_both_models_both_sizes(rfa, oracles):
-    """north_star's contract for the benchmarked precision, gated: >= 200 seeded frames -- both models, 448 x 448 and 1280 x 896,
-    submitted as 8- and 32-image batches (the target matrix's batch sizes) -- against the fp32 oracle.  Identical anchor sets on
-    every frame (up to the oracle's own near-tie twin anchors, tests/anchor_twins.py: counted, printed and capped), worst 1 - IoU <= 9e-4 (the bound is 1e-3; the margin is asserted, not hoped for), candidate counts within the
+FP16_CONTRACT = {}          # stem -> (worst 1 - IoU per frame, labelled rows, twin firings): filled per model, judged together by the summary test
+
+
+@pytest.mark.parametrize("stem", STEMS)
+def test_fp16_contract_over_200_frames_both_models_both_sizes(rfa, oracles, stem):
+    """north_star's contract for the benchmarked precision, gated: >= 200 seeded frames -- both models (one parametrisation each: 104 frames),
+    448 x 448 and 1280 x 896, submitted as 8- and 32-image batches (the target matrix's batch sizes) -- against the fp32 oracle.  Identical anchor sets on
+    every frame (up to the oracle's own near-tie twin anchors, tests/anchor_twins.py: allowed ONLY on the one frame where it is known to fire), worst 1 - IoU <= 9e-4 (the bound is 1e-3; the margin is asserted, not hoped for), candidate counts within the
     threshold band.  The distribution is printed so a kernel change is judged by its margin."""
     from retinaface_amd.frames import synth_frames
     worst_all, rows, bands, twin_frames, logit_errs = [], [], [], [], []
-    for stem in STEMS:
-        for hw, plan in (((448, 448), ((32, 400), (8, 401), (8, 402), (8, 403), (8, 404))), ((896, 1280), ((32, 410), (8, 411)))):
-            for nb, cfg in plan:
-                frames = synth_frames(hw[0], hw[1], nb, config=cfg)
-                det = engine(rfa, stem, FP16, hw, max_batch=nb)
-                got = det.detectBatchImages(frames, 0.5)
-                ncand = det.last_candidate_counts(nb)
-                for i, f in enumerate(frames):
-                    ref = oracles[stem].detect(f, 0.5, 0.4, net_hw=hw)
-                    # faces are matched by global anchor index -- identical sets, except where the engine kept the oracle's own near-tie
-                    # TWIN of an anchor (tests/anchor_twins.py: counted and printed below; the box is then measured against the oracle's
-                    # box of that twin); the ORDER must be the oracle's wherever its scores differ by more than twice the fp16 score
-                    # noise (closer pairs may swap places)
-                    got_idx = [d.anchor_index for d in got[i]]
-                    ref_rows, swaps, canon = resolve(got_idx, ref.rows(), ref.anchor_indices(), twins_of_result(ref, NMS_THRESHOLD, SCORE_NOISE))
-                    if swaps:
-                        twin_frames.append((f"{stem} {hw[1]}x{hw[0]} b{nb} cfg{cfg} #{i}", got_idx, ref.anchor_indices().tolist()))
-                    same_order_where_the_oracle_is_decisive(canon, [d.anchor_index for d in ref.detections],
-                                                            [d.score for d in ref.detections], FP16)
-                    band = ncand_band(FP16, heads=ref.heads, thr=0.5)
-                    bands.append(band)
-                    assert abs(ncand[i] - len(ref.candidates)) <= band, (stem, hw, cfg, i, ncand[i], len(ref.candidates), band)
-                    for d, r in zip(got[i], ref_rows):
-                        assert abs(d.score - r[0]) <= score_tol(FP16, r[0]), (stem, hw, cfg, i, d.anchor_index, d.score, r[0])
-                        if 0.02 < r[0] < 0.98:
-                            logit_errs.append(abs(np.log(d.score / (1 - d.score)) - np.log(float(r[0]) / (1 - float(r[0])))))
-                    w = max([1 - iou_plus1(d.rect, r[1:5]) for d, r in zip(got[i], ref_rows)], default=0.0)
-                    worst_all.append(w)
-                    rows.append((w, f"{stem} {hw[1]}x{hw[0]} b{nb} cfg{cfg} #{i}"))
+    for hw, plan in (((448, 448), ((32, 400), (8, 401), (8, 402), (8, 403), (8, 404))), ((896, 1280), ((32, 410), (8, 411)))):
+        dets = {}
+        for nb, cfg in plan:
+            frames = synth_frames(hw[0], hw[1], nb, config=cfg)
+            if nb not in dets:
+                dets[nb] = engine(rfa, stem, FP16, hw, max_batch=nb)          # one engine per (frame size, batch), shared by the seeds
+            det = dets[nb]
+            got = det.detectBatchImages(frames, 0.5)
+            ncand = det.last_candidate_counts(nb)
+            for i, f in enumerate(frames):
+                ref = oracles[stem].detect(f, 0.5, 0.4, net_hw=hw)
+                # faces are matched by global anchor index -- identical sets, except where the engine kept the oracle's own near-tie
+                # TWIN of an anchor (tests/anchor_twins.py: counted and printed below; the box is then measured against the oracle's
+                # box of that twin); the ORDER must be the oracle's wherever its scores differ by more than twice the fp16 score
+                # noise (closer pairs may swap places)
+                got_idx = [d.anchor_index for d in got[i]]
+                ref_rows, swaps, canon = resolve(got_idx, ref.rows(), ref.anchor_indices(), twins_of_result(ref, NMS_THRESHOLD, SCORE_NOISE))
+                if swaps:
+                    twin_frames.append((f"{stem} {hw[1]}x{hw[0]} b{nb} cfg{cfg} #{i}", got_idx, ref.anchor_indices().tolist()))
+                same_order_where_the_oracle_is_decisive(canon, [d.anchor_index for d in ref.detections],
+                                                        [d.score for d in ref.detections], FP16)
+                band = ncand_band(FP16, heads=ref.heads, thr=0.5)
+                bands.append(band)
+                assert abs(ncand[i] - len(ref.candidates)) <= band, (stem, hw, cfg, i, ncand[i], len(ref.candidates), band)
+                for d, r in zip(got[i], ref_rows):
+                    assert abs(d.score - r[0]) <= score_tol(FP16, r[0]), (stem, hw, cfg, i, d.anchor_index, d.score, r[0])
+                    if 0.02 < r[0] < 0.98:
+                        logit_errs.append(abs(np.log(d.score / (1 - d.score)) - np.log(float(r[0]) / (1 - float(r[0])))))
+                w = max([1 - iou_plus1(d.rect, r[1:5]) for d, r in zip(got[i], ref_rows)], default=0.0)
+                worst_all.append(w)
+                rows.append((w, f"{stem} {hw[1]}x{hw[0]} b{nb} cfg{cfg} #{i}"))
+        for d in dets.values():
+            d.close()
     ws = np.array(worst_all)
     rows.sort(key=lambda r: -r[0])
-    print(f"fp16 contract: {len(ws)} frames, worst 1-IoU {ws.max():.3e}, mean {ws.mean():.3e}, p99 {np.quantile(ws, 0.99):.3e}; worst: "
+    print(f"fp16 contract {stem}: {len(ws)} frames, worst 1-IoU {ws.max():.3e}, mean {ws.mean():.3e}, p99 {np.quantile(ws, 0.99):.3e}; worst: "
           + "; ".join(f"{w:.2e} {n}" for w, n in rows[:4]))
-    print(f"fp16 contract: candidate-count bands (anchors within {SCORE_NOISE} of the threshold): max {max(bands)}, mean {np.mean(bands):.2f}, "
+    print(f"fp16 contract {stem}: candidate-count bands (anchors within {SCORE_NOISE} of the threshold): max {max(bands)}, mean {np.mean(bands):.2f}, "
           f"{sum(b == 0 for b in bands)} of {len(bands)} frames with an empty band (count must then be identical)")
-    print(f"fp16 contract: logit error of the {len(logit_errs)} unsaturated detections (0.02 < p < 0.98): max {max(logit_errs, default=0.0):.4f} of the "
+    print(f"fp16 contract {stem}: logit error of the {len(logit_errs)} unsaturated detections (0.02 < p < 0.98): max {max(logit_errs, default=0.0):.4f} of the "
           f"{float(golden('threshold_bands.npz')['logit_noise']):.4f} plain fp16 storage is predicted to cost")
-    print(f"fp16 contract: anchor-twin band fired on {len(twin_frames)} of {len(ws)} frames: " + "; ".join(f"{n}: engine {g} oracle {r}" for n, g, r in twin_frames))
-    assert len(ws) >= 200 and ws.max() <= 9e-4, rows[:6]
-    assert len(twin_frames) <= 2, twin_frames            # a near-tie of two oracle candidates within 4e-3 on the same face: 1 of 208 frames
+    print(f"fp16 contract {stem}: anchor-twin band fired on {len(twin_frames)} of {len(ws)} frames: " + "; ".join(f"{n}: engine {g} oracle {r}" for n, g, r in twin_frames))
+    FP16_CONTRACT[stem] = (ws, rows, twin_frames)
+    assert len(ws) == 104 and ws.max() <= 9e-4, rows[:6]
+    # The anchor-twin band (tests/anchor_twins.py) may fire ONLY where it is known to: one frame of the 208, where the oracle's own scores
+    # of the two anchors differ by 3e-6 (0.997809 / 0.997806).  A firing anywhere else is a set divergence this test must not absorb
+    # (ADVICE r5): it fails until a person has looked at the pair and added it here.
+    known = {("mnet-deconv-0517 448x448 b8 cfg402 #1", (1593, 301), (1593, 300))}
+    fired = {(n, tuple(g), tuple(int(a) for a in r)) for n, g, r in twin_frames}
+    assert fired <= known, fired - known
+
+
+def test_fp16_contract_summary():
+    """The two halves of the contract together: >= 200 frames, one worst figure (what DESIGN.md quotes)."""
+    if set(FP16_CONTRACT) != set(STEMS):
+        pytest.skip("the per-model contract tests did not both run in this session")
+    ws = np.concatenate([FP16_CONTRACT[s][0] for s in STEMS])
+    rows = sorted(sum((FP16_CONTRACT[s][1] for s in STEMS), []), key=lambda r: -r[0])
+    print(f"fp16 contract: {len(ws)} frames, worst 1-IoU {ws.max():.3e}, mean {ws.mean():.3e}, p99 {np.quantile(ws, 0.99):.3e}; worst: "
+          + "; ".join(f"{w:.2e} {n}" for w, n in rows[:4]) + f"; twin band fired on {sum(len(FP16_CONTRACT[s][2]) for s in STEMS)} frame(s)")
+    assert len(ws) >= 200 and ws.max() <= 9e-4
+
+
+def test_handle_refuses_concurrent_entry(rfa):
+    """include/retinaface_amd.h: one handle = one caller thread at a time, ENFORCED (round 6): while a long synchronous call is in flight, calls
+    from a second thread on the same handle come back RF_ERR_INVALID_ARG with "handle in use by another thread" and do not disturb the call
+    in flight (same detections as an undisturbed run); afterwards the handle works from any thread."""
+    import ctypes as C
+    import threading
+    from retinaface_amd import _lib
+    from retinaface_amd.frames import synth_frames
+    frames = synth_frames(448, 448, 256, config=5)
+    det = engine(rfa, "mnet25", FP16, (448, 448), max_batch=32)
+    quiet = _key(det.detectBatchImages(frames, 0.5))
+    lib = _lib.load_library()
+    refused, other, stop = [], [], threading.Event()
+
+    def intruder():
+        counts = (C.c_int * 8)()
+        while not stop.is_set():
+            st = lib.rf_last_candidate_counts(det._h, counts, 8)
+            if st == _lib.RF_ERR_INVALID_ARG:
+                refused.append(lib.rf_last_error(det._h).decode())
+            else:
+                other.append(st)
+
+    th = threading.Thread(target=intruder)
+    th.start()
+    try:
+        busy = [_key(det.detectBatchImages(frames, 0.5)) for _ in range(3)]
+    finally:
+        stop.set()
+        th.join()
+    assert all(b == quiet for b in busy)
+    assert refused and all("in use by another thread" in r for r in refused), (len(refused), len(other))
+    assert all(st >= 0 for st in other), sorted(set(other))
+    counts = (C.c_int * 8)()
+    assert lib.rf_last_candidate_counts(det._h, counts, 8) >= 0          # the refusal left no state behind
+    assert _key(det.detectBatchImages(frames[:8], 0.5)) == quiet[:8]
+    det.close()
 
 
 def test_candidate_overflow_is_reported(rfa, crop448):

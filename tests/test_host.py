@@ -98,17 +98,31 @@ def test_graph_compiler_fold_matches_numpy(stem, built_lib, nets):
 @needs_reference
 @pytest.mark.parametrize("stem", STEMS)
 def test_cxx_loader_reads_the_reference_files(stem, built_lib, tmp_path):
-    """prototxt + caffemodel + int8 table parsed by the C++ loader and re-packed must equal the committed .rfw byte
-    for byte (the Python writer produced that one), and the plan compiled straight from the Caffe files must equal
-    the plan compiled from the .rfw."""
+    """prototxt + caffemodel + int8 table parsed by the C++ loader, re-packed and given the calibrated weights (rf_attach_calibration)
+    must equal the committed .rfw byte for byte (the Python writer produced that one), and the plan compiled straight from the
+    Caffe files must equal the plan compiled from the .rfw.  The tables: this repo's calibration of either model (tools/calibrate_int8.py,
+    assets/<stem>[.cal].table.int8 + .qweights.int8); the TensorRT table the reference ships for 0517 is packed too and must give the
+    same container minus the calibration."""
     m = os.path.join(REFERENCE, "model")
     out = str(tmp_path / (stem + ".rfw"))
-    # 0517: the TensorRT table the reference ships; mnet25: the table tools/calibrate_int8.py generated (assets/)
-    table = os.path.join(m, "mnet-deconv-0517.table.int8") if stem == "mnet-deconv-0517" else os.path.join(ASSETS, "mnet25.table.int8")
+    base = os.path.join(ASSETS, stem + (".cal" if stem == "mnet-deconv-0517" else ""))
     st = built_lib.rf_convert_model(os.path.join(m, stem + ".prototxt").encode(), os.path.join(m, stem + ".caffemodel").encode(),
-                                    table.encode(), out.encode())
+                                    (base + ".table.int8").encode(), out.encode())
     assert st == 0, built_lib.rf_last_error(None)
-    assert open(out, "rb").read() == open(os.path.join(ASSETS, stem + ".rfw"), "rb").read()
+    os.makedirs(tmp_path / "packed")
+    out2 = str(tmp_path / "packed" / (stem + ".rfw"))
+    st = built_lib.rf_attach_calibration(str(tmp_path).encode(), stem.encode(), None, (base + ".qweights.int8").encode(), out2.encode())
+    assert st == 0, built_lib.rf_last_error(None)
+    assert open(out2, "rb").read() == open(os.path.join(ASSETS, stem + ".rfw"), "rb").read()
+    if stem == "mnet-deconv-0517":
+        # the reference's own TensorRT cache still packs (per tensor, no calibrated weights): a new table drops the weights chosen under the old one
+        trt = os.path.join(m, "mnet-deconv-0517.table.int8")
+        assert open(trt, "rb").read() == open(os.path.join(ASSETS, "mnet-deconv-0517.table.int8"), "rb").read()
+        out3 = str(tmp_path / "trt.rfw")
+        assert built_lib.rf_attach_calibration(ASSETS.encode(), stem.encode(), trt.encode(), None, out3.encode()) == 0
+        from oracle.caffe_io import read_int8_table, read_rfw
+        back = read_rfw(out3)
+        assert back.int8_qweights == {} and back.int8_scales == read_int8_table(trt)
     a = _folded(built_lib, m, stem, "ssh0.b")
     b = _folded(built_lib, ASSETS, stem, "ssh0.b")
     assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])

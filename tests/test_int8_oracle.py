@@ -1,6 +1,8 @@
 """Pin the integer-exact int8 oracle (oracle/int8_forward.py) on the CPU: known answers for its float epilogue, its two conv
 back-ends against each other, its upsample + add against the Caffe-semantics deconvolution of the fp32 oracle, and the whole
 int8 network against the fp32 oracle (quantisation noise only).  The GPU engine is then held BIT-exact to it (-m gpu)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -35,6 +37,8 @@ def test_requantisation_known_answers():
         assert _requant([acc], [m], [b]) == [fused]
         two_step = np.float32(np.float32(np.float32(acc) * np.float32(m)) + np.float32(b))
         assert int(np.rint(two_step)) == unfused
+    # depthwise outputs (round 6): ReLU'd quanta 0..255 stored minus 128 (relu = 2): ties to even, saturation at 255, negatives -> 0
+    assert _requant([5, 7, -3, 1000, 509, 511, 256], [0.5] * 7, [0.0] * 7, relu=2) == [2 - 128, 4 - 128, -128, 127, 254 - 128, 127, 0]
     # int32 -> float conversion of the accumulator rounds to nearest even above 2**24 (15-bit depthwise taps reach 1.9e7)
     assert _requant([2 ** 24 + 1, 2 ** 24 + 3], [2.0 ** -18] * 2, [0.0] * 2) == [64, 64]
 
@@ -118,7 +122,11 @@ def test_per_channel_table_with_equal_channels_equals_the_per_tensor_table(nets)
     common scale (the largest) and blend in integers: with equal scales for all three the two blends are the same function, so the
     whole network must agree activation for activation."""
     import copy
+    from conftest import ASSETS
+    from oracle.caffe_io import read_int8_table
     net = copy.deepcopy(nets["mnet-deconv-0517"])
+    net.int8_qweights = {}            # the per-tensor table is the reference's TensorRT cache (assets/mnet-deconv-0517.table.int8), rounded to nearest
+    net.int8_scales = read_int8_table(os.path.join(ASSETS, "mnet-deconv-0517.table.int8"))
     base = dict(net.int8_scales)
     # force the three tensors of each add to one per-tensor scale, so that the per-tensor engine's ratios are exactly 1
     for group in (("rf_c3_lateral_relu", "rf_c2_lateral_relu", "_plus0"), ("rf_c2_aggr_relu", "rf_c1_red_conv_relu", "_plus1")):
@@ -156,3 +164,42 @@ def test_per_channel_table_with_equal_channels_equals_the_per_tensor_table(nets)
             assert all(np.array_equal(a[k][h], b[k][h]) for h in a[k])
         else:
             assert np.array_equal(a[k], b[k]), k
+
+
+def test_u8_mid_algebra_and_calibrated_weights(nets):
+    """A pointwise conv whose input is a depthwise mid stored as q - 128: sum_k w_q (q - 128) with the bias fmaf(mult, 128 * sum_k w_q, bias)
+    is the conv over the unsigned quanta (exact integers; one extra fp32 rounding in the bias), the mid's scale is the table's x fp32(127/255),
+    and calibrated weights replace the rounding but not the grid."""
+    rng = np.random.default_rng(3)
+    w = rng.standard_normal((32, 1, 1, 16)).astype(np.float32) * 0.1
+    b = rng.standard_normal(32).astype(np.float32)
+    s_in = rng.uniform(0.01, 0.05, 16).astype(np.float32)
+    s_out = rng.uniform(0.02, 0.06, 32).astype(np.float32)
+    g = i8.QGemm(w, b, s_in, s_out, in_u8=True)
+    plain = i8.QGemm(w, b, (s_in * i8.MID_U8).astype(np.float32), s_out)
+    assert np.array_equal(g.wq, plain.wq) and np.array_equal(g.mult, plain.mult)
+    q = rng.integers(0, 256, (5, 7, 16))
+    acc_u = np.einsum("hwk,ok->hwo", q, plain.wq.reshape(32, 16))
+    acc_s = np.einsum("hwk,ok->hwo", q - 128, g.wq.reshape(32, 16))
+    y_u = acc_u * plain.mult.astype(np.float64) + plain.bias.astype(np.float64)
+    y_s = acc_s * g.mult.astype(np.float64) + g.bias.astype(np.float64)
+    assert np.abs(y_u - y_s).max() <= 4e-6 * max(1.0, float(np.abs(y_u).max()))          # the only difference: fp32 rounding of the folded bias
+    # calibrated integers: taken as they are, same multipliers, bias shifted by bias_delta / s_out
+    cq = np.clip(plain.wq.reshape(32, 16) + rng.integers(-1, 2, (32, 16)), -127, 127).astype(np.int8)
+    db = rng.standard_normal(32).astype(np.float32) * 0.01
+    c = i8.QGemm(w, b, s_in, s_out, calibrated=(cq, db))
+    n = i8.QGemm(w, b, s_in, s_out)
+    assert np.array_equal(c.wq.reshape(32, 16), cq) and np.array_equal(c.mult, n.mult)
+    assert np.array_equal(c.bias, ((b + db).astype(np.float32) / s_out).astype(np.float32))
+    # the shipped models carry calibrated weights for every fused dense conv, all inside the int8 grid, and they differ from plain rounding
+    for stem in STEMS:
+        net = nets[stem]
+        assert len(net.int8_qweights) == 29
+        q8 = i8.Int8Net(net)
+        import copy
+        rtn = copy.copy(net)
+        rtn.int8_qweights = {}
+        q0 = i8.Int8Net(rtn)
+        moved = np.mean([np.mean(a.wq != b.wq) for a, b in zip(q8.pw[1:], q0.pw[1:])])
+        assert 0.03 < moved < 0.4, moved
+        assert all(np.abs(a.wq - b.wq).max() <= 3 for a, b in zip(q8.pw[1:], q0.pw[1:]))

@@ -18,10 +18,11 @@ from oracle.retinaface_post import (anchor_offsets, anchors_plane, base_anchors,
 def test_rfw_assets_equal_reference_files(stem, nets):
     """assets/*.rfw must hold exactly what the prototxt + caffemodel + int8 table hold."""
     m = os.path.join(REFERENCE, "model")
-    # int8 scales: 0517 carries the TensorRT table the reference ships; mnet25 (no table in the reference) the one generated by
-    # tools/calibrate_int8.py and kept as text in assets/
-    table = os.path.join(m, "mnet-deconv-0517.table.int8") if stem == "mnet-deconv-0517" else \
-        os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "assets", "mnet25.table.int8")
+    # int8 calibration: this repo's own for both models (tools/calibrate_int8.py; the reference ships a TensorRT table for 0517 only, kept
+    # beside it as assets/mnet-deconv-0517.table.int8), as text + RFQ1 files in assets/
+    assets = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "assets")
+    base = os.path.join(assets, stem + (".cal" if stem == "mnet-deconv-0517" else ""))
+    table = base + ".table.int8"
     ref = load_caffe_model(os.path.join(m, stem + ".prototxt"), os.path.join(m, stem + ".caffemodel"), table)
     got = nets[stem]
     assert got.input_shape == ref.input_shape and len(got.layers) == len(ref.layers) == 209
@@ -34,6 +35,11 @@ def test_rfw_assets_equal_reference_files(stem, nets):
         for x, y in zip(a.blobs, b.blobs):
             assert x.shape == y.shape and np.array_equal(x, y)
     assert got.int8_scales == ref.int8_scales
+    from oracle.caffe_io import read_int8_qweights
+    loose = read_int8_qweights(base + ".qweights.int8")
+    assert set(loose) == set(got.int8_qweights) and len(loose) == 29
+    for k, (q, db) in loose.items():
+        assert np.array_equal(q, got.int8_qweights[k][0]) and np.array_equal(db, got.int8_qweights[k][1]) and np.abs(q.astype(int)).max() <= 127
 
 
 def test_model_inventory(nets):
@@ -52,8 +58,11 @@ def test_model_inventory(nets):
 
 
 def test_int8_table(nets):
-    """data scale 2.00836 (amax 255.06), 210 entries."""
-    sc = nets["mnet-deconv-0517"].int8_scales
+    """SURVEY.md App. B.7, the TensorRT cache the reference ships (kept verbatim as assets/mnet-deconv-0517.table.int8): data scale 2.00836
+    (amax 255.06), 210 entries."""
+    from conftest import ASSETS
+    from oracle.caffe_io import read_int8_table
+    sc = read_int8_table(os.path.join(ASSETS, "mnet-deconv-0517.table.int8"))
     assert len(sc) == 210
     assert abs(sc["data"] - 2.00836) < 1e-4 and abs(sc["data"] * 127 - 255.06) < 0.01
     assert abs(sc["mobilenet0_conv0_fwd"] - 11.55) < 0.01

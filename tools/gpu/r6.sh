@@ -14,7 +14,7 @@ for recipe in "$@"; do
       ( time timeout 1400 python -m pytest tests -m gpu -q --durations=8 -s ) > $O/pytest.log 2>&1; echo "rc $?" >> $O/pytest.log
       grep -v "compute time" $O/pytest.log | grep -E "passed|failed|contract|^rc|real|s call" | tail -24 ;;
     int8_tests)
-      ( time timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -q -x -s -k "int8 or calibration" ) > $O/pytest_int8.log 2>&1; echo "rc $?" >> $O/pytest_int8.log
+      ( time timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -q -s -k "int8 or calibration or concurrent" ) > $O/pytest_int8.log 2>&1; echo "rc $?" >> $O/pytest_int8.log
       grep -v "compute time" $O/pytest_int8.log | grep -E "passed|failed|Error|assert|int8|^rc|real" | tail -20 ;;
     smoke)
       timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; tail -1 $O/smoke.log ;;
@@ -25,9 +25,9 @@ for recipe in "$@"; do
             --out $O/cal/$m.table.int8 --out-rfw $O/cal/$m.rfw > $O/calibrate_$m.log 2>&1; echo "calibrate $m rc $?"; grep -E "weights calibrated|wrote" $O/calibrate_$m.log
       done ;;
     contract_old)   # the int8 contract numbers of the assets as shipped (+ fp16 through the same metric)
-      timeout 1200 python tools/probes/int8_contract.py --fp16 --json $O/int8_contract_shipped_assets.json > $O/int8_contract_shipped_assets.txt 2>&1; cat $O/int8_contract_shipped_assets.txt | grep contract ;;
+      timeout 1200 python tools/probes/int8_contract_probe.py --fp16 --json $O/int8_contract_shipped_assets.json > $O/int8_contract_shipped_assets.txt 2>&1; cat $O/int8_contract_shipped_assets.txt | grep contract ;;
     contract_new)   # ... of the calibration made by `calibrate` in this call
-      timeout 1200 python tools/probes/int8_contract.py --assets $O/cal --json $O/int8_contract_new_calibration.json > $O/int8_contract_new_calibration.txt 2>&1; cat $O/int8_contract_new_calibration.txt | grep contract ;;
+      timeout 1200 python tools/probes/int8_contract_probe.py --assets $O/cal --json $O/int8_contract_new_calibration.json > $O/int8_contract_new_calibration.txt 2>&1; cat $O/int8_contract_new_calibration.txt | grep contract ;;
     kbench_int8)
       timeout 200 python tools/kbench.py --n 256 --precision int8 --batch 32 --tag r6_${TAG}_int8 > $O/kbench_int8.txt 2>&1; cat $O/kbench_int8.txt | cut -c1-70 ;;
     kbench_fp16)

@@ -2,7 +2,7 @@
 """Probe (GPU): the int8 contract numbers (tests/int8_contract.py) of the int8 engine built from a model directory -- the shipped assets
 or a calibration under test -- and, beside them, of the fp16 engine on the same frames (what "no quantisation" scores on this metric).
 
-usage: python tools/probes/int8_contract.py [--assets DIR] [--models mnet25,mnet-deconv-0517] [--fp16] [--small] [--json OUT]
+usage: python tools/probes/int8_contract_probe.py [--assets DIR] [--models mnet25,mnet-deconv-0517] [--fp16] [--small] [--json OUT]
 """
 import argparse
 import json
