@@ -411,6 +411,39 @@ def main() -> int:
     dt, faces = regions[med]
     region_rates = [regions_all[i][1] / regions_all[i][0] for i in range(len(regions_all))]
 
+    # N > 1: every rank's own rate over the median region (a straggler GPU is invisible in MAX / SUM), then rank 0 ALONE -- the other ranks idle at
+    # the barrier -- for the same loop without the gather: `scaling_efficiency` = value / (N x that rate), measured inside this run
+    per_rank = None
+    if world > 1:
+        mine = torch.tensor([[float(rank), dt, float(faces), float(steps * B)]], dtype=torch.float64, device=cdev)
+        allr = torch.empty((world, 4), dtype=torch.float64, device=cdev)
+        dist.all_gather_into_tensor(allr, mine)
+        rows_ = sorted(allr.cpu().tolist())
+        ips = [r[3] / max(r[1], 1e-12) for r in rows_]
+        per_rank = {"images_per_sec": ips, "faces_per_sec": [r[2] / max(r[1], 1e-12) for r in rows_], "seconds": [r[1] for r in rows_],
+                    "min_images_per_sec": min(ips), "max_images_per_sec": max(ips), "slowest_rank": int(ips.index(min(ips))),
+                    "min_over_max": min(ips) / max(max(ips), 1e-12),
+                    "note": "each rank's own clock around its own steps of the median region (the line's value uses the MAX time over ranks)"}
+        alone_steps = max(slots, min(steps, int(np.ceil(max(args.extra_seconds, 0.05) / max(dt / steps, 1e-9))) // slots * slots)) if not args.dry else slots
+        barrier()
+        alone = torch.zeros(2, dtype=torch.float64, device=cdev)
+        if rank == 0:
+            t0 = time.perf_counter()
+            f0 = run(alone_steps, prepared_ring, False)
+            if not args.dry:
+                torch.cuda.synchronize()
+            alone = torch.tensor([time.perf_counter() - t0, float(f0)], dtype=torch.float64, device=cdev)
+        barrier()
+        dist.broadcast(alone, src=0)
+        per_rank["rank0_alone"] = {"steps": alone_steps, "seconds": float(alone[0]), "images_per_sec": alone_steps * B / max(float(alone[0]), 1e-12),
+                                   "faces_per_sec": float(alone[1]) / max(float(alone[0]), 1e-12),
+                                   "note": "rank 0 runs the same loop with every other rank idle and no gather: the denominator of scaling_efficiency"}
+
+    # N > 1: the BATCH SPLIT north_star prescribes, A/B'd between the ranks (every rank takes part): see split_ab()
+    split_leg = None
+    if world > 1 and not strong and not args.timed_only and not args.no_extra_configs and args.extra_seconds > 0:
+        split_leg = split_ab(args, world, rank, dev, cdev, barrier, backend, thr)
+
     # N > 1, weak-scaling invocation (what the driver's SCALE run types): a short STRONG-scaling leg of BASELINE.json configs[4] as stated
     # follows -- ONE global batch of 256 int8 images per step, rank r runs shard_range(256, r, N) of it, records gathered in the region
     strong_leg = None
@@ -494,9 +527,17 @@ def main() -> int:
                                     "ranks_in_communicator": comm["ranks_in_communicator"], "rank_device": comm["ranks"],
                                     "gathers_in_timed_region": gather_state["gathers"],
                                     "bytes_per_rank_per_gather": int(per_launch * B_pad * R.rec_w * 4),
-                                    "records_gathered": int(gather_state["images"].item()), "expected": images_total}
+                                    "records_gathered": int(gather_state["images"].item()), "expected": images_total,
+                                    "per_rank": per_rank}
+            alone_ips = per_rank["rank0_alone"]["images_per_sec"]
+            out["scaling_efficiency"] = {"value": out["images_per_sec"] / max(world * alone_ips, 1e-12), "n_gpus": world,
+                                         "is": "images/s of the N-rank job / (N x images/s of rank 0 running ALONE in this same run)",
+                                         "rank0_alone_images_per_sec": alone_ips, "scaling": "strong" if strong else "weak",
+                                         "on_distinct_devices": comm.get("distinct_devices", 1) == world}
         if strong_leg is not None:
             out["configs4_strong"] = strong_leg
+        if split_leg is not None:
+            out["batch_split_ab"] = split_leg
         if with_library_leg:
             try:
                 out["library_multi_device"] = library_leg(args, world, thr)
@@ -541,7 +582,7 @@ def main() -> int:
             if rank == 0:
                 store.set("rf_library_leg", "done")
             else:
-                store.wait(["rf_library_leg"], datetime.timedelta(seconds=900))
+                store.wait(["rf_library_leg"], datetime.timedelta(seconds=120))      # the library leg is bounded (LIBRARY_LEG_BUDGET_S): 120 s = build + leg + slack
         dist.barrier()
         dist.destroy_process_group()
     return 0
@@ -763,6 +804,122 @@ def finish_extra_counters(holder, entries, n_cu):
                                "mfma_busy": whole.get("mfma_busy")}
 
 
+def split_ab(args, world, rank, dev, cdev, barrier, backend, thr, G=256):
+    """north_star: "RCCL over xGMI only for the batch split / gather" (ncclGroupStart{ncclSend / ncclRecv} scatter, "alternative to measure
+    against: direct H2D").  One step = ONE batch of G = 256 mnet25 int8 448 x 448 frames (BASELINE.json configs[4]); rank r runs shard_range(G, r, N) of
+    it through ONE synchronous call on its own engine and the per-image counts come back through an all_gather.  Three ways the slice reaches rank r:
+      rccl_send_recv   all G frames live on rank 0's GPU; torch.distributed.batch_isend_irecv = one ncclGroupStart{ncclSend x (N-1)} on rank 0 and one
+                       ncclRecv on every other rank (backend nccl = RCCL over xGMI), slice 0 is read in place;
+      direct_h2d       every rank's slice waits in ITS OWN pinned host memory and crosses PCIe with one hipMemcpyAsync (no inter-GPU traffic at all);
+      resident         the slice is already on the rank's GPU (the floor: detect + gather only).
+    ms per step each, MAX over ranks.  The in-library split (hipMemcpyPeerAsync, one handle over N devices) is library_multi_device.split_ab.
+    With ranks sharing a GPU (--oversubscribe) or --dry the backend is gloo and the 'xGMI' legs move host tensors: a rehearsal of the code path."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from retinaface_amd import shard
+    H = W = 448
+    lo, hi = shard.shard_range(G, rank, world)
+    Bs = hi - lo
+    fb = 16 if args.dry else H * W * 3
+    rehearsal = backend != "nccl"
+    if args.dry:
+        det = StubEngine(max(Bs, 1), 0, 0)
+        whole = torch.zeros((G, 16), dtype=torch.uint8) if rank == 0 else None           # stand-in "frames": 16 bytes each
+        mine = torch.zeros((max(Bs, 1), 16), dtype=torch.uint8)
+        host = mine.clone()
+        prep = lambda: 1000 * rank                                                        # noqa: E731
+    else:
+        import retinaface_amd
+        from retinaface_amd.frames import synth_frames
+        det = retinaface_amd.RetinaFace(os.path.join(ROOT, "assets"), "net3", 0.4, precision=2, net_hw=(H, W), max_batch=max(Bs, 1), model_stem="mnet25")
+        src = np.stack(synth_frames(H, W, 64, config=47))
+        whole_np = src[np.arange(G) % 64]
+        xdev = cdev if rehearsal else dev                      # where the tensors of the send / recv live (gloo: host)
+        whole = torch.from_numpy(whole_np).to(xdev) if rank == 0 else None
+        mine = torch.empty((max(Bs, 1), H, W, 3), dtype=torch.uint8, device=dev)       # the rank's slice on ITS GPU: what the engine reads
+        recv = mine if not rehearsal else torch.empty((max(Bs, 1), H, W, 3), dtype=torch.uint8)
+        host = torch.from_numpy(whole_np[lo:hi].copy()).pin_memory()
+        mine[:Bs].copy_(host)
+        torch.cuda.synchronize()
+        pb = det.prepare_device_batch([mine[i].data_ptr() for i in range(Bs)], [H] * Bs, [W] * Bs)
+        prep = lambda: pb                                                                 # noqa: E731
+
+    def detect():
+        if Bs == 0:
+            return 0
+        return sum(det.wait_counts(det.enqueue_prepared(prep(), thr), Bs))
+
+    def move_rccl():
+        ops = []
+        if rank == 0:
+            for r in range(1, world):
+                a, b = shard.shard_range(G, r, world)
+                if b > a:
+                    ops.append(dist.P2POp(dist.isend, whole[a:b], r))
+            if not args.dry and Bs:
+                mine[:Bs].copy_(whole[lo:hi], non_blocking=True)        # slice 0: on this GPU already (a device-to-device copy stands in for "read in place")
+        elif Bs:
+            ops.append(dist.P2POp(dist.irecv, (mine if args.dry else recv)[:Bs], 0))
+        for q in (dist.batch_isend_irecv(ops) if ops else []):
+            q.wait()
+        if not args.dry:
+            if rehearsal and rank != 0 and Bs:
+                mine[:Bs].copy_(recv[:Bs], non_blocking=True)
+            torch.cuda.synchronize()                                    # the engine's lanes are their own streams: the slice must have landed
+
+    def move_h2d():
+        if not args.dry and Bs:
+            mine[:Bs].copy_(host, non_blocking=True)
+            torch.cuda.synchronize()
+
+    out = {"workload": f"mnet25 int8 HIP, 448x448, ONE batch of {G} frames per step split over {world} rank(s) by shard_range, one synchronous call per rank "
+                       "(BASELINE.json configs[4]); how the slice reaches the rank is what varies",
+           "global_batch": G, "bytes_per_step": G * fb, "backend": backend, "rehearsal_not_xgmi": bool(rehearsal or args.dry), "legs": {}}
+    cnt = torch.zeros((max(-(-G // world), 1),), dtype=torch.int32)
+    allc = torch.empty((world * cnt.numel(),), dtype=torch.int32, device=cdev)
+    budget = 0.05 if args.dry else max(args.extra_seconds, 0.2)
+    for name, move in (("resident", lambda: None), ("rccl_send_recv", move_rccl), ("direct_h2d", move_h2d)):
+        for _ in range(2):                                   # warm-up: communicator / engine / graph
+            move()
+            detect()
+        barrier()
+        lat, faces, t_start = [], 0, time.perf_counter()
+        while True:
+            go = torch.tensor([1.0 if (len(lat) < 3 or time.perf_counter() - t_start < budget) and len(lat) < 400 else 0.0], device=cdev)
+            dist.broadcast(go, src=0)                        # every rank runs the same number of steps (rank 0 decides)
+            if float(go.item()) == 0.0:
+                break
+            barrier()
+            t = time.perf_counter()
+            move()
+            faces = detect()
+            cnt.zero_()
+            cnt[0] = faces
+            dist.all_gather_into_tensor(allc, cnt.to(cdev))
+            if not args.dry:
+                torch.cuda.synchronize()
+            lat.append(time.perf_counter() - t)
+        med = torch.tensor([float(np.median(lat))], dtype=torch.float64, device=cdev)
+        dist.all_reduce(med, op=dist.ReduceOp.MAX)
+        tot = torch.tensor([float(faces)], dtype=torch.float64, device=cdev)
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        ms = float(med.item()) * 1e3
+        out["legs"][name] = {"ms_per_step": ms, "images_per_sec": G / (ms * 1e-3), "faces_per_step": float(tot.item()), "steps_timed": len(lat)}
+    base = out["legs"]["resident"]["ms_per_step"]
+    for name in ("rccl_send_recv", "direct_h2d"):
+        leg = out["legs"][name]
+        leg["split_ms_over_resident"] = leg["ms_per_step"] - base
+        moved = (G - (shard.shard_range(G, 0, world)[1])) * fb if name == "rccl_send_recv" else G * fb
+        leg["bytes_moved_per_step"] = moved
+        leg["GBs_if_serial"] = moved / max(leg["split_ms_over_resident"] * 1e-3, 1e-9) / 1e9 if leg["split_ms_over_resident"] > 0 else None
+    same = len({round(v["faces_per_step"]) for v in out["legs"].values()}) == 1
+    out["same_detections_every_leg"] = bool(same)
+    out["winner"] = None if out["rehearsal_not_xgmi"] else min(("rccl_send_recv", "direct_h2d"), key=lambda k: out["legs"][k]["ms_per_step"])
+    det.close()
+    return out
+
+
 def strong_config4(args, world, rank, dev, cdev, barrier, frames, thr, G=256):
     """BASELINE.json configs[4] as stated, on this job's N ranks: a step is ONE batch of G = 256 mnet25 int8 448x448 images, rank r runs
     shard_range(G, r, N) of it, every image's record comes back through the all_gather inside the timed region.  Every rank calls this."""
@@ -824,7 +981,10 @@ def library_leg(args, n_devices, thr, G=256, seconds=None):
     import numpy as np
     import torch
     if args.dry:
-        return {"dry": True, "devices": list(range(n_devices)), "global_batch": G, "images_per_engine": -(-G // n_devices)}
+        return {"dry": True, "devices": list(range(n_devices)), "global_batch": G, "images_per_engine": -(-G // n_devices),
+                "split_ab": {"peer_copy_per_slice": None, "peer_copy_per_frame": None, "host_frames_direct_h2d": None,
+                             "rccl_send_recv": "see batch_split_ab (needs one process per GPU)", "measured_over_xgmi": False},
+                "leg_budget_seconds": LIBRARY_LEG_BUDGET_S}
     import retinaface_amd
     from retinaface_amd.frames import synth_frames
     H = W = 448
@@ -842,24 +1002,82 @@ def library_leg(args, n_devices, thr, G=256, seconds=None):
     want = one.detect_device(ptrs, [H] * G, [W] * G, thr)
     sync_one = sync_batch_measure(one, ptrs, H, W, thr, reps=12)           # timed at the C ABI: the Python binding spends ~3 ms building 256 images' result objects
     one.close()
-    had = os.environ.get("RF_FORCE_SCATTER")
-    if forced:
-        os.environ["RF_FORCE_SCATTER"] = "1"          # read by the engines when they are built
-    try:
-        multi = retinaface_amd.RetinaFace(os.path.join(ROOT, "assets"), "net3", 0.4, precision=2, net_hw=(H, W), max_batch=32, model_stem="mnet25",
-                                          devices=devices)
-    finally:
-        if forced and had is None:
-            os.environ.pop("RF_FORCE_SCATTER", None)
+    def build_multi(per_frame):
+        """one handle over `devices`; RF_FORCE_SCATTER / RF_SCATTER_PER_FRAME are read by the engines when they are built"""
+        had = {k: os.environ.get(k) for k in ("RF_FORCE_SCATTER", "RF_SCATTER_PER_FRAME")}
+        if forced:
+            os.environ["RF_FORCE_SCATTER"] = "1"
+        if per_frame:
+            os.environ["RF_SCATTER_PER_FRAME"] = "1"
+        else:
+            os.environ.pop("RF_SCATTER_PER_FRAME", None)
+        try:
+            return retinaface_amd.RetinaFace(os.path.join(ROOT, "assets"), "net3", 0.4, precision=2, net_hw=(H, W), max_batch=32, model_stem="mnet25",
+                                             devices=devices)
+        finally:
+            for k, v in had.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
+
     key = lambda res: [[(d.anchor_index, d.as_row().tobytes()) for d in r] for r in res]      # noqa: E731
+    t_leg = time.perf_counter()
+    multi = build_multi(False)
+    s0 = multi.scatter_stats()
     got = multi.detect_device(ptrs, [H] * G, [W] * G, thr)
+    s1 = multi.scatter_stats()                                             # the counters of exactly ONE 256-image call
     identical = key(got) == key(want)
     sync = sync_batch_measure(multi, ptrs, H, W, thr, reps=12, seconds=seconds)
+    calls = 1
     nd = multi.num_devices()
-    multi.close()
     per = -(-G // n_devices)
     travelled = G if forced else sum(min(per, max(0, G - g * per)) for g in range(n_devices) if devices[g] != 0)
     med = sync["ms_per_call"] * 1e-3
+    # ---- the split A/B (VERDICT r5 next #2a): how the slices reach their engines, ms per 256-image call each.  Runs whenever frames travel
+    # (more than one visible GPU, or the forced rehearsal); every entry null on a plain one-GPU run.  The RCCL send / recv variant needs one
+    # process per GPU and lives in the N-rank part of this bench: `batch_split_ab`.
+    split = {"peer_copy_per_slice": None, "peer_copy_per_frame": None, "host_frames_direct_h2d": None, "rccl_send_recv": "see batch_split_ab (needs one process per GPU)",
+             "what": "ms per rf_detect_batch* call of 256 images through ONE handle over the devices; per_slice = one hipMemcpyPeerAsync per contiguous run of "
+                     "frames (round 6 default), per_frame = one per frame (rounds 3-5, RF_SCATTER_PER_FRAME=1), host_frames_direct_h2d = the same frames in pinned "
+                     "HOST memory through rf_detect_batch: each engine uploads its own slice over its own PCIe link, no inter-GPU traffic",
+             "measured_over_xgmi": bool(not forced and len(distinct) > 1)}
+    if forced or len(distinct) > 1:
+        budget_left = lambda: LIBRARY_LEG_BUDGET_S - (time.perf_counter() - t_leg)      # noqa: E731
+        split["peer_copy_per_slice"] = {"ms_per_call": sync["ms_per_call"], "peer_copies_per_call": (s1["peer_copies"] - s0["peer_copies"]) / calls,
+                                        "frames_scattered_per_call": (s1["frames"] - s0["frames"]) / calls}
+        if budget_left() > 6:
+            pf = build_multi(True)
+            a0 = pf.scatter_stats()
+            same_pf = key(pf.detect_device(ptrs, [H] * G, [W] * G, thr)) == key(want)
+            a1 = pf.scatter_stats()
+            spf = sync_batch_measure(pf, ptrs, H, W, thr, reps=12, seconds=min(seconds, 0.5))
+            split["peer_copy_per_frame"] = {"ms_per_call": spf["ms_per_call"], "peer_copies_per_call": a1["peer_copies"] - a0["peer_copies"],
+                                            "frames_scattered_per_call": a1["frames"] - a0["frames"], "detections_identical": bool(same_pf)}
+            pf.close()
+        if budget_left() > 4:
+            import ctypes as C
+            from retinaface_amd._lib import rf_face
+            hostbuf = np.ascontiguousarray(frames.cpu().numpy()[np.arange(G) % 64])
+            multi.host_register(hostbuf)
+            pa = (C.c_void_p * G)(*[hostbuf[i].ctypes.data for i in range(G)])
+            ra, ca, sa = (C.c_int * G)(*([H] * G)), (C.c_int * G)(*([W] * G)), (C.c_int * G)(*([3 * W] * G))
+            outb, cnt = (rf_face * (G * multi.max_detections))(), (C.c_int * G)()
+            lat = []
+            t0 = time.perf_counter()
+            while len(lat) < 6 or (time.perf_counter() - t0 < min(seconds, 0.5) and len(lat) < 200):
+                t = time.perf_counter()
+                multi._lib.rf_detect_batch(multi._h, pa, ra, ca, sa, G, C.c_float(thr), outb, multi.max_detections, cnt)
+                lat.append(time.perf_counter() - t)
+            want_counts = [len(r) for r in want]
+            split["host_frames_direct_h2d"] = {"ms_per_call": float(np.median(lat[1:]) * 1e3), "bytes_uploaded_per_call": G * H * W * 3,
+                                               "face_counts_identical": [cnt[i] for i in range(G)] == want_counts,
+                                               "note": "caller memory pinned once with rf_host_register (DMA in place)"}
+            multi.host_unregister(hostbuf)
+        done = [k for k in ("peer_copy_per_slice", "peer_copy_per_frame", "host_frames_direct_h2d") if isinstance(split[k], dict)]
+        split["fastest"] = min(done, key=lambda k: split[k]["ms_per_call"]) if done else None
+        split["fastest_is_a_measurement_of_xgmi"] = split["measured_over_xgmi"]
+    multi.close()
     return {"workload": f"mnet25 int8 HIP, 448x448, ONE handle over devices {devices}, {G} images per rf_detect_batch_device call, all frames resident on GPU 0 "
                         "(BASELINE.json configs[4] as stated, through rf_options.devices / multi.cpp)",
             "devices": devices, "engines": nd, "visible_gpus": ndev, "forced_scatter_rehearsal": forced, "peer_access": {"devices": distinct, "matrix": peer},
@@ -867,11 +1085,15 @@ def library_leg(args, n_devices, thr, G=256, seconds=None):
             "faces_per_sec": sync["faces_per_sec"], "timed_at": "the C ABI (rf_detect_batch_device with argument / result arrays built once)",
             "frames_scattered_per_call": travelled, "bytes_scattered_per_call": travelled * H * W * 3,
             "scatter_GBs_at_this_rate": travelled * H * W * 3 / med / 1e9,
+            "split_ab": split, "leg_seconds": time.perf_counter() - t_leg, "leg_budget_seconds": LIBRARY_LEG_BUDGET_S,
             "single_engine_same_call": {"ms_per_call": sync_one["ms_per_call"], "images_per_sec": sync_one["images_per_sec"],
                                         "note": "one engine on GPU 0 takes the same 256-image call (its eight 32-image chunks coalesce into one 256-image launch sequence)"},
             "detections_identical_to_single_engine": bool(identical), "dtype": "i8", "scaling": "strong",
             "note": "one synchronous call at a time: the per-engine slice of 32 images is a small-batch launch sequence (latency-bound); the pipelined "
                     "per-GPU rate is `configs`[id 4] / the N-rank `value`"}
+
+
+LIBRARY_LEG_BUDGET_S = 20.0      # rank 0 runs the library leg while the other ranks wait on the store (120 s): optional parts are skipped when it runs out
 
 
 SQ_COUNTERS = "SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE"

@@ -187,6 +187,11 @@ int rf_invalidate_residency(rf_handle h);
 /* Engines behind the handle: 1, or options.n_devices for an image-sharding multi-device handle. */
 int rf_num_devices(rf_handle h);
 
+/* The batch split in numbers (since rf_create, summed over the handle's engines): device frames that were found resident on ANOTHER
+ * GPU and pulled over xGMI before their launch, and the hipMemcpyPeerAsync calls that carried them (frames that follow each other in
+ * memory travel as one copy: a contiguous slice of a sharded batch = 1 copy; RF_SCATTER_PER_FRAME=1 in the environment = 1 per frame). */
+int rf_scatter_stats(rf_handle h, long long *frames, long long *copies);
+
 /* Global anchor index (offset(stride) + a*h*w + iy*w + ix, strides 32,16,8) of each
  * detection of image `image` of the most recent completed batch, in the same order as out[]. */
 int rf_last_anchor_indices(rf_handle h, int image, int32_t *out, int cap);

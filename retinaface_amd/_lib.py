@@ -60,6 +60,7 @@ SYMBOLS = {
     "rf_host_unregister": (C.c_int, [C.c_void_p, C.c_void_p]),
     "rf_invalidate_residency": (C.c_int, [C.c_void_p]),
     "rf_num_devices": (C.c_int, [C.c_void_p]),
+    "rf_scatter_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]),
     "rf_last_anchor_indices": (C.c_int, [C.c_void_p, C.c_int, _PP(C.c_int32), C.c_int]),
     "rf_last_candidate_counts": (C.c_int, [C.c_void_p, _PP(C.c_int), C.c_int]),
     "rf_last_timings": (C.c_int, [C.c_void_p, _PP(C.c_float), _PP(C.c_float), _PP(C.c_float), _PP(C.c_float)]),

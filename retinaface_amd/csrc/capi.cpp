@@ -254,6 +254,11 @@ int rf_invalidate_residency(rf_handle h) {
 
 int rf_num_devices(rf_handle h) { return h ? h->eng->num_devices() : RF_ERR_INVALID_ARG; }
 
+int rf_scatter_stats(rf_handle h, long long *frames, long long *copies) {
+    if (!h || !frames || !copies) return RF_ERR_INVALID_ARG;
+    return guarded(h, [&]() -> int { *frames = 0; *copies = 0; h->eng->scatter_stats(frames, copies); return RF_OK; });
+}
+
 int rf_wait(rf_handle h, int ticket, rf_face *out, int cap_per_image, int *counts) {
     if (!h) return RF_ERR_INVALID_ARG;
     return guarded(h, [&]() -> int {

@@ -154,6 +154,7 @@ public:
         // device frames are checked for residency whenever another device exists they could live on (RF_FORCE_SCATTER: test knob,
         // treats every device frame as foreign so the scatter path runs on a one-GPU box)
         force_scatter_ = knob(K_FORCE_SCATTER) != 0;
+        scatter_per_frame_ = knob(K_SCATTER_PER_FRAME) != 0;
         head_start_max_ = knob(K_HEAD_START) ? opt_.max_batch : 0;      // launches of up to max_batch images = synchronous calls and un-coalesced tickets
         copy_streams_ = knob(K_COPY_STREAMS) > 1 ? 2 : 1;       // probe knob RF_COPY_STREAMS (tools/probes/host_rate.py)
         check_residency_ = ndev > 1 || force_scatter_;
@@ -290,6 +291,7 @@ public:
     void host_unregister(const void *ptr) override { drop_range(ptr, true); }
     void host_forget(const void *ptr) override { drop_range(ptr, false); }
     void invalidate_residency() override { residency_.clear(); }
+    void scatter_stats(long long *frames, long long *copies) const override { *frames += scattered_frames_; *copies += peer_copies_; }
 
     // tickets the caller may keep outstanding before it has to wait: every lane can hold a full super-batch
     int num_slots() const override { return (int)lanes_.size() * opt_.coalesce; }
@@ -957,20 +959,22 @@ private:
                 if (cacheable && fresh.base == r.base && fresh.bytes == r.bytes && fresh.owner == r.owner) { r.checked_us = fresh.checked_us; return r.where; }
                 residency_.erase(it);
                 residency_revalidation_misses_++;
-                if (cacheable) residency_[fresh.base] = fresh;
+                if (cacheable) insert_residency(fresh);
                 return fresh.where;
             }
         }
         Residency fresh;
-        if (lookup_residency(p, &fresh)) {
-            if (residency_.size() > 4096) residency_.clear();
-            // a new allocation may overlap stale entries of freed ones: drop every entry that intersects it
-            auto lo = residency_.lower_bound(fresh.base);
-            if (lo != residency_.begin()) { auto pv = std::prev(lo); if (pv->second.base + pv->second.bytes > fresh.base) lo = pv; }
-            while (lo != residency_.end() && lo->second.base < fresh.base + fresh.bytes) lo = residency_.erase(lo);
-            residency_[fresh.base] = fresh;
-        }
+        if (lookup_residency(p, &fresh)) insert_residency(fresh);
         return fresh.where;
+    }
+    // a new allocation may overlap stale entries of freed ones: drop every entry that intersects it (both the miss path and the
+    // stale-revalidation path come through here)
+    void insert_residency(const Residency &fresh) {
+        if (residency_.size() > 4096) residency_.clear();
+        auto lo = residency_.lower_bound(fresh.base);
+        if (lo != residency_.begin()) { auto pv = std::prev(lo); if (pv->second.base + pv->second.bytes > fresh.base) lo = pv; }
+        while (lo != residency_.end() && lo->second.base < fresh.base + fresh.bytes) lo = residency_.erase(lo);
+        residency_[fresh.base] = fresh;
     }
 
     bool is_registered(const uint8_t *p, size_t bytes) const {
@@ -1200,12 +1204,22 @@ private:
                 if (on_device) {
                     // the batch split of a multi-GPU node: frames resident on another device cross xGMI as one peer copy each
                     // (SDMA, on this lane's stream: it overlaps the compute of the super-batches in flight on the other lanes)
-                    for (int i = 0; i < n; i++)
-                        if (!empty[i] && src_dev[i] >= 0) {
-                            RF_HIP(hipMemcpyPeerAsync(dbase + off[i], device_, frames[i], src_dev[i],
-                                                      (size_t)(rows[i] - 1) * steps[i] + (size_t)cols[i] * 3, s.stream));
-                            scattered_frames_++;
-                        }
+                    // Frames that follow each other in the source allocation AND in the staging block (dense rows, a span that is a
+                    // multiple of the 256-byte staging alignment: every BASELINE shape) travel as ONE copy per run -- a contiguous slice of a
+                    // sharded batch is one SDMA descriptor instead of 32 (round 6; RF_SCATTER_PER_FRAME=1 keeps one copy per frame for the A/B).
+                    for (int i = 0; i < n; i++) {
+                        if (empty[i] || src_dev[i] < 0) continue;
+                        size_t run = (size_t)(rows[i] - 1) * steps[i] + (size_t)cols[i] * 3;
+                        int j = i + 1;
+                        if (!scatter_per_frame_ && steps[i] == cols[i] * 3)
+                            while (j < n && !empty[j] && src_dev[j] == src_dev[i] && steps[j] == cols[j] * 3 && frames[j] == frames[i] + run &&
+                                   off[j] == off[i] + run)
+                                run += (size_t)rows[j] * cols[j] * 3, j++;
+                        RF_HIP(hipMemcpyPeerAsync(dbase + off[i], device_, frames[i], src_dev[i], run, s.stream));
+                        scattered_frames_ += j - i;
+                        peer_copies_++;
+                        i = j - 1;
+                    }
                 } else if (all_registered) {
                     // caller buffers pinned with rf_host_register: the DMA engine reads them in place.  Frames with dense rows
                     // that follow each other in memory (a ring of camera buffers) and in the staging block go as ONE copy.
@@ -1278,10 +1292,11 @@ private:
     // ------------------------------------------------------------------------------------------ state
     int device_ = 0;
     HostTrace trace_;
-    bool check_residency_ = false, force_scatter_ = false;
+    bool check_residency_ = false, force_scatter_ = false, scatter_per_frame_ = false;
     int copy_streams_ = 2;
     int head_start_max_ = 0;                   // launches of at most this many images start their first kernel eagerly ahead of the graph
-    long scattered_frames_ = 0;               // device frames that arrived from another device (peer copies issued)
+    long scattered_frames_ = 0;               // device frames that arrived from another device
+    long peer_copies_ = 0;                    // ... in this many hipMemcpyPeerAsync calls (one per contiguous run of frames)
     std::vector<float> ratios_;                // the network preset's anchor ratios (empty: a preset without anchors)
     int na_ = 2;                               // anchors per cell the preset decodes (head_a_: what the model's heads carry)
     std::unique_ptr<ParallelCopier> copier_;

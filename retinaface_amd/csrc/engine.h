@@ -92,6 +92,8 @@ public:
     virtual void host_forget(const void *ptr) = 0;
     // drop what the engine remembers about where device frame pointers live (callers that free / re-home frame buffers)
     virtual void invalidate_residency() = 0;
+    // device frames that arrived from another device since the handle was built, and the peer copies that carried them
+    virtual void scatter_stats(long long *frames, long long *copies) const = 0;
 
     virtual int last_anchor_indices(int image, int32_t *out, int cap) const = 0;
     virtual int last_candidate_counts(int *counts, int n) const = 0;

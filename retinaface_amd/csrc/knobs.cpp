@@ -30,6 +30,7 @@ struct Spec {
 const Spec kSpecs[K_COUNT] = {
     {"RF_BLEND_FP32", true, 0, {kPresence}},
     {"RF_FORCE_SCATTER", true, 0, {kPresence}},
+    {"RF_SCATTER_PER_FRAME", true, 0, {kPresence}},
     {"RF_PREBUILD_LANES", true, 0, {0, 1, kAny}},
     {"RF_HOST_TRACE", true, 0, {kPresence}},
     {"RF_STEM2", false, 1, {0, 1, 2, 3, kAny}},
@@ -95,9 +96,10 @@ void parse_all() {
     }
     if (kProbes) {
         if (const char *e = getenv("RF_PERSIST_MIN_ROUNDS")) {
-            const float v = (float)atof(e);
-            if (v >= 0.f && v <= 64.f) g_min_rounds = v;
-            else fprintf(stderr, "[retinaface_amd] RF_PERSIST_MIN_ROUNDS=%s out of range [0, 64]: using 1\n", e);
+            char *end = nullptr;
+            const float v = strtof(e, &end);
+            if (end != e && *end == '\0' && v >= 0.f && v <= 64.f) g_min_rounds = v;
+            else fprintf(stderr, "[retinaface_amd] RF_PERSIST_MIN_ROUNDS=%s is not a number in [0, 64]: using the default %g\n", e, (double)g_min_rounds);
         }
     }
 }

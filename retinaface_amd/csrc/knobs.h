@@ -19,6 +19,7 @@ enum Knob {
     // ---- semantic (every build)
     K_BLEND_FP32,          // RF_BLEND_FP32: int8 aggregation convs blend in fp32 instead of packed integers (bit-identical; test knob)
     K_FORCE_SCATTER,       // RF_FORCE_SCATTER: treat every device frame as resident on another GPU (peer-copy path on a one-GPU box)
+    K_SCATTER_PER_FRAME,   // RF_SCATTER_PER_FRAME: one peer copy per foreign frame (rounds 3-5) instead of one per contiguous run of frames (the split A/B of bench.py)
     K_PREBUILD_LANES,      // RF_PREBUILD_LANES: build every lane at rf_create instead of on first use
     K_HOST_TRACE,          // RF_HOST_TRACE: per-stage host wall clock of the calls, printed when the engine is destroyed
     // ---- probe (probe build only; the product build returns the default)

@@ -196,6 +196,9 @@ public:
     void invalidate_residency() override {
         for (auto &e : eng_) e->invalidate_residency();
     }
+    void scatter_stats(long long *frames, long long *copies) const override {
+        for (auto &e : eng_) e->scatter_stats(frames, copies);
+    }
 
     int last_anchor_indices(int image, int32_t *out, int cap) const override {
         if (last_from_wait_ >= 0) return eng_[last_from_wait_]->last_anchor_indices(image, out, cap);

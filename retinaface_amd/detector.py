@@ -190,6 +190,12 @@ class RetinaFace:
     def num_devices(self) -> int:
         return self._lib.rf_num_devices(self._h)
 
+    def scatter_stats(self) -> dict:
+        """rf_scatter_stats: device frames pulled from other GPUs since the handle was built, and the peer copies that carried them."""
+        f, c = C.c_longlong(), C.c_longlong()
+        _lib.check(self._lib.rf_scatter_stats(self._h, C.byref(f), C.byref(c)), self._h)
+        return {"frames": f.value, "peer_copies": c.value}
+
     def prepare_device_batch(self, ptrs, rows, cols, steps=None):
         """Build the C argument arrays of rf_enqueue_batch_device once for a batch of device frames that is submitted
         repeatedly (a ring of camera buffers): what a C/C++ caller keeps on its side anyway.  Returns an opaque batch."""

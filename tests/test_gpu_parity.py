@@ -95,7 +95,7 @@ _engines = {}
 
 def engine(rfa, stem, prec, hw, **kw):
     key = (stem, prec, hw, tuple(sorted(kw.items())))
-    if key not in _engines:
+    if key not in _engines or not _engines[key]._h:           # (a test may have closed the engine it was handed: build it again)
         _engines[key] = rfa.RetinaFace(ASSETS, "net3", 0.4, precision=prec, net_hw=hw, model_stem=stem, **kw)
     return _engines[key]
 
@@ -377,7 +377,8 @@ def test_int8_contract_over_200_frames(rfa, oracles, stem):
     all) for the int8 engine, on held-out faces: identical face count on every frame, same-anchor IoU, anchor agreement, per-face IoU
     distribution and |dscore| -- printed against VERDICT r5's targets and gated at INT8_BAR."""
     from int8_contract import run_contract
-    s = run_contract(lambda hw, nb: engine(rfa, stem, INT8, hw, max_batch=nb), oracles[stem])
+    # run_contract closes each engine when its batch is done: hand it fresh engines, never the session's cached ones (engine())
+    s = run_contract(lambda hw, nb: rfa.RetinaFace(ASSETS, "net3", 0.4, precision=INT8, net_hw=hw, model_stem=stem, max_batch=nb), oracles[stem])
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     with open(os.path.join(ROOT, "gpurun_out", f"int8_contract_{stem}.json"), "w") as f:
         json.dump(s, f, indent=1)

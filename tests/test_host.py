@@ -296,6 +296,20 @@ def test_bench_self_launches_n_ranks_and_gathers_results():
     # the peer scatter), while the other ranks wait on the rendezvous store; --dry reports the plan only
     lib = j["library_multi_device"]
     assert lib["devices"] == [0, 1] and lib["global_batch"] == 256 and lib["images_per_engine"] == 128
+    # round 6: the N > 1 line diagnoses itself.  (a) every way the batch split can be carried has a slot: the library's peer
+    # copies per slice / per frame and direct H2D (null until frames really travel), RCCL send / recv between the ranks in batch_split_ab
+    assert set(lib["split_ab"]) >= {"peer_copy_per_slice", "peer_copy_per_frame", "host_frames_direct_h2d", "rccl_send_recv", "measured_over_xgmi"}
+    assert lib["split_ab"]["peer_copy_per_slice"] is None and lib["split_ab"]["measured_over_xgmi"] is False and lib["leg_budget_seconds"] <= 20
+    ab = j["batch_split_ab"]
+    assert set(ab["legs"]) == {"resident", "rccl_send_recv", "direct_h2d"} and ab["global_batch"] == 256 and ab["same_detections_every_leg"]
+    assert all(leg["ms_per_step"] > 0 and leg["steps_timed"] >= 3 for leg in ab["legs"].values())
+    assert ab["rehearsal_not_xgmi"] is True and ab["winner"] is None          # gloo / dry: the path is rehearsed, no winner is declared
+    # (b) every rank's own rate (a straggler is visible), and the scaling efficiency against rank 0 running alone in the same run
+    pr = g["per_rank"]
+    assert len(pr["images_per_sec"]) == 2 and pr["min_images_per_sec"] <= pr["max_images_per_sec"] and 0 < pr["min_over_max"] <= 1
+    assert pr["slowest_rank"] in (0, 1) and pr["rank0_alone"]["images_per_sec"] > 0
+    se = j["scaling_efficiency"]
+    assert se["n_gpus"] == 2 and abs(se["value"] - j["images_per_sec"] / (2 * pr["rank0_alone"]["images_per_sec"])) < 1e-9 and se["on_distinct_devices"] is False
     # under an external launcher the rank count must agree with --gpus
     env2 = dict(env, WORLD_SIZE="3", RANK="0", LOCAL_RANK="0")
     bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry"], capture_output=True, text=True,

@@ -40,6 +40,7 @@ class Sim:
     c{s}_a (conv1 | ctx1: 48 ch), c{s}_b (ctx2 | ctx3_1: 32 ch), c{s}_c (16 ch).  mode[name] in {"i8", "f16", "f32"}."""
 
     WEIGHT_BITS = 8          # 0: weights stay real (isolates the activation quantisation)
+    W16 = ()                 # key prefixes (pw, lat, aggr, ssh, head; "dw" for the stencils) whose weights carry 16 bits (two int8 limbs): taken as real
 
     def __init__(self, net, table):
         self.net, self.table = net, table
@@ -103,6 +104,9 @@ class Sim:
             return x
         if mode == "f16":
             return x.half().float()
+        if mode == "i16":                                            # ReLU'd tensor on 0..32767 quanta (two int8 limbs in an engine), int8 weights
+            sv = t(s).view(1, -1, 1, 1) * (127.0 / 32767.0)
+            return torch.round(torch.clamp(x / sv, 0, 32767)) * sv
         if mode == "u8":                                             # ReLU'd tensor on 0..255 quanta of half the size (stored as q - 128)
             sv = t(s).view(1, -1, 1, 1) * (127.0 / 255.0)
             return torch.round(torch.clamp(x / sv, 0, 255)) * sv
@@ -118,13 +122,16 @@ class Sim:
             cols = Fn.unfold(x, w.shape[1], padding=pad)[0].double()    # (cin*k*k, L), rows ordered (cin, ky, kx) = wt.flatten(1)'s columns
             g, m, n = self.hess.get(key, (0, 0, 0))
             self.hess[key] = (g + cols @ cols.T, m + cols.sum(dim=1), n + cols.shape[1])
-        if mode_in in ("i8", "u8", "w8"):
+        if mode_in in ("i8", "u8", "w8", "i16"):
             si = t(s_in).view(1, -1, 1, 1) * (127.0 / 255.0 if mode_in == "u8" else 1.0)
             ws = wt * si                                                # per-input-channel scale folded into the weights
             amax = ws.abs().flatten(1).max(dim=1).values
             sw = torch.where(amax > 0, amax / 127, torch.ones_like(amax)).view(-1, 1, 1, 1)
-            wq = torch.clamp(torch.round(ws / sw), -127, 127) if Sim.WEIGHT_BITS == 8 else ws / sw
-            if self.gptq is not None and key in self.gram and Sim.WEIGHT_BITS == 8:
+            w16 = key is not None and any(key.startswith(p_) for p_ in Sim.W16)
+            wq = torch.clamp(torch.round(ws / sw), -127, 127) if (Sim.WEIGHT_BITS == 8 and not w16) else torch.round(ws / sw * 128) / 128
+            if w16:
+                pass
+            elif self.gptq is not None and key in self.gram and Sim.WEIGHT_BITS == 8:
                 ck = (key, mode_in, s_in.tobytes())
                 if ck not in self.gptq:
                     self.gptq[ck] = self._gptq(key, ws, sw, si)
@@ -165,6 +172,8 @@ class Sim:
         w, b = wb
         c = w.shape[0]
         wt = t(w.transpose(0, 3, 1, 2).copy())                           # (c, 1, 3, 3)
+        if mode_out == "i16":                                            # a 15-bit mid: the stencil itself is exact enough to be taken as real
+            mode_out = "f32"
         if mode_in in ("i8", "u8", "w8") and mode_out in ("i8", "u8", "w8"):
             s_in = s_in * np.float32(127.0 / 255.0 if mode_in == "u8" else 1.0)
             s_mid = s_mid * np.float32(127.0 / 255.0 if mode_out == "u8" else 1.0)
@@ -309,6 +318,9 @@ VARIANTS = {
     "backbone_only_i8": {**{f"c{c}_{p}": "f16" for c in (3, 2, 1) for p in "abc"}, "lat3": "f16", "P2": "f16", "P1": "f16", "lat2": "f16", "lat1": "f16",
                          "plus0": "f16", "plus1": "f16", "relu10": "f16", "relu22": "f16", "relu26": "f16"},
     "dwmid_f16": {f"relu{2 * i + 1}": "f16" for i in range(1, 13)},
+    "dwmid_u8": {f"relu{2 * i + 1}": "u8" for i in range(1, 13)},
+    "dwmid_i16": {f"relu{2 * i + 1}": "i16" for i in range(1, 13)},
+    "dwmid_w8": {f"relu{2 * i + 1}": "w8" for i in range(1, 13)},
 }
 
 
@@ -379,8 +391,12 @@ def main():
     ap.add_argument("--cal-frames", type=int, default=24)
     ap.add_argument("--per-tensor", action="store_true")
     ap.add_argument("--threads", type=int, default=8)
+    ap.add_argument("--w16", default="", help="comma list of contraction-key prefixes whose weights carry 16 bits: pw, pw5 (one block), lat, aggr, ssh, head")
+    ap.add_argument("--weight-bits", type=int, default=8)
     args = ap.parse_args()
     torch.set_num_threads(args.threads)
+    Sim.W16 = tuple(k for k in args.w16.split(",") if k)
+    Sim.WEIGHT_BITS = args.weight_bits
     net = read_rfw(os.path.join(ROOT, "assets", args.model + ".rfw"))
     table = read_int8_table(args.table) if args.table else dict(net.int8_scales)
     sim = Sim(net, table)
