@@ -484,6 +484,10 @@ def main() -> int:
         extra["sync_call_ms_c_abi"] = extra["sync_batch"]["ms_per_call"]
         if args.host_seconds > 0:
             extra["host_frames"] = host_frames(det, frames_np, args, slots, B, run, rank)
+            extra["sync_batch_host"] = sync_batch_host_measure(
+                det, frames, B, H, W, args.threshold,
+                make_unsplit=lambda: retinaface_amd.RetinaFace(os.path.join(ROOT, "assets"), "net3", 0.4, precision=prec, net_hw=(H, W), max_batch=B_pad,
+                                                               model_stem=args.model, lanes=args.lanes, coalesce=args.coalesce))
 
     # N > 1 (the driver's SCALE run): after everything the ranks measure together, rank 0 times the in-library split over the same N devices
     with_library_leg = world > 1 and not strong and not args.timed_only and not args.no_extra_configs and args.extra_seconds > 0
@@ -557,7 +561,7 @@ def main() -> int:
                                        ms_per_step=out["ms_per_step"], dtype=out["dtype"], dominant_kernel=out["roofline"]["kernel_instance"],
                                        dominant_kernel_ms=out["roofline"]["kernel_ms"], bound=out["roofline"]["bound"],
                                        bound_frac=out["roofline"]["bound_frac"], hbm_frac_measured=out["roofline"]["hbm_frac_measured"],
-                                       useful=out["roofline"]["useful"], sync_batch=out["sync_batch"],
+                                       useful=out["roofline"]["useful"], sync_batch=out["sync_batch"], sync_batch_host=out.get("sync_batch_host"),
                                        note="the metric point: this line's `value`")]
                 out["configs"] += [measure_extra_config(c, args, frames, dev) for c in EXTRA_CONFIGS]
                 _FRAME_CACHE.clear()
@@ -608,6 +612,69 @@ def sync_batch_measure(det, ptrs, H, W, thr, reps=120, seconds=None):
     nf = int(sum(cnt[i] for i in range(B)))
     return {"batch": B, "ms_per_call": ms, "images_per_sec": B / (ms * 1e-3), "faces_per_sec": nf / (ms * 1e-3), "calls_timed": reps - reps // 6,
             "note": "one synchronous rf_detect_batch_device call at a time (no pipelining, no coalescing)"}
+
+
+def sync_batch_host_measure(det, frames_dev, B, H, W, thr, seconds=0.25, make_unsplit=None):
+    """The reference's calling convention with the frames where its callers hold them (detectBatchImages(vector<cv::Mat>),
+    RetinaFace.cpp:749-846: upload + preprocess + infer inside ONE call): ONE synchronous rf_detect_batch of B HOST frames at a time, timed
+    at the C ABI -- pageable caller memory (the engine stages it through pinned memory) and memory pinned once with rf_host_register (DMA in
+    place).  Round 6 stages and sends the frames of such a call in pipelined pieces (engine.cpp submit(): the host stages piece k + 1 while piece k
+    is on the bus); `unsplit` is the same call on an engine built with RF_SYNC_SPLIT=0 (one piece: rounds 1-5), in the same run.  The result
+    block must equal the device-frame call's byte for byte."""
+    import ctypes as C
+    import numpy as np
+    from retinaface_amd._lib import rf_face
+    host = np.ascontiguousarray(frames_dev[:B].cpu().numpy())
+    cap = det.max_detections
+
+    def call_arrays(ptrs):
+        return ((C.c_void_p * B)(*ptrs), (C.c_int * B)(*([H] * B)), (C.c_int * B)(*([W] * B)), (C.c_int * B)(*([3 * W] * B)),
+                (rf_face * (B * cap))(), (C.c_int * B)())
+
+    def timed(d, fn, arrs):
+        pa, ra, ca, sa, outb, cnt = arrs
+        lat, t0 = [], time.perf_counter()
+        while len(lat) < 12 or (time.perf_counter() - t0 < seconds and len(lat) < 2000):
+            t = time.perf_counter()
+            st = fn(d._h, pa, ra, ca, sa, B, C.c_float(thr), outb, cap, cnt)
+            lat.append(time.perf_counter() - t)
+            assert st >= 0 or st == -6, st
+        lat = lat[len(lat) // 6:]
+        return float(np.median(lat) * 1e3), bytes(outb), [cnt[i] for i in range(B)]
+
+    def measure(d):
+        res = {}
+        dev_arrs = call_arrays([frames_dev[i].data_ptr() for i in range(B)])
+        _, ref_bytes, ref_cnt = timed(d, d._lib.rf_detect_batch_device, dev_arrs)
+        ms, ob, oc = timed(d, d._lib.rf_detect_batch, call_arrays([host[i].ctypes.data for i in range(B)]))
+        res["pageable"] = {"ms_per_call": ms, "byte_identical_to_device_frames": bool(ob == ref_bytes and oc == ref_cnt)}
+        pinned = host.copy()
+        d.host_register(pinned)
+        ms, ob, oc = timed(d, d._lib.rf_detect_batch, call_arrays([pinned[i].ctypes.data for i in range(B)]))
+        d.host_unregister(pinned)
+        res["registered"] = {"ms_per_call": ms, "byte_identical_to_device_frames": bool(ob == ref_bytes and oc == ref_cnt)}
+        return res
+
+    out = measure(det)
+    out.update({"batch": B, "frame": [H, W], "bytes_per_call": B * H * W * 3, "pcie_ms_at_spec": B * H * W * 3 / (PCIE_GEN5_X16_GBS * 1e9) * 1e3,
+                "timed_at": "the C ABI (rf_detect_batch with argument / result arrays built once), median after the first sixth of the calls",
+                "pipelined_staging": "pageable frames are staged + sent in pieces of ~1.2 MB, staging of piece k + 1 overlapping the transfer of piece k "
+                                     "(RF_SYNC_SPLIT=1, the default); registered memory is read in place: nothing to pipeline"})
+    if make_unsplit is not None:
+        had = os.environ.get("RF_SYNC_SPLIT")
+        os.environ["RF_SYNC_SPLIT"] = "0"
+        try:
+            d0 = make_unsplit()
+        finally:
+            if had is None:
+                os.environ.pop("RF_SYNC_SPLIT", None)
+            else:
+                os.environ["RF_SYNC_SPLIT"] = had
+        u = measure(d0)
+        d0.close()
+        out["unsplit"] = {"pageable_ms_per_call": u["pageable"]["ms_per_call"], "registered_ms_per_call": u["registered"]["ms_per_call"],
+                          "is": "the same calls on an engine built with RF_SYNC_SPLIT=0: staging, then transfer, then compute (rounds 1-5)"}
+    return out
 
 
 def host_frames(det, frames_np, args, slots, B, run, rank):
@@ -726,13 +793,14 @@ def measure_extra_config(cfg, args, frames_main, dev):
             break
         steps = -(-int(np.ceil(steps * 1.2 * args.extra_seconds / max(dt, 1e-6))) // slots) * slots
     sync = sync_batch_measure(det, [frames[i % frames.shape[0]].data_ptr() for i in range(B)], H, W, float(args.threshold), reps=90)
+    sync_host = sync_batch_host_measure(det, frames, min(B, frames.shape[0]), H, W, float(args.threshold), seconds=0.15) if args.host_seconds > 0 else None
     det.close()
     if cfg.get("matrix"):
         return {"id": cfg["id"], "workload": f"{cfg['model']} {cfg['precision']} HIP, {W}x{H}, batch {B} per GPU (north_star's batch x frame-size matrix)",
                 "images_per_sec": steps * B / dt, "faces_per_sec": faces / dt, "ms_per_step": dt / steps * 1e3, "steps": steps, "timed_seconds": dt,
                 "dtype": {"fp16": "f16", "fp32": "f32", "int8": "i8"}[cfg["precision"]],
                 "input": f"{frames.shape[0]} distinct HBM-resident frames ({frames.shape[0] * H * W * 3 / 1e6:.0f} MB; {how})",
-                "tickets_in_flight": slots, "sync_batch": sync,
+                "tickets_in_flight": slots, "sync_batch": sync, "sync_batch_host": sync_host,
                 "note": "same kernel instances as the BASELINE config of this frame size: no separate per-kernel / counter passes"}
     eager = retinaface_amd.RetinaFace(os.path.join(ROOT, "assets"), "net3", 0.4, precision=prec, net_hw=(H, W), max_batch=B,
                                       model_stem=cfg["model"], use_graph=False, lanes=1)
@@ -750,7 +818,7 @@ def measure_extra_config(cfg, args, frames_main, dev):
            "dominant_kernel_share_of_gpu_time": dom["ms"] / kernel_ms,
            "frac_layerwise_credit": dom["alg_bytes"] / (dom["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
            "useful": useful_fractions(dom, cfg["precision"]), "whole_path_useful": useful_fractions(prof, cfg["precision"]),
-           "sync_batch": sync,
+           "sync_batch": sync, "sync_batch_host": sync_host,
            "bound": None, "bound_frac": None, "hbm_frac_measured": None,
            "_pmc": {"n": n_prof, "precision": cfg["precision"], "model": cfg["model"], "H": H, "W": W, "B": B},
            "_kernels": {p["kernel"]: p["ms"] for p in prof}}

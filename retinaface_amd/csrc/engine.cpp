@@ -155,6 +155,8 @@ public:
         // treats every device frame as foreign so the scatter path runs on a one-GPU box)
         force_scatter_ = knob(K_FORCE_SCATTER) != 0;
         scatter_per_frame_ = knob(K_SCATTER_PER_FRAME) != 0;
+        if (knob(K_SYNC_SPLIT) == 0) stage_pieces_ = 1;
+        else if (const char *e = getenv("RF_SYNC_PIECES")) { const int v = atoi(e); if (v >= 1 && v <= 64) stage_pieces_ = v; }      // measurement knob of the A/B
         head_start_max_ = knob(K_HEAD_START) ? opt_.max_batch : 0;      // launches of up to max_batch images = synchronous calls and un-coalesced tickets
         copy_streams_ = knob(K_COPY_STREAMS) > 1 ? 2 : 1;       // probe knob RF_COPY_STREAMS (tools/probes/host_rate.py)
         check_residency_ = ndev > 1 || force_scatter_;
@@ -627,6 +629,7 @@ private:
                 Stem2Params sp;
                 sp.frames = L.d_frames + mb; sp.out = out;
                 sp.w0 = arena_.template ptr<half_t>(c0_hi_); sp.b0 = arena_.template ptr<float>(WP::c0_b_mma_);
+                sp.w0_raw = arena_.template ptr<half_t>(WP::c0_raw_);
                 sp.dw0_w = arena_.template ptr<float>(stem_dw_.w); sp.dw0_b = arena_.template ptr<float>(stem_dw_.b);
                 sp.pw0_w = arena_.template ptr<half_t>(stem_pw_.w); sp.pw0_b = arena_.template ptr<float>(WP::stem2_c2_b_);
                 sp.c2_floor = arena_.template ptr<uint32_t>(WP::stem2_c2_floor_); sp.c3_floor = arena_.template ptr<uint32_t>(WP::stem2_c3_floor_);
@@ -1194,6 +1197,19 @@ private:
         Lane &s = lanes_[pending_lane_];
         Ticket &t = tickets_[id];
         t.state = Ticket::PENDING; t.lane = pending_lane_; t.first_image = s.n_images; t.n = n; t.timed = eager_timed;
+        // the launch's frame table (nothing below reads it before it is complete; a throw leaves n_images where it was)
+        for (int i = 0; i < n; i++) {
+            const int img = s.n_images + i;
+            FrameDesc src{nullptr, 0, 0, 0, 0};
+            s.empty[img] = empty[i];
+            if (!empty[i]) {
+                if (on_device && src_dev[i] < 0) src = FrameDesc{frames[i], rows[i], cols[i], steps[i], 0};
+                else if (on_device) src = FrameDesc{s.d_stage + s.stage_used + off[i], rows[i], cols[i], steps[i], 0};
+                else src = FrameDesc{s.d_stage + s.stage_used + off[i], rows[i], cols[i], cols[i] * 3, 0};
+            }
+            s.h_frames[img] = src;
+            s.h_frames[mb + img] = src;       // replaced by the canvas in launch_pending() when a resize is needed
+        }
         try {
             if (stage_need) {
                 uint8_t *hbase = s.h_stage + s.stage_used, *dbase = s.d_stage + s.stage_used;
@@ -1223,45 +1239,56 @@ private:
                 } else if (all_registered) {
                     // caller buffers pinned with rf_host_register: the DMA engine reads them in place.  Frames with dense rows
                     // that follow each other in memory (a ring of camera buffers) and in the staging block go as ONE copy.
-                    for (int i = 0; i < n; i++) {
-                        if (empty[i]) continue;
-                        const size_t fb = (size_t)rows[i] * cols[i] * 3;
-                        if (steps[i] != cols[i] * 3) {
-                            RF_HIP(hipMemcpy2DAsync(dbase + off[i], (size_t)cols[i] * 3, frames[i], (size_t)steps[i], (size_t)cols[i] * 3,
-                                                    (size_t)rows[i], hipMemcpyHostToDevice, up));
-                            continue;
-                        }
-                        size_t run = fb;
-                        int j = i + 1;
-                        while (j < n && !empty[j] && steps[j] == cols[j] * 3 && frames[j] == frames[i] + run && off[j] == off[i] + run)
-                            run += (size_t)rows[j] * cols[j] * 3, j++;
-                        RF_HIP(hipMemcpyAsync(dbase + off[i], frames[i], run, hipMemcpyHostToDevice, up));
-                        i = j - 1;
-                    }
+                    upload_registered(frames, rows, cols, steps, empty, off, 0, n, dbase, up);
                 } else {
-                    copy_jobs_.clear();
-                    for (int i = 0; i < n; i++)
-                        if (!empty[i])
-                            copy_jobs_.push_back(ParallelCopier::Job{hbase + off[i], frames[i], (size_t)cols[i] * 3, (size_t)rows[i], (size_t)steps[i]});
-                    copier_->run(copy_jobs_);          // the caller's buffers are free again when this returns
-                    RF_HIP(hipMemcpyAsync(dbase, hbase, stage_need, hipMemcpyHostToDevice, up));
+                    // PIPELINED STAGING of a synchronous call (round 6): the reference's calling convention is ONE call
+                    // that uploads, preprocesses and infers (RetinaFace.cpp:749-846), and through round 5 such a call ran staging copy, PCIe
+                    // transfer and compute strictly one after the other (batch 8 at 448 x 448, C ABI: 0.285 ms = 0.06 + 0.10 + 0.13).  The frames
+                    // are now staged and sent in pieces of ~kStagePieceBytes: while piece k crosses the bus the host stages piece k + 1.  Same
+                    // stream, same bytes, same launch afterwards: results are byte-identical (RF_SYNC_SPLIT=0 = one piece, the A/B).
+                    // Measured and rejected in the same round (profiles/r06_sync_host_call_ab.txt): sending the pieces on the copy stream and
+                    // starting the STEM of each piece behind its event -- 4 events + 4 cross-stream waits + 4 eager launches + a second graph
+                    // cost more host time (0.309 / 0.278 ms pageable / registered) than the 13 us stem they hid (0.285 / 0.224 ms unsplit).
+                    const int pieces = (sync_call && stage_pieces_ > 1) ? (int)std::min<size_t>((size_t)stage_pieces_, std::max<size_t>(1, stage_need / kStagePieceBytes)) : 1;
+                    if (pieces <= 1) {
+                        copy_jobs_.clear();
+                        for (int i = 0; i < n; i++)
+                            if (!empty[i])
+                                copy_jobs_.push_back(ParallelCopier::Job{hbase + off[i], frames[i], (size_t)cols[i] * 3, (size_t)rows[i], (size_t)steps[i]});
+                        copier_->run(copy_jobs_);          // the caller's buffers are free again when this returns
+                        RF_HIP(hipMemcpyAsync(dbase, hbase, stage_need, hipMemcpyHostToDevice, up));
+                    } else {
+                        // piece boundaries are byte positions of the staging block cut at row granularity: a piece is whole frames and / or a
+                        // row range of a frame, so ONE large frame (1280 x 896 = 3.4 MB) is pipelined as well
+                        size_t sent = 0;
+                        int i = 0, r = 0;                          // next frame / next row of it to stage
+                        for (int pc = 0; pc < pieces; pc++) {
+                            const size_t goal = pc == pieces - 1 ? stage_need : stage_need * (pc + 1) / pieces;
+                            copy_jobs_.clear();
+                            size_t end = sent;
+                            while (i < n && end < goal) {
+                                if (empty[i]) { i++; r = 0; continue; }
+                                const size_t rb = (size_t)cols[i] * 3, at = off[i] + (size_t)r * rb;
+                                int take = rows[i] - r;
+                                if (at + (size_t)take * rb > goal) take = (int)std::max<size_t>(1, (goal - std::min(goal, at) + rb - 1) / rb);
+                                take = std::min(take, rows[i] - r);
+                                copy_jobs_.push_back(ParallelCopier::Job{hbase + at, frames[i] + (size_t)r * steps[i], rb, (size_t)take, (size_t)steps[i]});
+                                end = at + (size_t)take * rb;
+                                r += take;
+                                if (r == rows[i]) { i++; r = 0; }
+                            }
+                            if (copy_jobs_.empty()) continue;
+                            copier_->run(copy_jobs_);      // the caller's rows of this piece are free again when this returns
+                            RF_HIP(hipMemcpyAsync(dbase + sent, hbase + sent, end - sent, hipMemcpyHostToDevice, up));
+                            sent = end;
+                        }
+                        staged_pieces_ += pieces;
+                    }
                 }
             }
         } catch (...) {
             t.state = Ticket::FREE;
             throw;
-        }
-        for (int i = 0; i < n; i++) {
-            const int img = s.n_images + i;
-            FrameDesc src{nullptr, 0, 0, 0, 0};
-            s.empty[img] = empty[i];
-            if (!empty[i]) {
-                if (on_device && src_dev[i] < 0) src = FrameDesc{frames[i], rows[i], cols[i], steps[i], 0};
-                else if (on_device) src = FrameDesc{s.d_stage + s.stage_used + off[i], rows[i], cols[i], steps[i], 0};
-                else src = FrameDesc{s.d_stage + s.stage_used + off[i], rows[i], cols[i], cols[i] * 3, 0};
-            }
-            s.h_frames[img] = src;
-            s.h_frames[mb + img] = src;       // replaced by the canvas in launch_pending() when a resize is needed
         }
         s.stage_used += stage_need;
         s.need_resize = s.need_resize || need_resize;
@@ -1270,6 +1297,27 @@ private:
         // launch now when full, when the caller is synchronous, or when coalescing is off
         if (s.n_images + 1 > mb || sync_call || opt_.coalesce == 1) launch_pending();
         return id;
+    }
+
+    // frames [a, b) of a chunk, in pinned caller memory, to their places in the device staging block: one DMA per run of dense frames that
+    // follow each other in memory and in the block, a 2-D copy for frames with a row pitch
+    void upload_registered(const uint8_t *const *frames, const int *rows, const int *cols, const int *steps, const std::vector<char> &empty,
+                           const std::vector<size_t> &off, int a, int b, uint8_t *dbase, hipStream_t up) {
+        for (int i = a; i < b; i++) {
+            if (empty[i]) continue;
+            const size_t fb = (size_t)rows[i] * cols[i] * 3;
+            if (steps[i] != cols[i] * 3) {
+                RF_HIP(hipMemcpy2DAsync(dbase + off[i], (size_t)cols[i] * 3, frames[i], (size_t)steps[i], (size_t)cols[i] * 3,
+                                        (size_t)rows[i], hipMemcpyHostToDevice, up));
+                continue;
+            }
+            size_t run = fb;
+            int j = i + 1;
+            while (j < b && !empty[j] && steps[j] == cols[j] * 3 && frames[j] == frames[i] + run && off[j] == off[i] + run)
+                run += (size_t)rows[j] * cols[j] * 3, j++;
+            RF_HIP(hipMemcpyAsync(dbase + off[i], frames[i], run, hipMemcpyHostToDevice, up));
+            i = j - 1;
+        }
     }
 
     hipGraphExec_t capture(Lane &L, int n, size_t first_op = 0) {
@@ -1293,6 +1341,9 @@ private:
     int device_ = 0;
     HostTrace trace_;
     bool check_residency_ = false, force_scatter_ = false, scatter_per_frame_ = false;
+    int stage_pieces_ = 4;                    // most pieces a synchronous host-frame call is staged + sent in (RF_SYNC_SPLIT=0: one, as rounds 1-5; RF_SYNC_PIECES=n)
+    static constexpr size_t kStagePieceBytes = 1200 << 10;      // ~2 frames of 448 x 448: 24 us on the bus, ~15 us of staging
+    long staged_pieces_ = 0;
     int copy_streams_ = 2;
     int head_start_max_ = 0;                   // launches of at most this many images start their first kernel eagerly ahead of the graph
     long scattered_frames_ = 0;               // device frames that arrived from another device

@@ -80,6 +80,7 @@ template <typename TO> void launch_stem(hipStream_t s, const StemParams<TO> &p);
 struct Stem2Params {
     const FrameDesc *frames; half_t *out;          // out: [n][net_h/4][net_w/4][32]
     const half_t *w0; const float *b0;
+    const half_t *w0_raw = nullptr;                // conv0 fragments of the raw-row staging (weights.h c0_raw_): [2 parities][4][64][8]
     const float *dw0_w; const float *dw0_b; const half_t *pw0_w; const float *pw0_b;
     const uint32_t *dw1_mma; const float *dw1_b;   // conv3: taps as diagonal MFMA A fragments [5][64] dwords (pack.h), bias [16]
     const half_t *pw1_w; const float *pw1_b;       // conv4: 32 x 16 as hi | lo along K (k < 16: rn16(w), k >= 16: rn16(w - hi)), MFMA-fragment packed, bias [32]

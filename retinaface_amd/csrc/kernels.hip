@@ -838,6 +838,7 @@ template <int TW_, bool F16P, int PADKB = 0> struct Stem2Cfg {     // F16P: the 
 struct Stem2Args {
     const FrameDesc *frames; half_t *out;           // out: [n][ho4][wo4][32]
     const half_t *w0; const float *b0;              // conv0 (as StemArgs)
+    const half_t *w0_raw;                           // conv0 for the raw-row staging: [2 column parities][4 fragments][64][8] (weights.h c0_raw_)
     const float *dw0_w; const float *dw0_b; const half_t *pw0_w; const float *pw0_b;     // conv1 / conv2 (as StemArgs)
     const uint32_t *dw1_mma; const float *dw1_b;    // conv3 taps as diagonal MFMA A fragments [5][64] dwords (pack.h dw_mma_dword), bias [16]
     const half_t *pw1_w; const float *pw1_b;        // conv4: 32 x 16 as hi | lo along K (32 K slots, all used), bias [32]
@@ -889,8 +890,19 @@ __global__ __launch_bounds__((Stem2Cfg<TW_, F16P, PADKB>::THREADS), (Stem2Cfg<TW
     RF_TRACE_KEY(a.nblk);
     RF_TRACE(4, 0);
 
+    // RAW staging (round 6, V2 bit 3): frames whose base and row pitch are multiples of 16 B and that fill the net's
+    // width (every BASELINE shape: 448 x 3 = 1344 = 16 x 84, 1280 x 3 = 3840) bring their patch rows into LDS as they are -- 3 bytes per
+    // pixel, `buffer_load_dwordx4 ... lds`, no VGPR round trip, rows above / below the frame zero-filled by the descriptor's range check --
+    // instead of the load / realign / border-mask / BGR -> BGRX repack of the general path (~100 of this kernel's ~584 VALU instructions per
+    // wave: profiles/r05_stem2_conv0_loop_isa.txt).  conv0 then reads each pixel's 9 bytes per kernel row from an aligned 12-byte window
+    // (weights.h c0_raw_: one fragment set per column parity, waves 0-1 take the even conv0 columns, waves 2-3 the odd ones).  Anything
+    // else (odd pointers, ROIs, frames narrower than the net) takes the general path: tests/test_gpu_parity.py
+    // test_device_frames_unaligned_pointer_odd_step_and_roi.  Wave-uniform per workgroup.
+    constexpr bool RAWCAP = (V2 & 8) != 0 && !F16P && NT == 256 && TW == 8;
+    const bool raw = RAWCAP && ((((uintptr_t)fd.ptr) | (uintptr_t)(unsigned)fd.step) & 15u) == 0 && fd.cols == 2 * a.wo && a.w0_raw != nullptr;
+
     // ---- phase 0: operands that depend only on kernel arguments
-    const f16x8 *wf = (const f16x8 *)a.w0 + lane;
+    const f16x8 *wf = (raw ? (const f16x8 *)a.w0_raw + (wave >> 1) * 256 : (const f16x8 *)a.w0) + lane;
     const f16x8 w_hi1 = wf[0], w_lo1 = wf[64], w_hi2 = wf[128], w_lo2 = wf[192];
     const f32x4 b0 = lane < 32 ? *(const f32x4 *)(a.b0 + kb * 4) : vzero<f32x4, 4>();
     // (the operands of phases 4 and 6 are loaded one phase ahead of their use, not here: 24 more live registers across the
@@ -898,7 +910,24 @@ __global__ __launch_bounds__((Stem2Cfg<TW_, F16P, PADKB>::THREADS), (Stem2Cfg<TW
 
     // ---- phase 1: stage the u8 patch as BGRX dwords (K_a' phase 1; the patch now starts 5 pixels left of / above the first
     //      conv0 pixel's centre, so an item can lie entirely or partly left of the frame)
-    {
+    if (raw) {
+        // raw rows: LDS row r (128 B = 8 lanes x 16 B) holds the frame bytes [bxa, bxa + 128) of input row iy0 + r, bxa = 3 (4 ox0 - 5) - 1 =
+        // 12 ox0 - 16 (a multiple of 16: ox0 is a multiple of 8), so patch pixel px starts at LDS byte 1 + 3 px.  One wave-instruction = 8 rows.
+        const int iy0 = 4 * oy0 - 5, bxa = 12 * ox0 - 16;
+        const unsigned fbytes = (unsigned)(fd.rows - 1) * (unsigned)fd.step + (unsigned)fd.cols * 3u;
+        const auto rs = image_rsrc(fd.ptr, fbytes);
+        constexpr int PIECES = (IR + 7) / 8;                           // 5 for the 35-row patch; rows 35..39 exist in LDS (finite bytes, never used)
+        static_assert(PIECES * 1024 <= C::REGION_A, "raw patch fits region A");
+#pragma unroll 1
+        for (int k = wave; k < PIECES; k += NW) {
+            const int r = 8 * k + (lane >> 3), cb = bxa + 16 * (lane & 7);
+            // rows above / below the frame: the offset is negative (wraps) or past the last row = out of range = zeros.  Bytes LEFT of the
+            // row start belong to the previous row and are in range: the one chunk that can lie there (tile column 0, chunk 0) is forced out.
+            const unsigned off = cb < 0 ? kOobOffset : (unsigned)((iy0 + r) * fd.step + cb);
+            lds_dma16(rs, s_raw + k * 1024, off);
+        }
+        wait_vmcnt<0>();
+    } else {
         const int iy0 = 4 * oy0 - 5;                                  // input row of patch row 0
         const int bx0 = (4 * ox0 - 5) * 3;                            // input byte column of patch pixel 0
         const uintptr_t fp = (uintptr_t)fd.ptr;
@@ -964,7 +993,52 @@ __global__ __launch_bounds__((Stem2Cfg<TW_, F16P, PADKB>::THREADS), (Stem2Cfg<TW
     __syncthreads();
 
     // ---- phase 2: conv0 on the (R0H x R0W) region, K = 4*(3*ky + kx) + c4 (K_a' phase 2)
-    {
+    if (raw) {
+        // raw rows: K = 16 ky + (byte of the pixel's aligned 12-byte window); MFMA 1 = kernel rows 0 and 1 (lane groups kb 0,1 | 2,3),
+        // MFMA 2 = kernel row 2 (kb 0,1; kb 2,3 meet zero weights).  A lane reads two consecutive dwords per MFMA (ds_read2_b32).
+        typedef uint32_t u32x2a4 __attribute__((ext_vector_type(2), aligned(4)));
+        const uint32_t *s_rows = (const uint32_t *)s_raw;
+        // waves 0,1: even conv0 columns (10 of the 19), waves 2,3: odd ones (9); the parity is a compile-time constant of each copy of the
+        // loop, so the pixel -> (row, column) division is by a constant
+        auto conv0_raw = [&](auto parity) {
+            constexpr int par = decltype(parity)::value;
+            constexpr int wp = par ? R0W / 2 : (R0W + 1) / 2;
+            constexpr int tiles = (wp * C::R0H + 15) / 16;
+#pragma unroll 1
+            for (int t = wave & 1; t < tiles; t += 2) {
+                const int qq = t * 16 + (lane & 15);
+                const int hy = qq / wp, m = qq - hy * wp;
+                const int hx = 2 * m + par;
+                const uint32_t *p1 = s_rows + (2 * hy + (kb >> 1)) * 32 + 3 * m + par + 2 * (kb & 1);
+                const uint32_t *p2 = s_rows + (2 * hy + 2) * 32 + 3 * m + par + 2 * (kb & 1);
+                const u32x2a4 d1 = *(const u32x2a4 *)p1, d2 = *(const u32x2a4 *)p2;
+                f16x8 x1, x2;
+                u8x4_to_f16(d1[0], x1, 0);
+                u8x4_to_f16(d1[1], x1, 4);
+                u8x4_to_f16(d2[0], x2, 0);
+                u8x4_to_f16(d2[1], x2, 4);
+                f32x4 acc = b0;
+                acc = M::mma(w_hi1, x1, acc);
+                acc = M::mma(w_lo1, x1, acc);
+                acc = M::mma(w_hi2, x2, acc);
+                acc = M::mma(w_lo2, x2, acc);
+                if (lane < 32 && hy < C::R0H) {
+                    float lim = __builtin_inff();
+                    if (!interior) {
+                        asm volatile("" ::: "memory");
+                        const int cy = 2 * oy0 - 2 + hy, cx = 2 * ox0 - 2 + hx;
+                        lim = ((unsigned)cy < (unsigned)a.ho && (unsigned)cx < (unsigned)a.wo) ? __builtin_inff() : 0.f;
+                    }
+                    f32x4 h;
+#pragma unroll
+                    for (int r = 0; r < 4; r++) h[r] = __builtin_amdgcn_fmed3f(acc[r], 0.f, lim);
+                    *(f32x4 *)(s_c0 + kb * C0_PLANE + (hy * R0W + hx) * 4) = h;
+                }
+            }
+        };
+        if (wave < 2) conv0_raw(std::integral_constant<int, 0>());
+        else conv0_raw(std::integral_constant<int, 1>());
+    } else {
         const int ppA = 2 * kb, ppB = 2 * kb + 1;
         const int offA = (ppA / 3) * ROWD + ppA % 3, offB = (ppB / 3) * ROWD + ppB % 3, offC = 2 * ROWD + 2;
 #pragma unroll 1
@@ -1209,7 +1283,7 @@ int stem2_variant() { return knob(K_STEM2); }      // probe knob RF_STEM2: 1 = 7
 
 void launch_stem2(hipStream_t s, const Stem2Params &p) {
     Stem2Args a;
-    a.frames = p.frames; a.out = p.out; a.w0 = p.w0; a.b0 = p.b0;
+    a.frames = p.frames; a.out = p.out; a.w0 = p.w0; a.b0 = p.b0; a.w0_raw = p.w0_raw;
     a.dw0_w = p.dw0_w; a.dw0_b = p.dw0_b; a.pw0_w = p.pw0_w; a.pw0_b = p.pw0_b;
     a.dw1_mma = p.dw1_mma; a.dw1_b = p.dw1_b; a.pw1_w = p.pw1_w; a.pw1_b = p.pw1_b;
     a.c2_floor = p.c2_floor; a.c3_floor = p.c3_floor;
@@ -1232,6 +1306,7 @@ void launch_stem2(hipStream_t s, const Stem2Params &p) {
     // RF_STEM2_V2 (probe knob): bit 0 = planar conv2 tile, bit 1 = conv3 -> conv4 chained in registers, bit 2 = rotated thread -> pixel map of the
     // depthwise-1 phase; 0 = round 3; 5 = round 4's default (bit-identical to round 3: 250.3 -> 246.5 -> 238.6 us, tools/gpu/rounds_3_4.sh r4_call30, r4_call32)
     switch (knob(K_STEM2_V2)) {
+        case 7: hipLaunchKernelGGL((stem2_kernel<8, false, 0, 7>), dim3(a.nblk), dim3(kThreads), 0, s, a); return;      // round 5's product
         case 5: hipLaunchKernelGGL((stem2_kernel<8, false, 0, 5>), dim3(a.nblk), dim3(kThreads), 0, s, a); return;
         case 3: hipLaunchKernelGGL((stem2_kernel<8, false, 0, 3>), dim3(a.nblk), dim3(kThreads), 0, s, a); return;
         case 2: hipLaunchKernelGGL((stem2_kernel<8, false, 0, 2>), dim3(a.nblk), dim3(kThreads), 0, s, a); return;
@@ -1244,7 +1319,8 @@ void launch_stem2(hipStream_t s, const Stem2Params &p) {
     // (tools/gpu/rounds_3_4.sh r4_call35).  The chain permutes conv4's K order, i.e. re-rolls its fp32 summation: on one of the 208 contract frames the
     // NMS winner moves between twin anchors 300 / 301 whose oracle scores are 0.997809 / 0.997806 -- which the anchor-twin band of the parity
     // tests (tests/anchor_twins.py) admits, and nothing else.
-    hipLaunchKernelGGL((stem2_kernel<8, false, 0, 7>), dim3(a.nblk), dim3(kThreads), 0, s, a);
+    // V2 = 15 (round 6): + bit 3, the raw-row staging of aligned full-width frames (see the kernel).  It re-orders conv0's K axis as well.
+    hipLaunchKernelGGL((stem2_kernel<8, false, 0, 15>), dim3(a.nblk), dim3(kThreads), 0, s, a);
 }
 
 // =============================================================================================

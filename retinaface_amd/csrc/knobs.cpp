@@ -31,11 +31,12 @@ const Spec kSpecs[K_COUNT] = {
     {"RF_BLEND_FP32", true, 0, {kPresence}},
     {"RF_FORCE_SCATTER", true, 0, {kPresence}},
     {"RF_SCATTER_PER_FRAME", true, 0, {kPresence}},
+    {"RF_SYNC_SPLIT", true, 1, {0, 1, kAny}},
     {"RF_PREBUILD_LANES", true, 0, {0, 1, kAny}},
     {"RF_HOST_TRACE", true, 0, {kPresence}},
     {"RF_STEM2", false, 1, {0, 1, 2, 3, kAny}},
     {"RF_STEM2_PAD", false, 0, {0, 3, 7, kAny}},
-    {"RF_STEM2_V2", false, 7, {0, 1, 2, 3, 5, 7, kAny}},
+    {"RF_STEM2_V2", false, 15, {0, 1, 2, 3, 5, 7, 15, kAny}},
     {"RF_STEM2_DC", false, 1, {0, 1, kAny}},
     {"RF_DWPWWS", false, 0, {0, 2, 3, 12, 13, kAny}},
     {"RF_DWPAD", false, 1, {0, 1, kAny}},

@@ -20,12 +20,13 @@ enum Knob {
     K_BLEND_FP32,          // RF_BLEND_FP32: int8 aggregation convs blend in fp32 instead of packed integers (bit-identical; test knob)
     K_FORCE_SCATTER,       // RF_FORCE_SCATTER: treat every device frame as resident on another GPU (peer-copy path on a one-GPU box)
     K_SCATTER_PER_FRAME,   // RF_SCATTER_PER_FRAME: one peer copy per foreign frame (rounds 3-5) instead of one per contiguous run of frames (the split A/B of bench.py)
+    K_SYNC_SPLIT,          // RF_SYNC_SPLIT=0: a synchronous host-frame call stages + uploads its frames in ONE piece (rounds 1-5) instead of pipelined pieces
     K_PREBUILD_LANES,      // RF_PREBUILD_LANES: build every lane at rf_create instead of on first use
     K_HOST_TRACE,          // RF_HOST_TRACE: per-stage host wall clock of the calls, printed when the engine is destroyed
     // ---- probe (probe build only; the product build returns the default)
     K_STEM2,               // 0 = K_a' + a separate dwpw<16,32,s2>; 1 = stem2 7x8 tiles; 2 = 7x16, 8 waves; 3 = fp16 patch
     K_STEM2_PAD,           // 0 | 3 | 7 KB of unused LDS (occupancy probe)
-    K_STEM2_V2,            // bit 0 planar conv2 tile, bit 1 conv3 -> conv4 register chain, bit 2 rotated depthwise-1 map; default 7
+    K_STEM2_V2,            // bit 0 planar conv2 tile, bit 1 conv3 -> conv4 register chain, bit 2 rotated depthwise-1 map, bit 3 raw-row staging; default 15
     K_STEM2_DC,            // 0 = stem2 tiles without DC centring (another packed image)
     K_DWPWWS,              // 0 | 2 | 3 | 12 | 13: warp-specialised / per-wave-DMA depthwise-pointwise blocks
     K_DWPAD,               // 0 = round-1 halo layout of the depthwise-pointwise blocks

@@ -79,7 +79,7 @@ template <typename T> constexpr int mma_kpl() { return sizeof(T) == 1 ? 16 : siz
 
 
 // ---------------------------------------------------------------------------------------------------- byte archive
-constexpr uint32_t kPlanCacheVersion = 8;      // bump when the packing / layout of anything below changes
+constexpr uint32_t kPlanCacheVersion = 9;      // bump when the packing / layout of anything below changes
 
 struct ArOut {
     std::string b;
@@ -131,6 +131,7 @@ struct WeightPack {
 
     Arena arena_;
     size_t c0_w_ = 0, c0_b_ = 0, c0_hi_ = 0, c0_b_mma_ = 0;      // c0_b_mma_: conv0 bias of the MFMA stems (offset-folded, see pack())
+    size_t c0_raw_ = 0;                                          // conv0 fragments for the raw-row staging of stem2 (two column parities, see pack())
     DwW stem_dw_{0, 0}, stem2_dw_{0, 0};
     GemmW stem_pw_{0, 0}, stem2_pw_{0, 0};
     size_t stem2_c2_b_ = 0, stem2_c2_floor_ = 0, stem2_c3_floor_ = 0;      // stem2's DC-centred tiles (pack())
@@ -375,6 +376,25 @@ struct WeightPack {
                         frag[((half * 2 + 1) * 64 + lane) * 8 + el] = (half_t)(w - (float)h);
                     }
             c0_hi_ = arena_.put(frag);
+            // The same weights for stem2's RAW staging (round 6): the patch rows sit in LDS as the frame's own bytes (3 per pixel, brought in
+            // by LDS-DMA), and a conv0 pixel's three input pixels of one row are 9 consecutive bytes inside an ALIGNED 12-byte window --
+            // bytes 1..9 of it when the conv0 column is even, 3..11 when it is odd (the patch starts at byte 1 of its first dword and a conv0
+            // column advances 6 bytes).  K = 16 * ky + j, j = byte of the window (12..15: the next dword, zero weights), one fragment set per
+            // parity: [parity][hi k<32 | lo k<32 | hi k>=32 | lo k>=32][lane 64][8].  Same hi / lo split, same 27 products per output.
+            std::vector<half_t> raw(2 * 4 * 64 * 8, (half_t)0);
+            for (int par = 0; par < 2; par++)
+                for (int half = 0; half < 2; half++)
+                    for (int lane = 0; lane < 64; lane++)
+                        for (int el = 0; el < 8; el++) {
+                            const int row = lane & 15, k = half * 32 + (lane >> 4) * 8 + el;
+                            const int ky = k / 16, j = k % 16, b = j - (par ? 3 : 1);      // b = 3 * kx + frame channel
+                            if (row >= 8 || ky >= 3 || b < 0 || b >= 9) continue;
+                            const float w = plan.conv0.w[(size_t)row * 27 + (ky * 3 + b / 3) * 3 + (2 - b % 3)];
+                            const half_t h = (half_t)w;
+                            raw[(((size_t)par * 4 + half * 2 + 0) * 64 + lane) * 8 + el] = h;
+                            raw[(((size_t)par * 4 + half * 2 + 1) * 64 + lane) * 8 + el] = (half_t)(w - (float)h);
+                        }
+            c0_raw_ = arena_.put(raw);
             // the stems feed 1024 + pixel into those fragments (kernels.hip u8x4_to_f16): bias - 1024 * sum of the hi + lo weights
             {
                 std::vector<float> bm(plan.conv0.b);
@@ -594,7 +614,7 @@ struct WeightPack {
 
     // ------------------------------------------------------------------------------------------ (de)serialisation
     template <class Ar> void io(Ar &ar) {
-        ar.pod(c0_w_); ar.pod(c0_b_); ar.pod(c0_hi_); ar.pod(c0_b_mma_);
+        ar.pod(c0_w_); ar.pod(c0_b_); ar.pod(c0_hi_); ar.pod(c0_b_mma_); ar.pod(c0_raw_);
         ar.pod(stem_dw_); ar.pod(stem2_dw_); ar.pod(stem_pw_); ar.pod(stem2_pw_);
         ar.pod(stem2_c2_b_); ar.pod(stem2_c2_floor_); ar.pod(stem2_c3_floor_);
         ar.pod(aggr_a_lat_); ar.pod(aggr_a_up_); ar.pod(head_a_);
@@ -618,7 +638,7 @@ struct WeightPack {
         auto ok = [n](size_t off) { return off == kNone || off < n; };
         auto okg = [&](const GemmW &g) { return ok(g.w) && ok(g.b) && ok(g.m); };
         auto okd = [&](const DwW &d) { return ok(d.w) && ok(d.b) && ok(d.mma) && ok(d.m); };
-        bool good = ok(c0_w_) && ok(c0_b_) && ok(c0_hi_) && ok(c0_b_mma_) && okd(stem_dw_) && okd(stem2_dw_) && okg(stem_pw_) && okg(stem2_pw_) &&
+        bool good = ok(c0_w_) && ok(c0_b_) && ok(c0_hi_) && ok(c0_b_mma_) && ok(c0_raw_) && okd(stem_dw_) && okd(stem2_dw_) && okg(stem_pw_) && okg(stem2_pw_) &&
                     ok(stem2_c2_b_) && ok(stem2_c2_floor_) && ok(stem2_c3_floor_);
         for (const auto &d : dw_w_) good = good && okd(d);
         for (const auto &g : pw_w_) good = good && okg(g);

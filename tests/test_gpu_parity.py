@@ -843,6 +843,58 @@ def test_device_resident_and_async_entry_points(rfa):
         assert [[d.anchor_index for d in r] for r in o] == [[d.anchor_index for d in r] for r in host[:n]]
 
 
+@pytest.mark.parametrize("prec", [FP16, INT8])
+def test_synchronous_host_call_with_split_upload_is_byte_identical(rfa, prec):
+    """Round 6: ONE synchronous rf_detect_batch of host frames (the reference's calling convention, RetinaFace.cpp:749-846) stages and sends its
+    frames in pipelined pieces cut at row granularity (engine.cpp submit()).  Every byte of every detection must equal the device-frame call's and
+    the one-piece engine's (RF_SYNC_SPLIT=0): batch 8 and ragged batch 5 at 448 x 448, an empty frame and a strided view inside the batch, the
+    same frames from memory pinned with rf_host_register, and ONE 1280 x 896 frame (pieces are row ranges of it)."""
+    import torch
+    from retinaface_amd.frames import synth_frames
+    frames = synth_frames(448, 448, 8, config=23)
+    wide = np.zeros((448, 500, 3), np.uint8)
+    wide[:, :448] = frames[2]
+    mixed = [frames[0], None, wide[:, :448], frames[3], frames[4]]
+    os.environ["RF_SYNC_SPLIT"] = "0"
+    try:
+        plain = rfa.RetinaFace(ASSETS, "net3", 0.4, precision=prec, net_hw=(448, 448), model_stem="mnet25", max_batch=8)
+    finally:
+        os.environ.pop("RF_SYNC_SPLIT", None)
+    det = rfa.RetinaFace(ASSETS, "net3", 0.4, precision=prec, net_hw=(448, 448), model_stem="mnet25", max_batch=8)
+    dev = torch.from_numpy(np.stack(frames)).cuda()
+    want = _key(det.detect_device([dev[i].data_ptr() for i in range(8)], [448] * 8, [448] * 8, 0.5))
+    assert sum(len(w) for w in want) >= 8
+    for _ in range(3):
+        assert _key(det.detectBatchImages(frames, 0.5)) == want == _key(plain.detectBatchImages(frames, 0.5))
+        assert _key(det.detectBatchImages(frames[:5], 0.5)) == want[:5]
+        assert _key(det.detectBatchImages(mixed, 0.5)) == [want[0], [], want[2], want[3], want[4]]
+    pinned = np.stack(frames)
+    det.host_register(pinned)
+    for _ in range(2):
+        assert _key(det.detectBatchImages([pinned[i] for i in range(8)], 0.5)) == want
+        assert _key(det.detectBatchImages([pinned[i] for i in (6, 1, 3)], 0.5)) == [want[6], want[1], want[3]]
+    det.host_unregister(pinned)
+    # device-frame and asynchronous calls in between are untouched by the split state
+    t = det.enqueue_host(frames[:4], 0.5)
+    assert _key(det.wait(t, 4)) == want[:4] and _key(det.detectBatchImages(frames, 0.5)) == want
+    det.close()
+    plain.close()
+    big = synth_frames(896, 1280, 2, config=24)
+    os.environ["RF_SYNC_SPLIT"] = "0"
+    try:
+        plain = rfa.RetinaFace(ASSETS, "net3", 0.4, precision=prec, net_hw=(896, 1280), model_stem="mnet25", max_batch=2)
+    finally:
+        os.environ.pop("RF_SYNC_SPLIT", None)
+    det = rfa.RetinaFace(ASSETS, "net3", 0.4, precision=prec, net_hw=(896, 1280), model_stem="mnet25", max_batch=2)
+    ref = _key(plain.detectBatchImages(big, 0.5))
+    assert sum(len(w) for w in ref) >= 2
+    for _ in range(3):
+        assert _key([det.detect(big[0], 0.5)]) == ref[:1]                  # one frame: row pieces
+        assert _key(det.detectBatchImages(big, 0.5)) == ref
+    det.close()
+    plain.close()
+
+
 def test_host_frames_async_pipeline_and_registered_buffers(rfa):
     """rf_enqueue_batch (frames in host memory, staged through pinned memory by the copy threads, one DMA per enqueue) and the
     rf_host_register path (DMA straight from the caller's pinned range): bit-identical to the synchronous host call, with more
@@ -1038,13 +1090,24 @@ def test_configs4_rehearsal_eight_engines_share_the_one_gpu(rfa):
         multi = rfa.RetinaFace(ASSETS, "net3", 0.4, precision=INT8, net_hw=(448, 448), model_stem="mnet25", max_batch=32, devices=[0] * 8)
         assert multi.num_devices() == 8
         for rep in range(2):                                   # the second call reuses the eight lanes' staging blocks
+            before = multi.scatter_stats()
             assert _key(multi.detect_device(ptrs, [448] * 256, [448] * 256, 0.5)) == want
             assert multi.last_candidate_counts(256) == want_nc
+            # round 6: a contiguous slice crosses as ONE peer copy (rf_scatter_stats): 256 frames travelled in 8 copies, not 256
+            after = multi.scatter_stats()
+            assert after["frames"] - before["frames"] == 256 and after["peer_copies"] - before["peer_copies"] == 8, (before, after)
         # ragged: 250 images = 7 slices of 32 + one of 26
         assert _key(multi.detect_device(ptrs[:250], [448] * 250, [448] * 250, 0.5)) == want[:250]
         multi.close()
+        # ... and RF_SCATTER_PER_FRAME=1 (the A/B leg of bench.py's library_multi_device.split_ab) keeps rounds 3-5's one copy per frame
+        os.environ["RF_SCATTER_PER_FRAME"] = "1"
+        per_frame = rfa.RetinaFace(ASSETS, "net3", 0.4, precision=INT8, net_hw=(448, 448), model_stem="mnet25", max_batch=32, devices=[0] * 8)
+        assert _key(per_frame.detect_device(ptrs, [448] * 256, [448] * 256, 0.5)) == want
+        assert per_frame.scatter_stats() == {"frames": 256, "peer_copies": 256}
+        per_frame.close()
     finally:
         os.environ.pop("RF_FORCE_SCATTER", None)
+        os.environ.pop("RF_SCATTER_PER_FRAME", None)
 
 
 def test_bench_strong_mode_with_real_engines_two_ranks_on_the_one_gpu(rfa):

@@ -49,6 +49,46 @@ PY
     bench_driver)
       timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extra-configs --no-pmc > $O/bench_driver_invocation_steps20_warmup5.json 2> $O/bench_driver.err
       python -c "import json;j=json.loads(open('$O/bench_driver_invocation_steps20_warmup5.json').read().strip().splitlines()[-1]);print('driver invocation', round(j['images_per_sec']), 'img/s', round(j['value']), 'faces/s')" ;;
+    new_tests)      # the tests this round added / touched
+      ( time timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -q -s -x -k "split_upload or rehearsal or concurrent or composition_invariant or two_ranks" ) > $O/pytest_new.log 2>&1; echo "rc $?" >> $O/pytest_new.log
+      grep -E "passed|failed|Error|assert|^rc|real" $O/pytest_new.log | tail -20 ;;
+    multi_rehearsal)  # the N > 1 line on the one-GPU box: 2 ranks sharing the GPU (gloo), library leg over 8 ordinals with forced scatter
+      timeout 600 python bench.py --gpus 2 --oversubscribe --no-cpu-baseline --host-seconds 0 --no-pmc --no-pipeline-trace --profile-iters 5 --ring-mb 80 --min-seconds 0.5 \
+          > $O/bench_2ranks_one_gpu.json 2> $O/bench_2ranks_one_gpu.err; echo "2 ranks rc $?"
+      timeout 300 python bench.py --library-devices 8 > $O/bench_library_leg_8_engines_one_gpu.json 2> $O/bench_library_leg.err; echo "library leg rc $?"
+      python - <<PY
+import json
+j=json.loads(open("$O/bench_2ranks_one_gpu.json").read().strip().splitlines()[-1])
+print("2 ranks:", round(j["images_per_sec"]), "img/s; efficiency", j.get("scaling_efficiency",{}).get("value"), "per rank", j["result_gather"]["per_rank"]["images_per_sec"])
+print(" split_ab", {k:round(v["ms_per_step"],3) for k,v in j["batch_split_ab"]["legs"].items()}, "same", j["batch_split_ab"]["same_detections_every_leg"])
+l=j.get("library_multi_device",{})
+print(" library leg", l.get("ms_per_call"), l.get("leg_seconds"), l.get("error"))
+l=json.loads(open("$O/bench_library_leg_8_engines_one_gpu.json").read().strip().splitlines()[-1])["library_multi_device"]
+print("library 8:", round(l["ms_per_call"],3), "ms; identical", l["detections_identical_to_single_engine"], "leg s", round(l["leg_seconds"],1))
+print(" split_ab", {k:(v if not isinstance(v,dict) else {a:(round(b,3) if isinstance(b,float) else b) for a,b in v.items()}) for k,v in l["split_ab"].items() if k!="what"})
+PY
+      ;;
+    sync_pieces)    # piece-count sweep of the pipelined staging (RF_SYNC_PIECES), batch 8 and 32 at 448 x 448, one 1280 x 896 frame
+      for pc in 1 2 4 8 16; do RF_SYNC_PIECES=$pc timeout 120 python tools/probes/sync_host_pieces.py; done > $O/sync_host_pieces.txt 2>&1; cat $O/sync_host_pieces.txt ;;
+    sync_host)      # one synchronous host-frame call, pipelined staging vs RF_SYNC_SPLIT=0, every config
+      timeout 600 python bench.py --no-cpu-baseline --no-pmc --no-pipeline-trace --profile-iters 5 > $O/bench_sync_host.json 2> $O/bench_sync_host.err; echo "rc $?"
+      python - <<PY
+import json
+j=json.loads(open("$O/bench_sync_host.json").read().strip().splitlines()[-1])
+print("value", round(j["images_per_sec"]), "img/s")
+for c in [dict(id="main", sync_batch_host=j.get("sync_batch_host"), sync_batch=j["sync_batch"])] + j.get("configs", []):
+    h=c.get("sync_batch_host")
+    if h: print(" cfg", c["id"], "device", round(c["sync_batch"]["ms_per_call"],4), "pageable", round(h["pageable"]["ms_per_call"],4), h["pageable"]["byte_identical_to_device_frames"], "registered", round(h["registered"]["ms_per_call"],4), h["registered"]["byte_identical_to_device_frames"], "unsplit", h.get("unsplit"))
+PY
+      ;;
+    stem_ab)        # stem2 raw-row staging (V2 = 15) vs round 5's product (V2 = 7), probe build, interleaved; then the tests that look at the stem
+      for rep in 1 2; do for v in 7 15; do
+        RETINAFACE_AMD_LIB=$R/retinaface_amd/lib/libretinaface_amd_probe.so RF_STEM2_V2=$v timeout 200 python tools/kbench.py --n 256 --tag r6_${TAG}_stemv$v > $O/kbench_stem_v${v}_$rep.txt 2>&1
+        grep -E "total|stem2" $O/kbench_stem_v${v}_$rep.txt | cut -c1-90 | sed "s/^/V2=$v rep $rep: /"
+      done; done
+      for v in 7 15; do RETINAFACE_AMD_LIB=$R/retinaface_amd/lib/libretinaface_amd_probe.so RF_STEM2_V2=$v timeout 200 python tools/kbench.py --n 64 --hw 896 1280 --tag r6_${TAG}_stemv${v}_big 2>&1 | grep -E "total|stem2" | cut -c1-90 | sed "s/^/V2=$v 1280x896: /"; done
+      ( time timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -q -s -x -k "fused_op or head_blobs or unaligned or network_presets or fp16_contract or oversize or pad32 or smoke" ) > $O/pytest_stem.log 2>&1; echo "rc $?" >> $O/pytest_stem.log
+      grep -E "passed|failed|Error|assert|^rc|real|contract" $O/pytest_stem.log | cut -c1-400 | tail -20 ;;
     *) echo "unknown recipe $recipe" ;;
   esac
 done
