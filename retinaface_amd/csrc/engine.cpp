@@ -682,6 +682,7 @@ private:
             StemParams<T> sp;
             sp.frames = L.d_frames + mb; sp.out = out;
             sp.w0 = arena_.template ptr<half_t>(c0_hi_); sp.b0 = arena_.template ptr<float>(WP::c0_b_mma_);
+            sp.w0_raw = knob(K_STEM_RAW) ? arena_.template ptr<half_t>(WP::c0_raw_) : nullptr;
             sp.dw_w = arena_.template ptr<float>(stem_dw_.w); sp.dw_b = arena_.template ptr<float>(stem_dw_.b);
             sp.pw_w = arena_.template ptr<half_t>(stem_pw_.w); sp.pw_b = arena_.template ptr<float>(stem_pw_.b);
             sp.pw_m = mult_ptr(stem_pw_);

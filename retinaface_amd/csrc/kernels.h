@@ -69,6 +69,7 @@ template <typename TO>
 struct StemParams {
     const FrameDesc *frames; TO *out;              // out: [n][net_h/2][net_w/2][16], fp16 or int8
     const half_t *w0; const float *b0;             // conv0: 4 A fragments (hi/lo x k<32/k>=32), K = (ky,kx,BGRX) 36 -> 64
+    const half_t *w0_raw = nullptr;                // ... for the raw-row staging (weights.h c0_raw_), nullptr = general path only
     const float *dw_w; const float *dw_b;          // depthwise taps [9][8], fp32
     const half_t *pw_w; const float *pw_b;         // pointwise 16 x 8 as one A fragment with K slots [hi | hi | lo | 0] (pack.h)
     const float *pw_m = nullptr;                   // int8 output: 1 / out_scale per channel (pw_b pre-divided)

@@ -565,6 +565,7 @@ template <typename TO>
 struct StemArgs {
     const FrameDesc *frames; TO *out;
     const half_t *w0;                 // conv0 weights: 4 A fragments [hi k<32 | lo k<32 | hi k>=32 | lo k>=32][64 lanes][8]
+    const half_t *w0_raw;             // the same for the raw-row staging: [2 window types][4][64][8] (weights.h c0_raw_), or nullptr
     const float *b0;                  // [8]
     const float *dw_w; const float *dw_b;     // depthwise taps [9][8] fp32
     const half_t *pw_w; const float *pw_b;    // pointwise 16 x 8 as ONE A fragment, K slots [hi | hi | lo | 0] (stem_pw_fragment, pack.h)
@@ -627,8 +628,14 @@ __global__ __launch_bounds__(kThreads, (StemCfg<TO>::OCC)) void stem_kernel(Stem
     const int oy0 = ty * ST_TH, ox0 = tx * ST_TW;
     const FrameDesc fd = a.frames[img];
 
+    // RAW staging (round 6, as stem2_kernel): frames whose base and row pitch are multiples of 16 B and that fill the net's width bring
+    // their patch rows into LDS as they are (LDS-DMA, 16 B per lane, 16 lanes = 256 B per row: bytes [192 tx - 16, +256) of the row, so
+    // patch pixel px starts at LDS byte 7 + 3 px); conv0 reads a pixel's 9 bytes per kernel row from an aligned 12-byte window -- bytes
+    // 3..11 of it for even conv0 columns (weights.h c0_raw_ set 1), 1..9 for odd ones (set 0).  Waves 0,1: even columns, 2,3: odd.
+    const bool raw = ((((uintptr_t)fd.ptr) | (uintptr_t)(unsigned)fd.step) & 15u) == 0 && fd.cols == 2 * a.wo && a.w0_raw != nullptr;
+
     // ---- phase 0: operands that depend only on kernel arguments
-    const f16x8 *wf = (const f16x8 *)a.w0 + lane;
+    const f16x8 *wf = (raw ? (const f16x8 *)a.w0_raw + (wave < 2 ? 256 : 0) : (const f16x8 *)a.w0) + lane;
     const f16x8 w_hi1 = wf[0], w_lo1 = wf[64], w_hi2 = wf[128], w_lo2 = wf[192];
     const f32x4 b0 = lane < 32 ? *(const f32x4 *)(a.b0 + (lane >> 4) * 4) : vzero<f32x4, 4>();
     // (the operands of phases 3 and 4 are loaded one phase ahead of their use, not here: 20 more live registers across the
@@ -641,7 +648,21 @@ __global__ __launch_bounds__(kThreads, (StemCfg<TO>::OCC)) void stem_kernel(Stem
     //      is an aligned memory dword holding at least one frame byte (never straddles a page); rows above the frame are
     //      negative offsets and read 0 (hardware range check), rows below are poisoned; bytes left / right of a row are
     //      cleared here.  All 32-bit: no 64-bit address arithmetic or compares on the saturated VALU.
-    {
+    if (raw) {
+        const int iy0 = 2 * oy0 - 3, bxa = 6 * ox0 - 16;
+        const unsigned fbytes = (unsigned)(fd.rows - 1) * (unsigned)fd.step + (unsigned)fd.cols * 3u;
+        const auto rs = image_rsrc(fd.ptr, fbytes);
+        constexpr int PIECES = (ST_IR + 3) / 4;                        // 4 rows of 256 B per wave-instruction: 6 for the 21-row patch
+        static_assert(PIECES * 1024 <= SC::REGION_A, "raw patch fits region A");
+#pragma unroll 1
+        for (int k = wave; k < PIECES; k += 4) {
+            const int r = 4 * k + (lane >> 4), cb = bxa + 16 * (lane & 15);
+            // rows above / below the frame: out of range = zeros; the chunk left of the row start (tile column 0, chunk 0) is forced out
+            const unsigned off = cb < 0 ? kOobOffset : (unsigned)((iy0 + r) * fd.step + cb);
+            lds_dma16(rs, s_raw + k * 1024, off);
+        }
+        wait_vmcnt<0>();
+    } else {
         const int iy0 = 2 * oy0 - 3;                                  // input row of patch row 0
         const int bx0 = (2 * ox0 - 3) * 3;                            // input byte column of patch pixel 0
         const uintptr_t fp = (uintptr_t)fd.ptr;
@@ -688,6 +709,41 @@ __global__ __launch_bounds__(kThreads, (StemCfg<TO>::OCC)) void stem_kernel(Stem
     // ---- phase 2: conv0 on the 10 x 34 halo'd region: D[cout 16 (8 real)][pixel 16] += W[16][64] x patch[64][16]
     //      k = 4*(3*ky + kx) + c4.  Lane group kb supplies window pixels 2kb, 2kb+1 (MFMA 1) and pixel 8 (MFMA 2, kb 0 only).
     const int kb = lane >> 4;
+    if (raw) {
+        typedef uint32_t u32x2a4 __attribute__((ext_vector_type(2), aligned(4)));
+        const uint32_t *s_rows = (const uint32_t *)s_raw;
+        constexpr int wp = ST_HC / 2;                               // 17 even and 17 odd conv0 columns of the 34
+        constexpr int tiles = (wp * ST_HR + 15) / 16;               // 11 per parity
+        const int par = wave >> 1;
+        const int d0 = par ? 3 : 1;                                 // first dword of column 0's / column 1's aligned window
+#pragma unroll 1
+        for (int t = wave & 1; t < tiles; t += 2) {
+            const int qq = t * 16 + (lane & 15);
+            const int hy = qq / wp, m = qq - hy * wp;
+            const int hx = 2 * m + par;
+            const uint32_t *p1 = s_rows + (2 * hy + (kb >> 1)) * 64 + 3 * m + d0 + 2 * (kb & 1);
+            const uint32_t *p2 = s_rows + (2 * hy + 2) * 64 + 3 * m + d0 + 2 * (kb & 1);
+            const u32x2a4 d1 = *(const u32x2a4 *)p1, d2 = *(const u32x2a4 *)p2;
+            f16x8 x1, x2;
+            u8x4_to_f16(d1[0], x1, 0);
+            u8x4_to_f16(d1[1], x1, 4);
+            u8x4_to_f16(d2[0], x2, 0);
+            u8x4_to_f16(d2[1], x2, 4);
+            f32x4 acc = b0;
+            acc = M::mma(w_hi1, x1, acc);
+            acc = M::mma(w_lo1, x1, acc);
+            acc = M::mma(w_hi2, x2, acc);
+            acc = M::mma(w_lo2, x2, acc);
+            if (lane < 32 && hy < ST_HR) {
+                const int cy = oy0 - 1 + hy, cx = ox0 - 1 + hx;
+                const float lim = ((unsigned)cy < (unsigned)a.ho && (unsigned)cx < (unsigned)a.wo) ? __builtin_inff() : 0.f;
+                f32x4 h;
+#pragma unroll
+                for (int r = 0; r < 4; r++) h[r] = __builtin_amdgcn_fmed3f(acc[r], 0.f, lim);
+                *(f32x4 *)(s_c0 + kb * C0_PLANE + (hy * ST_HC + hx) * 4) = h;
+            }
+        }
+    } else {
     const int ppA = 2 * kb, ppB = 2 * kb + 1;
     const int offA = (ppA / 3) * ST_ROWD + ppA % 3, offB = (ppB / 3) * ST_ROWD + ppB % 3, offC = 2 * ST_ROWD + 2;
     for (int t = wave; t < ST_PTILES; t += 4) {
@@ -716,6 +772,7 @@ __global__ __launch_bounds__(kThreads, (StemCfg<TO>::OCC)) void stem_kernel(Stem
             for (int r = 0; r < 4; r++) h[r] = __builtin_amdgcn_fmed3f(acc[r], 0.f, lim);
             *(f32x4 *)(s_c0 + kb * C0_PLANE + q * 4) = h;
         }
+    }
     }
     __syncthreads();
 
@@ -790,7 +847,7 @@ __global__ __launch_bounds__(kThreads, (StemCfg<TO>::OCC)) void stem_kernel(Stem
 template <typename TO> void launch_stem(hipStream_t s, const StemParams<TO> &p) {
     const int ho = p.net_h / 2, wo = p.net_w / 2;      // conv2 output = conv0 output size (stride-1 block)
     StemArgs<TO> a;
-    a.frames = p.frames; a.out = p.out; a.w0 = p.w0; a.b0 = p.b0;
+    a.frames = p.frames; a.out = p.out; a.w0 = p.w0; a.b0 = p.b0; a.w0_raw = p.w0_raw;
     a.dw_w = p.dw_w; a.dw_b = p.dw_b; a.pw_w = p.pw_w; a.pw_b = p.pw_b; a.pw_m = p.pw_m;
     a.ho = ho; a.wo = wo;
     a.tiles_x = (wo + ST_TW - 1) / ST_TW; a.tiles_y = (ho + ST_TH - 1) / ST_TH;

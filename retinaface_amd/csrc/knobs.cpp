@@ -35,6 +35,7 @@ const Spec kSpecs[K_COUNT] = {
     {"RF_PREBUILD_LANES", true, 0, {0, 1, kAny}},
     {"RF_HOST_TRACE", true, 0, {kPresence}},
     {"RF_STEM2", false, 1, {0, 1, 2, 3, kAny}},
+    {"RF_STEM_RAW", false, 1, {0, 1, kAny}},
     {"RF_STEM2_PAD", false, 0, {0, 3, 7, kAny}},
     {"RF_STEM2_V2", false, 15, {0, 1, 2, 3, 5, 7, 15, kAny}},
     {"RF_STEM2_DC", false, 1, {0, 1, kAny}},

@@ -25,6 +25,7 @@ enum Knob {
     K_HOST_TRACE,          // RF_HOST_TRACE: per-stage host wall clock of the calls, printed when the engine is destroyed
     // ---- probe (probe build only; the product build returns the default)
     K_STEM2,               // 0 = K_a' + a separate dwpw<16,32,s2>; 1 = stem2 7x8 tiles; 2 = 7x16, 8 waves; 3 = fp16 patch
+    K_STEM_RAW,            // 1 default: the int8 stem stages aligned full-width frames as raw rows by LDS-DMA (round 6); 0 = general path only
     K_STEM2_PAD,           // 0 | 3 | 7 KB of unused LDS (occupancy probe)
     K_STEM2_V2,            // bit 0 planar conv2 tile, bit 1 conv3 -> conv4 register chain, bit 2 rotated depthwise-1 map, bit 3 raw-row staging; default 15
     K_STEM2_DC,            // 0 = stem2 tiles without DC centring (another packed image)

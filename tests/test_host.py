@@ -239,11 +239,11 @@ def test_knob_table_validates_and_separates_probe_from_product(tmp_path):
         return dict(l.split() for l in r.stdout.splitlines()), r.stderr
 
     d, err = run("product")
-    assert d["probes"] == "0" and d["RF_STEM2_V2"] == "7" and d["RF_CONV3WS"] == "1" and d["RF_TILE128"] == "-1" and d["RF_WIDE_I8"] == "3" and err == ""
+    assert d["probes"] == "0" and d["RF_STEM2_V2"] == "15" and d["RF_CONV3WS"] == "1" and d["RF_TILE128"] == "-1" and d["RF_WIDE_I8"] == "3" and err == ""
     assert d["RF_FORCE_SCATTER"] == "0" and d["RF_PREBUILD_LANES"] == "0" and d["RF_BLEND_FP32"] == "0" and d["min_rounds"] == "1.00"
     # a probe knob in the product build: ignored, loudly; a semantic knob: honoured
     d, err = run("product", RF_STEM2_V2="5", RF_FORCE_SCATTER="1", RF_PREBUILD_LANES="1", RF_PERSIST_MIN_ROUNDS="3")
-    assert d["RF_STEM2_V2"] == "7" and "RF_STEM2_V2=5 ignored" in err and "libretinaface_amd_probe.so" in err
+    assert d["RF_STEM2_V2"] == "15" and "RF_STEM2_V2=5 ignored" in err and "libretinaface_amd_probe.so" in err
     assert d["RF_FORCE_SCATTER"] == "1" and d["RF_PREBUILD_LANES"] == "1" and d["min_rounds"] == "1.00"
     # the probe build takes the values the dispatch code knows ...
     d, err = run("probe", RF_STEM2_V2="5", RF_CONV3WS="132", RF_TILE128="2", RF_WIDE_I8="6", RF_PERSIST_MIN_ROUNDS="3")
@@ -251,7 +251,7 @@ def test_knob_table_validates_and_separates_probe_from_product(tmp_path):
     assert d["min_rounds"] == "3.00"
     # ... and refuses the ones it does not (round 4: RF_STEM2_V2=4 silently selected round 3's layout, RF_CONV3WS=5 the int8 kernel)
     d, err = run("probe", RF_STEM2_V2="4", RF_CONV3WS="5", RF_TILE128="banana")
-    assert d["RF_STEM2_V2"] == "7" and d["RF_CONV3WS"] == "1" and d["RF_TILE128"] == "-1"
+    assert d["RF_STEM2_V2"] == "15" and d["RF_CONV3WS"] == "1" and d["RF_TILE128"] == "-1"
     assert err.count("is not a value this knob knows") == 3
 
 

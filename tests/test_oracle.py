@@ -299,3 +299,26 @@ def test_anchor_twin_band_admits_only_the_oracles_own_near_ties(oracles):
     flat = sum(1 for w_row, w_a in zip(rows, idx) for t_row, t_a in zip(crow, cidx)
                if t_a not in idx and abs(float(w_row[0]) - float(t_row[0])) <= 2 * noise)
     assert flat > 4 * len(minted)
+
+
+def test_contract_golden_equals_a_live_oracle_run(oracles):
+    """tests/golden/contract_oracle_1280x896.npz (tests/oracle_cache.py, minted by tools/make_contract_golden.py) serves the GPU contract tests
+    the oracle's results on their 1280 x 896 frames: re-derive entries live -- one per model and face set -- and require the same detections,
+    candidates, anchor indices and candidate-count band; a frame whose pixels differ from the minted one is NOT served from the file."""
+    import oracle_cache
+    from int8_contract import HELD_OUT_FACES
+    from retinaface_amd.frames import synth_frames
+    hw = (896, 1280)
+    for stem, faces, cfg, i in (("mnet25", None, 411, 3), ("mnet-deconv-0517", HELD_OUT_FACES, 410, 17)):
+        f = synth_frames(hw[0], hw[1], i + 1, config=cfg, faces=faces)[i]
+        hit = oracle_cache.lookup(oracle_cache.frame_key(stem, hw, cfg, faces, i), f, hw)
+        assert hit is not None, (stem, cfg, i)
+        live = oracles[stem].detect(f, 0.5, 0.4, net_hw=hw)
+        # (identical on the machine that minted the file; another CPU's convolution library may round the last bits of a sum differently)
+        assert np.allclose(hit.rows(), live.rows(), rtol=0, atol=2e-3) and np.array_equal(hit.anchor_indices(), live.anchor_indices())
+        assert [c.anchor_index for c in hit.candidates] == [c.anchor_index for c in live.candidates]
+        assert all(np.allclose(a.as_row(), b.as_row(), rtol=0, atol=2e-3) for a, b in zip(hit.candidates, live.candidates)) and len(hit.detections) >= 1
+        assert abs(hit.band - oracle_cache.band_of(live.heads)) <= 1
+        g = f.copy()
+        g[0, 0, 0] ^= 1
+        assert oracle_cache.lookup(oracle_cache.frame_key(stem, hw, cfg, faces, i), g, hw) is None

@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 6: ONE parametrised script for every GPU call of the round (as tools/gpu/r5.sh).
+# round 6: ONE parametrised script for every GPU call of the round (as tools/gpu/archive/r5.sh did for round 5).
 #   gpurun --timeout T -- 'bash tools/gpu/r6.sh <tag> <recipe> [<recipe> ...]'      output -> gpurun_out/r6_<tag>/
 R=${GRAFT_REPO_ROOT:-/root/repo}
 TAG=$1; shift
@@ -89,6 +89,32 @@ PY
       for v in 7 15; do RETINAFACE_AMD_LIB=$R/retinaface_amd/lib/libretinaface_amd_probe.so RF_STEM2_V2=$v timeout 200 python tools/kbench.py --n 64 --hw 896 1280 --tag r6_${TAG}_stemv${v}_big 2>&1 | grep -E "total|stem2" | cut -c1-90 | sed "s/^/V2=$v 1280x896: /"; done
       ( time timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -q -s -x -k "fused_op or head_blobs or unaligned or network_presets or fp16_contract or oversize or pad32 or smoke" ) > $O/pytest_stem.log 2>&1; echo "rc $?" >> $O/pytest_stem.log
       grep -E "passed|failed|Error|assert|^rc|real|contract" $O/pytest_stem.log | cut -c1-400 | tail -20 ;;
+    insts)          # dynamic instruction mix per kernel (SQ_INSTS_* / SQ_WAVES): the product, and stem2 of round 5 (V2 = 7, probe build) beside it
+      ( cd /tmp && rocprofv3 -L 2>/dev/null | grep -o "SQ_INSTS_[A-Z_0-9]*" | sort -u | tr "\n" " " ) > $O/sq_insts_counters_available.txt; cat $O/sq_insts_counters_available.txt; echo
+      for v in product 7; do
+        rm -rf /tmp/im$v
+        if [ $v = product ]; then E=""; else E="RETINAFACE_AMD_LIB=$R/retinaface_amd/lib/libretinaface_amd_probe.so RF_STEM2_V2=$v"; fi
+        ( cd /tmp && env $E timeout 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_WAVES -d /tmp/im$v -o pmc -- python $R/tools/probes/pmc_probe.py 256 > $O/insts_$v.log 2>&1 )
+        db=$(find /tmp/im$v -name "*.db" | head -1)
+        if [ -z "$db" ]; then ( cd /tmp && env $E timeout 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES -d /tmp/im$v -o pmc -- python $R/tools/probes/pmc_probe.py 256 >> $O/insts_$v.log 2>&1 ); db=$(find /tmp/im$v -name "*.db" | head -1); fi
+        echo "--- $v"; python tools/pmc_insts.py $db $O/instruction_mix_$v.json | head -20
+      done ;;
+    stem8_ab)       # int8 stem: raw-row staging (RF_STEM_RAW=1, default) vs the general path, probe build, interleaved
+      for rep in 1 2; do for v in 0 1; do
+        RETINAFACE_AMD_LIB=$R/retinaface_amd/lib/libretinaface_amd_probe.so RF_STEM_RAW=$v timeout 200 python tools/kbench.py --n 256 --precision int8 --batch 32 --tag r6_${TAG}_stem8raw$v 2>&1 | grep -E "total|stem " | cut -c1-90 | sed "s/^/RAW=$v rep $rep: /"
+      done; done ;;
+    probes)         # the measured-and-rejected kernel variants of the probe build, held to the default path's parity bar
+      make -C retinaface_amd/csrc probe > /dev/null 2>&1
+      ( time RF_PROBE_TESTS=1 timeout 1500 python -m pytest tests/test_gpu_parity.py -m gpu -q -k probe_knob ) > $O/pytest_probe_knobs.log 2>&1; tail -4 $O/pytest_probe_knobs.log ;;
+    trace1)         # single-lane rocprofv3 kernel trace of the timed loop (fp16 metric point, then int8 configs[4] shape)
+      rm -rf /tmp/kt1; ( cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/kt1 -o kt -- python $R/bench.py --timed-only --lanes 1 --no-pmc > $O/trace1_bench.json 2> $O/trace1.err )
+      db=$(find /tmp/kt1 -name "*.db" | head -1); python tools/rocpd_summary.py $db $O/kernel_trace_lanes1_fp16.txt > /dev/null; head -24 $O/kernel_trace_lanes1_fp16.txt | cut -c1-60,104-190
+      rm -rf /tmp/kt2; ( cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/kt2 -o kt -- python $R/bench.py --timed-only --lanes 1 --no-pmc --precision int8 --batch 32 > $O/trace1_int8_bench.json 2> $O/trace1_int8.err )
+      db=$(find /tmp/kt2 -name "*.db" | head -1); python tools/rocpd_summary.py $db $O/kernel_trace_lanes1_int8.txt > /dev/null; head -26 $O/kernel_trace_lanes1_int8.txt | cut -c1-60,104-190 ;;
+    bench_int8)     # the dedicated lines of configs[4] (per-GPU shape) and configs[2]
+      timeout 400 python bench.py --precision int8 --model mnet25 --batch 32 --no-cpu-baseline --no-extra-configs > $O/bench_int8_mnet25_b32.json 2> $O/bench_int8_mnet25.err
+      timeout 400 python bench.py --precision int8 --model mnet-deconv-0517 --batch 32 --no-cpu-baseline --no-extra-configs > $O/bench_int8_0517_b32.json 2> $O/bench_int8_0517.err
+      for f in bench_int8_mnet25_b32 bench_int8_0517_b32; do python -c "import json;j=json.loads(open('$O/$f.json').read().strip().splitlines()[-1]);print('$f', round(j['images_per_sec']), 'img/s', j['roofline']['kernel_instance'], round(j['roofline']['kernel_ms']*1e3,1), 'us')"; done ;;
     *) echo "unknown recipe $recipe" ;;
   esac
 done
