@@ -575,6 +575,7 @@ def main() -> int:
                 finish_extra_counters(start_extra_counters(args, counted), counted, torch.cuda.get_device_properties(0).multi_processor_count)
             if world == 1:
                 attach_pipeline_trace(out["roofline"], measure_pipeline_trace(args))
+            attach_instruction_mix(out["roofline"], args.precision)
         assert out["n_gpus"] == args.gpus
         print(json.dumps(out), flush=True)
     det.close()
@@ -1461,6 +1462,49 @@ def attach_pipeline_trace(roofline, trace):
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     with open(os.path.join(ROOT, "gpurun_out", "bench_pipeline_trace.json"), "w") as f:
         json.dump(trace, f, indent=1)
+
+
+# what the stems' tile geometry recomputes: conv4 tile 7 x 8 <- conv2 region 15 x 17 <- conv0 region 17 x 19 <- 35 x 39 input pixels (kernels.hip Stem2Cfg);
+# int8 stem: conv2 tile 8 x 32 <- conv0 region 10 x 34 <- 21 x 69 input pixels (ST_*)
+HALO_REDUNDANCY = {"stem2": {"conv0_pixels_computed_per_pixel_needed": (17 * 19) / (14 * 16.0), "conv2_pixels_computed_per_pixel_needed": (15 * 17) / (14 * 16.0),
+                             "input_pixels_staged_per_pixel_covered": (35 * 39) / (28 * 32.0)},
+                   "stem": {"conv0_pixels_computed_per_pixel_needed": (10 * 34) / (8 * 32.0), "input_pixels_staged_per_pixel_covered": (21 * 69) / (16 * 64.0)}}
+
+
+def attach_instruction_mix(roofline, precision):
+    """`roofline.frac` of a VALU-bound kernel is an OCCUPANCY of the issue port; this says what is issued.  Measured per-wave dynamic instruction counts of
+    the dominant kernel (rocprofv3 --pmc SQ_INSTS_* / SQ_WAVES over one eager 256-image launch sequence: tools/pmc_insts.py, tools/gpu/r6.sh insts; the newest
+    committed summary under profiles/ is joined -- the counts are a property of the code object, not of the run), the MFMA instructions among them, and the
+    share of the kernel's work that is halo recomputation by tile geometry.  VERDICT r5 next #3."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_instruction_mix_{precision}_product.json")))
+    if not files:
+        roofline["instruction_mix"] = None
+        return
+    mix = json.load(open(files[-1]))
+    mine = [k for k in mix["kernels"] if k["kernel"] == roofline["kernel_instance"]]
+    if not mine:
+        roofline["instruction_mix"] = None
+        return
+    k = max(mine, key=lambda e: e.get("waves", 0))
+    valu, mops = k.get("sq_insts_valu_per_wave"), k.get("sq_insts_valu_mfma_mops_f16_per_wave")
+    out = {"per_wave": {n[len("sq_insts_"):-len("_per_wave")]: v for n, v in k.items() if n.endswith("_per_wave")}, "waves_per_launch": k.get("waves"),
+           "source": os.path.relpath(files[-1], ROOT), "is": "wave-instructions issued per wave launched, loops and divergent branches included (measured, not static)"}
+    if valu and mops is not None:
+        mfma = mops / 32.0                  # one v_mfma_f32_16x16x32_f16 = 32 MOPS of 512 FLOPs
+        out["mfma_instructions_per_wave"] = mfma
+        out["valu_non_mfma_per_wave"] = valu - mfma
+        out["valu_cycles_floor_ms"] = valu * k.get("waves", 0) * 4 / 1024.0 / 2.4e9 * 1e3      # 4 issue cycles per wave64 VALU instruction, 1024 SIMDs, 2.4 GHz
+        out["valu_cycles_floor_is"] = "VALU instructions x 4 cycles / 1024 SIMDs / 2.4 GHz: the time the kernel's instruction count alone costs (compare kernel_ms)"
+    if roofline["kernel_instance"] in HALO_REDUNDANCY:
+        out["halo_recompute_by_tile_geometry"] = HALO_REDUNDANCY[roofline["kernel_instance"]]
+    prev = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_instruction_mix_{precision}_stem2_round5.json")))
+    if prev and roofline["kernel_instance"] == "stem2":
+        old = [e for e in json.load(open(prev[-1]))["kernels"] if e["kernel"] == "stem2"]
+        if old:
+            out["round5_valu_per_wave"] = old[0].get("sq_insts_valu_per_wave")
+            out["round5_is"] = "the same kernel with round 5's register staging of the patch (RF_STEM2_V2=7, probe build), same pass: the raw-row LDS-DMA staging is the difference"
+    roofline["instruction_mix"] = out
 
 
 def baseline_config(args) -> str:

@@ -582,6 +582,25 @@ def test_bench_physical_fractions_pick_the_binding_resource():
     assert r["bound"] == "hbm" and "valu_active" not in r
 
 
+def test_bench_roofline_carries_the_measured_instruction_mix():
+    """`roofline.frac` of a VALU-bound kernel is an occupancy; `roofline.instruction_mix` (round 6) says what is issued: the per-wave
+    dynamic counts of the dominant kernel from the committed rocprofv3 SQ_INSTS_* summary, the MFMA instructions among them, the time the VALU count alone
+    costs, and the halo recomputation the tile geometry implies.  stem2: <= 520 VALU instructions per wave (round 5: 548)."""
+    sys.path.insert(0, ROOT)
+    import bench
+    r = {"kernel_instance": "stem2", "kernel_ms": 0.228}
+    bench.attach_instruction_mix(r, "fp16")
+    m = r["instruction_mix"]
+    assert m["source"].startswith("profiles/r06_instruction_mix_fp16") and m["per_wave"]["valu"] <= 520 < m["round5_valu_per_wave"]
+    assert 20 <= m["mfma_instructions_per_wave"] <= 40 and abs(m["valu_non_mfma_per_wave"] + m["mfma_instructions_per_wave"] - m["per_wave"]["valu"]) < 1e-9
+    assert 0.5 * r["kernel_ms"] < m["valu_cycles_floor_ms"] < r["kernel_ms"]
+    g = m["halo_recompute_by_tile_geometry"]
+    assert abs(g["conv0_pixels_computed_per_pixel_needed"] - 323 / 224) < 1e-12 and abs(g["input_pixels_staged_per_pixel_covered"] - 1365 / 896) < 1e-12
+    r = {"kernel_instance": "no such kernel", "kernel_ms": 1.0}
+    bench.attach_instruction_mix(r, "fp16")
+    assert r["instruction_mix"] is None
+
+
 def test_lds_model_known_cases():
     """tools/lds_model.py (the LDS-array cycle model behind dwpw2's and stem2's tile layouts): the guide's published cases and the
     three dwpw2 layouts whose totals the SQ_LDS_IDX_ACTIVE counter confirmed on the GPU (521 / 449 / 365 cycles per wave and tile)."""

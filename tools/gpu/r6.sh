@@ -91,12 +91,14 @@ PY
       grep -E "passed|failed|Error|assert|^rc|real|contract" $O/pytest_stem.log | cut -c1-400 | tail -20 ;;
     insts)          # dynamic instruction mix per kernel (SQ_INSTS_* / SQ_WAVES): the product, and stem2 of round 5 (V2 = 7, probe build) beside it
       ( cd /tmp && rocprofv3 -L 2>/dev/null | grep -o "SQ_INSTS_[A-Z_0-9]*" | sort -u | tr "\n" " " ) > $O/sq_insts_counters_available.txt; cat $O/sq_insts_counters_available.txt; echo
-      for v in product 7; do
+      for v in product 7 int8; do
         rm -rf /tmp/im$v
-        if [ $v = product ]; then E=""; else E="RETINAFACE_AMD_LIB=$R/retinaface_amd/lib/libretinaface_amd_probe.so RF_STEM2_V2=$v"; fi
-        ( cd /tmp && env $E timeout 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_WAVES -d /tmp/im$v -o pmc -- python $R/tools/probes/pmc_probe.py 256 > $O/insts_$v.log 2>&1 )
+        E=""; W="256"; M=SQ_INSTS_VALU_MFMA_MOPS_F16
+        if [ $v = 7 ]; then E="RETINAFACE_AMD_LIB=$R/retinaface_amd/lib/libretinaface_amd_probe.so RF_STEM2_V2=$v"; fi
+        if [ $v = int8 ]; then W="256 int8 mnet25 448 448 32"; M=SQ_INSTS_VALU_MFMA_MOPS_I8; fi
+        ( cd /tmp && env $E timeout 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS $M SQ_WAVES -d /tmp/im$v -o pmc -- python $R/tools/probes/pmc_probe.py $W > $O/insts_$v.log 2>&1 )
         db=$(find /tmp/im$v -name "*.db" | head -1)
-        if [ -z "$db" ]; then ( cd /tmp && env $E timeout 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES -d /tmp/im$v -o pmc -- python $R/tools/probes/pmc_probe.py 256 >> $O/insts_$v.log 2>&1 ); db=$(find /tmp/im$v -name "*.db" | head -1); fi
+        if [ -z "$db" ]; then ( cd /tmp && env $E timeout 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES -d /tmp/im$v -o pmc -- python $R/tools/probes/pmc_probe.py $W >> $O/insts_$v.log 2>&1 ); db=$(find /tmp/im$v -name "*.db" | head -1); fi
         echo "--- $v"; python tools/pmc_insts.py $db $O/instruction_mix_$v.json | head -20
       done ;;
     stem8_ab)       # int8 stem: raw-row staging (RF_STEM_RAW=1, default) vs the general path, probe build, interleaved
@@ -115,6 +117,17 @@ PY
       timeout 400 python bench.py --precision int8 --model mnet25 --batch 32 --no-cpu-baseline --no-extra-configs > $O/bench_int8_mnet25_b32.json 2> $O/bench_int8_mnet25.err
       timeout 400 python bench.py --precision int8 --model mnet-deconv-0517 --batch 32 --no-cpu-baseline --no-extra-configs > $O/bench_int8_0517_b32.json 2> $O/bench_int8_0517.err
       for f in bench_int8_mnet25_b32 bench_int8_0517_b32; do python -c "import json;j=json.loads(open('$O/$f.json').read().strip().splitlines()[-1]);print('$f', round(j['images_per_sec']), 'img/s', j['roofline']['kernel_instance'], round(j['roofline']['kernel_ms']*1e3,1), 'us')"; done ;;
+    inst_classes)   # VALU instruction classes per kernel (conversion / integer / fp arithmetic / MFMA), product library, fp16 then int8
+      for v in fp16 int8; do
+        W="256"; if [ $v = int8 ]; then W="256 int8 mnet25 448 448 32"; fi
+        for pass in a b; do
+          rm -rf /tmp/ic$v$pass
+          if [ $pass = a ]; then C="SQ_INSTS_VALU SQ_INSTS_VALU_CVT SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_MFMA SQ_WAVES"; else C="SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F16 SQ_INSTS_VALU_ADD_F16 SQ_INSTS_VALU_MUL_F16 SQ_WAVES"; fi
+          ( cd /tmp && timeout 300 rocprofv3 --pmc $C -d /tmp/ic$v$pass -o pmc -- python $R/tools/probes/pmc_probe.py $W > $O/inst_classes_${v}_$pass.log 2>&1 )
+          db=$(find /tmp/ic$v$pass -name "*.db" | head -1)
+          echo "--- $v pass $pass"; python tools/pmc_insts.py $db $O/instruction_classes_${v}_$pass.json | head -8
+        done
+      done ;;
     *) echo "unknown recipe $recipe" ;;
   esac
 done

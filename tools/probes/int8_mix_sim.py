@@ -324,7 +324,7 @@ VARIANTS = {
 }
 
 
-def calibrate(sim, frames, rule="amax", per_channel=True, floor=1 / 64.0):
+def calibrate(sim, frames, rule="amax", per_channel=True, floor=1 / 64.0, margin=1.0):
     """table (blob-name -> scale, incl. `#c` lines) from the fp32 replay of `frames`"""
     amax, store = {}, []
     ones = {k: np.ones(1, np.float32) for k in ()}
@@ -347,7 +347,7 @@ def calibrate(sim, frames, rule="amax", per_channel=True, floor=1 / 64.0):
             tc = np.array([np.quantile(v[v > 0], q) if (v > 0).any() else 0.0 for v in allv])
             vv = allv[allv > 0]
             tt = float(np.quantile(vv, q)) if vv.size else 1.0
-        thr[n] = (tt, np.maximum(tc, tt * floor))
+        thr[n] = (tt * margin, np.maximum(tc, tt * floor) * margin)
     return sim_table(thr, per_channel)
 
 
@@ -390,6 +390,8 @@ def main():
     ap.add_argument("--recal", default=None, help="recalibrate on CPU with this rule (amax, p0.9999, ...) on --cal-frames frames of faces 0,2,4")
     ap.add_argument("--cal-frames", type=int, default=24)
     ap.add_argument("--per-tensor", action="store_true")
+    ap.add_argument("--margin", type=float, default=1.0, help="head-room factor on the recalibrated thresholds (tools/calibrate_int8.py --margin)")
+    ap.add_argument("--gptq", action="store_true", help="error-compensated weight rounding + bias correction on the recalibration frames")
     ap.add_argument("--threads", type=int, default=8)
     ap.add_argument("--w16", default="", help="comma list of contraction-key prefixes whose weights carry 16 bits: pw, pw5 (one block), lat, aggr, ssh, head")
     ap.add_argument("--weight-bits", type=int, default=8)
@@ -402,7 +404,9 @@ def main():
     sim = Sim(net, table)
     if args.recal:
         cal = synth_frames(448, 448, args.cal_frames, config=77, faces=[0, 2, 4])
-        sim.table = calibrate(sim, cal, args.recal, per_channel=not args.per_tensor)
+        sim.table = calibrate(sim, cal, args.recal, per_channel=not args.per_tensor, margin=args.margin)
+        if args.gptq:
+            sim.gptq = {}
     scales = sim.tensor_scales()
     frames = synth_frames(448, 448, args.frames, config=args.config, faces=[1, 3, 5])
     refs = []
