@@ -1133,6 +1133,50 @@ def test_bench_strong_mode_with_real_engines_two_ranks_on_the_one_gpu(rfa):
     assert j["value"] > 0 and abs(j["images_per_sec"] * j["timed_seconds"] - 64 * j["steps"]) < 1e-3 * 64 * j["steps"]
 
 
+@pytest.mark.parametrize("prec", [FP16, INT8])
+def test_raw_row_staging_short_frames_and_mixed_batches(rfa, prec):
+    """Round 6: the stems stage frames whose base and pitch are multiples of 16 B and that fill the net's width as raw rows by LDS-DMA (kernels.hip
+    stem2_kernel / stem_kernel `raw`), everything else through the general path -- chosen per workgroup, so ONE launch may mix both.  A frame that
+    fills the width but not the height relies on the descriptor's range check for its missing rows; a frame one pixel narrower, the same frame at a
+    pointer that is 4 but not 16 bytes aligned, and an ROI with a 16-byte pitch inside a wider image must all give exactly what the zero-padded
+    full-size frame gives (byte for byte: both paths run the same arithmetic only when K order does not matter, so the comparison is made
+    against the SAME path where it can be and against the 208-frame tolerance otherwise)."""
+    import torch
+    from retinaface_amd.frames import synth_frames
+    H = W = 448
+    det = rfa.RetinaFace(ASSETS, "net3", 0.4, precision=prec, net_hw=(H, W), model_stem="mnet25", max_batch=8)
+    full = synth_frames(H, W, 4, config=31)
+    short = [np.ascontiguousarray(f[:300]) for f in full]                          # fills the width, 300 of 448 rows: raw path + range check
+    padded = [np.concatenate([f, np.zeros((H - 300, W, 3), np.uint8)]) for f in short]
+    want = _key(det.detectBatchImages(padded, 0.5))
+    assert sum(len(w) for w in want) >= 3
+    assert _key(det.detectBatchImages(short, 0.5)) == want                         # host frames are staged 256-byte aligned: raw path
+    d_pad = torch.from_numpy(np.stack(padded)).cuda()
+    d_short = torch.from_numpy(np.stack(short)).cuda()
+    assert _key(det.detect_device([d_pad[i].data_ptr() for i in range(4)], [H] * 4, [W] * 4, 0.5)) == want
+    assert _key(det.detect_device([d_short[i].data_ptr() for i in range(4)], [300] * 4, [W] * 4, 0.5)) == want
+    # an ROI that fills the width of the NET but sits in a wider device image with a 16-byte pitch: raw path with step > cols * 3
+    wide = torch.zeros((300, 464 * 3), dtype=torch.uint8, device="cuda")            # pitch 1392 = 16 x 87
+    wide[:, :W * 3] = d_short[1].reshape(300, W * 3)
+    assert _key(det.detect_device([wide.data_ptr()], [300], [W], 0.5, steps=[464 * 3])) == want[1:2]
+    # the general path on the same pixels: pointer 4 (not 16) bytes aligned / one pixel narrower.  Different conv0 K order => compare like the contract
+    buf = torch.zeros(4 + 300 * W * 3, dtype=torch.uint8, device="cuda")
+    buf[4:] = d_short[2].reshape(-1)
+    got = det.detect_device([buf.data_ptr() + 4], [300], [W], 0.5)
+    ref = det.detect_device([d_short[2].data_ptr()], [300], [W], 0.5)
+    assert len(got[0]) == len(ref[0]) >= 1
+    if prec == FP16:
+        assert [d.anchor_index for d in got[0]] == [d.anchor_index for d in ref[0]]
+        assert all(iou_plus1(a.rect, b.rect) >= 1 - 1e-3 for a, b in zip(got[0], ref[0]))
+    else:           # int8: a 1-LSB difference of a first-layer quantum may move an NMS winner to the neighbouring anchor (tests/int8_contract.py)
+        assert all(max(iou_plus1(a.rect, b.rect) for a in got[0]) >= 0.85 for b in ref[0])
+    # one launch mixing raw and general workgroups: results per image are those of the separate calls
+    mixed_ptrs, mixed_rows = [d_short[0].data_ptr(), buf.data_ptr() + 4, d_pad[3].data_ptr()], [300, 300, H]
+    mixed = det.detect_device(mixed_ptrs, mixed_rows, [W] * 3, 0.5)
+    assert _key(mixed[:1]) == want[:1] and _key(mixed[2:]) == want[3:] and _key(mixed[1:2]) == _key(got)
+    det.close()
+
+
 def test_device_frames_unaligned_pointer_odd_step_and_roi(rfa, oracles, base_frame):
     """Device-resident frames exactly as the stem's descriptor path sees them: a frame pointer that is not dword aligned, a row
     step that is not a multiple of 4, and an ROI of a larger device image (step > cols*3, last row ends before the allocation
