@@ -576,6 +576,8 @@ def main() -> int:
             if world == 1:
                 attach_pipeline_trace(out["roofline"], measure_pipeline_trace(args))
             attach_instruction_mix(out["roofline"], args.precision)
+            if args.precision == "int8":
+                out["int8_distance_to_fp32"] = int8_contract_summary(args.model)
         assert out["n_gpus"] == args.gpus
         print(json.dumps(out), flush=True)
     det.close()
@@ -825,7 +827,27 @@ def measure_extra_config(cfg, args, frames_main, dev):
            "_kernels": {p["kernel"]: p["ms"] for p in prof}}
     if "note" in cfg:
         res["note"] = cfg["note"]
+    if cfg["precision"] == "int8":
+        res["int8_distance_to_fp32"] = int8_contract_summary(cfg["model"])
     return res
+
+
+def int8_contract_summary(model):
+    """The int8 engine's distance to the fp32 oracle for `model`, as measured by the GPU parity suite (tests/test_gpu_parity.py::
+    test_int8_contract_over_200_frames: 104 held-out frames, both frame sizes, batches of 8 and 32; metrics of tests/int8_contract.py) -- joined from the newest
+    committed summary under profiles/ (the bench's product path may not touch the oracle; the numbers are a property of the shipped calibration, not of this run)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_int8_contract.json")))
+    if not files:
+        return None
+    c = json.load(open(files[-1])).get("contract", {}).get(model)
+    if not c:
+        return None
+    keep = ("frames", "faces", "same_count", "anchor_agreement", "anchor_iou_worst", "anchor_iou_p01", "anchor_iou_mean", "iou_worst", "iou_p01", "iou_mean", "dscore_max")
+    out = {k: c[k] for k in keep if k in c}
+    out.update({"source": os.path.relpath(files[-1], ROOT), "parity_bar": "bit-exact against oracle/int8_forward.py (every int8 activation); THIS is the reported distance to fp32",
+                "iou_worst_includes": "NMS-winner flips between neighbouring anchors of one face (the fp16 engine: 0.877 on the same metric); anchor_iou_* is the regression error alone"})
+    return out
 
 
 def start_extra_counters(args, entries):

@@ -630,6 +630,7 @@ private:
                 sp.frames = L.d_frames + mb; sp.out = out;
                 sp.w0 = arena_.template ptr<half_t>(c0_hi_); sp.b0 = arena_.template ptr<float>(WP::c0_b_mma_);
                 sp.w0_raw = arena_.template ptr<half_t>(WP::c0_raw_);
+                sp.c0_tab = arena_.template ptr<uint32_t>(WP::stem2_c0tab_); sp.dw1_mma4 = arena_.template ptr<uint32_t>(WP::stem2_dw4_);
                 sp.dw0_w = arena_.template ptr<float>(stem_dw_.w); sp.dw0_b = arena_.template ptr<float>(stem_dw_.b);
                 sp.pw0_w = arena_.template ptr<half_t>(stem_pw_.w); sp.pw0_b = arena_.template ptr<float>(WP::stem2_c2_b_);
                 sp.c2_floor = arena_.template ptr<uint32_t>(WP::stem2_c2_floor_); sp.c3_floor = arena_.template ptr<uint32_t>(WP::stem2_c3_floor_);
@@ -683,6 +684,7 @@ private:
             sp.frames = L.d_frames + mb; sp.out = out;
             sp.w0 = arena_.template ptr<half_t>(c0_hi_); sp.b0 = arena_.template ptr<float>(WP::c0_b_mma_);
             sp.w0_raw = knob(K_STEM_RAW) ? arena_.template ptr<half_t>(WP::c0_raw_) : nullptr;
+            sp.c0_tab = knob(K_STEM_RAW) == 2 ? arena_.template ptr<uint32_t>(WP::stem_c0tab_) : nullptr;
             sp.dw_w = arena_.template ptr<float>(stem_dw_.w); sp.dw_b = arena_.template ptr<float>(stem_dw_.b);
             sp.pw_w = arena_.template ptr<half_t>(stem_pw_.w); sp.pw_b = arena_.template ptr<float>(stem_pw_.b);
             sp.pw_m = mult_ptr(stem_pw_);

@@ -70,6 +70,7 @@ struct StemParams {
     const FrameDesc *frames; TO *out;              // out: [n][net_h/2][net_w/2][16], fp16 or int8
     const half_t *w0; const float *b0;             // conv0: 4 A fragments (hi/lo x k<32/k>=32), K = (ky,kx,BGRX) 36 -> 64
     const half_t *w0_raw = nullptr;                // ... for the raw-row staging (weights.h c0_raw_), nullptr = general path only
+    const uint32_t *c0_tab = nullptr;              // conv0 pixel table of the raw path (pack.h stem_conv0_table), nullptr = index arithmetic
     const float *dw_w; const float *dw_b;          // depthwise taps [9][8], fp32
     const half_t *pw_w; const float *pw_b;         // pointwise 16 x 8 as one A fragment with K slots [hi | hi | lo | 0] (pack.h)
     const float *pw_m = nullptr;                   // int8 output: 1 / out_scale per channel (pw_b pre-divided)
@@ -82,6 +83,8 @@ struct Stem2Params {
     const FrameDesc *frames; half_t *out;          // out: [n][net_h/4][net_w/4][32]
     const half_t *w0; const float *b0;
     const half_t *w0_raw = nullptr;                // conv0 fragments of the raw-row staging (weights.h c0_raw_): [2 parities][4][64][8]
+    const uint32_t *c0_tab = nullptr;              // conv0 pixel table of the raw path (pack.h stem2_conv0_table): [4][6][64] x uint2
+    const uint32_t *dw1_mma4 = nullptr;            // conv3's diagonal A fragments expanded: [5][64][4] dwords (weights.h stem2_dw4_)
     const float *dw0_w; const float *dw0_b; const half_t *pw0_w; const float *pw0_b;
     const uint32_t *dw1_mma; const float *dw1_b;   // conv3: taps as diagonal MFMA A fragments [5][64] dwords (pack.h), bias [16]
     const half_t *pw1_w; const float *pw1_b;       // conv4: 32 x 16 as hi | lo along K (k < 16: rn16(w), k >= 16: rn16(w - hi)), MFMA-fragment packed, bias [32]

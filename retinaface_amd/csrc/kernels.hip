@@ -566,6 +566,7 @@ struct StemArgs {
     const FrameDesc *frames; TO *out;
     const half_t *w0;                 // conv0 weights: 4 A fragments [hi k<32 | lo k<32 | hi k>=32 | lo k>=32][64 lanes][8]
     const half_t *w0_raw;             // the same for the raw-row staging: [2 window types][4][64][8] (weights.h c0_raw_), or nullptr
+    const uint2 *c0_tab;              // conv0 pixel table of the raw path [4 waves][6 tiles][64 lanes] (pack.h stem_conv0_table), or nullptr
     const float *b0;                  // [8]
     const float *dw_w; const float *dw_b;     // depthwise taps [9][8] fp32
     const half_t *pw_w; const float *pw_b;    // pointwise 16 x 8 as ONE A fragment, K slots [hi | hi | lo | 0] (stem_pw_fragment, pack.h)
@@ -633,6 +634,14 @@ __global__ __launch_bounds__(kThreads, (StemCfg<TO>::OCC)) void stem_kernel(Stem
     // patch pixel px starts at LDS byte 7 + 3 px); conv0 reads a pixel's 9 bytes per kernel row from an aligned 12-byte window -- bytes
     // 3..11 of it for even conv0 columns (weights.h c0_raw_ set 1), 1..9 for odd ones (set 0).  Waves 0,1: even columns, 2,3: odd.
     const bool raw = ((((uintptr_t)fd.ptr) | (uintptr_t)(unsigned)fd.step) & 15u) == 0 && fd.cols == 2 * a.wo && a.w0_raw != nullptr;
+
+    // conv0's pixel table (as stem2_kernel, V2 bit 4): which pixel a lane of the wave's k-th tile computes comes from memory, not from the VALU
+    static_assert(ST_HR == kStemR0H && ST_HC == kStemR0W && C0_PLANE == kStemC0Plane, "pack.h stem_conv0_table is built for this geometry");
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const bool tab = raw && a.c0_tab != nullptr;
+    const uint2 *c0_tab = a.c0_tab + (wave_u * kStemC0Tiles) * 64;
+    uint2 c0_e = {0u, 0u};
+    if (tab) c0_e = c0_tab[lane];
 
     // ---- phase 0: operands that depend only on kernel arguments
     const f16x8 *wf = (raw ? (const f16x8 *)a.w0_raw + (wave < 2 ? 256 : 0) : (const f16x8 *)a.w0) + lane;
@@ -709,7 +718,36 @@ __global__ __launch_bounds__(kThreads, (StemCfg<TO>::OCC)) void stem_kernel(Stem
     // ---- phase 2: conv0 on the 10 x 34 halo'd region: D[cout 16 (8 real)][pixel 16] += W[16][64] x patch[64][16]
     //      k = 4*(3*ky + kx) + c4.  Lane group kb supplies window pixels 2kb, 2kb+1 (MFMA 1) and pixel 8 (MFMA 2, kb 0 only).
     const int kb = lane >> 4;
-    if (raw) {
+    if (tab) {
+        typedef uint32_t u32x2a4 __attribute__((ext_vector_type(2), aligned(4)));
+        const int n = (wave_u & 1) == 0 ? kStemC0Tiles : kStemC0Tiles - 1;      // 11 tiles per column parity over two waves
+        const unsigned p2d = (unsigned)(2 - (kb >> 1)) * 256u;
+#pragma unroll 1
+        for (int k = 0; k < n; k++) {
+            const uint2 e = c0_e;
+            c0_e = c0_tab[(k + 1) * 64 + lane];                                 // (slot n exists: unused, the next wave's first, or the spare row at the table's end)
+            const unsigned p1 = e.x & 0xffffu, ob = e.x >> 16;
+            const u32x2a4 d1 = *(const u32x2a4 *)(s_raw + p1), d2 = *(const u32x2a4 *)(s_raw + p1 + p2d);
+            f16x8 x1, x2;
+            u8x4_to_f16(d1[0], x1, 0);
+            u8x4_to_f16(d1[1], x1, 4);
+            u8x4_to_f16(d2[0], x2, 0);
+            u8x4_to_f16(d2[1], x2, 4);
+            f32x4 acc = b0;
+            acc = M::mma(w_hi1, x1, acc);
+            acc = M::mma(w_lo1, x1, acc);
+            acc = M::mma(w_hi2, x2, acc);
+            acc = M::mma(w_lo2, x2, acc);
+            if (e.y >> 16) {
+                const int cy = oy0 - 1 + (int)(e.y & 0xffu), cx = ox0 - 1 + (int)((e.y >> 8) & 0xffu);
+                const float lim = ((unsigned)cy < (unsigned)a.ho && (unsigned)cx < (unsigned)a.wo) ? __builtin_inff() : 0.f;
+                f32x4 h;
+#pragma unroll
+                for (int r = 0; r < 4; r++) h[r] = __builtin_amdgcn_fmed3f(acc[r], 0.f, lim);
+                *(f32x4 *)((unsigned char *)s_c0 + ob) = h;
+            }
+        }
+    } else if (raw) {
         typedef uint32_t u32x2a4 __attribute__((ext_vector_type(2), aligned(4)));
         const uint32_t *s_rows = (const uint32_t *)s_raw;
         constexpr int wp = ST_HC / 2;                               // 17 even and 17 odd conv0 columns of the 34
@@ -847,7 +885,7 @@ __global__ __launch_bounds__(kThreads, (StemCfg<TO>::OCC)) void stem_kernel(Stem
 template <typename TO> void launch_stem(hipStream_t s, const StemParams<TO> &p) {
     const int ho = p.net_h / 2, wo = p.net_w / 2;      // conv2 output = conv0 output size (stride-1 block)
     StemArgs<TO> a;
-    a.frames = p.frames; a.out = p.out; a.w0 = p.w0; a.b0 = p.b0; a.w0_raw = p.w0_raw;
+    a.frames = p.frames; a.out = p.out; a.w0 = p.w0; a.b0 = p.b0; a.w0_raw = p.w0_raw; a.c0_tab = (const uint2 *)p.c0_tab;
     a.dw_w = p.dw_w; a.dw_b = p.dw_b; a.pw_w = p.pw_w; a.pw_b = p.pw_b; a.pw_m = p.pw_m;
     a.ho = ho; a.wo = wo;
     a.tiles_x = (wo + ST_TW - 1) / ST_TW; a.tiles_y = (ho + ST_TH - 1) / ST_TH;
@@ -896,6 +934,8 @@ struct Stem2Args {
     const FrameDesc *frames; half_t *out;           // out: [n][ho4][wo4][32]
     const half_t *w0; const float *b0;              // conv0 (as StemArgs)
     const half_t *w0_raw;                           // conv0 for the raw-row staging: [2 column parities][4 fragments][64][8] (weights.h c0_raw_)
+    const uint2 *c0_tab;                            // ... its pixel table [4 waves][6 tiles][64 lanes] (pack.h stem2_conv0_table)
+    const u32x4 *dw1_mma4;                          // conv3's diagonal A fragments expanded to 4 dwords per lane [5][64]
     const float *dw0_w; const float *dw0_b; const half_t *pw0_w; const float *pw0_b;     // conv1 / conv2 (as StemArgs)
     const uint32_t *dw1_mma; const float *dw1_b;    // conv3 taps as diagonal MFMA A fragments [5][64] dwords (pack.h dw_mma_dword), bias [16]
     const half_t *pw1_w; const float *pw1_b;        // conv4: 32 x 16 as hi | lo along K (32 K slots, all used), bias [32]
@@ -957,6 +997,20 @@ __global__ __launch_bounds__((Stem2Cfg<TW_, F16P, PADKB>::THREADS), (Stem2Cfg<TW
     // test_device_frames_unaligned_pointer_odd_step_and_roi.  Wave-uniform per workgroup.
     constexpr bool RAWCAP = (V2 & 8) != 0 && !F16P && NT == 256 && TW == 8;
     const bool raw = RAWCAP && ((((uintptr_t)fd.ptr) | (uintptr_t)(unsigned)fd.step) & 15u) == 0 && fd.cols == 2 * a.wo && a.w0_raw != nullptr;
+    // V2 bits 4 / 5 / 6 (round 6, MEASURED AND REJECTED, probe build only): index arithmetic that is the same for every workgroup taken from memory instead of the
+    // VALU -- bit 4: conv0's pixel table on the raw path (pack.h stem2_conv0_table: 30 -> 19 VALU instructions per MFMA tile), bit 5: conv3's diagonal A fragments
+    // already expanded (20 v_cndmask per wave less), bit 6: the table path's LDS reads as explicit ds_read2_b32.  All bit-identical, all slower: 234.5 us base ->
+    // 239.7 (bit 5), 241.7 (4 + 6), 257.9 (all); and 407 us with bit 4 alone, because the compiler reads the 4-byte-aligned dword pair with ONE ds_read_b64, which
+    // this chip executes at a fraction of the rate of ds_read2_b32 when the address is not 8-byte aligned.  The kernel is VALU-bound at 0.86, not VALU-ONLY-bound: a
+    // dependent global load per tile costs more than the 11 instructions it replaces (profiles/r06_stem_index_tables_rejected.txt).
+    constexpr bool TAB = (V2 & 16) != 0 && RAWCAP;
+    constexpr bool TABASM = (V2 & 64) != 0;                      // the table path's two LDS reads as explicit ds_read2_b32 (the compiler picks ds_read_b64 at 4-byte alignment)
+    static_assert(!TAB || (C::R0H == kStem2R0H && C::R0W == kStem2R0W && C0_PLANE == kStem2C0Plane), "pack.h stem2_conv0_table is built for this geometry");
+    // (the wave index as a scalar: the table pointer of tile k is then base + SGPR arithmetic + one constant per-lane offset, no VALU per tile)
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const uint2 *c0_tab = a.c0_tab + (wave_u * kStem2C0Tiles) * 64;
+    uint2 c0_e = {0u, 0u};
+    if (TAB && raw) c0_e = c0_tab[lane];                         // the first tile's entry: requested before the patch is staged
 
     // ---- phase 0: operands that depend only on kernel arguments
     const f16x8 *wf = (raw ? (const f16x8 *)a.w0_raw + (wave >> 1) * 256 : (const f16x8 *)a.w0) + lane;
@@ -1055,6 +1109,49 @@ __global__ __launch_bounds__((Stem2Cfg<TW_, F16P, PADKB>::THREADS), (Stem2Cfg<TW
         // MFMA 2 = kernel row 2 (kb 0,1; kb 2,3 meet zero weights).  A lane reads two consecutive dwords per MFMA (ds_read2_b32).
         typedef uint32_t u32x2a4 __attribute__((ext_vector_type(2), aligned(4)));
         const uint32_t *s_rows = (const uint32_t *)s_raw;
+        if constexpr (TAB) {
+            const int n = wave_u == 0 ? kStem2C0Tiles : kStem2C0Tiles - 1;    // 11 even-column tiles over waves 0,1; 10 odd-column tiles over waves 2,3
+            const unsigned p2d = (unsigned)(2 - (kb >> 1)) * 128u;            // MFMA 2 reads kernel row 2: two rows (kb 0,1) / one row (kb 2,3: zero weights) further down
+#pragma unroll 1
+            for (int k = 0; k < n; k++) {
+                const uint2 e = c0_e;
+                c0_e = c0_tab[(k + 1) * 64 + lane];                           // next tile's entry, in flight during this tile's MFMAs (entry n of the
+                                                                              // last tile's prefetch exists: an unused slot or the next wave's first)
+                const unsigned p1 = e.x & 0xffffu, ob = e.x >> 16;
+                u32x2a4 d1, d2;
+                if constexpr (TABASM) {
+                    typedef uint32_t u32x2r __attribute__((ext_vector_type(2)));
+                    u32x2r r1, r2;
+                    const unsigned l1 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)s_raw + p1;
+                    asm volatile("ds_read2_b32 %0, %2 offset1:1\n\tds_read2_b32 %1, %3 offset1:1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(r1), "=&v"(r2) : "v"(l1), "v"(l1 + p2d) : "memory");
+                    d1[0] = r1[0]; d1[1] = r1[1]; d2[0] = r2[0]; d2[1] = r2[1];
+                } else {
+                    d1 = *(const u32x2a4 *)(s_raw + p1); d2 = *(const u32x2a4 *)(s_raw + p1 + p2d);
+                }
+                f16x8 x1, x2;
+                u8x4_to_f16(d1[0], x1, 0);
+                u8x4_to_f16(d1[1], x1, 4);
+                u8x4_to_f16(d2[0], x2, 0);
+                u8x4_to_f16(d2[1], x2, 4);
+                f32x4 acc = b0;
+                acc = M::mma(w_hi1, x1, acc);
+                acc = M::mma(w_lo1, x1, acc);
+                acc = M::mma(w_hi2, x2, acc);
+                acc = M::mma(w_lo2, x2, acc);
+                if (e.y >> 16) {
+                    float lim = __builtin_inff();
+                    if (!interior) {
+                        asm volatile("" ::: "memory");
+                        const int cy = 2 * oy0 - 2 + (int)(e.y & 0xffu), cx = 2 * ox0 - 2 + (int)((e.y >> 8) & 0xffu);
+                        lim = ((unsigned)cy < (unsigned)a.ho && (unsigned)cx < (unsigned)a.wo) ? __builtin_inff() : 0.f;
+                    }
+                    f32x4 h;
+#pragma unroll
+                    for (int r = 0; r < 4; r++) h[r] = __builtin_amdgcn_fmed3f(acc[r], 0.f, lim);
+                    *(f32x4 *)((unsigned char *)s_c0 + ob) = h;
+                }
+            }
+        } else {
         // waves 0,1: even conv0 columns (10 of the 19), waves 2,3: odd ones (9); the parity is a compile-time constant of each copy of the
         // loop, so the pixel -> (row, column) division is by a constant
         auto conv0_raw = [&](auto parity) {
@@ -1095,6 +1192,7 @@ __global__ __launch_bounds__((Stem2Cfg<TW_, F16P, PADKB>::THREADS), (Stem2Cfg<TW
         };
         if (wave < 2) conv0_raw(std::integral_constant<int, 0>());
         else conv0_raw(std::integral_constant<int, 1>());
+        }
     } else {
         const int ppA = 2 * kb, ppB = 2 * kb + 1;
         const int offA = (ppA / 3) * ROWD + ppA % 3, offB = (ppB / 3) * ROWD + ppB % 3, offC = 2 * ROWD + 2;
@@ -1228,9 +1326,14 @@ __global__ __launch_bounds__((Stem2Cfg<TW_, F16P, PADKB>::THREADS), (Stem2Cfg<TW
         if constexpr (PLANAR) *(uint2 *)(s_c2 + (kb >> 1) * C2_PLANE + i * 8 + (kb & 1) * 4) = h;
         else *(uint2 *)(s_c2 + i * 16 + kb * 4) = h;
     }
+    constexpr bool DW4 = (V2 & 32) != 0;                     // conv3's A fragments arrive expanded (4 dwords per lane and chunk): no v_cndmask in phase 5
     uint32_t dw1v[kDwMmaChunks];                             // phase 5's operands: requested before the barrier
+    u32x4 dw1v4[kDwMmaChunks];
 #pragma unroll
-    for (int kc = 0; kc < kDwMmaChunks; kc++) dw1v[kc] = a.dw1_mma[kc * 64 + lane];
+    for (int kc = 0; kc < kDwMmaChunks; kc++) {
+        if constexpr (DW4) dw1v4[kc] = a.dw1_mma4[kc * 64 + lane];
+        else dw1v[kc] = a.dw1_mma[kc * 64 + lane];
+    }
     const f32x4 dbias = *(const f32x4 *)(a.dw1_b + kb * 4);           // bias + mu2 * sum(taps) - mu3 (host)
     const uint2 c3_floor = *(const uint2 *)(a.c3_floor + kb * 2);     // the conv3 result is stored centred as well (conv4 is 1x1: its bias takes W mu3)
     // V2: conv4's operands too (its A fragments in the chained K order: halves 0-3 = W_hi of channels 4 kb .., 4-7 = W_lo of the same channels)
@@ -1275,10 +1378,14 @@ __global__ __launch_bounds__((Stem2Cfg<TW_, F16P, PADKB>::THREADS), (Stem2Cfg<TW
 #pragma unroll
             for (int kc = 0; kc < kDwMmaChunks; kc++) {
                 typedef uint32_t u32x4_ __attribute__((ext_vector_type(4)));
-                const uint32_t wd = dw1v[kc];
                 u32x4_ wa;
+                if constexpr (DW4) {
+                    wa = dw1v4[kc];
+                } else {
+                    const uint32_t wd = dw1v[kc];
 #pragma unroll
-                for (int d = 0; d < 4; d++) wa[d] = dsel == d ? wd : 0u;
+                    for (int d = 0; d < 4; d++) wa[d] = dsel == d ? wd : 0u;
+                }
                 acc = M::mma(__builtin_bit_cast(M::Frag, wa), bf[kc], acc);
             }
             uint2 h;
@@ -1341,6 +1448,7 @@ int stem2_variant() { return knob(K_STEM2); }      // probe knob RF_STEM2: 1 = 7
 void launch_stem2(hipStream_t s, const Stem2Params &p) {
     Stem2Args a;
     a.frames = p.frames; a.out = p.out; a.w0 = p.w0; a.b0 = p.b0; a.w0_raw = p.w0_raw;
+    a.c0_tab = (const uint2 *)p.c0_tab; a.dw1_mma4 = (const u32x4 *)p.dw1_mma4;
     a.dw0_w = p.dw0_w; a.dw0_b = p.dw0_b; a.pw0_w = p.pw0_w; a.pw0_b = p.pw0_b;
     a.dw1_mma = p.dw1_mma; a.dw1_b = p.dw1_b; a.pw1_w = p.pw1_w; a.pw1_b = p.pw1_b;
     a.c2_floor = p.c2_floor; a.c3_floor = p.c3_floor;
@@ -1363,6 +1471,11 @@ void launch_stem2(hipStream_t s, const Stem2Params &p) {
     // RF_STEM2_V2 (probe knob): bit 0 = planar conv2 tile, bit 1 = conv3 -> conv4 chained in registers, bit 2 = rotated thread -> pixel map of the
     // depthwise-1 phase; 0 = round 3; 5 = round 4's default (bit-identical to round 3: 250.3 -> 246.5 -> 238.6 us, tools/gpu/rounds_3_4.sh r4_call30, r4_call32)
     switch (knob(K_STEM2_V2)) {
+        case 15: hipLaunchKernelGGL((stem2_kernel<8, false, 0, 15>), dim3(a.nblk), dim3(kThreads), 0, s, a); return;    // raw-row staging without the index tables
+        case 31: hipLaunchKernelGGL((stem2_kernel<8, false, 0, 31>), dim3(a.nblk), dim3(kThreads), 0, s, a); return;    // + conv0 pixel table
+        case 47: hipLaunchKernelGGL((stem2_kernel<8, false, 0, 47>), dim3(a.nblk), dim3(kThreads), 0, s, a); return;    // + expanded conv3 fragments only
+        case 95: hipLaunchKernelGGL((stem2_kernel<8, false, 0, 95>), dim3(a.nblk), dim3(kThreads), 0, s, a); return;    // + table with explicit ds_read2_b32
+        case 127: hipLaunchKernelGGL((stem2_kernel<8, false, 0, 127>), dim3(a.nblk), dim3(kThreads), 0, s, a); return;  // all
         case 7: hipLaunchKernelGGL((stem2_kernel<8, false, 0, 7>), dim3(a.nblk), dim3(kThreads), 0, s, a); return;      // round 5's product
         case 5: hipLaunchKernelGGL((stem2_kernel<8, false, 0, 5>), dim3(a.nblk), dim3(kThreads), 0, s, a); return;
         case 3: hipLaunchKernelGGL((stem2_kernel<8, false, 0, 3>), dim3(a.nblk), dim3(kThreads), 0, s, a); return;
@@ -1376,7 +1489,8 @@ void launch_stem2(hipStream_t s, const Stem2Params &p) {
     // (tools/gpu/rounds_3_4.sh r4_call35).  The chain permutes conv4's K order, i.e. re-rolls its fp32 summation: on one of the 208 contract frames the
     // NMS winner moves between twin anchors 300 / 301 whose oracle scores are 0.997809 / 0.997806 -- which the anchor-twin band of the parity
     // tests (tests/anchor_twins.py) admits, and nothing else.
-    // V2 = 15 (round 6): + bit 3, the raw-row staging of aligned full-width frames (see the kernel).  It re-orders conv0's K axis as well.
+    // V2 = 15 (round 6): + bit 3, the raw-row staging of aligned full-width frames (see the kernel; it re-orders conv0's K axis as well).  Bits 4-6 (index
+    // tables from memory instead of index arithmetic, bit-identical) measured slower and live in the probe build: profiles/r06_stem_index_tables_rejected.txt.
     hipLaunchKernelGGL((stem2_kernel<8, false, 0, 15>), dim3(a.nblk), dim3(kThreads), 0, s, a);
 }
 

@@ -23,7 +23,7 @@ struct Spec {
     const char *name;
     bool semantic;          // exists in the product build
     int def;
-    int allowed[10];        // the values the dispatch code knows, terminated by kAny; {kPresence} = presence knob; {kAny} = any integer
+    int allowed[14];        // the values the dispatch code knows, terminated by kAny; {kPresence} = presence knob; {kAny} = any integer
 };
 
 // One row per knob, in the order of enum Knob.  `allowed` is what the dispatch code in kernels.hip / engine.cpp has a case for.
@@ -35,9 +35,9 @@ const Spec kSpecs[K_COUNT] = {
     {"RF_PREBUILD_LANES", true, 0, {0, 1, kAny}},
     {"RF_HOST_TRACE", true, 0, {kPresence}},
     {"RF_STEM2", false, 1, {0, 1, 2, 3, kAny}},
-    {"RF_STEM_RAW", false, 1, {0, 1, kAny}},
+    {"RF_STEM_RAW", false, 1, {0, 1, 2, kAny}},
     {"RF_STEM2_PAD", false, 0, {0, 3, 7, kAny}},
-    {"RF_STEM2_V2", false, 15, {0, 1, 2, 3, 5, 7, 15, kAny}},
+    {"RF_STEM2_V2", false, 15, {0, 1, 2, 3, 5, 7, 15, 31, 47, 95, 127, kAny}},
     {"RF_STEM2_DC", false, 1, {0, 1, kAny}},
     {"RF_DWPWWS", false, 0, {0, 2, 3, 12, 13, kAny}},
     {"RF_DWPAD", false, 1, {0, 1, kAny}},
@@ -82,7 +82,7 @@ void parse_all() {
         bool ok = end != e && *end == '\0';
         if (ok && s.allowed[0] != kAny) {
             ok = false;
-            for (int i = 0; i < 10 && s.allowed[i] != kAny; i++) ok = ok || s.allowed[i] == (int)v;
+            for (int i = 0; i < 14 && s.allowed[i] != kAny; i++) ok = ok || s.allowed[i] == (int)v;
         }
         if (!ok) {
             fprintf(stderr, "[retinaface_amd] %s=%s is not a value this knob knows: using the default %d\n", s.name, e, s.def);

@@ -25,9 +25,9 @@ enum Knob {
     K_HOST_TRACE,          // RF_HOST_TRACE: per-stage host wall clock of the calls, printed when the engine is destroyed
     // ---- probe (probe build only; the product build returns the default)
     K_STEM2,               // 0 = K_a' + a separate dwpw<16,32,s2>; 1 = stem2 7x8 tiles; 2 = 7x16, 8 waves; 3 = fp16 patch
-    K_STEM_RAW,            // 1 default: the int8 stem stages aligned full-width frames as raw rows by LDS-DMA (round 6); 0 = general path only
+    K_STEM_RAW,            // 1 default: the int8 stem stages aligned full-width frames as raw rows by LDS-DMA (round 6); 0 = general path only; 2 = + conv0's pixel indices from a table in memory (measured: slower)
     K_STEM2_PAD,           // 0 | 3 | 7 KB of unused LDS (occupancy probe)
-    K_STEM2_V2,            // bit 0 planar conv2 tile, bit 1 conv3 -> conv4 register chain, bit 2 rotated depthwise-1 map, bit 3 raw-row staging; default 15
+    K_STEM2_V2,            // bit 0 planar conv2 tile, bit 1 conv3 -> conv4 register chain, bit 2 rotated depthwise-1 map, bit 3 raw-row staging; default 15.  Measured and rejected: bit 4 conv0 pixel table from memory, bit 5 expanded conv3 fragments, bit 6 the table's LDS reads as explicit ds_read2_b32 (31, 47, 95, 127)
     K_STEM2_DC,            // 0 = stem2 tiles without DC centring (another packed image)
     K_DWPWWS,              // 0 | 2 | 3 | 12 | 13: warp-specialised / per-wave-DMA depthwise-pointwise blocks
     K_DWPAD,               // 0 = round-1 halo layout of the depthwise-pointwise blocks

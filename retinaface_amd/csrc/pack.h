@@ -14,6 +14,7 @@
 #pragma once
 #include <cstddef>
 #include <cstdint>
+#include <vector>
 
 #if defined(__HIPCC__)
 #define RF_HD __host__ __device__
@@ -86,6 +87,37 @@ RF_HD inline void dw_i8_split(int w_int, int8_t *hi, int8_t *lo) {
     *hi = (int8_t)h;
     *lo = (int8_t)(w_int - 128 * h);                               // [-64, 64] (up to +-127 only when h saturates; it cannot: |w| <= 16256)
 }
+
+// stem2's conv0 phase with raw-row staging (kernels.hip stem2_kernel, round 6): which conv0 pixel a lane of a wave's k-th MFMA tile computes, where its
+// bytes lie in the staged patch and where its result goes -- the same for every workgroup, so it is a TABLE ([4 waves][kStem2C0Tiles][64 lanes] x uint2)
+// instead of ~9 VALU instructions of index arithmetic per tile:
+//   x = LDS byte offset of the lane's first dword of MFMA 1 (row 2 hy + (kb >> 1), dword 3 m + parity + 2 (kb & 1))  |  (byte offset of its fp32 result in the
+//       conv0 tile, plane kb, << 16);   y = hy | hx << 8 | valid << 16   (valid: a real pixel of the 17 x 19 region in a lane that holds real channels)
+// Geometry = Stem2Cfg<8>: conv0 region 17 x 19, 10 even / 9 odd columns, tiles of 16 same-parity pixels, waves 0,1 even (tiles w, w + 2, ..), waves 2,3 odd.
+constexpr int kStem2R0H = 17, kStem2R0W = 19, kStem2C0Tiles = 6, kStem2C0Plane = ((kStem2R0H * kStem2R0W + 15) / 16) * 16 * 4;      // floats per 4-channel plane
+// the int8 engine's stem (stem_kernel): conv0 region 10 x 34 = 17 even + 17 odd columns, 256-byte rows, windows start at dword 1 (even) / 3 (odd)
+constexpr int kStemR0H = 10, kStemR0W = 34, kStemC0Tiles = 6, kStemC0Plane = ((kStemR0H * kStemR0W + 15) / 16) * 16 * 4;
+inline std::vector<uint32_t> conv0_raw_table(int r0h, int r0w, int tiles_per_wave, int plane, int row_dwords, int d0_even, int d0_odd) {
+    std::vector<uint32_t> t((size_t)4 * tiles_per_wave * 64 * 2, 0u);
+    for (int wave = 0; wave < 4; wave++) {
+        const int par = wave >> 1, wp = par ? r0w / 2 : (r0w + 1) / 2, d0 = par ? d0_odd : d0_even;
+        for (int k = 0; k < tiles_per_wave; k++)
+            for (int lane = 0; lane < 64; lane++) {
+                const int tile = (wave & 1) + 2 * k, kb = lane >> 4;
+                const int qq = tile * 16 + (lane & 15), hy = qq / wp, m = qq % wp, hx = 2 * m + par;
+                const bool real = hy < r0h;
+                // lanes past the region read row 0 (any finite bytes) and write nothing
+                const uint32_t p1 = real ? (uint32_t)(((2 * hy + (kb >> 1)) * row_dwords + 3 * m + d0 + 2 * (kb & 1)) * 4) : (uint32_t)((kb & 1) * 8);
+                const uint32_t out = real && lane < 32 ? (uint32_t)((kb * plane + (hy * r0w + hx) * 4) * 4) : 0u;
+                uint32_t *e = &t[(((size_t)wave * tiles_per_wave + k) * 64 + lane) * 2];
+                e[0] = p1 | (out << 16);
+                e[1] = (uint32_t)(real ? hy : 0) | ((uint32_t)(real ? hx : 0) << 8) | ((real && lane < 32) ? 1u << 16 : 0u);
+            }
+    }
+    return t;
+}
+inline std::vector<uint32_t> stem2_conv0_table() { return conv0_raw_table(kStem2R0H, kStem2R0W, kStem2C0Tiles, kStem2C0Plane, 32, 0, 1); }
+inline std::vector<uint32_t> stem_conv0_table() { return conv0_raw_table(kStemR0H, kStemR0W, kStemC0Tiles, kStemC0Plane, 64, 1, 3); }
 
 // Stem pointwise (8 -> 16 channels) as ONE v_mfma_f32_16x16x32_f16 with fp32-grade operands: the depthwise result reaches the
 // MFMA as an fp16 pair x = x_hi + x_lo (B operand: K group 0 = x_hi, 1 = x_lo, 2 = x_hi, 3 = 0) and the weight as w = w_hi + w_lo

@@ -79,7 +79,7 @@ template <typename T> constexpr int mma_kpl() { return sizeof(T) == 1 ? 16 : siz
 
 
 // ---------------------------------------------------------------------------------------------------- byte archive
-constexpr uint32_t kPlanCacheVersion = 9;      // bump when the packing / layout of anything below changes
+constexpr uint32_t kPlanCacheVersion = 11;      // bump when the packing / layout of anything below changes
 
 struct ArOut {
     std::string b;
@@ -132,6 +132,8 @@ struct WeightPack {
     Arena arena_;
     size_t c0_w_ = 0, c0_b_ = 0, c0_hi_ = 0, c0_b_mma_ = 0;      // c0_b_mma_: conv0 bias of the MFMA stems (offset-folded, see pack())
     size_t c0_raw_ = 0;                                          // conv0 fragments for the raw-row staging of stem2 (two column parities, see pack())
+    size_t stem_c0tab_ = 0;                                      // the int8 stem's conv0 pixel table (pack.h stem_conv0_table)
+    size_t stem2_dw4_ = 0, stem2_c0tab_ = 0;                     // stem2: conv3's diagonal A fragments expanded to 4 dwords per lane; conv0's pixel table (see pack())
     DwW stem_dw_{0, 0}, stem2_dw_{0, 0};
     GemmW stem_pw_{0, 0}, stem2_pw_{0, 0};
     size_t stem2_c2_b_ = 0, stem2_c2_floor_ = 0, stem2_c3_floor_ = 0;      // stem2's DC-centred tiles (pack())
@@ -395,6 +397,7 @@ struct WeightPack {
                             raw[(((size_t)par * 4 + half * 2 + 1) * 64 + lane) * 8 + el] = (half_t)(w - (float)h);
                         }
             c0_raw_ = arena_.put(raw);
+            stem_c0tab_ = arena_.put(stem_conv0_table());
             // the stems feed 1024 + pixel into those fragments (kernels.hip u8x4_to_f16): bias - 1024 * sum of the hi + lo weights
             {
                 std::vector<float> bm(plan.conv0.b);
@@ -497,6 +500,15 @@ struct WeightPack {
                         dwq.b[c] = (float)((double)dwq.b[c] + (double)mu2[c] * st - (double)mu3[c]);
                     }
                     stem2_dw_ = put_dw(dwq);
+                    {   // round 6: the same diagonal A fragments EXPANDED to the four dwords a lane feeds the MFMA -- [5][64][4] dwords, one 16-byte load
+                        // per chunk instead of one dword + four v_cndmask (20 VALU instructions per wave of stem2's conv3 phase)
+                        const uint32_t *mm = (const uint32_t *)(arena_.host().data() + stem2_dw_.mma);
+                        std::vector<uint32_t> ex((size_t)kDwMmaChunks * 64 * 4, 0u);
+                        for (int kc = 0; kc < kDwMmaChunks; kc++)
+                            for (int lane = 0; lane < 64; lane++) ex[((size_t)kc * 64 + lane) * 4 + dw_mma_dword_index(lane)] = mm[kc * 64 + lane];
+                        stem2_dw4_ = arena_.put(ex);
+                    }
+                    stem2_c0tab_ = arena_.put(stem2_conv0_table());
                     // conv4: K = 16 of the MFMA's 32 slots -> the weights ride as hi | lo along K; bias + (hi + lo) mu3
                     std::vector<float> w2((size_t)pwq.cout * 32, 0.f), b4(pwq.b);
                     for (int o = 0; o < pwq.cout; o++) {
@@ -614,7 +626,7 @@ struct WeightPack {
 
     // ------------------------------------------------------------------------------------------ (de)serialisation
     template <class Ar> void io(Ar &ar) {
-        ar.pod(c0_w_); ar.pod(c0_b_); ar.pod(c0_hi_); ar.pod(c0_b_mma_); ar.pod(c0_raw_);
+        ar.pod(c0_w_); ar.pod(c0_b_); ar.pod(c0_hi_); ar.pod(c0_b_mma_); ar.pod(c0_raw_); ar.pod(stem_c0tab_); ar.pod(stem2_dw4_); ar.pod(stem2_c0tab_);
         ar.pod(stem_dw_); ar.pod(stem2_dw_); ar.pod(stem_pw_); ar.pod(stem2_pw_);
         ar.pod(stem2_c2_b_); ar.pod(stem2_c2_floor_); ar.pod(stem2_c3_floor_);
         ar.pod(aggr_a_lat_); ar.pod(aggr_a_up_); ar.pod(head_a_);
@@ -638,7 +650,7 @@ struct WeightPack {
         auto ok = [n](size_t off) { return off == kNone || off < n; };
         auto okg = [&](const GemmW &g) { return ok(g.w) && ok(g.b) && ok(g.m); };
         auto okd = [&](const DwW &d) { return ok(d.w) && ok(d.b) && ok(d.mma) && ok(d.m); };
-        bool good = ok(c0_w_) && ok(c0_b_) && ok(c0_hi_) && ok(c0_b_mma_) && ok(c0_raw_) && okd(stem_dw_) && okd(stem2_dw_) && okg(stem_pw_) && okg(stem2_pw_) &&
+        bool good = ok(c0_w_) && ok(c0_b_) && ok(c0_hi_) && ok(c0_b_mma_) && ok(c0_raw_) && ok(stem_c0tab_) && ok(stem2_dw4_) && ok(stem2_c0tab_) && okd(stem_dw_) && okd(stem2_dw_) && okg(stem_pw_) && okg(stem2_pw_) &&
                     ok(stem2_c2_b_) && ok(stem2_c2_floor_) && ok(stem2_c3_floor_);
         for (const auto &d : dw_w_) good = good && okd(d);
         for (const auto &g : pw_w_) good = good && okg(g);

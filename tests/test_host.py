@@ -601,6 +601,18 @@ def test_bench_roofline_carries_the_measured_instruction_mix():
     assert r["instruction_mix"] is None
 
 
+def test_bench_int8_entries_carry_the_contract_numbers():
+    """the int8 entries of the bench line (`configs[]` ids 2 and 4, and an int8 run's own line) carry the engine's measured distance to the fp32
+    oracle, joined from the committed contract summary: same face count on every frame, anchor agreement, same-anchor IoU, per-face IoU."""
+    sys.path.insert(0, ROOT)
+    import bench
+    for model in ("mnet25", "mnet-deconv-0517"):
+        c = bench.int8_contract_summary(model)
+        assert c["frames"] == c["same_count"] == 104 and c["faces"] >= 250 and c["source"].startswith("profiles/r06_int8_contract")
+        assert c["anchor_iou_worst"] >= 0.96 and c["anchor_agreement"] >= 0.92 and c["iou_mean"] >= 0.985      # = INT8_BAR of tests/test_gpu_parity.py
+    assert bench.int8_contract_summary("no such model") is None
+
+
 def test_lds_model_known_cases():
     """tools/lds_model.py (the LDS-array cycle model behind dwpw2's and stem2's tile layouts): the guide's published cases and the
     three dwpw2 layouts whose totals the SQ_LDS_IDX_ACTIVE counter confirmed on the GPU (521 / 449 / 365 cycles per wave and tile)."""

@@ -128,6 +128,21 @@ PY
           echo "--- $v pass $pass"; python tools/pmc_insts.py $db $O/instruction_classes_${v}_$pass.json | head -8
         done
       done ;;
+    stem_bits)      # which of stem2's index-from-memory bits pays: 15 base | 47 expanded conv3 fragments | 31 conv0 table | 95 table + explicit ds_read2_b32 | 127 all
+      for rep in 1 2; do for v in 15 47 31 95 127; do
+        RETINAFACE_AMD_LIB=$R/retinaface_amd/lib/libretinaface_amd_probe.so RF_STEM2_V2=$v timeout 200 python tools/kbench.py --n 256 --tag r6_${TAG}_stemv$v 2>&1 | grep -E "stem2" | cut -c1-60 | sed "s/^/V2=$v rep $rep: /"
+      done; done
+      RETINAFACE_AMD_LIB=$R/retinaface_amd/lib/libretinaface_amd_probe.so timeout 400 python tools/probes/knob_equal.py --precision 1 --n 16 RF_STEM2_V2=47 RF_STEM2_V2=95 RF_STEM2_V2=127 2>&1 | tail -3
+      for rep in 1 2; do for v in 1 2; do
+        RETINAFACE_AMD_LIB=$R/retinaface_amd/lib/libretinaface_amd_probe.so RF_STEM_RAW=$v timeout 200 python tools/kbench.py --n 256 --precision int8 --batch 32 --tag r6_${TAG}_stem8raw$v 2>&1 | grep -E "stem " | cut -c1-60 | sed "s/^/int8 RAW=$v rep $rep: /"
+      done; done ;;
+    stem_tab)       # stem2 with index tables (V2 = 31, the product) vs raw staging alone (V2 = 15), probe build, interleaved; bit-identity of the two
+      for rep in 1 2; do for v in 15 31; do
+        RETINAFACE_AMD_LIB=$R/retinaface_amd/lib/libretinaface_amd_probe.so RF_STEM2_V2=$v timeout 200 python tools/kbench.py --n 256 --tag r6_${TAG}_stemv$v > $O/kbench_stem_v${v}_$rep.txt 2>&1
+        grep -E "total|stem2" $O/kbench_stem_v${v}_$rep.txt | cut -c1-90 | sed "s/^/V2=$v rep $rep: /"
+      done; done
+      for v in 15 31; do RETINAFACE_AMD_LIB=$R/retinaface_amd/lib/libretinaface_amd_probe.so RF_STEM2_V2=$v timeout 200 python tools/kbench.py --n 64 --hw 896 1280 --tag r6_${TAG}_stemv${v}_big 2>&1 | grep -E "total|stem2" | cut -c1-90 | sed "s/^/V2=$v 1280x896: /"; done
+      RETINAFACE_AMD_LIB=$R/retinaface_amd/lib/libretinaface_amd_probe.so timeout 300 python tools/probes/knob_equal.py --precision 1 --n 16 RF_STEM2_V2=15 RF_STEM2_V2=31 > $O/knob_equal_stem_tab.txt 2>&1; tail -4 $O/knob_equal_stem_tab.txt ;;
     *) echo "unknown recipe $recipe" ;;
   esac
 done
