@@ -333,7 +333,8 @@ def _match(got, ref_rows):
 # per-channel activation scales with 25 % head-room, error-compensated weight rounding + bias correction on 48 frames that show only fixture
 # faces 0 / 2 / 4; every frame below uses faces 1 / 3 / 5 and other seeds (held out).  Depthwise outputs carry 8 bits (0..255 quanta).
 #   same-anchor IoU  the regression error alone (engine's box vs the ORACLE'S box of the same anchor): the number north_star's "1e-3 IoU" is
-#                    about; fp16 scores 0.9993-0.9995 on this metric, int8 0.968-0.981 at worst over 280 faces (round 5 tables: 0.947-0.949).
+#                    about; fp16 scores 0.9993-0.9995 on this metric, int8 0.972-0.979 at worst over 280 faces on the final tree (0.968-0.981 before the
+#                    stem's raw-row staging re-rolled the first-layer rounding; round 5 tables: 0.947-0.949).  Agreement: 0.964 / 0.946.
 #   anchor agreement fraction of faces kept on the oracle's anchor.  Neighbouring anchors of one face score within ~1e-3 of each other in the
 #                    oracle itself, so any logit noise flips some winners (the fp16 engine: 2 of 280 on 0517); a flip shows up as a per-face
 #                    IoU of 0.88-0.95 although both boxes are the network's own predictions -- the per-face IoU is printed, and gated only loosely.
