@@ -156,6 +156,12 @@ static int num_cus() {
 // Below `min_rounds` x resident tiles the hardware dispatcher's dynamic one-tile-per-workgroup schedule is at least as
 // good as walking two tiles in sequence, so the grid stays one workgroup per tile.
 static int persistent_grid(int tiles, int resident_per_cu) {
+    const float frac = knob_grid_frac();           // probe knob RF_GRID_FRAC (1 in the product): leave a share of the resident slots to the other lanes' kernels
+    if (frac < 1.f) {
+        const int slots = num_cus() * (resident_per_cu > 0 ? resident_per_cu : 1);
+        const int part = (int)((float)slots * frac);
+        return persistent_grid_size(tiles, part > 0 ? part : 1, 0.f);
+    }
     return persistent_grid_size(tiles, num_cus() * (resident_per_cu > 0 ? resident_per_cu : 1), knob_persist_min_rounds());      // (probe knob RF_PERSIST_MIN_ROUNDS; 1 measured on MI355X)
 }
 template <typename F> static int resident_per_cu(F kern, size_t lds_bytes) {

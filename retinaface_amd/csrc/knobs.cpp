@@ -68,6 +68,7 @@ const Spec kSpecs[K_COUNT] = {
 
 int g_value[K_COUNT];
 float g_min_rounds = 1.0f;
+float g_grid_frac = 1.0f;
 std::once_flag g_once;
 
 void parse_all() {
@@ -103,6 +104,12 @@ void parse_all() {
             if (end != e && *end == '\0' && v >= 0.f && v <= 64.f) g_min_rounds = v;
             else fprintf(stderr, "[retinaface_amd] RF_PERSIST_MIN_ROUNDS=%s is not a number in [0, 64]: using the default %g\n", e, (double)g_min_rounds);
         }
+        if (const char *e = getenv("RF_GRID_FRAC")) {
+            char *end = nullptr;
+            const float v = strtof(e, &end);
+            if (end != e && *end == '\0' && v >= 0.1f && v <= 1.f) g_grid_frac = v;
+            else fprintf(stderr, "[retinaface_amd] RF_GRID_FRAC=%s is not a number in [0.1, 1]: using the default %g\n", e, (double)g_grid_frac);
+        }
     }
 }
 
@@ -123,6 +130,10 @@ int knob(Knob k) {
 float knob_persist_min_rounds() {
     std::call_once(g_once, parse_all);
     return g_min_rounds;
+}
+float knob_grid_frac() {
+    std::call_once(g_once, parse_all);
+    return g_grid_frac;
 }
 const char *knob_name(Knob k) { return kSpecs[k].name; }
 bool probes_compiled() { return kProbes; }

@@ -50,6 +50,7 @@ enum Knob {
 };
 
 int knob(Knob k);                 // validated value, read once per process
+float knob_grid_frac();           // RF_GRID_FRAC (probe): persistent grids sized for this fraction of the resident workgroup slots (another lane's kernel may take the rest)
 float knob_persist_min_rounds();  // RF_PERSIST_MIN_ROUNDS (probe): tiles per resident workgroup below which a persistent grid is not trimmed
 const char *knob_name(Knob k);
 bool probes_compiled();           // true in libretinaface_amd_probe.so

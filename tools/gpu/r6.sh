@@ -136,6 +136,11 @@ PY
       for rep in 1 2; do for v in 1 2; do
         RETINAFACE_AMD_LIB=$R/retinaface_amd/lib/libretinaface_amd_probe.so RF_STEM_RAW=$v timeout 200 python tools/kbench.py --n 256 --precision int8 --batch 32 --tag r6_${TAG}_stem8raw$v 2>&1 | grep -E "stem " | cut -c1-60 | sed "s/^/int8 RAW=$v rep $rep: /"
       done; done ;;
+    gridfrac)       # persistent grids sized for a FRACTION of the resident slots, so that another lane's kernel can be co-resident (RF_GRID_FRAC, probe build), x lanes
+      for rep in 1 2; do for cfg in "1.0 3" "0.75 3" "0.5 3" "0.5 4" "0.5 6" "0.67 4" "0.34 6" "1.0 3"; do set -- $cfg
+        env RETINAFACE_AMD_LIB=$R/retinaface_amd/lib/libretinaface_amd_probe.so RF_GRID_FRAC=$1 timeout 200 python bench.py --lanes $2 --no-cpu-baseline --no-extra-configs --no-pmc --no-pipeline-trace --host-seconds 0 --regions 2 --profile-iters 3 > $O/bench_frac$1_lanes$2_$rep.json 2> $O/bench_frac$1_lanes$2_$rep.err
+        python -c "import json;j=json.loads(open('$O/bench_frac$1_lanes$2_$rep.json').read().strip().splitlines()[-1]);print('frac $1 lanes $2 rep $rep:', round(j['images_per_sec']), 'img/s  burst', round(j['burst']['ms'],3), 'ms  sync', round(j['sync_batch']['ms_per_call'],4))" 2>&1 | tail -1
+      done; done ;;
     stem_tab)       # stem2 with index tables (V2 = 31, the product) vs raw staging alone (V2 = 15), probe build, interleaved; bit-identity of the two
       for rep in 1 2; do for v in 15 31; do
         RETINAFACE_AMD_LIB=$R/retinaface_amd/lib/libretinaface_amd_probe.so RF_STEM2_V2=$v timeout 200 python tools/kbench.py --n 256 --tag r6_${TAG}_stemv$v > $O/kbench_stem_v${v}_$rep.txt 2>&1
