@@ -914,27 +914,40 @@ def split_ab(args, world, rank, dev, cdev, barrier, backend, thr, G=256):
     Bs = hi - lo
     fb = 16 if args.dry else H * W * 3
     rehearsal = backend != "nccl"
-    if args.dry:
-        det = StubEngine(max(Bs, 1), 0, 0)
-        whole = torch.zeros((G, 16), dtype=torch.uint8) if rank == 0 else None           # stand-in "frames": 16 bytes each
-        mine = torch.zeros((max(Bs, 1), 16), dtype=torch.uint8)
-        host = mine.clone()
-        prep = lambda: 1000 * rank                                                        # noqa: E731
-    else:
-        import retinaface_amd
-        from retinaface_amd.frames import synth_frames
-        det = retinaface_amd.RetinaFace(os.path.join(ROOT, "assets"), "net3", 0.4, precision=2, net_hw=(H, W), max_batch=max(Bs, 1), model_stem="mnet25")
-        src = np.stack(synth_frames(H, W, 64, config=47))
-        whole_np = src[np.arange(G) % 64]
-        xdev = cdev if rehearsal else dev                      # where the tensors of the send / recv live (gloo: host)
-        whole = torch.from_numpy(whole_np).to(xdev) if rank == 0 else None
-        mine = torch.empty((max(Bs, 1), H, W, 3), dtype=torch.uint8, device=dev)       # the rank's slice on ITS GPU: what the engine reads
-        recv = mine if not rehearsal else torch.empty((max(Bs, 1), H, W, 3), dtype=torch.uint8)
-        host = torch.from_numpy(whole_np[lo:hi].copy()).pin_memory()
-        mine[:Bs].copy_(host)
-        torch.cuda.synchronize()
-        pb = det.prepare_device_batch([mine[i].data_ptr() for i in range(Bs)], [H] * Bs, [W] * Bs)
-        prep = lambda: pb                                                                 # noqa: E731
+    # Everything that can fail for a rank-local reason (engine build, allocations) happens BEFORE the first collective of this leg, and the ranks agree on
+    # the outcome: one rank that could not set up must not leave the others waiting in a send / recv it will never post.
+    det, setup_error = None, None
+    try:
+        if args.dry:
+            det = StubEngine(max(Bs, 1), 0, 0)
+            whole = torch.zeros((G, 16), dtype=torch.uint8) if rank == 0 else None           # stand-in "frames": 16 bytes each
+            mine = torch.zeros((max(Bs, 1), 16), dtype=torch.uint8)
+            host = mine.clone()
+            prep = lambda: 1000 * rank                                                        # noqa: E731
+        else:
+            import retinaface_amd
+            from retinaface_amd.frames import synth_frames
+            det = retinaface_amd.RetinaFace(os.path.join(ROOT, "assets"), "net3", 0.4, precision=2, net_hw=(H, W), max_batch=max(Bs, 1), model_stem="mnet25")
+            src = np.stack(synth_frames(H, W, 64, config=47))
+            whole_np = src[np.arange(G) % 64]
+            xdev = cdev if rehearsal else dev                      # where the tensors of the send / recv live (gloo: host)
+            whole = torch.from_numpy(whole_np).to(xdev) if rank == 0 else None
+            mine = torch.empty((max(Bs, 1), H, W, 3), dtype=torch.uint8, device=dev)       # the rank's slice on ITS GPU: what the engine reads
+            recv = mine if not rehearsal else torch.empty((max(Bs, 1), H, W, 3), dtype=torch.uint8)
+            host = torch.from_numpy(whole_np[lo:hi].copy()).pin_memory()
+            mine[:Bs].copy_(host)
+            torch.cuda.synchronize()
+            pb = det.prepare_device_batch([mine[i].data_ptr() for i in range(Bs)], [H] * Bs, [W] * Bs)
+            prep = lambda: pb                                                                 # noqa: E731
+            sum(det.wait_counts(det.enqueue_prepared(pb, thr), Bs)) if Bs else 0              # first (eager) call of this batch size
+    except Exception as e:  # noqa: BLE001
+        setup_error = f"{type(e).__name__}: {e}"
+    ok = torch.tensor([0.0 if setup_error else 1.0], device=cdev)
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    if float(ok.item()) == 0.0:
+        if det is not None:
+            det.close()
+        return {"error": setup_error or "another rank could not set this leg up", "skipped": True}
 
     def detect():
         if Bs == 0:
