@@ -48,11 +48,17 @@ assert oracle_cache.SCORE_NOISE == TOL[FP16]["score"]
 SCORE_NOISE = TOL[FP16]["score"]          # the width of the threshold / order / twin bands: fp16 score noise where the sigmoid is steepest (a logit error of 8e-3)
 
 
+LOGIT_NOISE = 0.028                       # what plain fp16 storage is predicted to cost the classification logit (tools/fp16_error_budget.py over the golden frames)
+LOGIT_ERR_GATE = 0.5 * LOGIT_NOISE        # the engine's measured worst logit error over the contract's unsaturated detections must stay under half of it (measured 0.36)
+
+
 def score_tol(prec, p):
     """Bound on |engine score - oracle score| for a detection whose oracle score is p (see the module docstring)."""
     if prec != FP16:
         return TOL[prec]["score"]
-    return float(golden("threshold_bands.npz")["logit_noise"]) * float(p) * (1.0 - float(p)) + 1e-5
+    # LOGIT_NOISE is a REVIEWED constant (ADVICE r5): the minted prediction must equal it, so regenerating the golden cannot move the bar silently
+    assert abs(float(golden("threshold_bands.npz")["logit_noise"]) - LOGIT_NOISE) < 5e-4
+    return LOGIT_NOISE * float(p) * (1.0 - float(p)) + 1e-5
 LAYER_ERR_FACTOR = 1.0                    # fp16 per-layer bar = the error-budget tool's prediction for plain fp16 storage (measured: 0.14-0.37 of it)
 
 
@@ -651,10 +657,11 @@ def test_fp16_contract_over_200_frames_both_models_both_sizes(rfa, oracles, stem
     print(f"fp16 contract {stem}: candidate-count bands (anchors within {SCORE_NOISE} of the threshold): max {max(bands)}, mean {np.mean(bands):.2f}, "
           f"{sum(b == 0 for b in bands)} of {len(bands)} frames with an empty band (count must then be identical)")
     print(f"fp16 contract {stem}: logit error of the {len(logit_errs)} unsaturated detections (0.02 < p < 0.98): max {max(logit_errs, default=0.0):.4f} of the "
-          f"{float(golden('threshold_bands.npz')['logit_noise']):.4f} plain fp16 storage is predicted to cost")
+          f"{LOGIT_NOISE:.4f} plain fp16 storage is predicted to cost (gate {LOGIT_ERR_GATE:.4f})")
     print(f"fp16 contract {stem}: anchor-twin band fired on {len(twin_frames)} of {len(ws)} frames: " + "; ".join(f"{n}: engine {g} oracle {r}" for n, g, r in twin_frames))
     FP16_CONTRACT[stem] = (ws, rows, twin_frames)
     assert len(ws) == 104 and ws.max() <= 9e-4, rows[:6]
+    assert max(logit_errs, default=0.0) <= LOGIT_ERR_GATE, max(logit_errs)
     # The anchor-twin band (tests/anchor_twins.py) may fire ONLY where it is known to: one frame of the 208, where the oracle's own scores
     # of the two anchors differ by 3e-6 (0.997809 / 0.997806).  A firing anywhere else is a set divergence this test must not absorb
     # (ADVICE r5): it fails until a person has looked at the pair and added it here.
