@@ -767,6 +767,7 @@ private:
             p.in = lat[i + 1]; p.in_ld = 64; p.in_off = 0; p.up = feat[i];
             p.w = arena_.template ptr<T>(aggr_w_[i].w); p.b = arena_.template ptr<float>(aggr_w_[i].b); p.m = mult_ptr(aggr_w_[i]);
             p.a_lat = aggr_a_lat_[i]; p.a_up = aggr_a_up_[i];
+            p.blend_fp32 = knob(K_BLEND_FP32) != 0;            // read once per lane (not per launch)
             p.out0 = feat[i + 1]; p.ld0 = 64; p.off0 = 0; p.n0 = 64; p.out1 = nullptr; p.ld1 = 0; p.off1 = 0;
             p.n = 0; p.h = fh; p.w_ = fw; p.cin = 64; p.cout = 64;
             OpInfo op;

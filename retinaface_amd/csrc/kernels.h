@@ -135,6 +135,7 @@ struct Conv3Params {
     const T *w; const float *b;           // packed (k = 9*cin), bias[cout]
     const float *m = nullptr;             // int8: per-output-channel requantisation multiplier
     float a_lat = 1.f, a_up = 1.f;        // fused upsample+add: staged = lat * a_lat + up * a_up (int8 scale ratios)
+    bool blend_fp32 = false;              // int8: blend in fp32 even where the packed-integer form applies (test knob RF_BLEND_FP32, read ONCE when the lane is built)
     T *out0; int ld0, off0, n0;           // output channels [0, n0)    -> out0[pixel*ld0 + off0 + c]
     T *out1; int ld1, off1;               // output channels [n0, cout) -> out1[pixel*ld1 + off1 + c - n0]
     int n, h, w_, cin, cout;

@@ -4341,7 +4341,7 @@ static TileInfo conv3_dispatch(hipStream_t s, const Conv3Params<T> *p, int nlv, 
         int tiles_x = (q.w_ + TW - 1) / TW, tiles_y = (q.h + TH - 1) / TH;
         a.lv[l] = Conv3Level<T>{q.in, q.up, q.w, q.b, q.m, q.out0, q.out1, q.in_ld, q.in_off, q.ld0, q.off0, q.n0, q.ld1, q.off1,
                                 q.h, q.w_, tiles_x, tiles_y, q.n * tiles_x * tiles_y, 0, 1, q.a_lat, q.a_up,
-                                (sizeof(T) == 1 && q.a_lat == 1.f && q.a_up == 1.f && !knob(K_BLEND_FP32)) ? 1 : 0};      // RF_BLEND_FP32: test knob
+                                (sizeof(T) == 1 && q.a_lat == 1.f && q.a_up == 1.f && !q.blend_fp32) ? 1 : 0};      // blend_fp32: test knob RF_BLEND_FP32, read by the engine
         if (l < nlv) total += q.n * tiles_x * tiles_y;
     }
     if (p[0].up) {
@@ -4385,7 +4385,7 @@ static void conv3_up_ws_launch(hipStream_t s, const Conv3Params<T> &q) {
     for (int l = 0; l < 3; l++)
         a.lv[l] = Conv3Level<T>{q.in, q.up, q.w, q.b, q.m, q.out0, q.out1, q.in_ld, q.in_off, q.ld0, q.off0, q.n0, q.ld1, q.off1,
                                 q.h, q.w_, tiles_x, tiles_y, q.n * tiles_x * tiles_y, 0, 1, q.a_lat, q.a_up,
-                                (sizeof(T) == 1 && q.a_lat == 1.f && q.a_up == 1.f && !knob(K_BLEND_FP32)) ? 1 : 0};
+                                (sizeof(T) == 1 && q.a_lat == 1.f && q.a_up == 1.f && !q.blend_fp32) ? 1 : 0};
     const int total = q.n * tiles_x * tiles_y;
     if (total == 0) return;
     a.lv[0].gsz = persistent_grid(total, resident);
