@@ -44,6 +44,12 @@ std::string slurp(const std::string &path, bool binary) {
 // ------------------------------------------------------------------------------------------
 namespace {
 
+// integer scalar of a text-format field; a malformed one is a ModelError, not a std::invalid_argument escaping the reader
+static long scalar_long(const std::string &text, const char *what) {
+    try { size_t used = 0; const long v = std::stol(text, &used); if (used == text.size()) return v; } catch (const std::exception &) {}
+    throw ModelError(std::string("prototxt: ") + what + " is not an integer: '" + text.substr(0, 40) + "'");
+}
+
 struct TextNode;
 using Fields = std::vector<std::pair<std::string, TextNode>>;
 struct TextNode {
@@ -64,13 +70,18 @@ struct TextNode {
         const TextNode *n = first(k);
         return n ? n->scalar : def;
     }
+    // (std::stol / std::stod throw std::invalid_argument / std::out_of_range on a malformed scalar: a corrupt prototxt is a ModelError)
     long num(const std::string &k, long def) const {
         const TextNode *n = first(k);
-        return n ? std::stol(n->scalar) : def;
+        if (!n) return def;
+        try { size_t used = 0; const long v = std::stol(n->scalar, &used); if (used == n->scalar.size()) return v; } catch (const std::exception &) {}
+        throw ModelError("prototxt: field '" + k + "' is not an integer: '" + n->scalar.substr(0, 40) + "'");
     }
     double real(const std::string &k, double def) const {
         const TextNode *n = first(k);
-        return n ? std::stod(n->scalar) : def;
+        if (!n) return def;
+        try { size_t used = 0; const double v = std::stod(n->scalar, &used); if (used == n->scalar.size()) return v; } catch (const std::exception &) {}
+        throw ModelError("prototxt: field '" + k + "' is not a number: '" + n->scalar.substr(0, 40) + "'");
     }
     bool flag(const std::string &k, bool def) const {
         const TextNode *n = first(k);
@@ -161,7 +172,7 @@ Model load_prototxt(const std::string &path) {
             if (!sh) throw ModelError("prototxt: Input layer without input_param.shape");
             auto dims = sh->all("dim");
             if (dims.size() != 4) throw ModelError("prototxt: Input shape must have 4 dims");
-            for (int i = 0; i < 4; i++) m.input_shape[i] = (int)std::stol(dims[i]->scalar);
+            for (int i = 0; i < 4; i++) m.input_shape[i] = (int)scalar_long(dims[i]->scalar, "Input shape dim");
             if (!l.tops.empty()) m.input_name = l.tops[0];
             have_input = true;
             continue;
@@ -190,11 +201,11 @@ Model load_prototxt(const std::string &path) {
         } else if (l.type == "Crop") {
             const TextNode *cp = ln->first("crop_param");
             l.axis = (int)(cp ? cp->num("axis", 2) : 2);
-            if (cp) for (const TextNode *o : cp->all("offset")) l.crop_offsets.push_back((int)std::stol(o->scalar));
+            if (cp) for (const TextNode *o : cp->all("offset")) l.crop_offsets.push_back((int)scalar_long(o->scalar, "crop offset"));
         } else if (l.type == "Reshape") {
             const TextNode *rp = ln->first("reshape_param");
             const TextNode *sh = rp ? rp->first("shape") : nullptr;
-            if (sh) for (const TextNode *d : sh->all("dim")) l.reshape_dims.push_back((int)std::stol(d->scalar));
+            if (sh) for (const TextNode *d : sh->all("dim")) l.reshape_dims.push_back((int)scalar_long(d->scalar, "reshape dim"));
             l.reshape_axis = (int)(rp ? rp->num("axis", 0) : 0);
             l.reshape_num_axes = (int)(rp ? rp->num("num_axes", -1) : -1);
         } else if (l.type == "Eltwise") {
@@ -325,7 +336,11 @@ void attach_int8_table(Model &m, const std::string &path) {
         size_t pos = line.rfind(": ");
         if (pos == std::string::npos) continue;
         std::string name = line.substr(0, pos);
-        uint32_t bits = (uint32_t)std::stoul(line.substr(pos + 2), nullptr, 16);
+        // the value is exactly 1..8 hex digits (std::stoul would throw std::invalid_argument / out_of_range on anything else, and accept trailing junk)
+        const std::string hex = line.substr(pos + 2);
+        if (name.empty() || hex.empty() || hex.size() > 8 || hex.find_first_not_of("0123456789abcdefABCDEF") != std::string::npos)
+            throw ModelError("'" + path + "': malformed calibration line '" + line.substr(0, 80) + "'");
+        uint32_t bits = (uint32_t)std::stoul(hex, nullptr, 16);
         float f;
         memcpy(&f, &bits, 4);    // the hex text is the big-endian spelling of the IEEE-754 word
         m.int8_scales.emplace_back(name, f);

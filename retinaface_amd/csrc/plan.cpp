@@ -2,6 +2,8 @@
 #include "plan.h"
 
 #include <cmath>
+#include <new>
+#include <stdexcept>
 
 namespace rf {
 namespace {
@@ -114,7 +116,15 @@ void check_bilinear_upsample(const Model &m, const std::string &name, const std:
 
 }  // namespace
 
+static Plan compile_plan_checked(const Model &m);
+// (the walk indexes bottoms / tops with .at(): a layer that lacks the blob the topology needs is a ModelError, not a std::out_of_range)
 Plan compile_plan(const Model &m) {
+    try { return compile_plan_checked(m); }
+    catch (const std::out_of_range &) { throw ModelError("graph: a layer of the expected topology has no bottom / top / blob where the walk needs one"); }
+    catch (const std::length_error &) { throw ModelError("graph: a layer's dimensions do not describe a tensor that fits memory"); }
+    catch (const std::bad_alloc &) { throw ModelError("graph: a layer's dimensions do not describe a tensor that fits memory"); }
+}
+static Plan compile_plan_checked(const Model &m) {
     Plan p;
     expect(m.input_shape[1] == 3, "network input must have 3 channels");
     p.net_h = m.input_shape[2];

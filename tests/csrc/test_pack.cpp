@@ -162,6 +162,26 @@ int main() {
     // LDS rows: 16-byte aligned, at least as wide as asked, 32 mod 64 bytes
     if (lds_row<unsigned short>(64) != 80 || lds_row<unsigned short>(16) != 16 || lds_row<unsigned short>(32) != 48 || lds_row<float>(64) != 72 ||
         lds_row<signed char>(64) != 96 || lds_row<unsigned short>(48) != 48) { printf("FAIL lds_row\n"); bad++; }
+    // conv0 pixel tables of the stems' raw-row staging (round 6; measured-and-rejected in the kernels, kept with the probe build): every real pixel of the
+    // region appears exactly once in the lanes that hold real channels, its LDS window lies inside the staged rows, its result slot inside the conv0 tile
+    for (int which = 0; which < 2; which++) {
+        const int r0h = which ? kStemR0H : kStem2R0H, r0w = which ? kStemR0W : kStem2R0W, plane = which ? kStemC0Plane : kStem2C0Plane;
+        const int row_bytes = which ? 256 : 128, rows = 2 * r0h + 1, tiles = which ? kStemC0Tiles : kStem2C0Tiles;
+        const std::vector<uint32_t> t = which ? stem_conv0_table() : stem2_conv0_table();
+        std::vector<int> seen(r0h * r0w, 0);
+        for (int wave = 0; wave < 4; wave++) for (int k = 0; k < tiles; k++) for (int lane = 0; lane < 64; lane++) {
+            const uint32_t x = t[(((size_t)wave * tiles + k) * 64 + lane) * 2], y = t[(((size_t)wave * tiles + k) * 64 + lane) * 2 + 1];
+            const uint32_t p1 = x & 0xffffu, out = x >> 16, hy = y & 0xffu, hx = (y >> 8) & 0xffu, valid = y >> 16;
+            const int kb = lane >> 4;
+            if (p1 % 4 || p1 + 8 + (uint32_t)(2 - (kb >> 1)) * row_bytes > (uint32_t)(rows + 5) * row_bytes) { printf("FAIL conv0 table %d: window out of the patch\n", which); bad++; }
+            if (valid) {
+                if (lane >= 32 || hy >= (uint32_t)r0h || hx >= (uint32_t)r0w || (hx & 1) != (uint32_t)(wave >> 1)) { printf("FAIL conv0 table %d: bad pixel\n", which); bad++; continue; }
+                if (out != (uint32_t)((kb * plane + (hy * r0w + hx) * 4) * 4) || out + 16 > (uint32_t)(2 * plane * 4)) { printf("FAIL conv0 table %d: bad result slot\n", which); bad++; }
+                if (kb == 0) seen[hy * r0w + hx]++;
+            }
+        }
+        for (int v : seen) if (v != 1) { printf("FAIL conv0 table %d: a pixel is covered %d times\n", which, v); bad++; break; }
+    }
     printf(bad ? "test_pack: FAILED\n" : "test_pack: ok\n");
     return bad ? 1 : 0;
 }

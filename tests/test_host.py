@@ -10,7 +10,7 @@ import sys
 import numpy as np
 import pytest
 
-from conftest import ASSETS, REFERENCE, ROOT, STEMS, needs_reference
+from conftest import ASSETS, REFERENCE, ROOT, STEMS, has_reference, needs_reference
 from retinaface_amd import _lib
 
 
@@ -257,14 +257,16 @@ def test_knob_table_validates_and_separates_probe_from_product(tmp_path):
 
 def test_pack_index_math_host_emulation(tmp_path):
     exe = str(tmp_path / "test_pack")
-    subprocess.check_call(["g++", "-O1", "-std=c++17", "-o", exe, os.path.join(ROOT, "tests", "csrc", "test_pack.cpp")])
+    subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-o", exe,
+                           os.path.join(ROOT, "tests", "csrc", "test_pack.cpp")])
     out = subprocess.run([exe], capture_output=True, text=True)
     assert out.returncode == 0 and "ok" in out.stdout, out.stdout
 
 
 def test_staging_copier_and_shard_rule_host_unit(tmp_path):
     exe = str(tmp_path / "test_copier")
-    subprocess.check_call(["g++", "-O1", "-std=c++17", "-pthread", "-o", exe, os.path.join(ROOT, "tests", "csrc", "test_copier.cpp")])
+    subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-pthread", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-o", exe,
+                           os.path.join(ROOT, "tests", "csrc", "test_copier.cpp")])
     out = subprocess.run([exe], capture_output=True, text=True)
     assert out.returncode == 0 and "ok" in out.stdout, out.stdout
 
@@ -559,6 +561,21 @@ def test_plan_cache_round_trip_and_invalidation(built_lib, tmp_path):
     assert probe(1) == 0 and probe(1) == 1
     # nowhere to write: still works, never a hit
     assert probe(1, "/proc/definitely/not/writable.rfplan") == 0 and probe(1, "/proc/definitely/not/writable.rfplan") == 0
+
+
+def test_model_readers_under_sanitizers(tmp_path):
+    """The model readers and the graph compiler (model.cpp, plan.cpp: RFW1 container, calibration table, calibrated weights, and -- where
+    /root/reference is mounted -- the prototxt text reader and the caffemodel protobuf-wire reader) built with -fsanitize=address,undefined and fed
+    1 250 truncated / bit-flipped / length-blown variants of the real files: each either loads or is rejected with rf::IoError / rf::ModelError;
+    no out-of-bounds read, no overflow, no foreign exception type (round 6: found std::stoul / std::stol throwing std::invalid_argument out of the
+    table and prototxt readers and std::out_of_range out of the graph walk).  The reference scrapes fixed columns and exit(0)s (trtnetbase.cpp:149-204)."""
+    exe = str(tmp_path / "test_readers_sanitized")
+    csrc = os.path.join(ROOT, "retinaface_amd", "csrc")
+    subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-o", exe,
+                           os.path.join(ROOT, "tests", "csrc", "test_readers_sanitized.cpp"), os.path.join(csrc, "model.cpp"), os.path.join(csrc, "plan.cpp")])
+    args = [exe, ASSETS] + ([os.path.join(REFERENCE, "model")] if has_reference() else [])
+    out = subprocess.run(args, capture_output=True, text=True, env=dict(os.environ, TMPDIR=str(tmp_path), ASAN_OPTIONS="detect_leaks=1"), timeout=600)
+    assert out.returncode == 0 and "none crashed" in out.stdout, (out.stdout[-500:], out.stderr[-3000:])
 
 
 def test_bench_physical_fractions_pick_the_binding_resource():
