@@ -547,6 +547,10 @@ def main() -> int:
                 out["library_multi_device"] = library_leg(args, world, thr)
             except Exception as e:  # noqa: BLE001
                 out["library_multi_device"] = {"error": f"{type(e).__name__}: {e}"}
+            finally:
+                # the other ranks wait on the rendezvous store for exactly this leg (their GPUs had to be free for it); what rank 0 still measures
+                # alone afterwards (per-kernel profile, counter passes) they sit out in the closing barrier, whose watchdog is minutes, not this wait
+                dist.distributed_c10d._get_default_store().set("rf_library_leg", "done")
         if args.dry:
             out["dry"] = True
         elif args.timed_only:
@@ -586,10 +590,8 @@ def main() -> int:
             # the other ranks released their engines above and wait HERE, on the rendezvous store (host side): rank 0 may still be in the library leg
             import datetime
             store = dist.distributed_c10d._get_default_store()
-            if rank == 0:
-                store.set("rf_library_leg", "done")
-            else:
-                store.wait(["rf_library_leg"], datetime.timedelta(seconds=120))      # the library leg is bounded (LIBRARY_LEG_BUDGET_S): 120 s = build + leg + slack
+            if rank != 0:
+                store.wait(["rf_library_leg"], datetime.timedelta(seconds=120))      # the library leg is bounded (LIBRARY_LEG_BUDGET_S): 120 s = build + leg + slack; rank 0 sets the key when the leg ends
         dist.barrier()
         dist.destroy_process_group()
     return 0
