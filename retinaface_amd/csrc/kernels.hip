@@ -2603,7 +2603,7 @@ static TileInfo dwpw_dispatch(hipStream_t s, const DwPwParams<T> *p, int hout, i
     //         182-VGPR build has two 4-wave ones: 34.8 -> 33.0 us; the plain blocks 27.7 -> 28.0 us: they stay on K_b;
     //   int8: the other way round -- the four plain blocks 25.0 -> 23.1 us each (121 VGPRs), the lateral block 29.0 -> 30.6 us (148 VGPRs: one workgroup per CU).
     // Probe knobs: RF_WIDE128 (fp16) 0 = none, 1 = lateral block, 2 = all five; RF_WIDE_I8 bit 0 = 256-channel block, bit 1 = plain blocks, bit 2 = lateral block.
-    if constexpr (HAS_DW && STRIDE == 1 && CIN == 128 && COUT == 128 && ((sizeof(T) == 2 && TH == 4 && TW == 8) || (sizeof(T) == 1 && TH == 4 && TW == 16))) {
+    if constexpr (HAS_DW && STRIDE == 1 && CIN == 128 && COUT == 128 && ((sizeof(T) == 2 && TH == 4 && (TW == 8 || (kProbeBuild && TW == 16))) || (sizeof(T) == 1 && TH == 4 && TW == 16))) {
         constexpr bool I8W = sizeof(T) == 1;
         const int v = I8W ? knob(K_WIDE_I8) : knob(K_WIDE128);
         const bool lat_wide = I8W ? (v & 4) != 0 : v >= 1, plain_wide = I8W ? (v & 2) != 0 : v == 2;

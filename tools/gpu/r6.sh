@@ -141,6 +141,11 @@ PY
         env RETINAFACE_AMD_LIB=$R/retinaface_amd/lib/libretinaface_amd_probe.so RF_GRID_FRAC=$1 timeout 200 python bench.py --lanes $2 --no-cpu-baseline --no-extra-configs --no-pmc --no-pipeline-trace --host-seconds 0 --regions 2 --profile-iters 3 > $O/bench_frac$1_lanes$2_$rep.json 2> $O/bench_frac$1_lanes$2_$rep.err
         python -c "import json;j=json.loads(open('$O/bench_frac$1_lanes$2_$rep.json').read().strip().splitlines()[-1]);print('frac $1 lanes $2 rep $rep:', round(j['images_per_sec']), 'img/s  burst', round(j['burst']['ms'],3), 'ms  sync', round(j['sync_batch']['ms_per_call'],4))" 2>&1 | tail -1
       done; done ;;
+    wide128)        # fp16 plain 128-channel blocks: K_b 4x8 (product) | K_b 4x16 | K_b(8) 4x8 | K_b(8) 4x16 (probe build)
+      for rep in 1 2; do for cfg in "-1 1" "2 1" "-1 2" "2 2"; do set -- $cfg
+        RETINAFACE_AMD_LIB=$R/retinaface_amd/lib/libretinaface_amd_probe.so RF_TILE128=$1 RF_WIDE128=$2 timeout 200 python tools/kbench.py --n 256 --tag r6_${TAG}_t$1_w$2 2>&1 | grep -E "total|dwpw<128,128,s1>" | head -2 | cut -c1-80 | sed "s/^/TILE128=$1 WIDE128=$2 rep $rep: /"
+      done; done
+      RETINAFACE_AMD_LIB=$R/retinaface_amd/lib/libretinaface_amd_probe.so timeout 300 python tools/probes/knob_equal.py --precision 1 --n 16 "RF_TILE128=2" 2>&1 | tail -1 ;;
     stem_tab)       # stem2 with index tables (V2 = 31, the product) vs raw staging alone (V2 = 15), probe build, interleaved; bit-identity of the two
       for rep in 1 2; do for v in 15 31; do
         RETINAFACE_AMD_LIB=$R/retinaface_amd/lib/libretinaface_amd_probe.so RF_STEM2_V2=$v timeout 200 python tools/kbench.py --n 256 --tag r6_${TAG}_stemv$v > $O/kbench_stem_v${v}_$rep.txt 2>&1
