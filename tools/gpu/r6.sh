@@ -146,6 +146,12 @@ PY
         RETINAFACE_AMD_LIB=$R/retinaface_amd/lib/libretinaface_amd_probe.so RF_TILE128=$1 RF_WIDE128=$2 timeout 200 python tools/kbench.py --n 256 --tag r6_${TAG}_t$1_w$2 2>&1 | grep -E "total|dwpw<128,128,s1>" | head -2 | cut -c1-80 | sed "s/^/TILE128=$1 WIDE128=$2 rep $rep: /"
       done; done
       RETINAFACE_AMD_LIB=$R/retinaface_amd/lib/libretinaface_amd_probe.so timeout 300 python tools/probes/knob_equal.py --precision 1 --n 16 "RF_TILE128=2" 2>&1 | tail -1 ;;
+    upmerge)        # (round 6, rejected and removed from engine.cpp: see profiles/r06_sync_host_call_ab.txt (d); the knob no longer exists)
+                    # pipelined host frames (rf_enqueue_batch, pageable): one DMA per enqueue (0) vs merged uploads of >= N MB (RF_UPLOAD_MERGE_MB)
+      for rep in 1 2; do for mb in 0 8 16 32 64 0; do
+        RF_UPLOAD_MERGE_MB=$mb timeout 200 python bench.py --no-cpu-baseline --no-extra-configs --no-pmc --no-pipeline-trace --host-seconds 3 --profile-iters 3 --regions 1 --min-seconds 0.3 > $O/bench_upmerge${mb}_$rep.json 2> $O/bench_upmerge${mb}_$rep.err
+        python -c "import json;j=json.loads(open('$O/bench_upmerge${mb}_$rep.json').read().strip().splitlines()[-1]);h=j['host_frames'];print('merge $mb MB rep $rep: pageable', round(h['pageable']['images_per_sec']), 'img/s', round(h['pageable']['pcie_GBs'],1), 'GB/s | registered', round(h['registered']['images_per_sec']), '| pinned copy', round(h['pinned_copy_GBs_measured'],1), 'GB/s | device-frame value', round(j['images_per_sec']))" 2>&1 | tail -1
+      done; done ;;
     stem_tab)       # stem2 with index tables (V2 = 31, the product) vs raw staging alone (V2 = 15), probe build, interleaved; bit-identity of the two
       for rep in 1 2; do for v in 15 31; do
         RETINAFACE_AMD_LIB=$R/retinaface_amd/lib/libretinaface_amd_probe.so RF_STEM2_V2=$v timeout 200 python tools/kbench.py --n 256 --tag r6_${TAG}_stemv$v > $O/kbench_stem_v${v}_$rep.txt 2>&1
