@@ -152,6 +152,9 @@ PY
         RF_UPLOAD_MERGE_MB=$mb timeout 200 python bench.py --no-cpu-baseline --no-extra-configs --no-pmc --no-pipeline-trace --host-seconds 3 --profile-iters 3 --regions 1 --min-seconds 0.3 > $O/bench_upmerge${mb}_$rep.json 2> $O/bench_upmerge${mb}_$rep.err
         python -c "import json;j=json.loads(open('$O/bench_upmerge${mb}_$rep.json').read().strip().splitlines()[-1]);h=j['host_frames'];print('merge $mb MB rep $rep: pageable', round(h['pageable']['images_per_sec']), 'img/s', round(h['pageable']['pcie_GBs'],1), 'GB/s | registered', round(h['registered']['images_per_sec']), '| pinned copy', round(h['pinned_copy_GBs_measured'],1), 'GB/s | device-frame value', round(j['images_per_sec']))" 2>&1 | tail -1
       done; done ;;
+    driver_cmd)     # the driver's exact round-end commands, timed
+      ( time timeout 600 python3 bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_driver_exact.json 2> $O/bench_driver_exact.err ) 2> $O/bench_driver_exact_time.txt; tail -3 $O/bench_driver_exact_time.txt
+      python -c "import json;j=json.loads(open('$O/bench_driver_exact.json').read().strip().splitlines()[-1]);print('driver exact:', round(j['images_per_sec']), 'img/s', round(j['value']), j['unit'], 'steps', j['steps'], 'requested', j['steps_requested'], 'roofline.frac', j['roofline']['frac'], 'cpu_baseline', j['cpu_baseline']['value'], j['cpu_baseline']['unit'], 'instruction_mix valu', j['roofline']['instruction_mix']['per_wave']['valu'])" ;;
     stem_tab)       # stem2 with index tables (V2 = 31, the product) vs raw staging alone (V2 = 15), probe build, interleaved; bit-identity of the two
       for rep in 1 2; do for v in 15 31; do
         RETINAFACE_AMD_LIB=$R/retinaface_amd/lib/libretinaface_amd_probe.so RF_STEM2_V2=$v timeout 200 python tools/kbench.py --n 256 --tag r6_${TAG}_stemv$v > $O/kbench_stem_v${v}_$rep.txt 2>&1
