@@ -155,6 +155,10 @@ PY
     driver_cmd)     # the driver's exact round-end commands, timed
       ( time timeout 600 python3 bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_driver_exact.json 2> $O/bench_driver_exact.err ) 2> $O/bench_driver_exact_time.txt; tail -3 $O/bench_driver_exact_time.txt
       python -c "import json;j=json.loads(open('$O/bench_driver_exact.json').read().strip().splitlines()[-1]);print('driver exact:', round(j['images_per_sec']), 'img/s', round(j['value']), j['unit'], 'steps', j['steps'], 'requested', j['steps_requested'], 'roofline.frac', j['roofline']['frac'], 'cpu_baseline', j['cpu_baseline']['value'], j['cpu_baseline']['unit'], 'instruction_mix valu', j['roofline']['instruction_mix']['per_wave']['valu'])" ;;
+    stress)         # soak test of the scheduler: random interleavings of every entry point on one handle, every result compared byte for byte
+      for cfg in "fp16 1 8" "int8 2 32" "fp16 3 1"; do set -- $cfg
+        timeout 400 python tools/probes/stress.py --seconds ${STRESS_S:-60} --precision $1 --seed $2 --max-batch $3 2>&1 | tail -2
+      done | tee $O/stress.txt ;;
     stem_tab)       # stem2 with index tables (V2 = 31, the product) vs raw staging alone (V2 = 15), probe build, interleaved; bit-identity of the two
       for rep in 1 2; do for v in 15 31; do
         RETINAFACE_AMD_LIB=$R/retinaface_amd/lib/libretinaface_amd_probe.so RF_STEM2_V2=$v timeout 200 python tools/kbench.py --n 256 --tag r6_${TAG}_stemv$v > $O/kbench_stem_v${v}_$rep.txt 2>&1
