@@ -158,7 +158,10 @@ PY
     stress)         # soak test of the scheduler: random interleavings of every entry point on one handle, every result compared byte for byte
       for cfg in "fp16 1 8" "int8 2 32" "fp16 3 1"; do set -- $cfg
         timeout 400 python tools/probes/stress.py --seconds ${STRESS_S:-60} --precision $1 --seed $2 --max-batch $3 2>&1 | tail -2
-      done | tee $O/stress.txt ;;
+      done | tee $O/stress.txt
+      for cfg in "int8 4 8 4" "fp16 5 8 3"; do set -- $cfg      # ONE handle over several engines (multi.cpp), forced scatter
+        timeout 400 python tools/probes/stress.py --seconds ${STRESS_S:-60} --precision $1 --seed $2 --max-batch $3 --devices $4 2>&1 | tail -2
+      done | tee -a $O/stress.txt ;;
     stem_tab)       # stem2 with index tables (V2 = 31, the product) vs raw staging alone (V2 = 15), probe build, interleaved; bit-identity of the two
       for rep in 1 2; do for v in 15 31; do
         RETINAFACE_AMD_LIB=$R/retinaface_amd/lib/libretinaface_amd_probe.so RF_STEM2_V2=$v timeout 200 python tools/kbench.py --n 256 --tag r6_${TAG}_stemv$v > $O/kbench_stem_v${v}_$rep.txt 2>&1

@@ -21,6 +21,8 @@ def main():
     ap.add_argument("--precision", default="fp16")
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--max-batch", type=int, default=8)
+    ap.add_argument("--devices", type=int, default=0, help="N > 0: ONE handle over N engines on device 0 (multi.cpp: image sharding, one host thread per engine) with "
+                                                           "RF_FORCE_SCATTER=1, so that every device frame travels by peer copy")
     a = ap.parse_args()
     import torch
     import retinaface_amd
@@ -28,7 +30,10 @@ def main():
     rnd = random.Random(a.seed)
     H = W = 448
     prec = {"fp16": 1, "int8": 2, "fp32": 0}[a.precision]
-    det = retinaface_amd.RetinaFace(os.path.join(ROOT, "assets"), "net3", 0.4, precision=prec, net_hw=(H, W), max_batch=a.max_batch, model_stem="mnet25")
+    if a.devices > 0:
+        os.environ["RF_FORCE_SCATTER"] = "1"
+    det = retinaface_amd.RetinaFace(os.path.join(ROOT, "assets"), "net3", 0.4, precision=prec, net_hw=(H, W), max_batch=a.max_batch, model_stem="mnet25",
+                                    devices=[0] * a.devices if a.devices > 0 else None)
     N = 48
     frames = synth_frames(H, W, N, config=91)
     dev = torch.from_numpy(np.stack(frames)).cuda()
@@ -104,7 +109,7 @@ def main():
         checked += len(ids)
     det.host_unregister(pinned)
     det.close()
-    print(f"stress ok: {a.precision}, {time.time() - t0:.0f} s, {checked} frame results checked byte for byte, operations {dict(sorted(ops.items()))}")
+    print(f"stress ok: {a.precision}, engines {max(a.devices, 1)}, max_batch {a.max_batch}, {time.time() - t0:.0f} s, {checked} frame results checked byte for byte, operations {dict(sorted(ops.items()))}")
 
 
 if __name__ == "__main__":
