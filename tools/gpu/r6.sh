@@ -161,7 +161,8 @@ PY
       done | tee $O/stress.txt
       for cfg in "int8 4 8 4" "fp16 5 8 3"; do set -- $cfg      # ONE handle over several engines (multi.cpp), forced scatter
         timeout 400 python tools/probes/stress.py --seconds ${STRESS_S:-60} --precision $1 --seed $2 --max-batch $3 --devices $4 2>&1 | tail -2
-      done | tee -a $O/stress.txt ;;
+      done | tee -a $O/stress.txt
+      timeout 400 python tools/probes/stress.py --threads 3 --seconds ${STRESS_S:-60} --precision fp16 --seed 7 --max-batch 8 2>&1 | grep -E "stress|Error|error" | tee -a $O/stress.txt ;;      # three threads, three handles, one GPU
     stem_tab)       # stem2 with index tables (V2 = 31, the product) vs raw staging alone (V2 = 15), probe build, interleaved; bit-identity of the two
       for rep in 1 2; do for v in 15 31; do
         RETINAFACE_AMD_LIB=$R/retinaface_amd/lib/libretinaface_amd_probe.so RF_STEM2_V2=$v timeout 200 python tools/kbench.py --n 256 --tag r6_${TAG}_stemv$v > $O/kbench_stem_v${v}_$rep.txt 2>&1

@@ -16,6 +16,31 @@ sys.path.insert(0, ROOT)
 
 
 def main():
+    if "--threads" in sys.argv:                    # N worker threads, each with its OWN handle (different handles are independent: include/retinaface_amd.h)
+        import threading
+        k = sys.argv.index("--threads")
+        nthreads = int(sys.argv[k + 1])
+        del sys.argv[k:k + 2]
+        errs = []
+
+        def work(i):
+            try:
+                run(seed_offset=100 * i, label=f"thread {i}: ")
+            except BaseException as e:  # noqa: BLE001
+                errs.append((i, repr(e)))
+
+        th = [threading.Thread(target=work, args=(i,)) for i in range(nthreads)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        if errs:
+            raise SystemExit(f"stress FAILED in {errs}")
+        return
+    run()
+
+
+def run(seed_offset=0, label=""):
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=60.0)
     ap.add_argument("--precision", default="fp16")
@@ -27,7 +52,7 @@ def main():
     import torch
     import retinaface_amd
     from retinaface_amd.frames import synth_frames
-    rnd = random.Random(a.seed)
+    rnd = random.Random(a.seed + seed_offset)
     H = W = 448
     prec = {"fp16": 1, "int8": 2, "fp32": 0}[a.precision]
     if a.devices > 0:
@@ -109,7 +134,7 @@ def main():
         checked += len(ids)
     det.host_unregister(pinned)
     det.close()
-    print(f"stress ok: {a.precision}, engines {max(a.devices, 1)}, max_batch {a.max_batch}, {time.time() - t0:.0f} s, {checked} frame results checked byte for byte, operations {dict(sorted(ops.items()))}")
+    print(f"{label}stress ok: {a.precision}, engines {max(a.devices, 1)}, max_batch {a.max_batch}, {time.time() - t0:.0f} s, {checked} frame results checked byte for byte, operations {dict(sorted(ops.items()))}")
 
 
 if __name__ == "__main__":
