@@ -163,6 +163,20 @@ PY
         timeout 400 python tools/probes/stress.py --seconds ${STRESS_S:-60} --precision $1 --seed $2 --max-batch $3 --devices $4 2>&1 | tail -2
       done | tee -a $O/stress.txt
       timeout 400 python tools/probes/stress.py --threads 3 --seconds ${STRESS_S:-60} --precision fp16 --seed 7 --max-batch 8 2>&1 | grep -E "stress|Error|error" | tee -a $O/stress.txt ;;      # three threads, three handles, one GPU
+    ranks8)         # the whole `--gpus 8` flow with REAL engines, eight ranks sharing the one GPU (gloo; RCCL refuses duplicates): launcher, legs, accounting
+      ( time timeout 900 python bench.py --gpus 8 --oversubscribe --no-cpu-baseline --host-seconds 0 --no-pmc --no-pipeline-trace --profile-iters 3 --ring-mb 40 --min-seconds 0.3 --regions 1 \
+          > $O/bench_8ranks_one_gpu.json 2> $O/bench_8ranks_one_gpu.err ) 2> $O/bench_8ranks_time.txt; echo "8 ranks rc $?"; tail -3 $O/bench_8ranks_time.txt
+      python - <<PY
+import json
+j=json.loads(open("$O/bench_8ranks_one_gpu.json").read().strip().splitlines()[-1])
+g=j["result_gather"]
+print("8 ranks:", round(j["images_per_sec"]), "img/s; efficiency", round(j["scaling_efficiency"]["value"],3), "records", g["records_gathered"], "==", g["expected"], "ranks", g["ranks_in_communicator"])
+print(" per rank", [round(x) for x in g["per_rank"]["images_per_sec"]])
+print(" split_ab", {k:round(v["ms_per_step"],3) for k,v in j["batch_split_ab"]["legs"].items()}, "same", j["batch_split_ab"]["same_detections_every_leg"])
+print(" strong", round(j["configs4_strong"]["images_per_sec"]), "img/s records", j["configs4_strong"]["result_gather"]["records_gathered"], "==", j["configs4_strong"]["result_gather"]["expected"])
+l=j["library_multi_device"]; print(" library leg", l.get("ms_per_call"), "identical", l.get("detections_identical_to_single_engine"), l.get("error"))
+PY
+      ;;
     stem_tab)       # stem2 with index tables (V2 = 31, the product) vs raw staging alone (V2 = 15), probe build, interleaved; bit-identity of the two
       for rep in 1 2; do for v in 15 31; do
         RETINAFACE_AMD_LIB=$R/retinaface_amd/lib/libretinaface_amd_probe.so RF_STEM2_V2=$v timeout 200 python tools/kbench.py --n 256 --tag r6_${TAG}_stemv$v > $O/kbench_stem_v${v}_$rep.txt 2>&1
